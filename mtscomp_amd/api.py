@@ -1,0 +1,737 @@
+"""Host side of the drop-in: mtscomp's ``compress()/decompress()/Writer/Reader`` API and ``.cbin/.ch``
+on-disk format, with the per-chunk codec running on MI355X through ``libmtscomp_hip.so``.
+
+The interface mirrors /root/reference/mtscomp.py (names, argument meaning, error behaviour); every
+public item cites the reference lines it stands in for.  What changed is below the interface:
+
+* ``Writer.compress_batch`` hands a whole batch of chunks to ``mts_compress_chunks`` (one C-ABI call
+  per device) instead of ``pool.map(self._compress_chunk, ...)`` (mtscomp.py:399-423);
+* ``Reader.decompress_chunks`` / ``__getitem__`` hand all missing chunks to ``mts_decompress_chunks``
+  instead of ``pool.map(self._decompress_chunk, ...)`` (mtscomp.py:645-650, 810-812);
+* chunks are sharded round-robin over the visible GPUs (chunk i -> device i mod G); the only
+  cross-device step is the host-side gather of compressed sizes into ``chunk_offsets``.
+
+There is no CPU implementation of the codec in this package: the codec object is ``HipCodec`` and it
+raises if the HIP library or a gfx950 device is missing.
+"""
+import bisect
+import hashlib
+import json
+import logging
+import multiprocessing as mp
+import os
+import os.path as op
+from collections import OrderedDict
+from multiprocessing.dummy import Pool as ThreadPool
+from pathlib import Path
+from threading import Lock
+
+import numpy as np
+
+from . import hip
+
+__version__ = '0.1.0'
+FORMAT_VERSION = '1.0'          # mtscomp.py:41
+
+__all__ = ('load_raw_data', 'Writer', 'Reader', 'compress', 'decompress', 'check', 'diff_along_axis',
+           'cumsum_along_axis', 'read_config', 'write_config', 'add_default_handler', 'HipCodec')
+
+# mtscomp.py:46-57 -- same keys, same defaults; the .ch header only ever sees the reference's keys.
+DEFAULT_CONFIG = tuple(dict(
+    algorithm='zlib',
+    cache_size=10,
+    check_after_compress=True,
+    check_after_decompress=True,
+    chunk_duration=1.,
+    chunk_order='F',
+    comp_level=-1,              # stored in the header, never passed to the codec (mtscomp.py:394)
+    do_spatial_diff=False,
+    do_time_diff=True,
+    n_threads=mp.cpu_count(),   # kept for compatibility; the device path does not use host threads
+).items())
+
+CHECK_ATOL = 1e-16              # mtscomp.py:59
+CRITICAL_ERROR_URL = "https://github.com/int-brain-lab/mtscomp/issues/new?title=Critical+error"
+DEFAULT_BATCH_CHUNKS = 64       # chunks handed to one device call
+
+logger = logging.getLogger('mtscomp_amd')
+logger.setLevel(logging.INFO)
+logger.addHandler(logging.NullHandler())
+
+_seek_lock = Lock()
+
+
+def add_default_handler(level='INFO', logger=logger):
+    """Attach a stream handler (mtscomp.py:89-96)."""
+    handler = logging.StreamHandler()
+    handler.setLevel(level)
+    handler.setFormatter(logging.Formatter('%(asctime)s [%(levelname).1s] %(message)s', '%H:%M:%S'))
+    logger.addHandler(handler)
+
+
+class Bunch(dict):
+    """dict with attribute access (mtscomp.py:99-104)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.__dict__ = self
+
+
+def _clip(x, lo, hi):
+    return max(lo, min(hi, x))
+
+
+# ------------------------------------------------------------------------------------------------
+# config (mtscomp.py:176-209)
+# ------------------------------------------------------------------------------------------------
+def config_path():
+    return (Path('~') / '.mtscomp').expanduser()
+
+
+CONFIG_PATH = config_path()
+
+
+def read_config(**kwargs):
+    """Defaults < ~/.mtscomp < kwargs; None values are ignored (mtscomp.py:186-200)."""
+    params = dict(DEFAULT_CONFIG)
+    user = {}
+    if CONFIG_PATH.exists():
+        with CONFIG_PATH.open('r') as f:
+            user = json.load(f)
+    for layer in (user, kwargs):
+        params.update({k: v for k, v in layer.items() if v is not None})
+    return Bunch(params)
+
+
+def write_config(**kwargs):
+    """mtscomp.py:203-209."""
+    config = read_config(**kwargs)
+    CONFIG_PATH.parent.mkdir(exist_ok=True, parents=True)
+    with CONFIG_PATH.open('w') as f:
+        json.dump(config, f, indent=2, sort_keys=True)
+    return config
+
+
+# ------------------------------------------------------------------------------------------------
+# raw I/O (mtscomp.py:115-140)
+# ------------------------------------------------------------------------------------------------
+def load_raw_data(path=None, n_channels=None, dtype=None, offset=None, mmap=True):
+    """Memmap (or read) a flat binary file as an (n_samples, n_channels) array."""
+    path = Path(path)
+    assert path.exists(), "File %s does not exist." % path
+    assert dtype, "The data type must be provided."
+    n_channels = n_channels or 1
+    itemsize = np.dtype(dtype).itemsize
+    offset = offset or 0
+    f_size = op.getsize(str(path))
+    n_samples = (f_size - offset) // (itemsize * n_channels)
+    if n_samples * n_channels * itemsize != f_size - offset:
+        raise ValueError(
+            "The file size (%d bytes) is incompatible with the specified parameters "
+            "(n_channels=%d, dtype=%s, offset=%d)" % (f_size, n_channels, dtype, offset))
+    if n_samples * n_channels == 0:
+        return np.zeros((0, n_channels), dtype=dtype)
+    shape = (n_samples, n_channels)
+    if mmap:
+        return np.memmap(str(path), dtype=dtype, shape=shape, offset=offset)
+    if offset > 0:  # pragma: no cover
+        raise NotImplementedError()
+    return np.fromfile(str(path), dtype).reshape(shape)
+
+
+# ------------------------------------------------------------------------------------------------
+# the codec (device side)
+# ------------------------------------------------------------------------------------------------
+class HipCodec:
+    """Per-chunk codec on MI355X.  ``devices``: list of device indices (default: all visible)."""
+
+    name = 'hip'
+
+    def __init__(self, devices=None):
+        n = hip.require_device()
+        self.devices = list(range(n)) if devices is None else [int(d) for d in devices]
+        assert self.devices and all(0 <= d < n for d in self.devices), "invalid device list"
+
+    # -- transforms alone (diff_along_axis / cumsum_along_axis)
+    def delta(self, arr, flags):
+        return hip.delta_transpose(arr, flags, device=self.devices[0])
+
+    def cumsum(self, stream, nt, nc, dtype, flags):
+        return hip.cumsum_transpose(stream, nt, nc, dtype, flags, device=self.devices[0])
+
+    def _shards(self, n):
+        g = len(self.devices)
+        return [list(range(k, n, g)) for k in range(g)] if g > 1 and n > 1 else [list(range(n))]
+
+    def compress(self, chunks, flags, level=6):
+        """chunks: list of (n_t, n_c) arrays -> list of zlib streams (order preserved)."""
+        n = len(chunks)
+        out = [None] * n
+        shards = [s for s in self._shards(n) if s]
+
+        def run(k):
+            ids = shards[k]
+            rows = [chunks[i].shape[0] for i in ids]
+            data = chunks[ids[0]] if len(ids) == 1 else np.concatenate([chunks[i] for i in ids], axis=0)
+            bounds = np.concatenate(([0], np.cumsum(rows)))
+            res = hip.compress_chunks(data, bounds, flags, level, device=self.devices[k % len(self.devices)])
+            for i, b in zip(ids, res):
+                out[i] = b
+        self._run_shards(run, len(shards))
+        return out
+
+    def decompress(self, cbufs, n_rows, n_channels, dtype, flags):
+        """-> (status list, list of (n_rows[i], n_channels) arrays or None)."""
+        n = len(cbufs)
+        status, arrays = [0] * n, [None] * n
+        shards = [s for s in self._shards(n) if s]
+
+        def run(k):
+            ids = shards[k]
+            st, arrs = hip.decompress_chunks([cbufs[i] for i in ids], [n_rows[i] for i in ids], n_channels, dtype,
+                                             flags, device=self.devices[k % len(self.devices)])
+            for i, s, a in zip(ids, st, arrs):
+                status[i], arrays[i] = s, a
+        self._run_shards(run, len(shards))
+        return status, arrays
+
+    @staticmethod
+    def _run_shards(fn, n):
+        if n <= 1:
+            if n:
+                fn(0)
+            return
+        with ThreadPool(n) as pool:          # one host thread per GPU; ctypes releases the GIL
+            pool.map(fn, range(n))
+
+
+_default_codec = None
+
+
+def get_codec():
+    """The process-wide device codec (created on first use; raises without library/GPU)."""
+    global _default_codec
+    if _default_codec is None:
+        _default_codec = HipCodec()
+    return _default_codec
+
+
+def set_codec(codec):
+    """Install a codec object (tests inject the CPU oracle here to exercise the host logic without a
+    GPU; the package itself never constructs anything but ``HipCodec``)."""
+    global _default_codec
+    _default_codec = codec
+
+
+def _int_flags(do_time_diff, do_spatial_diff, chunk_order):
+    return hip.make_flags(bool(do_time_diff), bool(do_spatial_diff), chunk_order)
+
+
+def diff_along_axis(chunk, axis=None):
+    """np.diff along `axis` keeping the first row/column (mtscomp.py:143-159)."""
+    if axis is None:
+        return chunk
+    assert 0 <= axis < chunk.ndim
+    hip.check_dtype(chunk.dtype)
+    flags = hip.FLAG_TIME_DIFF if axis == 0 else hip.FLAG_SPATIAL_DIFF
+    chunk = np.ascontiguousarray(chunk)
+    out = get_codec().delta(chunk, flags)          # order 'C': same layout as the input
+    return out.view(chunk.dtype).reshape(chunk.shape)
+
+
+def cumsum_along_axis(chunk, axis=None):
+    """Inverse of diff_along_axis (mtscomp.py:162-169)."""
+    if axis is None:
+        return chunk
+    assert 0 <= axis < chunk.ndim
+    hip.check_dtype(chunk.dtype)
+    flags = hip.FLAG_TIME_DIFF if axis == 0 else hip.FLAG_SPATIAL_DIFF
+    chunk = np.ascontiguousarray(chunk)
+    return get_codec().cumsum(chunk, chunk.shape[0], chunk.shape[1], chunk.dtype, flags)
+
+
+# ------------------------------------------------------------------------------------------------
+# Writer (mtscomp.py:216-511)
+# ------------------------------------------------------------------------------------------------
+class Writer:
+    """Compress a raw data file chunk by chunk.
+
+    Keyword arguments as in the reference (chunk_duration, algorithm, comp_level, do_time_diff,
+    do_spatial_diff, n_threads, before_check, check_after_compress, chunk_order) plus
+    ``batch_chunks`` (chunks per device call) and ``codec`` (defaults to the MI355X codec).
+    """
+
+    def __init__(self, before_check=None, codec=None, **kwargs):
+        self.pool = None
+        self.quiet = kwargs.pop('quiet', False)
+        config = read_config(**kwargs)
+        self.config = config
+        self.chunk_duration = config.chunk_duration
+        self.algorithm = config.algorithm
+        assert self.algorithm == 'zlib', "Only zlib is currently supported."
+        self.comp_level = config.comp_level
+        self.do_time_diff = config.do_time_diff
+        self.do_spatial_diff = config.do_spatial_diff
+        self.n_threads = config.n_threads
+        self.before_check = before_check or (lambda x: None)
+        self.check_after_compress = config.check_after_compress
+        self.chunk_order = config.chunk_order
+        self.batch_chunks = int(config.get('batch_chunks', None) or DEFAULT_BATCH_CHUNKS)
+        self._codec = codec
+
+    @property
+    def codec(self):
+        return self._codec or get_codec()
+
+    def open(self, data_path, sample_rate=None, n_channels=None, dtype=None, offset=None, mmap=True):
+        """mtscomp.py:257-322."""
+        self.data_path = Path(data_path)
+        sample_rate = sample_rate or self.config.get('sample_rate', None)
+        if not sample_rate:
+            raise ValueError("Please provide a sample rate (-s option in the command-line).")
+        if str(data_path).endswith('.npy'):
+            self.data = np.load(data_path, mmap_mode='r')
+            self.shape = self.data.shape
+            if self.data.ndim >= 3:
+                self.data = np.reshape(self.data, (-1, self.data.shape[-1]))
+            self.dtype = dtype = self.data.dtype
+            self.n_channels = n_channels = self.data.shape[1]
+        else:
+            n_channels = n_channels or self.config.get('n_channels', None)
+            if not n_channels:
+                raise ValueError("Please provide n_channels (-n option in the command-line).")
+            dtype = dtype or self.config.get('dtype', None)
+            if not dtype:
+                raise ValueError("Please provide a dtype (-d option in the command-line).")
+            self.dtype = np.dtype(dtype)
+            self.data = load_raw_data(data_path, n_channels=n_channels, dtype=self.dtype)
+            self.shape = self.data.shape
+        self.sample_rate = float(sample_rate)
+        assert sample_rate > 0
+        assert n_channels > 0
+        self.file_size = self.data.size * self.data.itemsize
+        assert self.data.ndim == 2
+        self.n_samples, self.n_channels = self.data.shape
+        assert self.n_samples > 0
+        assert self.n_channels > 0
+        assert n_channels == self.n_channels
+        logger.info("Opening %s, duration %.1fs, %d channels.", data_path,
+                    self.data.shape[0] / self.sample_rate, self.n_channels)
+        self._compute_chunk_bounds()
+        self.sha1_compressed = hashlib.sha1()
+        self.sha1_uncompressed = hashlib.sha1()
+
+    def _compute_chunk_bounds(self):
+        """mtscomp.py:324-339 (np.round: half to even)."""
+        chunk_size = int(np.round(self.chunk_duration * self.sample_rate))
+        bounds = list(range(0, self.n_samples, chunk_size))
+        if bounds[-1] < self.n_samples:
+            bounds.append(self.n_samples)
+        self.chunk_bounds = bounds
+        self.n_chunks = len(bounds) - 1
+        assert bounds[0] == 0 and bounds[-1] == self.n_samples
+        # A batch is what one round of device calls processes (the reference: one chunk per thread).
+        self.batch_size = max(1, self.batch_chunks * max(1, len(getattr(self.codec, 'devices', [0]))))
+        self.n_batches = int(np.ceil(self.n_chunks / self.batch_size))
+
+    def get_cmeta(self):
+        """The .ch header (mtscomp.py:341-358): same keys, same value types."""
+        return {
+            'version': FORMAT_VERSION,
+            'algorithm': self.algorithm,
+            'comp_level': self.comp_level,
+            'do_time_diff': self.do_time_diff,
+            'do_spatial_diff': self.do_spatial_diff,
+            'dtype': str(np.dtype(self.dtype)),
+            'n_channels': self.n_channels,
+            'sample_rate': self.sample_rate,
+            'chunk_bounds': self.chunk_bounds,
+            'chunk_offsets': self.chunk_offsets,
+            'chunk_order': self.chunk_order,
+            'sha1_compressed': self.sha1_compressed.hexdigest(),
+            'sha1_uncompressed': self.sha1_uncompressed.hexdigest(),
+            'shape': self.shape,
+        }
+
+    def get_chunk(self, chunk_idx):
+        """mtscomp.py:360-373."""
+        assert 0 <= chunk_idx <= self.n_chunks - 1
+        return self.data[self.chunk_bounds[chunk_idx]:self.chunk_bounds[chunk_idx + 1], :]
+
+    def compress_batch(self, first_chunk, last_chunk):
+        """Chunks [first_chunk, last_chunk) -> {idx: (raw chunk, compressed bytes)}
+        (mtscomp.py:399-423; the per-chunk work of :375-397 happens on the device)."""
+        assert 0 <= first_chunk < last_chunk <= self.n_chunks
+        ids = list(range(first_chunk, last_chunk))
+        chunks = [self.get_chunk(i) for i in ids]
+        flags = _int_flags(self.do_time_diff, self.do_spatial_diff, self.chunk_order)
+        # the reference never forwards comp_level to zlib (mtscomp.py:394): level 6 always
+        cbufs = self.codec.compress(chunks, flags, 6)
+        return {i: (c, b) for i, c, b in zip(ids, chunks, cbufs)}
+
+    def write(self, out, outmeta):
+        """Write .cbin + .ch; returns csize / raw size (mtscomp.py:425-507)."""
+        if not out:
+            out = self.data_path.with_suffix('.c' + self.data_path.suffix[1:])
+        if not outmeta:
+            outmeta = self.data_path.with_suffix('.ch')
+        Path(out).parent.mkdir(exist_ok=True, parents=True)
+        offset = 0
+        self.chunk_offsets = [0]
+        logger.info("Starting compression on %s.", getattr(self.codec, 'name', 'codec'))
+        with open(out, 'wb') as fb:
+            for batch in range(self.n_batches):
+                first = self.batch_size * batch
+                last = min(self.batch_size * (batch + 1), self.n_chunks)
+                done = self.compress_batch(first, last)
+                assert set(done.keys()) <= set(range(first, last))
+                for idx in sorted(done.keys()):                 # strictly in file order
+                    raw_chunk, cbuf = done[idx]
+                    fb.write(cbuf)
+                    offset += len(cbuf)
+                    self.chunk_offsets.append(offset)
+                    self.sha1_uncompressed.update(np.ascontiguousarray(raw_chunk))
+                    self.sha1_compressed.update(cbuf)
+            csize = fb.tell()
+        assert self.chunk_offsets[-1] == csize
+        ratio = csize / self.file_size
+        logger.info("Wrote %s (%.1f GB, -%.3f%%).", out, csize / 1024 ** 3, 100 - 100 * ratio)
+        with open(outmeta, 'w') as f:
+            json.dump(self.get_cmeta(), f, indent=2, sort_keys=True)
+        if self.check_after_compress:
+            self.before_check(self)
+            try:
+                check(self.data, out, outmeta, codec=self._codec)
+            except AssertionError:
+                raise RuntimeError(
+                    "CRITICAL ERROR: automatic check failed when compressing the data. "
+                    "Report immediately to " + CRITICAL_ERROR_URL)
+            logger.debug("Automatic integrity check after compression PASSED.")
+        return ratio
+
+    def close(self):
+        """mtscomp.py:509-511."""
+        mm = getattr(self.data, '_mmap', None)
+        if mm is not None:
+            mm.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# Reader (mtscomp.py:514-859)
+# ------------------------------------------------------------------------------------------------
+class Reader:
+    """NumPy-style read access to a compressed file; chunks are decoded on the device."""
+
+    def __init__(self, codec=None, **kwargs):
+        self.pool = None
+        self.cdata = None
+        self.quiet = kwargs.pop('quiet', False)
+        self.config = read_config(**kwargs)
+        self.cache_size = self.config.cache_size
+        self.check_after_decompress = self.config.check_after_decompress
+        self.batch_chunks = int(self.config.get('batch_chunks', None) or DEFAULT_BATCH_CHUNKS)
+        self._codec = codec
+        self._cache = OrderedDict()
+
+    @property
+    def codec(self):
+        return self._codec or get_codec()
+
+    def open(self, cdata, cmeta=None):
+        """mtscomp.py:536-580."""
+        if cmeta is None:
+            cmeta = Path(cdata).with_suffix('.ch')
+        if not isinstance(cmeta, dict):
+            with open(cmeta, 'r') as f:
+                cmeta = json.load(f)
+        assert isinstance(cmeta, dict)
+        self.cmeta = Bunch(cmeta)
+        self.n_channels = self.cmeta.n_channels
+        self.sample_rate = self.cmeta.sample_rate
+        self.dtype = np.dtype(self.cmeta.dtype)
+        self.chunk_offsets = self.cmeta.chunk_offsets
+        self.chunk_bounds = self.cmeta.chunk_bounds
+        self.chunk_order = self.cmeta.chunk_order
+        self.n_samples = self.chunk_bounds[-1]
+        self.n_chunks = len(self.chunk_bounds) - 1
+        self.shape = (self.n_samples, self.n_channels)
+        self.ndim = 2
+        self.batch_size = max(1, self.batch_chunks * max(1, len(getattr(self.codec, 'devices', [0]))))
+        self.n_batches = int(np.ceil(self.n_chunks / self.batch_size))
+        if isinstance(cdata, (str, Path)):
+            if Path(cdata).suffix in ('.bin', '.dat'):  # pragma: no cover
+                logger.error("File to decompress has unexpected extension %s.", Path(cdata).suffix)
+            cdata = open(cdata, 'rb')
+        self.cdata = cdata
+        self.set_cache_size()
+
+    def set_cache_size(self, cache_size=None):
+        """LRU size for decoded chunks (mtscomp.py:582-588)."""
+        cache_size = cache_size or self.cache_size
+        assert cache_size > 0
+        self.cache_size = cache_size
+        while len(self._cache) > self.cache_size:
+            self._cache.popitem(last=False)
+
+    def iter_chunks(self, first_chunk=0, last_chunk=None):
+        """Yield (chunk_idx, chunk_start, chunk_length) (mtscomp.py:590-600)."""
+        last_chunk = last_chunk if last_chunk is not None else self.n_chunks - 1
+        for idx in range(first_chunk, last_chunk + 1):
+            yield idx, self.chunk_offsets[idx], self.chunk_offsets[idx + 1] - self.chunk_offsets[idx]
+
+    def _pread(self, length, start):
+        if hasattr(os, 'pread'):
+            buf = os.pread(self.cdata.fileno(), length, start)       # thread safe (mtscomp.py:609)
+        else:  # pragma: no cover
+            with _seek_lock:
+                self.cdata.seek(start)
+                buf = self.cdata.read(length)
+        assert len(buf) == length
+        return buf
+
+    def _flags(self):
+        return _int_flags(self.cmeta.do_time_diff, self.cmeta.do_spatial_diff, self.chunk_order)
+
+    def _decode(self, triples):
+        """Decode chunks [(idx, start, length)] not in the cache with ONE codec call; returns
+        {idx: array}.  Error mapping as mtscomp.py:618-628."""
+        todo = [t for t in triples if t[0] not in self._cache]
+        result = {}
+        if todo:
+            cbufs = [self._pread(length, start) for (_, start, length) in todo]
+            rows = [self.chunk_bounds[i + 1] - self.chunk_bounds[i] for (i, _, _) in todo]
+            status, arrays = self.codec.decompress(cbufs, rows, self.n_channels, self.dtype, self._flags())
+            for (idx, _, _), st, arr in zip(todo, status, arrays):
+                if st == hip.CHUNK_BADSIZE:
+                    raise AssertionError("Chunk #%d does not have the expected size." % idx)
+                if st != hip.CHUNK_OK:
+                    raise IOError("Compressed chunk #%d is corrupted." % idx)
+                result[idx] = arr
+        for idx, _, _ in triples:
+            if idx in self._cache:
+                self._cache.move_to_end(idx)
+                result[idx] = self._cache[idx]
+        for idx, arr in result.items():
+            self._cache[idx] = arr
+            self._cache.move_to_end(idx)
+        while len(self._cache) > self.cache_size:
+            self._cache.popitem(last=False)
+        return result
+
+    def read_chunk(self, chunk_idx, chunk_start, chunk_length):
+        """One decoded chunk, (n_samples_chunk, n_channels), C-contiguous (mtscomp.py:602-635)."""
+        return self._decode([(chunk_idx, chunk_start, chunk_length)])[chunk_idx]
+
+    def _decompress_chunk(self, chunk_idx):
+        """mtscomp.py:637-643."""
+        assert 0 <= chunk_idx <= self.n_chunks - 1
+        start = self.chunk_offsets[chunk_idx]
+        return chunk_idx, self.read_chunk(chunk_idx, start, self.chunk_offsets[chunk_idx + 1] - start)
+
+    def decompress_chunks(self, chunk_ids, pool=None):
+        """{chunk_idx: array} for the requested chunks, decoded in one device batch
+        (mtscomp.py:645-650; `pool` is accepted for compatibility and not needed)."""
+        ids = list(chunk_ids)
+        triples = [(i, self.chunk_offsets[i], self.chunk_offsets[i + 1] - self.chunk_offsets[i]) for i in ids]
+        keep = self.cache_size
+        if len(ids) > keep:
+            self.cache_size = len(ids)          # a batch must not evict itself
+        try:
+            out = self._decode(triples)
+        finally:
+            self.cache_size = keep
+            while len(self._cache) > self.cache_size:
+                self._cache.popitem(last=False)
+        assert set(out.keys()) == set(ids)
+        return out
+
+    def _validate_index(self, i, value_for_none=0):
+        """mtscomp.py:652-659."""
+        if i is None:
+            i = value_for_none
+        elif i < 0:
+            i += self.n_samples
+        i = _clip(i, 0, self.n_samples)
+        return int(i)
+
+    def _chunks_for_interval(self, i0, i1):
+        """First and last chunk to load for samples [i0, i1] -- i1 is treated as inclusive, exactly
+        like the reference (mtscomp.py:661-684; table pinned by tests.py:308-339)."""
+        i0 = _clip(i0, 0, self.n_samples - 1)
+        i1 = _clip(i1, i0, self.n_samples - 1)
+        first = _clip(bisect.bisect_right(self.chunk_bounds, i0) - 1, 0, self.n_chunks - 1)
+        last = _clip(bisect.bisect_right(self.chunk_bounds, i1, lo=first) - 1, 0, self.n_chunks - 1)
+        assert 0 <= first <= last <= self.n_chunks - 1
+        return first, last
+
+    def start_thread_pool(self):
+        """Kept for API compatibility (mtscomp.py:686-692); the device path does not need it."""
+        if self.pool:  # pragma: no cover
+            return self.pool
+        self.pool = ThreadPool(max(1, min(4, int(self.config.n_threads or 1))))
+        return self.pool
+
+    def stop_thread_pool(self):
+        """mtscomp.py:694-699."""
+        if self.pool:
+            self.pool.close()
+            self.pool.join()
+        self.pool = None
+
+    def tofile(self, out, overwrite=False):
+        """Decompress the whole file to a flat binary file (mtscomp.py:701-743)."""
+        if out is None:
+            out = Path(self.cdata.name).with_suffix('.bin')
+        out = Path(out)
+        if not overwrite and out.exists():  # pragma: no cover
+            raise ValueError("The output file %s already exists, use --overwrite or specify another "
+                             "output path." % out)
+        elif overwrite and out.exists():
+            out.unlink()
+        with open(out, 'wb') as fb:
+            for batch in range(self.n_batches):
+                first = self.batch_size * batch
+                last = min(self.batch_size * (batch + 1), self.n_chunks)
+                chunks = self.decompress_chunks(range(first, last))
+                for idx in sorted(chunks.keys()):
+                    fb.write(chunks[idx])
+            dsize = fb.tell()
+        assert dsize == self.chunk_bounds[-1] * self.n_channels * self.dtype.itemsize
+        logger.info("Wrote %s (%.1f GB).", out, dsize / 1024 ** 3)
+        if self.check_after_decompress:
+            decompressed = load_raw_data(out, n_channels=self.n_channels, dtype=self.dtype)
+            check(decompressed, self.cdata, self.cmeta, codec=self._codec)
+
+    def close(self):
+        """mtscomp.py:745-748."""
+        if self.cdata:
+            self.cdata.close()
+
+    def chop(self, n_chunks, out=None):
+        """Keep the first n_chunks chunks, without decoding (mtscomp.py:750-796)."""
+        assert n_chunks > 0
+        if n_chunks >= self.n_chunks:  # pragma: no cover
+            logger.warning("Cannot chop more chunks than there are in the original file.")
+            return
+        assert out is not None, "The output path must be specified."
+        out = Path(out)
+        assert out.suffix == '.cbin'
+        if out.exists():  # pragma: no cover
+            raise IOError("File %s already exists." % out)
+        out.parent.mkdir(exist_ok=True, parents=True)
+        end = self.chunk_offsets[n_chunks]
+        with open(out, 'wb') as f:
+            f.write(self._pread(end, 0))
+        outmeta = out.with_suffix('.ch')
+        if outmeta.exists():  # pragma: no cover
+            raise IOError("File %s already exists." % outmeta)
+        cmeta = Bunch(self.cmeta.copy())
+        cmeta['chunk_bounds'] = cmeta['chunk_bounds'][:n_chunks + 1]
+        cmeta['chunk_offsets'] = cmeta['chunk_offsets'][:n_chunks + 1]
+        assert cmeta['chunk_offsets'][-1] == end
+        cmeta['sha1_compressed'] = None
+        cmeta['sha1_uncompressed'] = None
+        cmeta['chopped'] = True
+        with open(outmeta, 'w') as f:
+            json.dump(cmeta, f, indent=2, sort_keys=True)
+
+    def __getitem__(self, item):
+        """NumPy-style slicing (mtscomp.py:798-856).  All chunks a slice touches are decoded in one
+        device batch."""
+        fallback = np.zeros((0, self.n_channels), dtype=self.dtype)
+        if isinstance(item, slice):
+            i0 = self._validate_index(item.start, 0)
+            i1 = self._validate_index(item.stop, self.n_samples)
+            if i1 <= i0:
+                return fallback
+            first, last = self._chunks_for_interval(i0, i1)
+            # the reference also loads the chunk that starts exactly at i1 (inclusive stop); its rows
+            # are never part of the result, so it is not decoded here
+            if last > first and self.chunk_bounds[last] >= i1:
+                last -= 1
+            triples = list(self.iter_chunks(first, last))
+            keep = self.cache_size
+            if len(triples) > keep:
+                self.cache_size = len(triples)
+            try:
+                decoded = self._decode(triples)
+            finally:
+                self.cache_size = keep
+                while len(self._cache) > self.cache_size:
+                    self._cache.popitem(last=False)
+            chunks = [decoded[i] for i in range(first, last + 1)]
+            arr = chunks[0] if len(chunks) == 1 else np.concatenate(chunks, axis=0)
+            a = i0 - self.chunk_bounds[first]
+            b = i1 - self.chunk_bounds[first]
+            assert 0 <= a <= b <= arr.shape[0]
+            out = arr[a:b:item.step, :]
+            assert out.shape[0] == len(range(i0, i1, item.step or 1))
+            return out
+        elif isinstance(item, tuple):
+            if len(item) == 1:
+                return self[item[0]]
+            elif len(item) == 2 and np.isscalar(item[0]):
+                return self[item[0]][item[1]]
+            elif len(item) == 2:
+                return self[item[0]][:, item[1]]
+        elif isinstance(item, (int, np.integer)):
+            item = int(item)
+            if item < 0:
+                item += self.n_samples * (-(item // self.n_samples))
+                assert 0 <= item < self.n_samples
+            if not 0 <= item < self.n_samples:  # pragma: no cover
+                raise IndexError("index %d is out of bounds for axis 0 with size %d" % (item, self.n_samples))
+            return self[item:item + 1][0]
+        elif isinstance(item, (list, np.ndarray)):  # pragma: no cover
+            raise NotImplementedError("Indexing with multiple values is currently unsupported.")
+        return fallback  # pragma: no cover
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# high-level API (mtscomp.py:862-997)
+# ------------------------------------------------------------------------------------------------
+def check(data, out, outmeta, codec=None):
+    """Decompress everything and compare with `data` (mtscomp.py:866-888)."""
+    unc = decompress(out, outmeta, codec=codec)
+    try:
+        for first in range(0, unc.n_chunks, unc.batch_size):
+            ids = range(first, min(first + unc.batch_size, unc.n_chunks))
+            chunks = unc.decompress_chunks(ids)
+            for idx in ids:
+                chunk = chunks[idx]
+                expected = data[unc.chunk_bounds[idx]:unc.chunk_bounds[idx + 1]]
+                assert chunk.dtype == expected.dtype
+                assert chunk.shape == expected.shape
+                if np.issubdtype(chunk.dtype, np.integer):
+                    assert np.array_equal(chunk, expected)
+                else:
+                    assert np.allclose(chunk, expected, atol=CHECK_ATOL)
+    finally:
+        unc.close()
+
+
+def compress(path, out=None, outmeta=None, sample_rate=None, n_channels=None, dtype=None, codec=None, **kwargs):
+    """Compress a flat binary (or .npy) file into `out` (.cbin) + `outmeta` (.ch); returns the
+    compression ratio, as the reference does (mtscomp.py:891-958)."""
+    w = Writer(codec=codec, **kwargs)
+    w.open(path, sample_rate=sample_rate, n_channels=n_channels, dtype=dtype)
+    ratio = w.write(out, outmeta)
+    w.close()
+    return ratio
+
+
+def decompress(cdata, cmeta=None, out=None, write_output=False, overwrite=False, codec=None, **kwargs):
+    """Open a compressed dataset; optionally write it out decompressed (mtscomp.py:961-997)."""
+    if out:
+        write_output = True
+    r = Reader(codec=codec, **kwargs)
+    r.open(cdata, cmeta)
+    if write_output:
+        r.tofile(out, overwrite=overwrite)
+    return r

@@ -1,0 +1,723 @@
+// C ABI of libmtscomp_hip.so (include/mtscomp_hip.h): per-device engine, workspace management, the
+// stage pipelines and the host-buffer entry points.  No CPU fallback anywhere: without a gfx950 device
+// every compute entry point returns MTS_E_NODEV.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace mts {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+static const LevelCfg LEVELS[10] = {{0, 0, 0, 0},     {4, 4, 8, 4},       {4, 5, 16, 8},       {4, 6, 32, 32},
+                                    {4, 4, 16, 16},   {8, 16, 32, 32},    {8, 16, 128, 128},   {8, 32, 128, 256},
+                                    {32, 128, 258, 1024}, {32, 258, 258, 4096}};
+
+// grow-only device buffer
+struct DBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return MTS_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return MTS_E_NOMEM; }
+            cap = bytes;
+        } else cap = want;
+        return MTS_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() { return (T *)p; }
+};
+
+constexpr int MAX_STAGES = 24;
+
+struct Engine {
+    int dev = -1;
+    std::mutex mu;
+    hipStream_t own = nullptr;
+    // compress workspace
+    DBuf stream, sort_a, sort_b, tables, tokens, marks, segbuf, blk, blkcodes, blkhdr, desc, adler, misc;
+    // host-API staging
+    DBuf h_in, h_out;
+    // inflate workspace
+    DBuf inf_scratch, inf_desc, segsums;
+    // stage timing
+    hipEvent_t ev[MAX_STAGES + 1];
+    bool ev_ok = false;
+    const char *stage_name[MAX_STAGES];
+    int n_stage = 0;
+    float stage_ms[MAX_STAGES];
+    int n_stage_done = 0;
+    const char *done_name[MAX_STAGES];
+
+    int init_events()
+    {
+        if (ev_ok) return MTS_OK;
+        for (int i = 0; i <= MAX_STAGES; i++) MTS_HIP(hipEventCreate(&ev[i]));
+        ev_ok = true;
+        return MTS_OK;
+    }
+    void t_begin(hipStream_t st) { n_stage = 0; (void)hipEventRecord(ev[0], st); }
+    void t_mark(hipStream_t st, const char *name)
+    {
+        if (n_stage < MAX_STAGES) { stage_name[n_stage] = name; n_stage++; (void)hipEventRecord(ev[n_stage], st); }
+    }
+    void t_collect(bool accumulate)
+    {
+        if (!accumulate) { n_stage_done = 0; }
+        for (int i = 0; i < n_stage; i++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            int k = -1;
+            for (int j = 0; j < n_stage_done; j++) if (!strcmp(done_name[j], stage_name[i])) k = j;
+            if (k < 0 && n_stage_done < MAX_STAGES) { k = n_stage_done++; done_name[k] = stage_name[i]; stage_ms[k] = 0; }
+            if (k >= 0) stage_ms[k] += ms;
+        }
+    }
+    void release_all()
+    {
+        DBuf *all[] = {&stream, &sort_a, &sort_b, &tables, &tokens, &marks, &segbuf, &blk, &blkcodes, &blkhdr, &desc,
+                       &adler, &misc, &h_in, &h_out, &inf_scratch, &inf_desc, &segsums};
+        for (DBuf *b : all) b->release();
+    }
+};
+
+static std::mutex g_mu;
+static std::vector<Engine *> g_engines;
+static int g_ndev = -2;
+
+static int device_count()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ndev != -2) return g_ndev;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    int ok = 0;
+    for (int d = 0; d < n; d++) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) break;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) break;     // code objects are gfx950 only
+        ok++;
+    }
+    g_ndev = ok;
+    g_engines.assign(ok, nullptr);
+    return g_ndev;
+}
+
+static int get_engine(int device, Engine **out)
+{
+    const int n = device_count();
+    if (n <= 0) { set_error("no gfx950 device visible (libmtscomp_hip has no CPU path)"); return MTS_E_NODEV; }
+    if (device < 0 || device >= n) { set_error("device %d out of range (%d visible)", device, n); return MTS_E_ARG; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_engines[device]) { g_engines[device] = new Engine(); g_engines[device]->dev = device; }
+    *out = g_engines[device];
+    return MTS_OK;
+}
+
+static long compress_bound(long n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 13; }
+
+// ------------------------------------------------------------------------------------------------
+// compress pipeline over one sub-batch of chunks (device resident)
+// ------------------------------------------------------------------------------------------------
+struct DebugTap {              // optional host copies of intermediates (tests)
+    unsigned *t_full = nullptr, *t_quarter = nullptr;
+    unsigned short *tokens = nullptr;
+    long *n_tokens = nullptr;
+};
+
+static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_is_stream, int nc, int sz,
+                          const long *bounds, int n_chunks, int flags, int level, u8 *d_out, const long *slot_off,
+                          long *out_sizes, bool accumulate_times, DebugTap *tap)
+{
+    const LevelCfg cfg = LEVELS[level];
+    std::vector<ChunkDesc> cd(n_chunks);
+    std::vector<TileDesc> tiles;
+    u64 soff = 0, toff = 0, sorted_off = 0;
+    u32 nseg = 0, nblk = 0, max_rows = 0;
+    const u64 row_bytes = (u64)nc * sz;
+    for (int i = 0; i < n_chunks; i++) {
+        const u64 rows = (u64)(bounds[i + 1] - bounds[i]);
+        const u64 n = raw_is_stream ? rows : rows * row_bytes;
+        if (n >= (1ull << 31)) { set_error("chunk %d is %llu bytes; chunks must be < 2 GiB", i, (unsigned long long)n); return MTS_E_ARG; }
+        ChunkDesc &c = cd[i];
+        c.stream_off = soff; c.tok_off = toff; c.out_off = (u64)slot_off[i];
+        c.raw_off = (u64)(bounds[i] - bounds[0]) * (raw_is_stream ? 1 : row_bytes);
+        c.n = (u32)n; c.n_rows = (u32)rows;
+        c.seg0 = nseg; c.nseg = (u32)((n + SEG - 1) / SEG);
+        c.blk0 = nblk; c.blk_cap = (u32)(n / BLOCK_TOKENS + 2);
+        if (c.out_off & 15) { set_error("output slot %d is not 16-byte aligned", i); return MTS_E_ARG; }
+        nseg += c.nseg; nblk += c.blk_cap;
+        if (rows > max_rows) max_rows = (u32)rows;
+        for (u64 a = 0; a < n; a += TILE) {
+            TileDesc t;
+            t.stream_off = soff; t.sorted_off = sorted_off; t.n = (u32)n; t.a = (u32)a;
+            t.w = (u32)(a >= (u64)HALO ? a - HALO : 0);
+            t.own_end = (u32)(a + TILE < n ? a + TILE : n);
+            const u64 hashed_end = n >= 3 ? (t.own_end < n - 2 ? t.own_end : n - 2) : 0;
+            t.wlen = hashed_end > t.w ? (u32)(hashed_end - t.w) : 0;
+            t.chunk = (u32)i;
+            sorted_off += align_up(t.wlen, 64);
+            tiles.push_back(t);
+        }
+        soff += align_up(n + STREAM_PAD, STREAM_ALIGN);
+        toff += n + 1;
+    }
+    const u64 stream_bytes = soff + STREAM_PAD;
+    // ---- workspace ----
+    int rc;
+    if (!raw_is_stream) { if ((rc = E.stream.ensure(stream_bytes))) return rc; }
+    if ((rc = E.sort_a.ensure((sorted_off + 64) * 4))) return rc;
+    if ((rc = E.sort_b.ensure((sorted_off + 64) * 4))) return rc;
+    if ((rc = E.tables.ensure((stream_bytes + 64) * sizeof(uint2)))) return rc;
+    if ((rc = E.tokens.ensure((toff + 64) * 4))) return rc;
+    if ((rc = E.marks.ensure(stream_bytes / 8 + 256))) return rc;
+    if ((rc = E.segbuf.ensure((size_t)(nseg + 64) * 4 * 7 + 256))) return rc;
+    if ((rc = E.blk.ensure((size_t)(nblk + 1) * (sizeof(BlockRec) + 8) + 256))) return rc;
+    if ((rc = E.blkcodes.ensure((size_t)(nblk + 1) * BLK_CODE_WORDS * 4))) return rc;
+    if ((rc = E.blkhdr.ensure((size_t)(nblk + 1) * BLK_HDR_WORDS * 4))) return rc;
+    const size_t desc_bytes = align_up(sizeof(ChunkDesc) * n_chunks, 256) + align_up(sizeof(TileDesc) * (tiles.size() + 1), 256) +
+                              align_up(sizeof(ChunkOut) * n_chunks, 256);
+    if ((rc = E.desc.ensure(desc_bytes))) return rc;
+    if ((rc = E.adler.ensure(sizeof(u64) * 2 * n_chunks + 256))) return rc;
+    if ((rc = E.init_events())) return rc;
+
+    u8 *dp = E.desc.as<u8>();
+    ChunkDesc *d_chunks = (ChunkDesc *)dp; dp += align_up(sizeof(ChunkDesc) * n_chunks, 256);
+    TileDesc *d_tiles = (TileDesc *)dp; dp += align_up(sizeof(TileDesc) * (tiles.size() + 1), 256);
+    ChunkOut *d_cout = (ChunkOut *)dp;
+    // per-segment arrays
+    u32 *sg = E.segbuf.as<u32>();
+    ParseBufs pb;
+    const size_t SN = nseg + 64;
+    pb.entry = sg; pb.exit_a = sg + SN; pb.exit_b = sg + 2 * SN; pb.cnt = sg + 3 * SN; pb.tokbase = sg + 4 * SN;
+    pb.seg_chunk = sg + 5 * SN; pb.seg_start = sg + 6 * SN;
+    pb.marks = E.marks.as<u32>();
+    pb.changed = (int *)(E.adler.as<u8>() + sizeof(u64) * 2 * n_chunks);
+    // block arrays
+    BlockRec *d_blocks = E.blk.as<BlockRec>();
+    u32 *d_blk_chunk = (u32 *)(d_blocks + nblk + 1);
+    u32 *d_blk_in_start = d_blk_chunk + nblk + 1;
+
+    std::vector<u32> h_seg(2 * (size_t)nseg), h_blk_chunk(nblk + 1);
+    for (int i = 0; i < n_chunks; i++) {
+        for (u32 k = 0; k < cd[i].nseg; k++) { h_seg[cd[i].seg0 + k] = (u32)i; h_seg[nseg + cd[i].seg0 + k] = k * SEG; }
+        for (u32 k = 0; k < cd[i].blk_cap; k++) h_blk_chunk[cd[i].blk0 + k] = (u32)i;
+    }
+    MTS_HIP(hipMemcpyAsync(d_chunks, cd.data(), sizeof(ChunkDesc) * n_chunks, hipMemcpyHostToDevice, st));
+    if (!tiles.empty()) MTS_HIP(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice, st));
+    if (nseg) {
+        MTS_HIP(hipMemcpyAsync(pb.seg_chunk, h_seg.data(), 4 * (size_t)nseg, hipMemcpyHostToDevice, st));
+        MTS_HIP(hipMemcpyAsync(pb.seg_start, h_seg.data() + nseg, 4 * (size_t)nseg, hipMemcpyHostToDevice, st));
+    }
+    MTS_HIP(hipMemcpyAsync(d_blk_chunk, h_blk_chunk.data(), 4 * (size_t)nblk, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemsetAsync(d_cout, 0, sizeof(ChunkOut) * n_chunks, st));
+    MTS_HIP(hipMemsetAsync(pb.marks, 0, stream_bytes / 8 + 256, st));
+    MTS_HIP(hipMemsetAsync(pb.changed, 0, 4, st));
+    // zero the output slots (the packer ORs bits into them)
+    {
+        u64 lo = ~0ull, hi = 0;
+        for (int i = 0; i < n_chunks; i++) {
+            const u64 a = cd[i].out_off, b = a + align_up((u64)compress_bound(cd[i].n), 16);
+            if (a < lo) lo = a;
+            if (b > hi) hi = b;
+        }
+        if (n_chunks) MTS_HIP(hipMemsetAsync(d_out + lo, 0, hi - lo, st));
+    }
+    // the host copies above must be complete before the std::vectors go away; they are pageable
+    // copies, which hipMemcpyAsync finishes staging before returning.
+
+    E.t_begin(st);
+    const u8 *d_stream;
+    u64 *d_adler = E.adler.as<u64>();
+    std::vector<u64> so(n_chunks); std::vector<u32> nn(n_chunks);
+    if (raw_is_stream) {
+        // debug path: the caller's bytes already are the transformed stream (one chunk)
+        d_stream = d_raw;
+        for (int i = 0; i < n_chunks; i++) { so[i] = cd[i].stream_off; nn[i] = cd[i].n; }
+        if ((rc = E.misc.ensure(12 * (size_t)n_chunks + 64))) return rc;
+        u64 *d_so = E.misc.as<u64>(); u32 *d_nn = (u32 *)(d_so + n_chunks);
+        MTS_HIP(hipMemcpyAsync(d_so, so.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+        MTS_HIP(hipMemcpyAsync(d_nn, nn.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+        u32 max_n = 0; for (int i = 0; i < n_chunks; i++) if (cd[i].n > max_n) max_n = cd[i].n;
+        if ((rc = launch_adler_stream(st, d_stream, d_so, d_nn, n_chunks, max_n, d_adler))) return rc;
+    } else {
+        if ((rc = launch_delta_transpose(st, d_raw, E.stream.p, d_chunks, n_chunks, max_rows, nc, sz, flags, d_adler))) return rc;
+        d_stream = E.stream.as<u8>();
+    }
+    E.t_mark(st, "delta_transpose");
+    if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), E.sort_a.as<u32>(), E.sort_b.as<u32>()))) return rc;
+    E.t_mark(st, "hash_sort");
+    uint2 *d_tables = E.tables.as<uint2>();
+    if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), E.sort_b.as<u32>(), d_tables, cfg))) return rc;
+    E.t_mark(st, "match");
+    if ((rc = launch_parse_spec(st, d_tables, d_chunks, pb, (int)nseg, cfg))) return rc;
+    int round = 0;
+    for (;;) {
+        if ((rc = launch_parse_fix(st, d_tables, d_chunks, pb, (int)nseg, cfg, round))) return rc;
+        round++;
+        int changed = 0;
+        MTS_HIP(hipMemcpyAsync(&changed, pb.changed, 4, hipMemcpyDeviceToHost, st));
+        MTS_HIP(hipStreamSynchronize(st));
+        if (!changed) break;
+        MTS_HIP(hipMemsetAsync(pb.changed, 0, 4, st));
+        if (round > (int)nseg + 2) { set_error("parse fixed point did not converge"); return MTS_E_INTERNAL; }
+    }
+    // after an odd number of fix rounds the current exits live in exit_b; nothing downstream needs them
+    E.t_mark(st, "parse_fixpoint");
+    if ((rc = launch_parse_count(st, d_tables, d_chunks, pb, (int)nseg, n_chunks, cfg, d_cout))) return rc;
+    u32 *d_tokens = E.tokens.as<u32>();
+    if ((rc = launch_parse_emit(st, d_stream, d_tables, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start))) return rc;
+    E.t_mark(st, "parse_emit");
+    if ((rc = launch_block_trees(st, d_chunks, d_blk_chunk, (int)nblk, d_tokens, d_blk_in_start, d_cout, d_blocks,
+                                 E.blkcodes.as<u32>(), E.blkhdr.as<u32>()))) return rc;
+    if ((rc = launch_block_layout(st, d_chunks, n_chunks, d_blocks, d_cout, d_adler))) return rc;
+    E.t_mark(st, "block_trees");
+    if ((rc = launch_block_pack(st, d_stream, d_chunks, d_blk_chunk, (int)nblk, d_tokens, d_blocks, E.blkcodes.as<u32>(),
+                                E.blkhdr.as<u32>(), d_cout, d_out, level))) return rc;
+    E.t_mark(st, "block_pack");
+    std::vector<ChunkOut> h_cout(n_chunks);
+    MTS_HIP(hipMemcpyAsync(h_cout.data(), d_cout, sizeof(ChunkOut) * n_chunks, hipMemcpyDeviceToHost, st));
+    MTS_HIP(hipStreamSynchronize(st));
+    E.t_collect(accumulate_times);
+    for (int i = 0; i < n_chunks; i++) out_sizes[i] = (long)h_cout[i].nbytes;
+    if (tap) {
+        // single-chunk debug taps
+        const u32 n = cd[0].n;
+        if (tap->t_full && n) {
+            std::vector<uint2> h(n);
+            MTS_HIP(hipMemcpy(h.data(), d_tables + cd[0].stream_off, sizeof(uint2) * n, hipMemcpyDeviceToHost));
+            for (u32 i = 0; i < n; i++) { tap->t_full[i] = h[i].x; tap->t_quarter[i] = h[i].y; }
+        }
+        if (tap->tokens) {
+            const u32 nt = h_cout[0].ntok;
+            if (nt) MTS_HIP(hipMemcpy(tap->tokens, d_tokens + cd[0].tok_off, 4 * (size_t)nt, hipMemcpyDeviceToHost));
+            *tap->n_tokens = nt;
+        }
+    }
+    return MTS_OK;
+}
+
+// split a call into sub-batches that fit the workspace budget (stream bytes per sub-batch)
+static size_t batch_budget_bytes()
+{
+    static size_t v = 0;
+    if (!v) {
+        const char *e = getenv("MTS_BATCH_BYTES");
+        v = e ? (size_t)atoll(e) : ((size_t)3 << 30);      // 3 GiB of stream -> ~75 GiB of workspace
+        if (v < (1u << 20)) v = 1u << 20;
+    }
+    return v;
+}
+
+static int dev_compress(Engine &E, hipStream_t st, const void *d_raw, int nc, int sz, const long *bounds, int n_chunks,
+                        int flags, int level, u8 *d_out, const long *slot_off, long *out_sizes)
+{
+    if (level == -1) level = 6;
+    if (level < 1 || level > 9) { set_error("level %d out of range", level); return MTS_E_ARG; }
+    if (level < 4) { set_error("levels 1-3 (deflate_fast) are not implemented on device yet"); return MTS_E_UNSUPPORTED; }
+    if (sz != 1 && sz != 2 && sz != 4 && sz != 8) { set_error("itemsize %d unsupported", sz); return MTS_E_ARG; }
+    if (nc <= 0 || n_chunks < 0) return MTS_E_ARG;
+    MTS_HIP(hipSetDevice(E.dev));
+    const size_t budget = batch_budget_bytes();
+    const u64 row_bytes = (u64)nc * sz;
+    int i = 0;
+    bool first = true;
+    while (i < n_chunks) {
+        int j = i;
+        size_t acc = 0;
+        while (j < n_chunks) {
+            const size_t n = (size_t)(bounds[j + 1] - bounds[j]) * row_bytes;
+            if (j > i && acc + n > budget) break;
+            acc += n; j++;
+        }
+        const u8 *raw = (const u8 *)d_raw + (u64)(bounds[i] - bounds[0]) * row_bytes;
+        int rc = compress_batch(E, st, raw, false, nc, sz, bounds + i, j - i, flags, level, d_out, slot_off + i, out_sizes + i,
+                                !first, nullptr);
+        if (rc) return rc;
+        first = false;
+        i = j;
+    }
+    if (n_chunks == 0) E.n_stage_done = 0;
+    return MTS_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// decompress pipeline over one sub-batch (device resident)
+// ------------------------------------------------------------------------------------------------
+static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const long *c_off, const long *c_len,
+                            const long *n_rows, int n_chunks, int nc, int sz, int flags, u8 *d_out, const long *out_off,
+                            int *status, bool accumulate_times, u8 *stream_copy_host /* debug: first chunk's stream */)
+{
+    std::vector<InfChunk> ic(n_chunks);
+    std::vector<u64> so(n_chunks), oo(n_chunks);
+    std::vector<u32> nn(n_chunks), rows(n_chunks);
+    u64 soff = 0, toff = 0;
+    u32 max_n = 0, max_rows = 0;
+    const u64 row_bytes = (u64)nc * sz;
+    for (int i = 0; i < n_chunks; i++) {
+        const u64 n = (u64)n_rows[i] * row_bytes;
+        if (n >= (1ull << 31)) { set_error("chunk %d is %llu bytes; chunks must be < 2 GiB", i, (unsigned long long)n); return MTS_E_ARG; }
+        ic[i].c_off = (u64)c_off[i]; ic[i].c_len = (u64)c_len[i];
+        ic[i].stream_off = soff; ic[i].tok_off = toff; ic[i].n_expect = (u32)n; ic[i].pad = 0;
+        so[i] = soff; oo[i] = (u64)out_off[i]; nn[i] = (u32)n; rows[i] = (u32)n_rows[i];
+        if (n > max_n) max_n = (u32)n;
+        if (n_rows[i] > (long)max_rows) max_rows = (u32)n_rows[i];
+        soff += align_up(n + STREAM_PAD, STREAM_ALIGN);
+        toff += n + 2;
+    }
+    int rc;
+    if ((rc = E.stream.ensure(soff + STREAM_PAD))) return rc;
+    if ((rc = E.tokens.ensure((toff + 64) * 4))) return rc;
+    const size_t o_ic = 0, o_res = align_up(sizeof(InfChunk) * n_chunks, 256), o_so = o_res + align_up(sizeof(InfResult) * n_chunks, 256),
+                 o_nn = o_so + align_up(8 * (size_t)n_chunks, 256), o_oo = o_nn + align_up(4 * (size_t)n_chunks, 256),
+                 o_rows = o_oo + align_up(8 * (size_t)n_chunks, 256), o_status = o_rows + align_up(4 * (size_t)n_chunks, 256),
+                 o_end = o_status + align_up(4 * (size_t)n_chunks, 256);
+    if ((rc = E.inf_desc.ensure(o_end + 256))) return rc;
+    if ((rc = E.adler.ensure(sizeof(u64) * 2 * n_chunks + 256))) return rc;
+    if ((rc = E.segsums.ensure(cumsum_scratch_bytes(n_chunks, max_rows, nc)))) return rc;
+    if ((rc = E.init_events())) return rc;
+    u8 *dp = E.inf_desc.as<u8>();
+    InfChunk *d_ic = (InfChunk *)(dp + o_ic);
+    InfResult *d_res = (InfResult *)(dp + o_res);
+    u64 *d_so = (u64 *)(dp + o_so);
+    u32 *d_nn = (u32 *)(dp + o_nn);
+    u64 *d_oo = (u64 *)(dp + o_oo);
+    u32 *d_rows = (u32 *)(dp + o_rows);
+    int *d_status = (int *)(dp + o_status);
+    // launch_inflate expects [stream offsets (u64) | lengths (u32)] contiguous in its scratch
+    if ((rc = E.inf_scratch.ensure(12 * (size_t)n_chunks + 256))) return rc;
+    u64 *d_so2 = E.inf_scratch.as<u64>();
+    u32 *d_nn2 = (u32 *)(d_so2 + n_chunks);
+    MTS_HIP(hipMemcpyAsync(d_ic, ic.data(), sizeof(InfChunk) * n_chunks, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(d_so, so.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(d_nn, nn.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(d_so2, so.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(d_nn2, nn.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(d_oo, oo.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(d_rows, rows.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    E.t_begin(st);
+    if ((rc = launch_inflate(st, d_cdata, d_ic, n_chunks, E.stream.as<u8>(), E.tokens.as<u32>(), d_res, E.adler.as<u64>(), max_n,
+                             d_status, E.inf_scratch.p, E.inf_scratch.cap, &E))) return rc;
+    if (d_out) {
+        if ((rc = launch_cumsum_transpose(st, E.stream.p, d_out, d_so, d_oo, d_rows, d_status, n_chunks, max_rows, nc, sz, flags,
+                                          E.segsums.p))) return rc;
+        E.t_mark(st, "cumsum_transpose");
+    }
+    MTS_HIP(hipMemcpyAsync(status, d_status, 4 * (size_t)n_chunks, hipMemcpyDeviceToHost, st));
+    MTS_HIP(hipStreamSynchronize(st));
+    E.t_collect(accumulate_times);
+    if (stream_copy_host && nn[0]) MTS_HIP(hipMemcpy(stream_copy_host, E.stream.as<u8>() + so[0], nn[0], hipMemcpyDeviceToHost));
+    return MTS_OK;
+}
+
+void inflate_mark(void *engine, hipStream_t st, const char *name) { ((Engine *)engine)->t_mark(st, name); }
+
+static int dev_decompress(Engine &E, hipStream_t st, const u8 *d_cdata, const long *c_off, const long *c_len, const long *n_rows,
+                          int n_chunks, int nc, int sz, int flags, u8 *d_out, const long *out_off, int *status)
+{
+    if (sz != 1 && sz != 2 && sz != 4 && sz != 8) { set_error("itemsize %d unsupported", sz); return MTS_E_ARG; }
+    if (nc <= 0 || n_chunks < 0) return MTS_E_ARG;
+    MTS_HIP(hipSetDevice(E.dev));
+    const size_t budget = batch_budget_bytes() * 4;          // inflate needs ~5 bytes of workspace per byte
+    const u64 row_bytes = (u64)nc * sz;
+    int i = 0;
+    bool first = true;
+    while (i < n_chunks) {
+        int j = i;
+        size_t acc = 0;
+        while (j < n_chunks) {
+            const size_t n = (size_t)n_rows[j] * row_bytes;
+            if (j > i && acc + n > budget) break;
+            acc += n; j++;
+        }
+        int rc = decompress_batch(E, st, d_cdata, c_off + i, c_len + i, n_rows + i, j - i, nc, sz, flags, d_out, out_off + i,
+                                  status + i, !first, nullptr);
+        if (rc) return rc;
+        first = false;
+        i = j;
+    }
+    if (n_chunks == 0) E.n_stage_done = 0;
+    return MTS_OK;
+}
+
+}  // namespace mts
+
+using namespace mts;
+
+// ================================================================================================
+// extern "C"
+// ================================================================================================
+extern "C" {
+
+int mts_version(void) { return 100; }
+
+int mts_device_count(void) { return device_count() > 0 ? device_count() : 0; }
+
+const char *mts_strerror(int code)
+{
+    switch (code) {
+    case MTS_OK: return "ok";
+    case MTS_E_ARG: return "bad argument";
+    case MTS_E_NODEV: return "no usable gfx950 device";
+    case MTS_E_HIP: return "HIP runtime error";
+    case MTS_E_NOMEM: return "out of memory";
+    case MTS_E_UNSUPPORTED: return "not implemented";
+    case MTS_E_INTERNAL: return "internal error";
+    default: return "unknown error";
+    }
+}
+
+const char *mts_last_error(void) { return g_err; }
+
+long mts_compress_bound(long raw_len) { return compress_bound(raw_len); }
+
+void mts_release(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (Engine *e : g_engines)
+        if (e) { std::lock_guard<std::mutex> l2(e->mu); (void)hipSetDevice(e->dev); e->release_all(); }
+}
+
+int mts_dev_compress_chunks(int device, void *stream, const void *d_raw, int n_channels, int itemsize,
+                            const long *chunk_bounds, int n_chunks, int flags, int level, unsigned char *d_out,
+                            const long *out_slot_offsets, long *out_sizes)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(E->mu);
+    return dev_compress(*E, (hipStream_t)stream, d_raw, n_channels, itemsize, chunk_bounds, n_chunks, flags, level, d_out,
+                        out_slot_offsets, out_sizes);
+}
+
+int mts_compress_chunks(int device, const void *raw, int n_channels, int itemsize, const long *chunk_bounds, int n_chunks,
+                        int flags, int level, unsigned char *out, const long *out_slot_offsets, long *out_sizes)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    if (n_chunks <= 0) return n_chunks == 0 ? MTS_OK : MTS_E_ARG;
+    std::lock_guard<std::mutex> lk(E->mu);
+    MTS_HIP(hipSetDevice(E->dev));
+    const u64 row_bytes = (u64)n_channels * itemsize;
+    const u64 raw_bytes = (u64)(chunk_bounds[n_chunks] - chunk_bounds[0]) * row_bytes;
+    std::vector<long> slots(n_chunks);
+    u64 total = 0;
+    for (int i = 0; i < n_chunks; i++) {
+        slots[i] = (long)total;
+        total += align_up((u64)compress_bound((long)((u64)(chunk_bounds[i + 1] - chunk_bounds[i]) * row_bytes)), 256);
+    }
+    if ((rc = E->h_in.ensure(raw_bytes + 256))) return rc;
+    if ((rc = E->h_out.ensure(total + 256))) return rc;
+    MTS_HIP(hipMemcpy(E->h_in.p, raw, raw_bytes, hipMemcpyHostToDevice));
+    rc = dev_compress(*E, nullptr, E->h_in.p, n_channels, itemsize, chunk_bounds, n_chunks, flags, level, E->h_out.as<u8>(),
+                      slots.data(), out_sizes);
+    if (rc) return rc;
+    for (int i = 0; i < n_chunks; i++)
+        MTS_HIP(hipMemcpy(out + out_slot_offsets[i], E->h_out.as<u8>() + slots[i], (size_t)out_sizes[i], hipMemcpyDeviceToHost));
+    return MTS_OK;
+}
+
+int mts_delta_transpose(int device, const void *raw, long n_samples, int n_channels, int itemsize, int flags,
+                        void *stream_out)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    if (itemsize != 1 && itemsize != 2 && itemsize != 4 && itemsize != 8) return MTS_E_ARG;
+    if (n_samples < 0 || n_channels <= 0) return MTS_E_ARG;
+    std::lock_guard<std::mutex> lk(E->mu);
+    MTS_HIP(hipSetDevice(E->dev));
+    const u64 n = (u64)n_samples * n_channels * itemsize;
+    if (n == 0) return MTS_OK;
+    if (n >= (1ull << 31)) return MTS_E_ARG;
+    if ((rc = E->h_in.ensure(n + 256))) return rc;
+    if ((rc = E->stream.ensure(n + 2 * STREAM_PAD))) return rc;
+    if ((rc = E->desc.ensure(4096))) return rc;
+    if ((rc = E->adler.ensure(4096))) return rc;
+    ChunkDesc c; memset(&c, 0, sizeof c);
+    c.n = (u32)n; c.n_rows = (u32)n_samples;
+    MTS_HIP(hipMemcpy(E->h_in.p, raw, n, hipMemcpyHostToDevice));
+    MTS_HIP(hipMemcpy(E->desc.p, &c, sizeof c, hipMemcpyHostToDevice));
+    if ((rc = launch_delta_transpose(nullptr, E->h_in.p, E->stream.p, E->desc.as<ChunkDesc>(), 1, (u32)n_samples, n_channels,
+                                     itemsize, flags, E->adler.as<u64>()))) return rc;
+    MTS_HIP(hipMemcpy(stream_out, E->stream.p, n, hipMemcpyDeviceToHost));
+    return MTS_OK;
+}
+
+int mts_cumsum_transpose(int device, const void *stream, long n_samples, int n_channels, int itemsize, int flags, void *out)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    if (itemsize != 1 && itemsize != 2 && itemsize != 4 && itemsize != 8) return MTS_E_ARG;
+    if (n_samples < 0 || n_channels <= 0) return MTS_E_ARG;
+    std::lock_guard<std::mutex> lk(E->mu);
+    MTS_HIP(hipSetDevice(E->dev));
+    const u64 n = (u64)n_samples * n_channels * itemsize;
+    if (n == 0) return MTS_OK;
+    if (n >= (1ull << 31)) return MTS_E_ARG;
+    if ((rc = E->stream.ensure(n + 2 * STREAM_PAD))) return rc;
+    if ((rc = E->h_out.ensure(n + 256))) return rc;
+    if ((rc = E->desc.ensure(4096))) return rc;
+    if ((rc = E->segsums.ensure(cumsum_scratch_bytes(1, (u32)n_samples, n_channels)))) return rc;
+    struct { u64 so, oo; u32 rows; } h = {0, 0, (u32)n_samples};
+    u8 *dp = E->desc.as<u8>();
+    MTS_HIP(hipMemcpy(E->stream.p, stream, n, hipMemcpyHostToDevice));
+    MTS_HIP(hipMemcpy(dp, &h.so, 8, hipMemcpyHostToDevice));
+    MTS_HIP(hipMemcpy(dp + 8, &h.oo, 8, hipMemcpyHostToDevice));
+    MTS_HIP(hipMemcpy(dp + 16, &h.rows, 4, hipMemcpyHostToDevice));
+    if ((rc = launch_cumsum_transpose(nullptr, E->stream.p, E->h_out.p, (u64 *)dp, (u64 *)(dp + 8), (u32 *)(dp + 16), nullptr, 1,
+                                      (u32)n_samples, n_channels, itemsize, flags, E->segsums.p))) return rc;
+    MTS_HIP(hipMemcpy(out, E->h_out.p, n, hipMemcpyDeviceToHost));
+    return MTS_OK;
+}
+
+int mts_dev_synth_int16(int device, void *stream, void *d_out, long t0, long t1, int n_channels, long seed)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(E->mu);
+    MTS_HIP(hipSetDevice(E->dev));
+    return launch_synth_int16((hipStream_t)stream, (int16_t *)d_out, t0, t1, n_channels, seed);
+}
+
+int mts_last_stage_times(int device, const char **names, float *ms, int cap)
+{
+    Engine *E;
+    if (get_engine(device, &E)) return 0;
+    std::lock_guard<std::mutex> lk(E->mu);
+    int n = E->n_stage_done < cap ? E->n_stage_done : cap;
+    for (int i = 0; i < n; i++) { names[i] = E->done_name[i]; ms[i] = E->stage_ms[i]; }
+    return n;
+}
+
+
+int mts_dev_decompress_chunks(int device, void *stream, const unsigned char *d_cdata, const long *c_offsets,
+                              const long *c_lengths, const long *n_rows, int n_chunks, int n_channels, int itemsize, int flags,
+                              void *d_out, const long *out_offsets, int *chunk_status)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(E->mu);
+    return dev_decompress(*E, (hipStream_t)stream, d_cdata, c_offsets, c_lengths, n_rows, n_chunks, n_channels, itemsize, flags,
+                          (u8 *)d_out, out_offsets, chunk_status);
+}
+
+int mts_decompress_chunks(int device, const unsigned char *cdata, const long *c_offsets, const long *c_lengths,
+                          const long *n_rows, int n_chunks, int n_channels, int itemsize, int flags, void *out,
+                          const long *out_offsets, int *chunk_status)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    if (n_chunks <= 0) return n_chunks == 0 ? MTS_OK : MTS_E_ARG;
+    std::lock_guard<std::mutex> lk(E->mu);
+    MTS_HIP(hipSetDevice(E->dev));
+    const u64 row_bytes = (u64)n_channels * itemsize;
+    std::vector<long> coff(n_chunks), ooff(n_chunks);
+    u64 ctot = 0, otot = 0;
+    for (int i = 0; i < n_chunks; i++) {
+        if (c_lengths[i] < 0 || n_rows[i] < 0) return MTS_E_ARG;
+        coff[i] = (long)ctot; ctot += align_up((u64)c_lengths[i] + 8, 16);
+        ooff[i] = (long)otot; otot += align_up((u64)n_rows[i] * row_bytes, 256);
+    }
+    if ((rc = E->h_in.ensure(ctot + 256))) return rc;
+    if ((rc = E->h_out.ensure(otot + 256))) return rc;
+    for (int i = 0; i < n_chunks; i++)
+        if (c_lengths[i]) MTS_HIP(hipMemcpyAsync(E->h_in.as<u8>() + coff[i], cdata + c_offsets[i], (size_t)c_lengths[i], hipMemcpyHostToDevice, nullptr));
+    rc = dev_decompress(*E, nullptr, E->h_in.as<u8>(), coff.data(), c_lengths, n_rows, n_chunks, n_channels, itemsize, flags,
+                        E->h_out.as<u8>(), ooff.data(), chunk_status);
+    if (rc) return rc;
+    for (int i = 0; i < n_chunks; i++)
+        if (chunk_status[i] == MTS_CHUNK_OK && n_rows[i])
+            MTS_HIP(hipMemcpy((u8 *)out + out_offsets[i], E->h_out.as<u8>() + ooff[i], (size_t)((u64)n_rows[i] * row_bytes), hipMemcpyDeviceToHost));
+    return MTS_OK;
+}
+
+int mts_debug_inflate(int device, const unsigned char *zbytes, long zlen, unsigned char *out, long out_cap, long *out_len, int *status)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    if (zlen < 0 || out_cap < 0) return MTS_E_ARG;
+    std::lock_guard<std::mutex> lk(E->mu);
+    MTS_HIP(hipSetDevice(E->dev));
+    if ((rc = E->h_in.ensure((u64)zlen + 256))) return rc;
+    if (zlen) MTS_HIP(hipMemcpy(E->h_in.p, zbytes, (size_t)zlen, hipMemcpyHostToDevice));
+    // the expected size is the caller's out_cap: status BADSIZE when the stream inflates to anything else
+    const long coff = 0, clen = zlen, rows = out_cap, ooff = 0;
+    rc = decompress_batch(*E, nullptr, E->h_in.as<u8>(), &coff, &clen, &rows, 1, 1, 1, 0, nullptr, &ooff, status, false, out);
+    if (rc) return rc;
+    if (out_len) *out_len = *status == MTS_CHUNK_OK ? out_cap : 0;
+    return MTS_OK;
+}
+
+// ---- debug taps ---------------------------------------------------------------------------------
+static int debug_compress_stream(int device, const void *stream_bytes, long n, int level, unsigned char *out, long out_cap,
+                                 long *out_len, DebugTap *tap)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    if (level == -1) level = 6;
+    if (level < 4 || level > 9) return MTS_E_UNSUPPORTED;
+    if (n < 0 || n >= (1l << 31)) return MTS_E_ARG;
+    std::lock_guard<std::mutex> lk(E->mu);
+    MTS_HIP(hipSetDevice(E->dev));
+    const u64 bound = align_up((u64)compress_bound(n), 256);
+    if ((rc = E->h_in.ensure((u64)n + 2 * STREAM_PAD))) return rc;
+    if ((rc = E->h_out.ensure(bound + 256))) return rc;
+    MTS_HIP(hipMemset(E->h_in.p, 0, (u64)n + 2 * STREAM_PAD));
+    if (n) MTS_HIP(hipMemcpy(E->h_in.p, stream_bytes, (size_t)n, hipMemcpyHostToDevice));
+    const long bounds[2] = {0, n};
+    const long slot = 0;
+    long size = 0;
+    rc = compress_batch(*E, nullptr, E->h_in.as<u8>(), true, 1, 1, bounds, 1, 0, level, E->h_out.as<u8>(), &slot, &size, false, tap);
+    if (rc) return rc;
+    if (out_len) *out_len = size;
+    if (out) {
+        if (size > out_cap) return MTS_E_ARG;
+        MTS_HIP(hipMemcpy(out, E->h_out.p, (size_t)size, hipMemcpyDeviceToHost));
+    }
+    return MTS_OK;
+}
+
+int mts_debug_match_tables(int device, const void *stream_bytes, long n, int level, unsigned *t_full, unsigned *t_quarter)
+{
+    DebugTap tap; tap.t_full = t_full; tap.t_quarter = t_quarter;
+    return debug_compress_stream(device, stream_bytes, n, level, nullptr, 0, nullptr, &tap);
+}
+int mts_debug_tokens(int device, const void *stream_bytes, long n, int level, unsigned short *tokens, long *n_tokens)
+{
+    DebugTap tap; tap.tokens = tokens; tap.n_tokens = n_tokens;
+    return debug_compress_stream(device, stream_bytes, n, level, nullptr, 0, nullptr, &tap);
+}
+int mts_debug_deflate(int device, const void *stream_bytes, long n, int level, unsigned char *out, long out_cap, long *out_len)
+{
+    return debug_compress_stream(device, stream_bytes, n, level, out, out_cap, out_len, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+// Internal declarations shared by the HIP translation units of libmtscomp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/mtscomp_hip.h"
+
+namespace mts {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---- DEFLATE constants (zlib 1.2.11, windowBits 15, memLevel 8) --------------------------------
+constexpr int MIN_MATCH = 3;
+constexpr int MAX_MATCH = 258;
+constexpr int WSIZE = 32768;
+constexpr int MAX_DIST = WSIZE - 262;      // 32506
+constexpr int TOO_FAR = 4096;
+constexpr int BLOCK_TOKENS = 16383;        // lit_bufsize - 1
+constexpr int L_CODES = 286;
+constexpr int D_CODES = 30;
+constexpr int BL_CODES = 19;
+
+// ---- stream layout ------------------------------------------------------------------------------
+// Every chunk's transformed byte stream lives in one device buffer at a 256-B aligned offset and is
+// followed by >= STREAM_PAD zero bytes, so kernels may over-read past a stream's end.
+constexpr int STREAM_PAD = 512;
+constexpr int STREAM_ALIGN = 256;
+
+// ---- match stage tiling ---------------------------------------------------------------------------
+constexpr int TILE = 98304;                // positions a match-stage workgroup owns
+constexpr int HALO = 32768;                // history it additionally needs (>= MAX_DIST)
+constexpr int WIN = TILE + HALO;           // 131072 = 2^17: window-relative positions fit 17 bits
+constexpr int REL_BITS = 17;
+constexpr u32 REL_MASK = (1u << REL_BITS) - 1;
+
+constexpr int SEG = 4096;                  // parse segment (positions per speculative walker)
+
+struct LevelCfg { int good, lazy, nice, chain; };
+
+// one match-stage tile
+struct TileDesc {
+    u64 stream_off;      // byte offset of the chunk's stream in the stream buffer
+    u64 sorted_off;      // entry offset of this tile's sorted window in the sort buffers
+    u32 n;               // stream length (bytes) of the chunk
+    u32 a;               // first owned position
+    u32 w;               // window start (= max(0, a - HALO))
+    u32 wlen;            // hashed positions in the window: positions [w, w + wlen), all <= n - 3
+    u32 own_end;         // owned positions are [a, own_end)
+    u32 chunk;
+};
+
+// per-chunk descriptor of a compress batch
+struct ChunkDesc {
+    u64 stream_off;      // into the stream buffer
+    u64 tok_off;         // into the token buffer (capacity n + 1 tokens)
+    u64 out_off;         // byte offset of the chunk's slot in the output buffer (16-B aligned)
+    u64 raw_off;         // byte offset of the chunk's first row in the raw input
+    u32 n;               // stream bytes
+    u32 n_rows;
+    u32 seg0;            // first parse segment (global index)
+    u32 nseg;
+    u32 blk0;            // first block slot (global index); capacity n / 16383 + 2
+    u32 blk_cap;
+};
+
+// per-block record produced by the tree stage
+struct BlockRec {
+    u32 tok0, ntok;          // token range (chunk-relative)
+    u32 in_start, in_len;    // input byte range
+    u32 nbits;               // bits of the block incl. the 3 header bits (stored: payload handled apart)
+    u32 btype;               // 0 stored 1 fixed 2 dynamic
+    u32 hdr_bits;            // dynamic: bits of the tree header (after the 3-bit block header)
+    u32 last;
+    u64 bit_start;           // bit offset in the chunk's zlib stream
+};
+
+struct ChunkOut {
+    u64 nbytes;              // compressed size
+    u32 ntok, nblk;
+    u32 adler;
+    u32 trailing;            // last token is the post-loop literal
+};
+
+inline __host__ __device__ u64 align_up(u64 x, u64 a) { return (x + a - 1) / a * a; }
+
+// ---- error plumbing -------------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+#define MTS_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            mts::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                           __LINE__);                                                       \
+            return MTS_E_HIP;                                                               \
+        }                                                                                   \
+    } while (0)
+
+// ---- kernel launchers (one per stage; all asynchronous on `st`) -----------------------------------
+// transform.hip
+int launch_delta_transpose(hipStream_t st, const void *d_raw, void *d_stream, const ChunkDesc *d_chunks,
+                           int n_chunks, u32 max_rows, int n_channels, int itemsize, int flags,
+                           u64 *d_adler_acc /* 2 per chunk, zeroed by the launcher */);
+int launch_cumsum_transpose(hipStream_t st, const void *d_stream, void *d_out, const u64 *d_stream_off,
+                            const u64 *d_out_off, const u32 *d_rows, const int *d_status, int n_chunks,
+                            u32 max_rows, int n_channels, int itemsize, int flags, void *d_segsums);
+size_t cumsum_scratch_bytes(int n_chunks, u32 max_rows, int n_channels);
+int launch_synth_int16(hipStream_t st, int16_t *d_out, long t0, long t1, int n_channels, long seed);
+int launch_adler_stream(hipStream_t st, const u8 *d_stream, const u64 *d_stream_off, const u32 *d_n,
+                        int n_chunks, u32 max_n, u64 *d_adler_acc);
+
+// deflate.hip
+int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles,
+                     u32 *d_tmp, u32 *d_sorted);
+int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles,
+                 const u32 *d_sorted, uint2 *d_tables, LevelCfg cfg);
+struct ParseBufs {
+    u32 *entry, *exit_a, *exit_b, *cnt, *tokbase;   // per segment
+    u32 *marks;                                     // 1 bit per stream byte (global stream offsets)
+    u32 *seg_chunk, *seg_start;                     // per segment: owning chunk / start position
+    int *changed;                                   // device flag
+};
+int launch_parse_spec(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb,
+                      int n_segs, LevelCfg cfg);
+int launch_parse_fix(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb,
+                     int n_segs, LevelCfg cfg, int round);
+int launch_parse_count(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb,
+                       int n_segs, int n_chunks, LevelCfg cfg, ChunkOut *d_cout);
+int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables,
+                      const ChunkDesc *d_chunks, ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens,
+                      u32 *d_blk_in_start);
+int launch_block_trees(hipStream_t st, const ChunkDesc *d_chunks, const u32 *d_blk_chunk, int total_blk_cap,
+                       const u32 *d_tokens, const u32 *d_blk_in_start, const ChunkOut *d_cout,
+                       BlockRec *d_blocks, u32 *d_blk_codes, u32 *d_blk_hdr);
+int launch_block_layout(hipStream_t st, const ChunkDesc *d_chunks, int n_chunks, BlockRec *d_blocks,
+                        ChunkOut *d_cout, const u64 *d_adler_acc);
+int launch_block_pack(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const u32 *d_blk_chunk,
+                      int total_blk_cap, const u32 *d_tokens, const BlockRec *d_blocks,
+                      const u32 *d_blk_codes, const u32 *d_blk_hdr, const ChunkOut *d_cout, u8 *d_out,
+                      int level);
+constexpr int BLK_CODE_WORDS = 320;     // per block: 286 lit/len + 30 dist (code | len << 16), padded
+constexpr int BLK_HDR_WORDS = 96;       // per block: packed dynamic-tree header bits (<= 3072 bits)
+
+// inflate.hip
+struct InfChunk {
+    u64 c_off;           // compressed bytes offset in d_cdata
+    u64 c_len;
+    u64 stream_off;      // where the inflated stream goes (stream buffer)
+    u64 tok_off;         // token buffer offset (capacity n + 2)
+    u32 n_expect;        // expected inflated size
+    u32 pad;
+};
+struct InfResult {
+    int status;          // MTS_CHUNK_*
+    u32 n_out;
+    u32 ntok;
+    u32 adler_stored;
+    u64 end_bit;
+};
+int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, int n_chunks,
+                   u8 *d_stream, u32 *d_tokens, InfResult *d_res, u64 *d_adler_acc, u32 max_n,
+                   int *d_status_out, void *d_scratch, size_t scratch_bytes, void *engine);
+void inflate_mark(void *engine, hipStream_t st, const char *name);   // stage timing hook (api.hip)
+size_t inflate_scratch_bytes(int n_chunks, u64 total_cbytes);
+
+}  // namespace mts

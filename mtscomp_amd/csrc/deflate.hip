@@ -1,0 +1,978 @@
+// Bit-exact zlib-1.2.11 DEFLATE (levels 4..9, i.e. deflate_slow) on gfx950.
+//
+// Replaces `zlib.compress(chunkd.tobytes(order))` (/root/reference/mtscomp.py:394).  The algorithm is
+// the parallel formulation of SURVEY.md Appendix A.3, checked stage by stage against
+// oracle/mtsc_oracle.c (orc_match_tables / orc_parse_tables / orc_deflate):
+//
+//   S  k_hash_sort     per tile (TILE owned positions + HALO history): stable 2-pass radix sort of the
+//                      positions by their 15-bit zlib hash -> every hash chain becomes a contiguous,
+//                      position-ordered run (parse independent because deflate_slow inserts every
+//                      position).
+//   M  k_match         per tile: window bytes in LDS; one lane per position walks its run newest first
+//                      (<= chain candidates, stop at nice / MAX_DIST) and records the best match within
+//                      the full budget and within budget>>2 (the prev_length >= good_match case).
+//   P  k_parse_*       lazy-evaluation state machine over the tables; one lane per SEG positions,
+//                      speculative entry, iterated to a fixed point (walks re-converge after a few
+//                      tokens); then count + emit tokens.
+//   T  k_block_trees   per 16383-token block: symbol histogram (LDS atomics) and zlib's exact
+//                      build_tree / gen_bitlen / scan_tree by one lane; stored/fixed/dynamic choice.
+//   L  k_block_layout  per chunk: bit offsets of the blocks, stream size, adler32.
+//   B  k_block_pack    per block: canonical codes -> bitstream (each lane packs a run of tokens).
+#include "common.h"
+
+namespace mts {
+
+// ================================================================================================
+// small device helpers
+// ================================================================================================
+__device__ __forceinline__ u32 alignbyte(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+
+__device__ __forceinline__ u32 gld_u32_unaligned(const u8 *s, u64 p)
+{
+    const u32 *q = (const u32 *)(s + (p & ~(u64)3));
+    return alignbyte(q[1], q[0], (u32)p & 3);
+}
+__device__ __forceinline__ u32 hash_of(u32 b012) { return (((b012 & 0xff) << 10) ^ (((b012 >> 8) & 0xff) << 5) ^ ((b012 >> 16) & 0xff)) & 0x7fff; }
+
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1; }
+
+// lanes (among `active`) holding the same NB-bit digit as this lane
+template <int NB>
+__device__ __forceinline__ u64 match_digit(u32 d, u64 active)
+{
+    u64 m = active;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const bool bit = (d >> b) & 1;
+        const u64 bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+
+__device__ __forceinline__ u32 wave_excl_scan_u32(u32 v, u32 &total)
+{
+    const int lane = threadIdx.x & 63;
+    u32 x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+// ================================================================================================
+// S: hash sort
+// ================================================================================================
+template <int NB, bool FIRST>
+__device__ __forceinline__ void radix_pass(const u8 *__restrict__ s, const u32 *__restrict__ src, u32 *__restrict__ dst,
+                                           u32 wlen, u32 (*cnt)[256], u32 *tot)
+{
+    constexpr int NBIN = 1 << NB;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 per = (((wlen + 15) / 16) + 63) & ~63u;
+    const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
+    for (int i = threadIdx.x; i < 16 * 256; i += 1024) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    for (u32 i = beg + lane; i < end; i += 64) {
+        u32 d;
+        if (FIRST) d = hash_of(gld_u32_unaligned(s, i)) & 255; else d = src[i] >> 25;
+        atomicAdd(&cnt[wave][d], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < NBIN) {
+        u32 run = 0;
+        for (int w = 0; w < 16; w++) { const u32 c = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += c; }
+        tot[threadIdx.x] = run;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        u32 v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = (lane * 4 + k < NBIN) ? tot[lane * 4 + k] : 0; sum += v[k]; }
+        u32 total;
+        u32 ex = wave_excl_scan_u32(sum, total);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (lane * 4 + k < NBIN) tot[lane * 4 + k] = ex; ex += v[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < NBIN) {
+        const u32 base = tot[threadIdx.x];
+        for (int w = 0; w < 16; w++) cnt[w][threadIdx.x] += base;
+    }
+    __syncthreads();
+    for (u32 base = beg; base < end; base += 64) {
+        const u32 i = base + lane;
+        const bool act = i < end;
+        u32 key = 0, d = 0;
+        if (act) {
+            if (FIRST) { const u32 h = hash_of(gld_u32_unaligned(s, i)); key = (h << REL_BITS) | i; d = h & 255; }
+            else { key = src[i]; d = key >> 25; }
+        }
+        const u64 actm = __ballot(act);
+        const u64 m = match_digit<NB>(d, actm);
+        const u32 rank = __popcll(m & lanemask_lt()), count = __popcll(m);
+        u32 off = 0;
+        if (act) off = cnt[wave][d];
+        __builtin_amdgcn_wave_barrier();
+        if (act) {
+            dst[off + rank] = key;
+            if (rank == count - 1) cnt[wave][d] = off + count;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
+                                                    u32 *__restrict__ tmp, u32 *__restrict__ sorted)
+{
+    const TileDesc td = tiles[blockIdx.x];
+    __shared__ u32 cnt[16][256];
+    __shared__ u32 tot[256];
+    if (td.wlen == 0) return;
+    const u8 *s = stream + td.stream_off + td.w;
+    u32 *t1 = tmp + td.sorted_off, *t2 = sorted + td.sorted_off;
+    radix_pass<8, true>(s, nullptr, t1, td.wlen, cnt, tot);      // low 8 bits of the hash
+    radix_pass<7, false>(s, t1, t2, td.wlen, cnt, tot);          // high 7 bits
+}
+
+int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp,
+                     u32 *d_sorted)
+{
+    if (n_tiles == 0) return MTS_OK;
+    hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(1024), 0, st, d_stream, d_tiles, d_tmp, d_sorted);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
+// ================================================================================================
+// M: per-position best matches (t_full, t_quarter) -- orc_match_tables() is the oracle
+// ================================================================================================
+constexpr int WINB = WIN + 320;                   // window bytes kept in LDS (+ MAX_MATCH over-read)
+constexpr int STAGE_WORDS = 128;                  // per wave: sorted entries being walked
+constexpr int MATCH_LDS = WINB + 16 * STAGE_WORDS * 4;
+
+__device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
+{
+    const u32 a = addr >> 2;
+    return alignbyte(win[a + 1], win[a], addr & 3);
+}
+
+__global__ __launch_bounds__(1024) void k_match(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
+                                                const u32 *__restrict__ sorted, uint2 *__restrict__ tables, LevelCfg cfg)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const TileDesc td = tiles[blockIdx.x];
+    u32 *win = (u32 *)smem;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32 *stage = (u32 *)(smem + WINB) + wave * STAGE_WORDS;
+    uint2 *T = tables + td.stream_off;
+    // positions past the last hashed one have no candidates
+    if (threadIdx.x < 2) {
+        const u32 hashed_end = td.w + td.wlen;                 // first owned position without a hash
+        const u32 p = hashed_end + threadIdx.x;
+        if (p >= td.a && p < td.own_end) T[p] = make_uint2(0, 0);
+    }
+    if (td.wlen == 0) return;
+    // window bytes -> LDS
+    {
+        const u32 nbytes = (td.own_end - td.w) + 288;
+        const uint4 *src = (const uint4 *)(stream + td.stream_off + td.w);
+        uint4 *dst = (uint4 *)win;
+        const u32 nvec = (nbytes + 15) / 16;
+        for (u32 i = threadIdx.x; i < nvec; i += 1024) dst[i] = src[i];
+    }
+    __syncthreads();
+    const u32 *srt = sorted + td.sorted_off;
+    const u32 wlen = td.wlen, n = td.n;
+    const u32 ngroups = (wlen + 63) / 64;
+    const u32 halo = td.a - td.w;
+    const int chain = cfg.chain, qchain = cfg.chain >> 2;
+    for (u32 g = wave; g < ngroups; g += 16) {
+        const u32 i0 = g * 64, i = i0 + lane;
+        const u32 e = i < wlen ? srt[i] : 0xffffffffu;
+        const u32 rel_p = e & REL_MASK;
+        const bool own = i < wlen && rel_p >= halo;
+        if (!__any(own)) continue;
+        const u32 p_abs = td.w + rel_p;
+        const u32 look = n - p_abs;
+        const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
+        const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
+        const u32 hp = e >> REL_BITS;
+        const u32 limit = p_abs > (u32)MAX_DIST ? p_abs - (u32)MAX_DIST : 0;
+        u32 pw0 = 0, pw1 = 0;
+        if (own) { pw0 = lds_u32(win, rel_p); pw1 = lds_u32(win, rel_p + 4); }
+        u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
+        bool done = !own;
+        for (int jb = 0; jb < chain && __any(!done); jb += 64) {
+            // entries i0 - jb - 64 + k, k in [0, 128)
+            const int s0 = (int)i0 - jb - 64 + lane;
+            __builtin_amdgcn_wave_barrier();
+            stage[lane] = s0 >= 0 ? srt[s0] : 0xffffffffu;
+            stage[lane + 64] = (s0 + 64 >= 0 && (u32)(s0 + 64) < wlen) ? srt[s0 + 64] : 0xffffffffu;
+            __builtin_amdgcn_wave_barrier();
+            for (int jj = 1; jj <= 64; jj++) {
+                const int j = jb + jj;
+                if (j > chain) break;
+                if (!done) {
+                    const u32 c = stage[lane + 64 - jj];
+                    const u32 rel_c = c & REL_MASK;
+                    const u32 abs_c = td.w + rel_c;
+                    const u32 dist = rel_p - rel_c;
+                    bool ok = (int)i - j >= 0 && (c >> REL_BITS) == hp;
+                    ok = ok && (j == 1 ? (abs_c != 0 && dist <= (u32)MAX_DIST) : abs_c > limit);
+                    if (!ok) done = true;
+                    else {
+                        u32 len;
+                        u32 x = lds_u32(win, rel_c) ^ pw0;
+                        if (x) len = (u32)__builtin_ctz(x) >> 3;
+                        else {
+                            x = lds_u32(win, rel_c + 4) ^ pw1;
+                            if (x) len = 4 + ((u32)__builtin_ctz(x) >> 3);
+                            else {
+                                len = 8;
+                                while (len < maxlen) {
+                                    x = lds_u32(win, rel_c + len) ^ lds_u32(win, rel_p + len);
+                                    if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+                                    len += 4;
+                                }
+                            }
+                        }
+                        if (len > maxlen) len = maxlen;
+                        if (len > best) { best = len; bdist = dist; if (len >= nice) done = true; }
+                    }
+                }
+                if (j <= qchain) { qbest = best; qdist = bdist; }
+                if (!__any(!done)) break;
+            }
+        }
+        if (own) T[p_abs] = make_uint2(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0);
+    }
+}
+
+int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted,
+                 uint2 *d_tables, LevelCfg cfg)
+{
+    if (n_tiles == 0) return MTS_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MTS_HIP(hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_match, dim3(n_tiles), dim3(1024), MATCH_LDS, st, d_stream, d_tiles, d_sorted, d_tables, cfg);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
+// ================================================================================================
+// P: lazy-evaluation parse over the tables -- orc_parse_tables() is the oracle
+// ================================================================================================
+// One step of the state machine from a base state (no pending match) at p0.  Emits the literals
+// b[p0 .. mpos-1] followed by match (mlen, mdist) at mpos, or the single literal b[p0] when mlen == 0.
+// Returns the next base position.
+__device__ __forceinline__ u32 lazy_step(const uint2 *__restrict__ T, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos,
+                                         u32 &mlen, u32 &mdist)
+{
+    u32 p = p0;
+    const u32 c = T[p].x;
+    u32 len = c >> 16, dist = c & 0xffff;
+    if (len == MIN_MATCH && dist > (u32)TOO_FAR) len = 0;
+    if (len < MIN_MATCH) { mpos = p0; mlen = 0; mdist = 0; return p0 + 1; }
+    for (;;) {
+        const u32 q = p + 1;
+        if (q < n && len < (u32)cfg.lazy) {
+            const uint2 d2 = T[q];
+            const u32 d = len >= (u32)cfg.good ? d2.y : d2.x;
+            if ((d >> 16) > len) { p = q; len = d >> 16; dist = d & 0xffff; continue; }
+        }
+        break;
+    }
+    mpos = p; mlen = len; mdist = dist;
+    return p + len;
+}
+
+__device__ __forceinline__ bool mark_test(const u32 *marks, u64 bit) { return (marks[bit >> 5] >> (bit & 31)) & 1; }
+__device__ __forceinline__ void mark_set(u32 *marks, u64 bit) { marks[bit >> 5] |= 1u << (bit & 31); }
+
+__global__ __launch_bounds__(64) void k_parse_spec(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
+                                                   ParseBufs pb, int n_segs, LevelCfg cfg)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_segs) return;
+    const ChunkDesc ch = chunks[pb.seg_chunk[g]];
+    const u32 s = pb.seg_start[g], n = ch.n;
+    const u32 segend = min(s + (u32)SEG, n);
+    const uint2 *T = tables + ch.stream_off;
+    u32 *marks = pb.marks;          // segments own whole mark words (SEG and stream_off are multiples of 32)
+    u32 pos = s, mp, ml, md;
+    while (pos < segend) { mark_set(marks, ch.stream_off + pos); pos = lazy_step(T, pos, n, cfg, mp, ml, md); }
+    pb.entry[g] = s;
+    pb.exit_a[g] = pos;
+}
+
+__global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
+                                                  ParseBufs pb, int n_segs, LevelCfg cfg, int round)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_segs) return;
+    const u32 *exit_in = (round & 1) ? pb.exit_b : pb.exit_a;
+    u32 *exit_out = (round & 1) ? pb.exit_a : pb.exit_b;
+    const u32 ci = pb.seg_chunk[g];
+    const ChunkDesc ch = chunks[ci];
+    const u32 old_exit = exit_in[g];
+    const bool first = (u32)g == ch.seg0;
+    const u32 ne = first ? 0 : exit_in[g - 1];
+    if (ne == pb.entry[g]) { exit_out[g] = old_exit; return; }
+    pb.entry[g] = ne;
+    const u32 s = pb.seg_start[g], n = ch.n;
+    const u32 segend = min(s + (u32)SEG, n);
+    const uint2 *T = tables + ch.stream_off;
+    u32 *marks = pb.marks;
+    u32 pos = ne, mp, ml, md;
+    bool merged = false;
+    while (pos < segend) {
+        if (mark_test(marks, ch.stream_off + pos)) { merged = true; break; }
+        pos = lazy_step(T, pos, n, cfg, mp, ml, md);
+    }
+    if (merged) {
+        // same tail as before: keep the exit, add the new prefix to the marks
+        const u32 pm = pos;
+        pos = ne;
+        while (pos < pm) { mark_set(marks, ch.stream_off + pos); pos = lazy_step(T, pos, n, cfg, mp, ml, md); }
+        exit_out[g] = old_exit;
+        return;
+    }
+    // a different exit: the old marks no longer lead to it -> rebuild this segment's marks
+    exit_out[g] = pos;
+    if (pos != old_exit) *pb.changed = 1;
+    const u64 w0 = (ch.stream_off + s) >> 5, w1 = (ch.stream_off + segend + 31) >> 5;
+    for (u64 w = w0; w < w1; w++) marks[w] = 0;
+    pos = ne;
+    while (pos < segend) { mark_set(marks, ch.stream_off + pos); pos = lazy_step(T, pos, n, cfg, mp, ml, md); }
+}
+
+__global__ __launch_bounds__(64) void k_parse_count(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
+                                                    ParseBufs pb, int n_segs, LevelCfg cfg, ChunkOut *cout)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_segs) return;
+    const u32 ci = pb.seg_chunk[g];
+    const ChunkDesc ch = chunks[ci];
+    const u32 s = pb.seg_start[g], n = ch.n;
+    const u32 segend = min(s + (u32)SEG, n);
+    const uint2 *T = tables + ch.stream_off;
+    u32 pos = pb.entry[g], mp, ml, md, cnt = 0;
+    while (pos < segend) {
+        const u32 p0 = pos;
+        pos = lazy_step(T, pos, n, cfg, mp, ml, md);
+        cnt += mp - p0 + 1;
+        if (pos >= n) cout[ci].trailing = (ml == 0) ? 1u : 0u;      // last token of the chunk
+    }
+    pb.cnt[g] = cnt;
+}
+
+// exclusive scan of the per-segment token counts of each chunk (one workgroup per chunk)
+__global__ __launch_bounds__(256) void k_seg_scan(const ChunkDesc *__restrict__ chunks, ParseBufs pb, ChunkOut *cout)
+{
+    const ChunkDesc ch = chunks[blockIdx.x];
+    __shared__ u32 wsum[4];
+    __shared__ u32 carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (u32 base = 0; base < ch.nseg; base += 256) {
+        const u32 k = base + threadIdx.x;
+        const u32 v = k < ch.nseg ? pb.cnt[ch.seg0 + k] : 0;
+        u32 tot;
+        u32 ex = wave_excl_scan_u32(v, tot);
+        if (lane == 0) wsum[wave] = tot;
+        __syncthreads();
+        u32 add = carry_s;
+        for (int w = 0; w < wave; w++) add += wsum[w];
+        if (k < ch.nseg) pb.tokbase[ch.seg0 + k] = ex + add;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cout[blockIdx.x].ntok = carry_s;
+        if (ch.n == 0) cout[blockIdx.x].trailing = 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream, const uint2 *__restrict__ tables,
+                                                   const ChunkDesc *__restrict__ chunks, ParseBufs pb, int n_segs,
+                                                   LevelCfg cfg, u32 *__restrict__ tokens, u32 *__restrict__ blk_in_start)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_segs) return;
+    const ChunkDesc ch = chunks[pb.seg_chunk[g]];
+    const u32 s = pb.seg_start[g], n = ch.n;
+    const u32 segend = min(s + (u32)SEG, n);
+    const uint2 *T = tables + ch.stream_off;
+    const u8 *b = stream + ch.stream_off;
+    u32 *tk = tokens + ch.tok_off;
+    u32 *bis = blk_in_start + ch.blk0;
+    u32 pos = pb.entry[g], mp, ml, md, k = pb.tokbase[g];
+    while (pos < segend) {
+        const u32 p0 = pos;
+        pos = lazy_step(T, pos, n, cfg, mp, ml, md);
+        const u32 nlit = ml ? mp - p0 : 1;
+        for (u32 q = 0; q < nlit; q++, k++) {
+            if (k % BLOCK_TOKENS == 0) bis[k / BLOCK_TOKENS] = p0 + q;
+            tk[k] = (u32)b[p0 + q] << 16;
+        }
+        if (ml) {
+            if (k % BLOCK_TOKENS == 0) bis[k / BLOCK_TOKENS] = mp;
+            tk[k++] = ((ml - MIN_MATCH) << 16) | md;
+        }
+    }
+}
+
+int launch_parse_spec(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs,
+                      LevelCfg cfg)
+{
+    if (n_segs == 0) return MTS_OK;
+    hipLaunchKernelGGL(k_parse_spec, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_tables, d_chunks, pb, n_segs, cfg);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+int launch_parse_fix(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs,
+                     LevelCfg cfg, int round)
+{
+    if (n_segs == 0) return MTS_OK;
+    hipLaunchKernelGGL(k_parse_fix, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_tables, d_chunks, pb, n_segs, cfg, round);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+int launch_parse_count(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs,
+                       int n_chunks, LevelCfg cfg, ChunkOut *d_cout)
+{
+    if (n_segs)
+        hipLaunchKernelGGL(k_parse_count, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_tables, d_chunks, pb, n_segs, cfg, d_cout);
+    hipLaunchKernelGGL(k_seg_scan, dim3(n_chunks), dim3(256), 0, st, d_chunks, pb, d_cout);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables, const ChunkDesc *d_chunks,
+                      ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start)
+{
+    if (n_segs == 0) return MTS_OK;
+    hipLaunchKernelGGL(k_parse_emit, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_stream, d_tables, d_chunks, pb, n_segs,
+                       cfg, d_tokens, d_blk_in_start);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
+// ================================================================================================
+// T: per-block Huffman trees (zlib trees.c, exact) -- flush_block() in the oracle
+// ================================================================================================
+__constant__ u8 c_extra_lbits[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+__constant__ u8 c_extra_dbits[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
+__constant__ u8 c_extra_blbits[19] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,2,3,7};
+__constant__ u8 c_bl_order[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
+
+// length code (0..28) of lc = len - 3, distance code (0..29) of d = dist - 1 (trees.c _length_code/_dist_code)
+__device__ __forceinline__ u32 len_code(u32 lc, u32 &extra)
+{
+    if (lc < 8) { extra = 0; return lc; }
+    if (lc == 255) { extra = 0; return 28; }
+    const u32 k = 31 - __builtin_clz(lc);
+    extra = k - 2;
+    return 4 * extra + 4 + ((lc >> extra) & 3);
+}
+__device__ __forceinline__ u32 dist_code(u32 d, u32 &extra)
+{
+    if (d < 4) { extra = 0; return d; }
+    const u32 k = 31 - __builtin_clz(d);
+    extra = k - 1;
+    return 2 * k + ((d >> (k - 1)) & 1);
+}
+__device__ __forceinline__ u32 static_llen(u32 n) { return n <= 143 ? 8 : n <= 255 ? 9 : n <= 279 ? 7 : 8; }
+__device__ __forceinline__ u32 bit_reverse(u32 code, int len) { return __brev(code) >> (32 - len); }
+
+constexpr int HEAP_SIZE = 2 * L_CODES + 1;       // 573
+
+struct TreeWS {                                  // scratch of one tree build (LDS)
+    u16 freq[HEAP_SIZE];
+    u16 len[HEAP_SIZE + 1];
+    u16 dad[HEAP_SIZE];
+    u16 heap[HEAP_SIZE];
+    u8 depth[HEAP_SIZE];
+    u16 bl_count[16];
+    int heap_len, heap_max, max_code;
+};
+
+__device__ __forceinline__ bool tw_smaller(const TreeWS &t, int n, int m)
+{
+    return t.freq[n] < t.freq[m] || (t.freq[n] == t.freq[m] && t.depth[n] <= t.depth[m]);
+}
+__device__ void tw_downheap(TreeWS &t, int k)
+{
+    const int v = t.heap[k];
+    int j = k << 1;
+    while (j <= t.heap_len) {
+        if (j < t.heap_len && tw_smaller(t, t.heap[j + 1], t.heap[j])) j++;
+        if (tw_smaller(t, v, t.heap[j])) break;
+        t.heap[k] = t.heap[j]; k = j; j <<= 1;
+    }
+    t.heap[k] = (u16)v;
+}
+
+// kind 0 literal/length, 1 distance, 2 bit-length.  freq[] is the input; len[] the output.
+__device__ void tw_build(TreeWS &t, int kind, long &opt_len, long &static_len)
+{
+    const int elems = kind == 0 ? L_CODES : kind == 1 ? D_CODES : BL_CODES;
+    const int max_length = kind == 2 ? 7 : 15;
+    const int base = kind == 0 ? 257 : 0;
+    int n, m, max_code = -1, node;
+    t.heap_len = 0; t.heap_max = HEAP_SIZE;
+    for (n = 0; n < elems; n++) {
+        if (t.freq[n] != 0) { t.heap[++t.heap_len] = (u16)(max_code = n); t.depth[n] = 0; }
+        else t.len[n] = 0;
+    }
+    while (t.heap_len < 2) {
+        node = (max_code < 2 ? ++max_code : 0);
+        t.heap[++t.heap_len] = (u16)node;
+        t.freq[node] = 1; t.depth[node] = 0; opt_len--;
+        if (kind == 0) static_len -= static_llen(node); else if (kind == 1) static_len -= 5;
+    }
+    t.max_code = max_code;
+    for (n = t.heap_len / 2; n >= 1; n--) tw_downheap(t, n);
+    node = elems;
+    do {
+        n = t.heap[1]; t.heap[1] = t.heap[t.heap_len--]; tw_downheap(t, 1);
+        m = t.heap[1];
+        t.heap[--t.heap_max] = (u16)n; t.heap[--t.heap_max] = (u16)m;
+        t.freq[node] = (u16)(t.freq[n] + t.freq[m]);
+        t.depth[node] = (u8)((t.depth[n] >= t.depth[m] ? t.depth[n] : t.depth[m]) + 1);
+        t.dad[n] = t.dad[m] = (u16)node;
+        t.heap[1] = (u16)node++;
+        tw_downheap(t, 1);
+    } while (t.heap_len >= 2);
+    t.heap[--t.heap_max] = t.heap[1];
+    // gen_bitlen
+    int h, bits, overflow = 0;
+    for (bits = 0; bits <= 15; bits++) t.bl_count[bits] = 0;
+    t.len[t.heap[t.heap_max]] = 0;
+    for (h = t.heap_max + 1; h < HEAP_SIZE; h++) {
+        n = t.heap[h];
+        bits = t.len[t.dad[n]] + 1;
+        if (bits > max_length) { bits = max_length; overflow++; }
+        t.len[n] = (u16)bits;
+        if (n > max_code) continue;
+        t.bl_count[bits]++;
+        int xbits = 0;
+        if (n >= base) xbits = kind == 0 ? c_extra_lbits[n - base] : kind == 1 ? c_extra_dbits[n - base] : c_extra_blbits[n - base];
+        const long f = t.freq[n];
+        opt_len += f * (bits + xbits);
+        if (kind == 0) static_len += f * ((long)static_llen(n) + xbits);
+        else if (kind == 1) static_len += f * (5 + xbits);
+    }
+    if (overflow > 0) {
+        do {
+            bits = max_length - 1;
+            while (t.bl_count[bits] == 0) bits--;
+            t.bl_count[bits]--; t.bl_count[bits + 1] += 2; t.bl_count[max_length]--;
+            overflow -= 2;
+        } while (overflow > 0);
+        for (bits = max_length; bits != 0; bits--) {
+            n = t.bl_count[bits];
+            while (n != 0) {
+                m = t.heap[--h];
+                if (m > max_code) continue;
+                if (t.len[m] != (u16)bits) {
+                    opt_len += ((long)bits - (long)t.len[m]) * (long)t.freq[m];
+                    t.len[m] = (u16)bits;
+                }
+                n--;
+            }
+        }
+    }
+}
+
+// canonical codes (bit reversed) from t.len[0..max_code] and t.bl_count; out[n] = code | len << 16
+__device__ void tw_gen_codes(const TreeWS &t, u32 *out, int elems)
+{
+    u32 next_code[16], code = 0;
+    for (int bits = 1; bits <= 15; bits++) { code = (code + t.bl_count[bits - 1]) << 1; next_code[bits] = code; }
+    for (int n = 0; n < elems; n++) {
+        const int l = n <= t.max_code ? t.len[n] : 0;
+        out[n] = l ? (bit_reverse(next_code[l]++, l) | ((u32)l << 16)) : 0;
+    }
+}
+
+__device__ void tw_scan_tree(const u16 *len, int max_code, u16 *blfreq)
+{
+    int prevlen = -1, curlen, nextlen = len[0], count = 0, max_count = 7, min_count = 4;
+    if (nextlen == 0) { max_count = 138; min_count = 3; }
+    for (int n = 0; n <= max_code; n++) {
+        curlen = nextlen; nextlen = n + 1 <= max_code ? len[n + 1] : 0xffff;
+        if (++count < max_count && curlen == nextlen) continue;
+        else if (count < min_count) blfreq[curlen] += (u16)count;
+        else if (curlen != 0) { if (curlen != prevlen) blfreq[curlen]++; blfreq[16]++; }
+        else if (count <= 10) blfreq[17]++;
+        else blfreq[18]++;
+        count = 0; prevlen = curlen;
+        if (nextlen == 0) { max_count = 138; min_count = 3; }
+        else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+        else { max_count = 7; min_count = 4; }
+    }
+}
+
+struct BitW { u32 *w; u64 acc; int nb; u32 pos; };   // sequential LSB-first writer into zeroed words
+__device__ __forceinline__ void bw_put(BitW &b, u32 v, int n)
+{
+    b.acc |= (u64)v << b.nb; b.nb += n;
+    if (b.nb >= 32) { b.w[b.pos++] = (u32)b.acc; b.acc >>= 32; b.nb -= 32; }
+}
+__device__ void tw_send_tree(BitW &bw, const u16 *len, int max_code, const u32 *blc)
+{
+    int prevlen = -1, curlen, nextlen = len[0], count = 0, max_count = 7, min_count = 4;
+    if (nextlen == 0) { max_count = 138; min_count = 3; }
+#define SEND_BL(c) bw_put(bw, blc[c] & 0xffff, (int)(blc[c] >> 16))
+    for (int n = 0; n <= max_code; n++) {
+        curlen = nextlen; nextlen = n + 1 <= max_code ? len[n + 1] : 0xffff;
+        if (++count < max_count && curlen == nextlen) continue;
+        else if (count < min_count) { do { SEND_BL(curlen); } while (--count != 0); }
+        else if (curlen != 0) {
+            if (curlen != prevlen) { SEND_BL(curlen); count--; }
+            SEND_BL(16); bw_put(bw, (u32)(count - 3), 2);
+        } else if (count <= 10) { SEND_BL(17); bw_put(bw, (u32)(count - 3), 3); }
+        else { SEND_BL(18); bw_put(bw, (u32)(count - 11), 7); }
+        count = 0; prevlen = curlen;
+        if (nextlen == 0) { max_count = 138; min_count = 3; }
+        else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+        else { max_count = 7; min_count = 4; }
+    }
+#undef SEND_BL
+}
+
+__device__ __forceinline__ u32 chunk_nblk(u32 ntok, u32 trailing)
+{
+    if (ntok == 0) return 1;
+    return (ntok + BLOCK_TOKENS - 1) / BLOCK_TOKENS + ((ntok % BLOCK_TOKENS == 0 && !trailing) ? 1 : 0);
+}
+
+// number of fill_window slides once the loop top at absolute position q has run (oracle: orc_slides_at)
+__device__ __forceinline__ u32 slides_at(u32 q, u32 n)
+{
+    u32 k = 0;
+    for (;;) {
+        const u64 edge = (u64)(k + 2) * WSIZE;
+        const u64 theta = edge - 261 - (n < edge ? 1 : 0);
+        if (q >= theta) k++; else break;
+    }
+    return k;
+}
+
+__global__ __launch_bounds__(64) void k_block_trees(const ChunkDesc *__restrict__ chunks, const u32 *__restrict__ blk_chunk,
+                                                    int total_blk_cap, const u32 *__restrict__ tokens,
+                                                    const u32 *__restrict__ blk_in_start, const ChunkOut *__restrict__ cout,
+                                                    BlockRec *__restrict__ blocks, u32 *__restrict__ blk_codes,
+                                                    u32 *__restrict__ blk_hdr)
+{
+    const int b = blockIdx.x;
+    if (b >= total_blk_cap) return;
+    const u32 ci = blk_chunk[b];
+    const ChunkDesc ch = chunks[ci];
+    const u32 bi = b - ch.blk0;
+    const u32 ntok_c = cout[ci].ntok;
+    const u32 nblk = chunk_nblk(ntok_c, cout[ci].trailing);
+    if (bi >= nblk) return;
+    const u32 tok0 = bi * BLOCK_TOKENS;
+    const u32 nt = ntok_c > tok0 ? min((u32)BLOCK_TOKENS, ntok_c - tok0) : 0;
+    const u32 last = bi == nblk - 1;
+    const u32 in_start = nt ? blk_in_start[b] : ch.n;
+    const u32 in_end = tok0 + nt < ntok_c ? blk_in_start[b + 1] : ch.n;
+    __shared__ u32 lfreq[L_CODES + 2], dfreq[D_CODES + 2];
+    __shared__ TreeWS tw;
+    __shared__ u16 llen_s[L_CODES + 2], dlen_s[D_CODES + 2];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < L_CODES + 2; i += 64) lfreq[i] = 0;
+    if (lane < D_CODES + 2) dfreq[lane] = 0;
+    __syncthreads();
+    const u32 *tk = tokens + ch.tok_off + tok0;
+    for (u32 i = lane; i < nt; i += 64) {
+        const u32 t = tk[i], dist = t & 0xffff, lc = t >> 16;
+        u32 ex;
+        if (dist == 0) atomicAdd(&lfreq[lc], 1u);
+        else { atomicAdd(&lfreq[257 + len_code(lc, ex)], 1u); atomicAdd(&dfreq[dist_code(dist - 1, ex)], 1u); }
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    lfreq[256] = 1;
+    long opt_len = 0, static_len = 0;
+    // literal/length tree
+    for (int i = 0; i < HEAP_SIZE; i++) tw.freq[i] = i < L_CODES ? (u16)lfreq[i] : 0;
+    tw_build(tw, 0, opt_len, static_len);
+    const int l_max = tw.max_code;
+    for (int i = 0; i <= l_max; i++) llen_s[i] = tw.len[i];
+    u32 *codes = blk_codes + (u64)b * BLK_CODE_WORDS;
+    tw_gen_codes(tw, codes, L_CODES);
+    // distance tree
+    for (int i = 0; i < HEAP_SIZE; i++) tw.freq[i] = i < D_CODES ? (u16)dfreq[i] : 0;
+    tw_build(tw, 1, opt_len, static_len);
+    const int d_max = tw.max_code;
+    for (int i = 0; i <= d_max; i++) dlen_s[i] = tw.len[i];
+    tw_gen_codes(tw, codes + L_CODES, D_CODES);
+    // bit-length tree
+    for (int i = 0; i < HEAP_SIZE; i++) tw.freq[i] = 0;
+    tw_scan_tree(llen_s, l_max, tw.freq);
+    tw_scan_tree(dlen_s, d_max, tw.freq);
+    tw_build(tw, 2, opt_len, static_len);
+    int max_blindex;
+    for (max_blindex = BL_CODES - 1; max_blindex >= 3; max_blindex--)
+        if (tw.len[c_bl_order[max_blindex]] != 0) break;
+    opt_len += 3 * (max_blindex + 1) + 5 + 5 + 4;
+    long opt_lenb = (opt_len + 3 + 7) >> 3;
+    const long static_lenb = (static_len + 3 + 7) >> 3;
+    if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+    const u32 in_len = in_end - in_start;
+    // _tr_flush_block's `buf != NULL`: the block start must still be inside the sliding window.
+    // The flush runs in the loop iteration whose top is at q: the literal branch flushes before
+    // strstart++ (q = block end), the match branch after the skip (q = position after the match's
+    // first byte + 1 = start of the last token + 1); the final flush follows the loop top at n.
+    u32 q_top;
+    if (last) q_top = ch.n;
+    else {
+        const u32 t_last = tk[nt - 1];
+        q_top = (t_last & 0xffff) ? in_end - ((t_last >> 16) + MIN_MATCH) + 1 : in_end;
+    }
+    const bool buf_ok = (u64)in_start >= (u64)slides_at(q_top, ch.n) * WSIZE;
+    BlockRec r;
+    r.tok0 = tok0; r.ntok = nt; r.in_start = in_start; r.in_len = in_len; r.last = last; r.hdr_bits = 0; r.bit_start = 0;
+    if ((long)in_len + 4 <= opt_lenb && buf_ok) {
+        r.btype = 0; r.nbits = 0;
+    } else if (static_lenb == opt_lenb) {
+        r.btype = 1; r.nbits = (u32)(3 + static_len);
+        // static codes
+        u32 next_code[16], code = 0;
+        const u32 cnt[10] = {0, 0, 0, 0, 0, 0, 0, 24, 152, 112};
+        for (int bits = 1; bits <= 9; bits++) { code = (code + cnt[bits - 1]) << 1; next_code[bits] = code; }
+        for (u32 n = 0; n < L_CODES; n++) { const u32 l = static_llen(n); codes[n] = bit_reverse(next_code[l]++, (int)l) | (l << 16); }
+        for (u32 n = 0; n < D_CODES; n++) codes[L_CODES + n] = bit_reverse(n, 5) | (5u << 16);
+    } else {
+        r.btype = 2; r.nbits = (u32)(3 + opt_len);
+        u32 blc[BL_CODES];
+        {
+            u32 next_code[16], code = 0;
+            for (int bits = 1; bits <= 7; bits++) { code = (code + tw.bl_count[bits - 1]) << 1; next_code[bits] = code; }
+            for (int n = 0; n < BL_CODES; n++) {
+                const int l = n <= tw.max_code ? tw.len[n] : 0;
+                blc[n] = l ? (bit_reverse(next_code[l]++, l) | ((u32)l << 16)) : 0;
+            }
+        }
+        u32 *hw = blk_hdr + (u64)b * BLK_HDR_WORDS;
+        for (int i = 0; i < BLK_HDR_WORDS; i++) hw[i] = 0;
+        BitW bw = {hw, 0, 0, 0};
+        bw_put(bw, (u32)(l_max + 1 - 257), 5);
+        bw_put(bw, (u32)(d_max + 1 - 1), 5);
+        bw_put(bw, (u32)(max_blindex + 1 - 4), 4);
+        for (int rank = 0; rank < max_blindex + 1; rank++) {
+            const int sym = c_bl_order[rank];
+            bw_put(bw, sym <= tw.max_code ? tw.len[sym] : 0, 3);
+        }
+        tw_send_tree(bw, llen_s, l_max, blc);
+        tw_send_tree(bw, dlen_s, d_max, blc);
+        r.hdr_bits = bw.pos * 32 + bw.nb;
+        if (bw.nb) hw[bw.pos] = (u32)bw.acc;
+    }
+    blocks[b] = r;
+}
+
+// ================================================================================================
+// L: block layout per chunk
+// ================================================================================================
+__global__ __launch_bounds__(64) void k_block_layout(const ChunkDesc *__restrict__ chunks, int n_chunks,
+                                                     BlockRec *__restrict__ blocks, ChunkOut *__restrict__ cout,
+                                                     const u64 *__restrict__ adler_acc)
+{
+    const int ci = blockIdx.x * 64 + threadIdx.x;
+    if (ci >= n_chunks) return;
+    const ChunkDesc ch = chunks[ci];
+    ChunkOut co = cout[ci];
+    const u32 nblk = chunk_nblk(co.ntok, co.trailing);
+    u64 bit = 16;
+    for (u32 bi = 0; bi < nblk; bi++) {
+        BlockRec &r = blocks[ch.blk0 + bi];
+        r.bit_start = bit;
+        if (r.btype == 0) { bit += 3; bit = (bit + 7) & ~7ull; bit += 32 + 8ull * r.in_len; }
+        else bit += r.nbits;
+    }
+    bit = (bit + 7) & ~7ull;
+    co.nblk = nblk;
+    co.nbytes = bit / 8 + 4;
+    const u32 a = (u32)((1 + adler_acc[2 * ci]) % 65521u), bb = (u32)((ch.n + adler_acc[2 * ci + 1]) % 65521u);
+    co.adler = (bb << 16) | a;
+    cout[ci] = co;
+}
+
+// ================================================================================================
+// B: bit packing
+// ================================================================================================
+// A lane's bit sink: it owns the bit range it writes.  Words it fully covers are stored, the two
+// edge words are OR-ed atomically (the output is zero-filled beforehand).
+struct Sink {
+    u32 *out; u64 acc; int nb; u64 word; bool first;
+    __device__ __forceinline__ void init(u32 *o, u64 bitpos) { out = o; word = bitpos >> 5; nb = (int)(bitpos & 31); acc = 0; first = true; }
+    __device__ __forceinline__ void put(u32 v, int n)
+    {
+        acc |= (u64)v << nb; nb += n;
+        if (nb >= 32) {
+            if (first) { atomicOr(&out[word], (u32)acc); first = false; } else out[word] = (u32)acc;
+            word++; acc >>= 32; nb -= 32;
+        }
+    }
+    __device__ __forceinline__ void flush() { if (nb > 0 && (u32)acc) atomicOr(&out[word], (u32)acc); }
+};
+
+__device__ __forceinline__ u32 token_bits(u32 t, const u32 *lc_tab, const u32 *dc_tab)
+{
+    const u32 dist = t & 0xffff, lc = t >> 16;
+    if (dist == 0) return lc_tab[lc] >> 16;
+    u32 el, ed;
+    const u32 lcode = len_code(lc, el), dcode = dist_code(dist - 1, ed);
+    return (lc_tab[257 + lcode] >> 16) + el + (dc_tab[dcode] >> 16) + ed;
+}
+__device__ __forceinline__ void token_put(Sink &s, u32 t, const u32 *lc_tab, const u32 *dc_tab)
+{
+    const u32 dist = t & 0xffff, lc = t >> 16;
+    if (dist == 0) { const u32 c = lc_tab[lc]; s.put(c & 0xffff, (int)(c >> 16)); return; }
+    u32 el, ed;
+    const u32 lcode = len_code(lc, el), dcode = dist_code(dist - 1, ed);
+    u32 c = lc_tab[257 + lcode];
+    // length code + extra bits (<= 15 + 5), distance code + extra bits (<= 15 + 13)
+    s.put((c & 0xffff) | ((lc & ((1u << el) - 1)) << (c >> 16)), (int)((c >> 16) + el));
+    c = dc_tab[dcode];
+    s.put((c & 0xffff) | (((dist - 1) & ((1u << ed) - 1)) << (c >> 16)), (int)((c >> 16) + ed));
+}
+
+constexpr int PACK_THREADS = 256;
+constexpr int PACK_RUN = (BLOCK_TOKENS + PACK_THREADS - 1) / PACK_THREADS;   // 64 tokens per lane
+
+__global__ __launch_bounds__(PACK_THREADS) void k_block_pack(const u8 *__restrict__ stream, const ChunkDesc *__restrict__ chunks,
+                                                             const u32 *__restrict__ blk_chunk, int total_blk_cap,
+                                                             const u32 *__restrict__ tokens, const BlockRec *__restrict__ blocks,
+                                                             const u32 *__restrict__ blk_codes, const u32 *__restrict__ blk_hdr,
+                                                             const ChunkOut *__restrict__ cout, u8 *__restrict__ outb, u32 zhdr)
+{
+    const int b = blockIdx.x;
+    if (b >= total_blk_cap) return;
+    const u32 ci = blk_chunk[b];
+    const ChunkDesc ch = chunks[ci];
+    const u32 bi = b - ch.blk0;
+    const ChunkOut co = cout[ci];
+    if (bi >= co.nblk) return;
+    const BlockRec r = blocks[b];
+    u32 *out = (u32 *)(outb + ch.out_off);
+    __shared__ u32 codes[BLK_CODE_WORDS];
+    __shared__ u32 wsum[PACK_THREADS / 64];
+    const int tid = threadIdx.x;
+    Sink sk;
+    if (r.btype == 0) {
+        // stored: [3 bits][pad][LEN][NLEN][bytes]
+        const u64 hdr_bit = r.bit_start;
+        const u64 pay_bit = ((hdr_bit + 3 + 7) & ~7ull) + 32;
+        if (tid == 0) {
+            sk.init(out, bi == 0 ? 0 : hdr_bit);
+            if (bi == 0) sk.put(zhdr, 16);
+            sk.put(r.last, 3);
+            sk.flush();
+            sk.init(out, pay_bit - 32);
+            sk.put(r.in_len & 0xffff, 16);
+            sk.put((~r.in_len) & 0xffff, 16);
+            sk.flush();
+        }
+        const u32 per = (r.in_len + PACK_THREADS - 1) / PACK_THREADS;
+        const u32 b0 = min((u32)tid * per, r.in_len), b1 = min(b0 + per, r.in_len);
+        if (b1 > b0) {
+            const u8 *src = stream + ch.stream_off + r.in_start;
+            sk.init(out, pay_bit + 8ull * b0);
+            for (u32 i = b0; i < b1; i++) sk.put(src[i], 8);
+            sk.flush();
+        }
+        if (r.last && tid == 0) {
+            sk.init(out, pay_bit + 8ull * r.in_len);
+            sk.put(__builtin_bswap32(co.adler), 32);
+            sk.flush();
+        }
+        return;
+    }
+    for (int i = tid; i < BLK_CODE_WORDS; i += PACK_THREADS) codes[i] = i < L_CODES + D_CODES ? blk_codes[(u64)b * BLK_CODE_WORDS + i] : 0;
+    __syncthreads();
+    const u32 *lc_tab = codes, *dc_tab = codes + L_CODES;
+    const u32 *tk = tokens + ch.tok_off + r.tok0;
+    const u32 t0 = min((u32)tid * PACK_RUN, r.ntok), t1 = min(t0 + PACK_RUN, r.ntok);
+    // bits this lane writes: (lane 0: stream header + block header + trees) + its tokens + (EOB for the owner of the end)
+    const bool owns_end = (r.ntok == 0) ? tid == 0 : (t1 == r.ntok && t0 < r.ntok);
+    u32 nbits = 0;
+    for (u32 i = t0; i < t1; i++) nbits += token_bits(tk[i], lc_tab, dc_tab);
+    if (owns_end) nbits += lc_tab[256] >> 16;
+    const u32 pre = tid == 0 ? 3 + r.hdr_bits : 0;
+    nbits += pre;
+    u32 wtot;
+    u32 ex = wave_excl_scan_u32(nbits, wtot);
+    if ((tid & 63) == 0) wsum[tid >> 6] = wtot;
+    __syncthreads();
+    for (int w = 0; w < (tid >> 6); w++) ex += wsum[w];
+    u64 bitpos = r.bit_start + ex;
+    if (tid == 0) {
+        if (bi == 0) { sk.init(out, 0); sk.put(zhdr, 16); } else sk.init(out, bitpos);
+        sk.put(r.last | (r.btype << 1), 3);
+        if (r.btype == 2) {
+            const u32 *hw = blk_hdr + (u64)b * BLK_HDR_WORDS;
+            u32 left = r.hdr_bits, k = 0;
+            while (left >= 32) { const u32 w = hw[k++]; sk.put(w & 0xffff, 16); sk.put(w >> 16, 16); left -= 32; }
+            if (left) { const u32 w = hw[k]; if (left > 16) { sk.put(w & 0xffff, 16); sk.put((w >> 16) & ((1u << (left - 16)) - 1), (int)left - 16); } else sk.put(w & ((1u << left) - 1), (int)left); }
+        }
+    } else sk.init(out, bitpos);
+    for (u32 i = t0; i < t1; i++) token_put(sk, tk[i], lc_tab, dc_tab);
+    if (owns_end) { const u32 c = lc_tab[256]; sk.put(c & 0xffff, (int)(c >> 16)); }
+    sk.flush();
+    if (r.last && owns_end) {
+        const u64 endbit = (r.bit_start + r.nbits + 7) & ~7ull;
+        sk.init(out, endbit);
+        sk.put(__builtin_bswap32(co.adler), 32);      // adler32 big-endian
+        sk.flush();
+    }
+}
+
+int launch_block_trees(hipStream_t st, const ChunkDesc *d_chunks, const u32 *d_blk_chunk, int total_blk_cap,
+                       const u32 *d_tokens, const u32 *d_blk_in_start, const ChunkOut *d_cout, BlockRec *d_blocks,
+                       u32 *d_blk_codes, u32 *d_blk_hdr)
+{
+    if (total_blk_cap == 0) return MTS_OK;
+    hipLaunchKernelGGL(k_block_trees, dim3(total_blk_cap), dim3(64), 0, st, d_chunks, d_blk_chunk, total_blk_cap, d_tokens,
+                       d_blk_in_start, d_cout, d_blocks, d_blk_codes, d_blk_hdr);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+int launch_block_layout(hipStream_t st, const ChunkDesc *d_chunks, int n_chunks, BlockRec *d_blocks, ChunkOut *d_cout,
+                        const u64 *d_adler_acc)
+{
+    if (n_chunks == 0) return MTS_OK;
+    hipLaunchKernelGGL(k_block_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_chunks, n_chunks, d_blocks, d_cout, d_adler_acc);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+int launch_block_pack(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const u32 *d_blk_chunk,
+                      int total_blk_cap, const u32 *d_tokens, const BlockRec *d_blocks, const u32 *d_blk_codes,
+                      const u32 *d_blk_hdr, const ChunkOut *d_cout, u8 *d_out, int level)
+{
+    if (total_blk_cap == 0) return MTS_OK;
+    // zlib header: CMF 0x78, FLG = level flags << 6 made a multiple of 31 (deflate.c)
+    const u32 lf = level < 2 ? 0 : level < 6 ? 1 : level == 6 ? 2 : 3;
+    u32 header = (0x78u << 8) | (lf << 6);
+    header += 31 - (header % 31);
+    const u32 zhdr = (header >> 8) | ((header & 0xff) << 8);      // first byte in the low bits
+    hipLaunchKernelGGL(k_block_pack, dim3(total_blk_cap), dim3(PACK_THREADS), 0, st, d_stream, d_chunks, d_blk_chunk,
+                       total_blk_cap, d_tokens, d_blocks, d_blk_codes, d_blk_hdr, d_cout, d_out, zhdr);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
+}  // namespace mts

@@ -1,0 +1,392 @@
+// K1 / K2: the np.diff + tobytes(order) transform and its cumsum inverse, adler32, synthetic data.
+//   K1 replaces diff_along_axis + ndarray.tobytes       (/root/reference/mtscomp.py:143-159, :381-394)
+//   K2 replaces reshape(order) + cumsum_along_axis + ascontiguousarray       (mtscomp.py:622-635)
+// Integer items of 1/2/4/8 bytes; arithmetic wraps in the item width like numpy's.
+#include "common.h"
+
+namespace mts {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 wave_sum_u64(u64 v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        u32 lo = __shfl_down((u32)v, off, 64), hi = __shfl_down((u32)(v >> 32), off, 64);
+        v += ((u64)hi << 32) | lo;
+    }
+    return v;
+}
+
+// block-wide sum of two u64 values (256 threads); result valid in thread 0
+__device__ __forceinline__ void block_sum2(u64 &a, u64 &b, u64 *sh /* 8 entries */)
+{
+    a = wave_sum_u64(a);
+    b = wave_sum_u64(b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    if (lane == 0) { sh[wave] = a; sh[4 + wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = 0; b = 0;
+        for (int w = 0; w < nw; w++) { a += sh[w]; b += sh[4 + w]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: delta + transpose (+ adler32 partial sums of the produced stream)
+//   grid (time tiles of 64, channel tiles of 64, chunks), 256 threads.
+//   adler: A = 1 + sum b_i, B = n + sum (n - i) b_i  (mod 65521); partial sums are atomically
+//   accumulated per chunk (already reduced mod 65521 per workgroup, so the u64 cannot overflow).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_delta_transpose(const u8 *__restrict__ raw, u8 *__restrict__ stream,
+                                                         const ChunkDesc *__restrict__ chunks, int nc,
+                                                         int flags, u64 *adler_acc)
+{
+    const ChunkDesc ch = chunks[blockIdx.z];
+    const long nt = ch.n_rows;
+    const long t0 = (long)blockIdx.x * 64;
+    if (t0 >= nt) return;
+    const int c0 = blockIdx.y * 64;
+    const T *x = (const T *)(raw + ch.raw_off);
+    T *out = (T *)(stream + ch.stream_off);
+    __shared__ T tile[65][66];          // row 0 = t0 - 1, col 0 = c0 - 1
+    __shared__ u64 red[8];
+    for (int idx = threadIdx.x; idx < 65 * 65; idx += 256) {
+        const int r = idx / 65, k = idx - r * 65;
+        const long t = t0 - 1 + r;
+        const int c = c0 - 1 + k;
+        T v = 0;
+        if (t >= 0 && t < nt && c >= 0 && c < nc) v = x[t * nc + c];
+        tile[r][k] = v;
+    }
+    __syncthreads();
+    const bool td = flags & MTS_FLAG_TIME_DIFF, sd = flags & MTS_FLAG_SPATIAL_DIFF, of = flags & MTS_FLAG_ORDER_F;
+    const u64 nbytes = (u64)nt * nc * sizeof(T);
+    u64 sa = 0, sb = 0;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        int tt, cc;
+        if (of) { cc = idx >> 6; tt = idx & 63; } else { tt = idx >> 6; cc = idx & 63; }
+        const long t = t0 + tt;
+        const int c = c0 + cc;
+        if (t >= nt || c >= nc) continue;
+        T d = tile[tt + 1][cc + 1];
+        if (td && t > 0) d -= tile[tt][cc + 1];
+        if (sd && c > 0) {
+            T dl = tile[tt + 1][cc];
+            if (td && t > 0) dl -= tile[tt][cc];
+            d -= dl;
+        }
+        const u64 I = of ? (u64)c * nt + t : (u64)t * nc + c;
+        out[I] = d;
+        u64 v = (u64)d;
+#pragma unroll
+        for (int k = 0; k < (int)sizeof(T); k++) {
+            const u64 b = (v >> (8 * k)) & 0xff;
+            sa += b;
+            sb += (nbytes - (I * sizeof(T) + k)) * b;
+        }
+    }
+    block_sum2(sa, sb, red);
+    if (threadIdx.x == 0) {
+        atomicAdd((unsigned long long *)&adler_acc[2 * blockIdx.z], (unsigned long long)(sa % 65521u));
+        atomicAdd((unsigned long long *)&adler_acc[2 * blockIdx.z + 1], (unsigned long long)(sb % 65521u));
+    }
+}
+
+int launch_delta_transpose(hipStream_t st, const void *d_raw, void *d_stream, const ChunkDesc *d_chunks,
+                           int n_chunks, u32 max_rows, int n_channels, int itemsize, int flags,
+                           u64 *d_adler_acc)
+{
+    if (n_chunks == 0 || max_rows == 0) return MTS_OK;
+    MTS_HIP(hipMemsetAsync(d_adler_acc, 0, sizeof(u64) * 2 * n_chunks, st));
+    dim3 grid((max_rows + 63) / 64, (n_channels + 63) / 64, n_chunks), block(256);
+    const u8 *raw = (const u8 *)d_raw;
+    u8 *stream = (u8 *)d_stream;
+    switch (itemsize) {
+    case 1: hipLaunchKernelGGL(k_delta_transpose<u8>, grid, block, 0, st, raw, stream, d_chunks, n_channels, flags, d_adler_acc); break;
+    case 2: hipLaunchKernelGGL(k_delta_transpose<u16>, grid, block, 0, st, raw, stream, d_chunks, n_channels, flags, d_adler_acc); break;
+    case 4: hipLaunchKernelGGL(k_delta_transpose<u32>, grid, block, 0, st, raw, stream, d_chunks, n_channels, flags, d_adler_acc); break;
+    case 8: hipLaunchKernelGGL(k_delta_transpose<u64>, grid, block, 0, st, raw, stream, d_chunks, n_channels, flags, d_adler_acc); break;
+    default: return MTS_E_ARG;
+    }
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adler32 partial sums of plain streams (inflate side: verify the trailer)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adler_stream(const u8 *__restrict__ stream, const u64 *__restrict__ stream_off,
+                                                      const u32 *__restrict__ n_arr, u64 *adler_acc)
+{
+    const int chunk = blockIdx.y;
+    const u64 n = n_arr[chunk];
+    const u64 base = (u64)blockIdx.x * (256 * 64);
+    if (base >= n) return;
+    const u8 *s = stream + stream_off[chunk];
+    __shared__ u64 red[8];
+    u64 sa = 0, sb = 0;
+    // 16 bytes per lane per step, 4 steps
+    for (int k = 0; k < 4; k++) {
+        const u64 i0 = base + ((u64)k * 256 + threadIdx.x) * 16;
+        if (i0 >= n) break;
+        if (i0 + 16 <= n) {
+            const uint4 v = *(const uint4 *)(s + i0);
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const u64 b = (w[j >> 2] >> (8 * (j & 3))) & 0xff;
+                sa += b; sb += (n - (i0 + j)) * b;
+            }
+        } else {
+            for (u64 i = i0; i < n; i++) { const u64 b = s[i]; sa += b; sb += (n - i) * b; }
+        }
+    }
+    block_sum2(sa, sb, red);
+    if (threadIdx.x == 0) {
+        atomicAdd((unsigned long long *)&adler_acc[2 * chunk], (unsigned long long)(sa % 65521u));
+        atomicAdd((unsigned long long *)&adler_acc[2 * chunk + 1], (unsigned long long)(sb % 65521u));
+    }
+}
+
+int launch_adler_stream(hipStream_t st, const u8 *d_stream, const u64 *d_stream_off, const u32 *d_n,
+                        int n_chunks, u32 max_n, u64 *d_adler_acc)
+{
+    if (n_chunks == 0) return MTS_OK;
+    MTS_HIP(hipMemsetAsync(d_adler_acc, 0, sizeof(u64) * 2 * n_chunks, st));
+    if (max_n == 0) return MTS_OK;
+    dim3 grid((max_n + 256 * 64 - 1) / (256 * 64), n_chunks), block(256);
+    hipLaunchKernelGGL(k_adler_stream, grid, block, 0, st, d_stream, d_stream_off, d_n, d_adler_acc);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: (spatial cumsum) + time cumsum + transpose back to C order
+//   pass S (only with do_spatial_diff): in-place prefix sum over channels, one thread per row
+//   pass A: per (segment of SEGR rows, channel) sums
+//   pass B: scan inside the segment with the carry of the previous segments, write C-order rows
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_spatial_cumsum(u8 *stream, const u64 *__restrict__ stream_off,
+                                                        const u32 *__restrict__ rows, const int *__restrict__ status,
+                                                        int nc, int order_f)
+{
+    const int chunk = blockIdx.y;
+    if (status && status[chunk] != 0) return;
+    const long nt = rows[chunk];
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nt) return;
+    T *d = (T *)(stream + stream_off[chunk]);
+    T acc = 0;
+    for (int c = 0; c < nc; c++) {
+        const u64 I = order_f ? (u64)c * nt + t : (u64)t * nc + c;
+        acc += d[I];
+        d[I] = acc;
+    }
+}
+
+template <typename T, int SEGR>
+__global__ __launch_bounds__(256) void k_seg_sums(const u8 *__restrict__ stream, const u64 *__restrict__ stream_off,
+                                                  const u32 *__restrict__ rows, const int *__restrict__ status,
+                                                  int nc, int order_f, int nseg_max, u64 *__restrict__ segsums)
+{
+    const int chunk = blockIdx.z;
+    if (status && status[chunk] != 0) return;
+    const long nt = rows[chunk];
+    const long t0 = (long)blockIdx.x * SEGR;
+    if (t0 >= nt) return;
+    const int c0 = blockIdx.y * 64;
+    const T *d = (const T *)(stream + stream_off[chunk]);
+    __shared__ u64 part[4][64];
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (order_f) {
+        // wave q sums channels q*16 .. q*16+15; lanes run along time
+        for (int k = 0; k < 16; k++) {
+            const int cc = q * 16 + k, c = c0 + cc;
+            u64 s = 0;
+            if (c < nc)
+                for (int tt = lane; tt < SEGR; tt += 64)
+                    if (t0 + tt < nt) s += (u64)d[(u64)c * nt + t0 + tt];
+            s = wave_sum_u64(s);
+            if (lane == 0) part[0][cc] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64 && c0 + threadIdx.x < nc)
+            segsums[((u64)chunk * nseg_max + blockIdx.x) * nc + c0 + threadIdx.x] = part[0][threadIdx.x];
+    } else {
+        const int c = c0 + lane;
+        u64 s = 0;
+        if (c < nc)
+            for (int tt = q; tt < SEGR; tt += 4)
+                if (t0 + tt < nt) s += (u64)d[(u64)(t0 + tt) * nc + c];
+        part[q][lane] = s;
+        __syncthreads();
+        if (threadIdx.x < 64 && c < nc)
+            segsums[((u64)chunk * nseg_max + blockIdx.x) * nc + c] =
+                part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    }
+}
+
+template <typename T, int SEGR>
+__global__ __launch_bounds__(256) void k_cumsum_transpose(const u8 *__restrict__ stream, u8 *__restrict__ outb,
+                                                          const u64 *__restrict__ stream_off,
+                                                          const u64 *__restrict__ out_off, const u32 *__restrict__ rows,
+                                                          const int *__restrict__ status, int nc, int flags,
+                                                          int nseg_max, const u64 *__restrict__ segsums)
+{
+    const int chunk = blockIdx.z;
+    if (status && status[chunk] != 0) return;
+    const long nt = rows[chunk];
+    const long t0 = (long)blockIdx.x * SEGR;
+    if (t0 >= nt) return;
+    const int c0 = blockIdx.y * 64;
+    const bool td = flags & MTS_FLAG_TIME_DIFF, of = flags & MTS_FLAG_ORDER_F;
+    const T *d = (const T *)(stream + stream_off[chunk]);
+    T *out = (T *)(outb + out_off[chunk]);
+    constexpr int PITCH = SEGR + (sizeof(T) >= 4 ? 1 : (int)(4 / sizeof(T)));   // odd number of dwords for 2-byte items
+    __shared__ T tile[64][PITCH];
+    __shared__ T carry[64];
+    __shared__ T qsum[4][64];
+    if (threadIdx.x < 64) {
+        T cy = 0;
+        const int c = c0 + threadIdx.x;
+        if (td && c < nc)
+            for (unsigned s = 0; s < blockIdx.x; s++) cy += (T)segsums[((u64)chunk * nseg_max + s) * nc + c];
+        carry[threadIdx.x] = cy;
+    }
+    for (int idx = threadIdx.x; idx < 64 * SEGR; idx += 256) {
+        int cc, tt;
+        if (of) { cc = idx / SEGR; tt = idx - cc * SEGR; } else { tt = idx >> 6; cc = idx & 63; }
+        const long t = t0 + tt;
+        const int c = c0 + cc;
+        T v = 0;
+        if (t < nt && c < nc) v = d[of ? (u64)c * nt + t : (u64)t * nc + c];
+        tile[cc][tt] = v;
+    }
+    __syncthreads();
+    if (td) {
+        // thread (cc, q) scans a quarter of the segment sequentially, then the quarters are chained
+        const int cc = threadIdx.x & 63, q = threadIdx.x >> 6;
+        constexpr int QR = SEGR / 4;
+        T acc = 0;
+        for (int k = 0; k < QR; k++) { acc += tile[cc][q * QR + k]; tile[cc][q * QR + k] = acc; }
+        qsum[q][cc] = acc;
+        __syncthreads();
+        T add = carry[cc];
+        for (int j = 0; j < q; j++) add += qsum[j][cc];
+        for (int k = 0; k < QR; k++) tile[cc][q * QR + k] += add;
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < 64 * SEGR; idx += 256) {
+        const int tt = idx >> 6, cc = idx & 63;
+        const long t = t0 + tt;
+        const int c = c0 + cc;
+        if (t < nt && c < nc) out[(u64)t * nc + c] = tile[cc][tt];
+    }
+}
+
+template <typename T, int SEGR>
+static int run_cumsum(hipStream_t st, const u8 *stream, u8 *out, const u64 *d_stream_off, const u64 *d_out_off,
+                      const u32 *d_rows, const int *d_status, int n_chunks, u32 max_rows, int nc, int flags,
+                      u64 *segsums)
+{
+    const int nseg = (max_rows + SEGR - 1) / SEGR;
+    const int of = (flags & MTS_FLAG_ORDER_F) ? 1 : 0;
+    if (flags & MTS_FLAG_SPATIAL_DIFF) {
+        dim3 g((max_rows + 255) / 256, n_chunks);
+        hipLaunchKernelGGL(k_spatial_cumsum<T>, g, dim3(256), 0, st, (u8 *)stream, d_stream_off, d_rows, d_status, nc, of);
+    }
+    dim3 grid(nseg, (nc + 63) / 64, n_chunks), block(256);
+    if (flags & MTS_FLAG_TIME_DIFF)
+        hipLaunchKernelGGL((k_seg_sums<T, SEGR>), grid, block, 0, st, stream, d_stream_off, d_rows, d_status, nc, of, nseg, segsums);
+    hipLaunchKernelGGL((k_cumsum_transpose<T, SEGR>), grid, block, 0, st, stream, out, d_stream_off, d_out_off, d_rows,
+                       d_status, nc, flags, nseg, segsums);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
+static int segr_for(int itemsize) { return itemsize <= 2 ? 256 : itemsize == 4 ? 128 : 64; }
+
+size_t cumsum_scratch_bytes(int n_chunks, u32 max_rows, int n_channels)
+{
+    // worst case SEGR = 64
+    return (size_t)n_chunks * ((max_rows + 63) / 64) * n_channels * sizeof(u64) + 256;
+}
+
+int launch_cumsum_transpose(hipStream_t st, const void *d_stream, void *d_out, const u64 *d_stream_off,
+                            const u64 *d_out_off, const u32 *d_rows, const int *d_status, int n_chunks,
+                            u32 max_rows, int n_channels, int itemsize, int flags, void *d_segsums)
+{
+    if (n_chunks == 0 || max_rows == 0) return MTS_OK;
+    const u8 *s = (const u8 *)d_stream;
+    u8 *o = (u8 *)d_out;
+    u64 *ss = (u64 *)d_segsums;
+    (void)segr_for;
+    switch (itemsize) {
+    case 1: return run_cumsum<u8, 256>(st, s, o, d_stream_off, d_out_off, d_rows, d_status, n_chunks, max_rows, n_channels, flags, ss);
+    case 2: return run_cumsum<u16, 256>(st, s, o, d_stream_off, d_out_off, d_rows, d_status, n_chunks, max_rows, n_channels, flags, ss);
+    case 4: return run_cumsum<u32, 128>(st, s, o, d_stream_off, d_out_off, d_rows, d_status, n_chunks, max_rows, n_channels, flags, ss);
+    case 8: return run_cumsum<u64, 64>(st, s, o, d_stream_off, d_out_off, d_rows, d_status, n_chunks, max_rows, n_channels, flags, ss);
+    default: return MTS_E_ARG;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic int16 recording: integer-exact, counter based
+// ------------------------------------------------------------------------------------------------
+__constant__ int c_taps[64] = {256, 230, 207, 187, 168, 151, 136, 122, 110, 99, 89, 80, 72, 65, 59, 53,
+                               47, 43, 38, 35, 31, 28, 25, 23, 20, 18, 17, 15, 13, 12, 11, 10,
+                               9, 8, 7, 6, 6, 5, 5, 4, 4, 3, 3, 3, 2, 2, 2, 2,
+                               2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0};
+
+__device__ __forceinline__ int synth_noise(long t, int c, int nc, u64 seedx)
+{
+    u64 idx = (u64)(t * (long)nc + c) ^ seedx;
+    u64 z = idx + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (int)((z & 0xffff) + ((z >> 16) & 0xffff) + ((z >> 32) & 0xffff) + (z >> 48)) - 131070;
+}
+
+// each thread produces RUN consecutive time samples of one channel, reusing the noise window
+constexpr int SYNTH_RUN = 32;
+__global__ __launch_bounds__(256) void k_synth(int16_t *out, long t0, long t1, int nc, u64 seedx)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nc) return;
+    const long ta = t0 + (long)blockIdx.y * SYNTH_RUN;
+    if (ta >= t1) return;
+    int s[64 + SYNTH_RUN - 1];
+#pragma unroll
+    for (int k = 0; k < 64 + SYNTH_RUN - 1; k++) s[k] = synth_noise(ta - 63 + k, c, nc, seedx);
+#pragma unroll
+    for (int r = 0; r < SYNTH_RUN; r++) {
+        const long t = ta + r;
+        if (t >= t1) break;
+        int y = 0;
+#pragma unroll
+        for (int k = 0; k < 60; k++) y += c_taps[k] * s[63 + r - k];
+        out[(t - t0) * nc + c] = (int16_t)((4 * y) >> 23);
+    }
+}
+
+int launch_synth_int16(hipStream_t st, int16_t *d_out, long t0, long t1, int n_channels, long seed)
+{
+    if (t1 <= t0) return MTS_OK;
+    const u64 seedx = (u64)seed * 0xD1B54A32D192ED03ull;
+    const long nrun = (t1 - t0 + SYNTH_RUN - 1) / SYNTH_RUN;
+    // grid.y is limited to 65535: loop in slabs
+    for (long y0 = 0; y0 < nrun; y0 += 65535) {
+        const long ny = nrun - y0 < 65535 ? nrun - y0 : 65535;
+        dim3 grid((n_channels + 255) / 256, (unsigned)ny);
+        hipLaunchKernelGGL(k_synth, grid, dim3(256), 0, st, d_out + (y0 * SYNTH_RUN) * n_channels, t0 + y0 * SYNTH_RUN, t1, n_channels, seedx);
+    }
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
+}  // namespace mts

@@ -1,0 +1,247 @@
+"""ctypes binding of libmtscomp_hip.so (include/mtscomp_hip.h).
+
+This is the only compute path of the package: there is no CPU fallback.  Loading fails loudly when
+the shared library has not been built (``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C mtscomp_amd/csrc``) and every compute call raises ``HipError`` when no MI355X is visible.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / 'libmtscomp_hip.so'
+
+FLAG_TIME_DIFF = 1
+FLAG_SPATIAL_DIFF = 2
+FLAG_ORDER_F = 4
+
+CHUNK_OK = 0
+CHUNK_CORRUPT = -1
+CHUNK_BADSIZE = -2
+
+E_NODEV = -2
+E_UNSUPPORTED = -5
+
+
+class HipError(RuntimeError):
+    def __init__(self, code, what, detail=''):
+        self.code = code
+        super().__init__('%s failed: %s (%d)%s' % (what, _strerror(code), code, (': ' + detail) if detail else ''))
+
+
+_lib = None
+
+
+def _strerror(code):
+    try:
+        return lib().mts_strerror(code).decode()
+    except Exception:  # pragma: no cover
+        return '?'
+
+
+def lib():
+    """The loaded shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            '%s is missing: build the HIP extension first (make -C mtscomp_amd/csrc). '
+            'mtscomp_amd has no CPU code path.' % LIB_PATH)
+    L = C.CDLL(str(LIB_PATH))
+    vp, lp, ip = C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_int)
+    L.mts_version.restype = C.c_int
+    L.mts_device_count.restype = C.c_int
+    L.mts_strerror.restype = C.c_char_p
+    L.mts_strerror.argtypes = [C.c_int]
+    L.mts_last_error.restype = C.c_char_p
+    L.mts_compress_bound.restype = C.c_long
+    L.mts_compress_bound.argtypes = [C.c_long]
+    L.mts_delta_transpose.argtypes = [C.c_int, vp, C.c_long, C.c_int, C.c_int, C.c_int, vp]
+    L.mts_cumsum_transpose.argtypes = [C.c_int, vp, C.c_long, C.c_int, C.c_int, C.c_int, vp]
+    L.mts_compress_chunks.argtypes = [C.c_int, vp, C.c_int, C.c_int, lp, C.c_int, C.c_int, C.c_int, vp, lp, lp]
+    L.mts_decompress_chunks.argtypes = [C.c_int, vp, lp, lp, lp, C.c_int, C.c_int, C.c_int, C.c_int, vp, lp, ip]
+    L.mts_dev_compress_chunks.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, lp, C.c_int, C.c_int, C.c_int, vp, lp, lp]
+    L.mts_dev_decompress_chunks.argtypes = [C.c_int, vp, vp, lp, lp, lp, C.c_int, C.c_int, C.c_int, C.c_int, vp, lp, ip]
+    L.mts_dev_synth_int16.argtypes = [C.c_int, vp, vp, C.c_long, C.c_long, C.c_int, C.c_long]
+    L.mts_last_stage_times.restype = C.c_int
+    L.mts_last_stage_times.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    L.mts_debug_match_tables.argtypes = [C.c_int, vp, C.c_long, C.c_int, vp, vp]
+    L.mts_debug_tokens.argtypes = [C.c_int, vp, C.c_long, C.c_int, vp, lp]
+    L.mts_debug_deflate.argtypes = [C.c_int, vp, C.c_long, C.c_int, vp, C.c_long, lp]
+    L.mts_debug_inflate.argtypes = [C.c_int, vp, C.c_long, vp, C.c_long, lp, ip]
+    L.mts_release.restype = None
+    _lib = L
+    return L
+
+
+EXPORTS = ['mts_version', 'mts_device_count', 'mts_strerror', 'mts_last_error', 'mts_compress_bound',
+           'mts_delta_transpose', 'mts_cumsum_transpose', 'mts_compress_chunks', 'mts_decompress_chunks',
+           'mts_dev_compress_chunks', 'mts_dev_decompress_chunks', 'mts_dev_synth_int16',
+           'mts_last_stage_times', 'mts_debug_match_tables', 'mts_debug_tokens', 'mts_debug_deflate',
+           'mts_debug_inflate', 'mts_release']
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise HipError(rc, what, lib().mts_last_error().decode())
+
+
+def device_count():
+    return int(lib().mts_device_count())
+
+
+def require_device():
+    n = device_count()
+    if n <= 0:
+        raise HipError(E_NODEV, 'mtscomp_amd', 'no MI355X (gfx950) device visible; there is no CPU fallback')
+    return n
+
+
+def compress_bound(n):
+    return int(lib().mts_compress_bound(int(n)))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _longs(seq):
+    return np.ascontiguousarray(np.asarray(seq, dtype=np.int64))
+
+
+def _lp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_long))
+
+
+def make_flags(do_time_diff=True, do_spatial_diff=False, chunk_order='F'):
+    return ((FLAG_TIME_DIFF if do_time_diff else 0) | (FLAG_SPATIAL_DIFF if do_spatial_diff else 0) |
+            (FLAG_ORDER_F if chunk_order == 'F' else 0))
+
+
+def check_dtype(dtype):
+    dtype = np.dtype(dtype)
+    if dtype.kind not in 'iu' or dtype.itemsize not in (1, 2, 4, 8):
+        raise NotImplementedError(
+            'the MI355X codec handles integer dtypes of 1/2/4/8 bytes; got %s' % dtype)
+    return dtype
+
+
+# ------------------------------------------------------------------------------------------------
+# host-buffer entry points
+# ------------------------------------------------------------------------------------------------
+def delta_transpose(chunk, flags, device=0):
+    chunk = np.ascontiguousarray(chunk)
+    check_dtype(chunk.dtype)
+    nt, nc = chunk.shape
+    out = np.empty(chunk.nbytes, dtype=np.uint8)
+    _check(lib().mts_delta_transpose(device, _ptr(chunk), nt, nc, chunk.itemsize, flags, _ptr(out)),
+           'mts_delta_transpose')
+    return out
+
+
+def cumsum_transpose(stream, nt, nc, dtype, flags, device=0):
+    dtype = check_dtype(dtype)
+    stream = np.ascontiguousarray(np.frombuffer(stream, dtype=np.uint8) if not isinstance(stream, np.ndarray)
+                                  else stream.view(np.uint8).ravel())
+    assert stream.size == nt * nc * dtype.itemsize
+    out = np.empty((nt, nc), dtype=dtype)
+    _check(lib().mts_cumsum_transpose(device, _ptr(stream), nt, nc, dtype.itemsize, flags, _ptr(out)),
+           'mts_cumsum_transpose')
+    return out
+
+
+def compress_chunks(data, chunk_bounds, flags, level=6, device=0):
+    """data: C-contiguous (rows, n_channels) array whose row 0 is chunk_bounds[0].
+    Returns the list of zlib streams, one per chunk."""
+    data = np.ascontiguousarray(data)
+    check_dtype(data.dtype)
+    b = _longs(chunk_bounds)
+    n_chunks = len(b) - 1
+    assert data.shape[0] == b[-1] - b[0]
+    row = data.shape[1] * data.itemsize
+    bounds = [(compress_bound(int(b[i + 1] - b[i]) * row) + 15) // 16 * 16 for i in range(n_chunks)]
+    slots = _longs(np.concatenate(([0], np.cumsum(bounds)))[:-1]) if n_chunks else _longs([])
+    out = np.empty(int(sum(bounds)) + 16, dtype=np.uint8)
+    sizes = np.zeros(max(n_chunks, 1), dtype=np.int64)
+    _check(lib().mts_compress_chunks(device, _ptr(data), data.shape[1], data.itemsize, _lp(b), n_chunks, flags,
+                                     level, _ptr(out), _lp(slots), _lp(sizes)), 'mts_compress_chunks')
+    return [out[int(slots[i]):int(slots[i]) + int(sizes[i])].tobytes() for i in range(n_chunks)]
+
+
+def decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=0):
+    """cbufs: list of bytes-like compressed chunks.  Returns (status list, list of arrays or None)."""
+    dtype = check_dtype(dtype)
+    n = len(cbufs)
+    if n == 0:
+        return [], []
+    lens = _longs([len(c) for c in cbufs])
+    offs = _longs(np.concatenate(([0], np.cumsum(lens)))[:-1])
+    cdata = np.frombuffer(b''.join(bytes(c) for c in cbufs) + b'\0' * 16, dtype=np.uint8)
+    rows = _longs(n_rows)
+    sizes = rows * (n_channels * dtype.itemsize)
+    ooffs = _longs(np.concatenate(([0], np.cumsum((sizes + 255) // 256 * 256)))[:-1])
+    out = np.empty(int(ooffs[-1] + sizes[-1]) + 256, dtype=np.uint8)
+    status = np.zeros(n, dtype=np.int32)
+    _check(lib().mts_decompress_chunks(device, _ptr(cdata), _lp(offs), _lp(lens), _lp(rows), n, n_channels,
+                                       dtype.itemsize, flags, _ptr(out), _lp(ooffs),
+                                       status.ctypes.data_as(C.POINTER(C.c_int))), 'mts_decompress_chunks')
+    arrays = []
+    for i in range(n):
+        if status[i] == CHUNK_OK:
+            a = out[int(ooffs[i]):int(ooffs[i] + sizes[i])].view(dtype).reshape(int(rows[i]), n_channels)
+            arrays.append(a.copy())
+        else:
+            arrays.append(None)
+    return [int(s) for s in status], arrays
+
+
+def last_stage_times(device=0):
+    names = (C.c_char_p * 32)()
+    ms = (C.c_float * 32)()
+    n = lib().mts_last_stage_times(device, names, ms, 32)
+    return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+
+# ------------------------------------------------------------------------------------------------
+# debug taps (GPU parity tests)
+# ------------------------------------------------------------------------------------------------
+def _u8(data):
+    return np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8)) if not isinstance(data, np.ndarray) \
+        else np.ascontiguousarray(data.view(np.uint8).ravel())
+
+
+def debug_match_tables(data, level=6, device=0):
+    a = _u8(data)
+    tf = np.zeros(max(a.size, 1), dtype=np.uint32)
+    tq = np.zeros(max(a.size, 1), dtype=np.uint32)
+    _check(lib().mts_debug_match_tables(device, _ptr(a), a.size, level, _ptr(tf), _ptr(tq)), 'mts_debug_match_tables')
+    return tf[:a.size], tq[:a.size]
+
+
+def debug_tokens(data, level=6, device=0):
+    a = _u8(data)
+    toks = np.zeros((a.size + 1, 2), dtype=np.uint16)
+    n = C.c_long(0)
+    _check(lib().mts_debug_tokens(device, _ptr(a), a.size, level, _ptr(toks), C.byref(n)), 'mts_debug_tokens')
+    return toks[:n.value].copy()
+
+
+def debug_deflate(data, level=6, device=0):
+    a = _u8(data)
+    cap = compress_bound(a.size) + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_long(0)
+    _check(lib().mts_debug_deflate(device, _ptr(a), a.size, level, _ptr(out), cap, C.byref(n)), 'mts_debug_deflate')
+    return out[:n.value].tobytes()
+
+
+def debug_inflate(zbytes, expect_len, device=0):
+    """Returns (status, bytes)."""
+    z = _u8(zbytes)
+    out = np.zeros(max(expect_len, 1), dtype=np.uint8)
+    n, st = C.c_long(0), C.c_int(0)
+    _check(lib().mts_debug_inflate(device, _ptr(z), z.size, _ptr(out), expect_len, C.byref(n), C.byref(st)),
+           'mts_debug_inflate')
+    return int(st.value), out[:n.value].tobytes()

@@ -1,0 +1,190 @@
+"""GPU parity, stage by stage, through the C ABI (libmtscomp_hip.so) against the CPU oracle.
+
+Bit-exact everywhere: these are integer / byte / index computations."""
+import zlib
+
+import numpy as np
+import pytest
+
+from mtscomp_amd import hip
+from oracle import oracle as O
+from tests.inputs import cases_small, ar1_stream, repeats
+
+pytestmark = pytest.mark.gpu
+CASES = cases_small()
+
+
+def _first_diff(a, b):
+    a = np.asarray(a).ravel()
+    b = np.asarray(b).ravel()
+    n = min(a.size, b.size)
+    d = np.nonzero(a[:n] != b[:n])[0]
+    return (int(d[0]) if d.size else n), a.size, b.size
+
+
+def test_device_visible():
+    assert hip.require_device() >= 1
+
+
+@pytest.mark.parametrize('dtype', ['int16', 'uint16', 'uint8', 'int8', 'int32', 'int64'])
+@pytest.mark.parametrize('flags', range(8))
+def test_k1_k2_transforms(dtype, flags):
+    r = np.random.RandomState(flags + 10)
+    info = np.iinfo(dtype)
+    for shape in [(37, 11), (1, 385), (700, 70), (513, 1), (300, 129)]:
+        x = r.randint(info.min, int(info.max) + 1, size=shape, dtype=np.int64).astype(dtype)
+        want = O.delta_transpose(x, flags)
+        got = hip.delta_transpose(x, flags)
+        assert np.array_equal(got, want), (shape, _first_diff(got, want))
+        back = hip.cumsum_transpose(want, shape[0], shape[1], dtype, flags)
+        assert back.dtype == x.dtype and np.array_equal(back, x), (shape, _first_diff(back, x))
+
+
+def test_k1_k2_neuropixels_shape():
+    from mtscomp_amd.synth import synth_int16
+    x = synth_int16(0, 3000, 385, 0)
+    want = O.delta_transpose(x, 5)
+    got = hip.delta_transpose(x, 5)
+    assert np.array_equal(got, want)
+    assert np.array_equal(hip.cumsum_transpose(want, 3000, 385, 'int16', 5), x)
+
+
+TABLE_CASES = ['three', 'aaa', 'zeros_1k', 'rand_300', 'first50', 'ar1_8ch', 'text_100k', 'zeros_70k',
+               'rand4_50k', 'repeats_200k', 'ar1_64ch_4k', 'rand_70k', 'ramp', 'wrap16']
+
+
+@pytest.mark.parametrize('name', TABLE_CASES)
+def test_match_tables(name):
+    data = CASES[name]
+    tf, tq = O.match_tables(data, 6)
+    gf, gq = hip.debug_match_tables(data, 6)
+    i, _, _ = _first_diff(gf, tf)
+    assert np.array_equal(gf, tf), ('t_full', i, hex(int(gf[i])), hex(int(tf[i])))
+    i, _, _ = _first_diff(gq, tq)
+    assert np.array_equal(gq, tq), ('t_quarter', i, hex(int(gq[i])), hex(int(tq[i])))
+
+
+@pytest.mark.parametrize('level', [4, 5, 7, 8, 9])
+def test_match_tables_other_levels(level):
+    data = CASES['repeats_200k'][:120000]
+    tf, tq = O.match_tables(data, level)
+    gf, gq = hip.debug_match_tables(data, level)
+    assert np.array_equal(gf, tf) and np.array_equal(gq, tq)
+
+
+@pytest.mark.parametrize('name', TABLE_CASES + ['empty', 'one', 'two'])
+def test_tokens(name):
+    data = CASES[name]
+    _, toks, _, _ = O.deflate(data, 6, report=True)
+    got = hip.debug_tokens(data, 6)
+    assert got.shape == toks.shape, (got.shape, toks.shape, _first_diff(got, toks))
+    assert np.array_equal(got, toks), _first_diff(got, toks)
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_deflate_bytes(name):
+    data = CASES[name]
+    want = zlib.compress(data, 6)
+    got = hip.debug_deflate(data, 6)
+    assert len(got) == len(want), (len(got), len(want), _first_diff(np.frombuffer(got, np.uint8), np.frombuffer(want, np.uint8)))
+    assert got == want, _first_diff(np.frombuffer(got, np.uint8), np.frombuffer(want, np.uint8))
+
+
+@pytest.mark.parametrize('level', [4, 5, 7, 8, 9])
+def test_deflate_bytes_levels(level):
+    for name in ('text_100k', 'ar1_8ch', 'repeats_200k'):
+        data = CASES[name]
+        assert hip.debug_deflate(data, level) == zlib.compress(data, level), name
+
+
+def test_deflate_block_boundaries():
+    r = np.random.RandomState(7)
+    base = r.randint(0, 256, size=16383 * 2 + 40).astype(np.uint8).tobytes()
+    for n in (16382, 16383, 16384, 32766, 32767):
+        assert hip.debug_deflate(base[:n], 6) == zlib.compress(base[:n], 6), n
+    for extra in (3, 5, 9):
+        d = base[:16382] + base[100:100 + extra]
+        assert hip.debug_deflate(d, 6) == zlib.compress(d, 6), extra
+
+
+def test_deflate_multi_tile():
+    # > TILE (98304) positions: exercises the halo between match-stage tiles and many parse segments
+    data = ar1_stream(7000, 16, seed=4)           # 224000 bytes
+    assert hip.debug_deflate(data, 6) == zlib.compress(data, 6)
+    data = repeats(350000, 9)
+    assert hip.debug_deflate(data, 6) == zlib.compress(data, 6)
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_inflate(name):
+    data = CASES[name]
+    for level in (0, 1, 6, 9):
+        z = zlib.compress(data, level)
+        st, out = hip.debug_inflate(z, len(data))
+        assert st == 0 and out == data, (level, st, _first_diff(np.frombuffer(out, np.uint8), np.frombuffer(data, np.uint8)))
+    st, out = hip.debug_inflate(zlib.compress(data) + b'trailing', len(data))
+    assert st == 0 and out == data
+
+
+def test_inflate_other_encoders():
+    data = CASES['text_100k']
+    for strategy in (zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+        co = zlib.compressobj(6, zlib.DEFLATED, 15, 8, strategy)
+        z = co.compress(data) + co.flush()
+        st, out = hip.debug_inflate(z, len(data))
+        assert st == 0 and out == data, strategy
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 8)
+    z = b''.join(co.compress(data[i:i + 5000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(data), 5000)) + co.flush()
+    st, out = hip.debug_inflate(z, len(data))
+    assert st == 0 and out == data
+
+
+def test_inflate_errors():
+    data = CASES['ar1_8ch']
+    z = zlib.compress(data)
+    bad = [b'', z[:len(z) // 2], z[:-2], z[:-1] + bytes([z[-1] ^ 1]), b'\x79' + z[1:], b'\x78\x9c\x07',
+           z[:len(z) // 2] + bytes([z[len(z) // 2] ^ 0x55]) + z[len(z) // 2 + 1:]]
+    for b in bad:
+        st, _ = hip.debug_inflate(b, len(data))
+        assert st == hip.CHUNK_CORRUPT, (len(b), st)
+    st, _ = hip.debug_inflate(z, len(data) - 1)
+    assert st == hip.CHUNK_BADSIZE
+    st, _ = hip.debug_inflate(z, len(data) + 1)
+    assert st == hip.CHUNK_BADSIZE
+    r = np.random.RandomState(5)
+    for _ in range(60):
+        b = bytearray(z)
+        i = int(r.randint(2, len(b) - 4))
+        b[i] ^= 1 << int(r.randint(0, 8))
+        try:
+            want = zlib.decompress(bytes(b))
+        except zlib.error:
+            want = None
+        st, out = hip.debug_inflate(bytes(b), len(data))
+        if want is None or len(want) != len(data):
+            assert st != 0
+        else:
+            assert st == 0 and out == want
+
+
+@pytest.mark.parametrize('flags', [5, 7, 4, 1, 0, 3])
+def test_compress_decompress_chunks(flags):
+    from mtscomp_amd.synth import synth_int16
+    x = synth_int16(0, 5300, 24, 3)
+    bounds = [0, 1000, 2000, 3000, 4000, 5000, 5300]
+    td, sd, order = bool(flags & 1), bool(flags & 2), 'F' if flags & 4 else 'C'
+    want = [O.ref_compress_chunk(x[bounds[i]:bounds[i + 1]], td, sd, order) for i in range(6)]
+    got = hip.compress_chunks(x, bounds, flags, 6)
+    for i in range(6):
+        assert got[i] == want[i], (i, len(got[i]), len(want[i]))
+    rows = [bounds[i + 1] - bounds[i] for i in range(6)]
+    st, arrs = hip.decompress_chunks(want, rows, 24, 'int16', flags)
+    assert st == [0] * 6
+    for i in range(6):
+        assert np.array_equal(arrs[i], x[bounds[i]:bounds[i + 1]]), i
+    # one corrupt chunk does not stop the others
+    bad = list(want)
+    bad[2] = bad[2][:50] + bytes([bad[2][50] ^ 0xff]) + bad[2][51:]
+    st, arrs = hip.decompress_chunks(bad, rows, 24, 'int16', flags)
+    assert st[2] != 0 and [s for i, s in enumerate(st) if i != 2] == [0] * 5
+    assert np.array_equal(arrs[5], x[5000:5300])
