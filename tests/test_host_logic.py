@@ -1,0 +1,216 @@
+"""Host-side logic without a GPU: C-ABI surface, error behaviour, scheduler/sharding, config, Reader
+semantics (driven through the test-only OracleCodec)."""
+import ctypes
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import mtscomp_amd
+from mtscomp_amd import api, hip
+from tests.codec_oracle import OracleCodec
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture
+def tmp_cfg(tmp_path, monkeypatch):
+    monkeypatch.setattr(api, 'CONFIG_PATH', tmp_path / '.mtscomp')
+    return tmp_path
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    header = (ROOT / 'include' / 'mtscomp_hip.h').read_text()
+    declared = set(re.findall(r'\b(mts_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(hip.EXPORTS)
+    L = ctypes.CDLL(str(hip.LIB_PATH))
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert hip.lib().mts_version() >= 100
+    assert hip.compress_bound(23100000) == 23100000 + (23100000 >> 12) + (23100000 >> 14) + (23100000 >> 25) + 13
+    assert hip.lib().mts_strerror(-2) == b'no usable gfx950 device'
+
+
+@pytest.mark.skipif(Path('/dev/kfd').exists(), reason='needs a box without GPU')
+def test_no_cpu_fallback_without_device(tmp_cfg):
+    assert hip.device_count() == 0
+    with pytest.raises(hip.HipError):
+        hip.delta_transpose(np.zeros((4, 4), dtype=np.int16), 5)
+    api.set_codec(None)
+    arr = np.zeros((100, 4), dtype=np.int16)
+    arr.tofile(tmp_cfg / 'd.bin')
+    with pytest.raises(hip.HipError):
+        mtscomp_amd.compress(tmp_cfg / 'd.bin', sample_rate=100., n_channels=4, dtype='int16')
+    # the product package must not reach for the oracle
+    src = ''.join(p.read_text() for p in (ROOT / 'mtscomp_amd').glob('*.py'))
+    assert 'oracle' not in src.replace('test-only', '').replace('CPU oracle here', '')
+
+
+def test_config_defaults_and_merge(tmp_cfg):
+    c = mtscomp_amd.read_config()
+    assert c.check_after_compress and c.check_after_decompress and c.do_time_diff and not c.do_spatial_diff
+    assert c.algorithm == 'zlib' and c.chunk_order == 'F' and c.comp_level == -1 and c.cache_size == 10
+    mtscomp_amd.write_config(sample_rate=1234, chunk_duration=None, foo='bar')
+    c = mtscomp_amd.read_config(n_channels=7)
+    assert c.sample_rate == 1234 and c.chunk_duration == 1. and c.foo == 'bar' and c.n_channels == 7
+
+
+def test_load_raw_data(tmp_cfg):
+    p = tmp_cfg / 'x.bin'
+    for arr in [np.zeros((0, 1)), np.zeros((10, 10)), (np.random.randn(100, 10) * 100).astype(np.int16)]:
+        arr.tofile(p)
+        for mmap in (True, False):
+            got = mtscomp_amd.load_raw_data(p, n_channels=arr.shape[1], dtype=arr.dtype, mmap=mmap)
+            assert np.array_equal(got, arr)
+            del got
+    with pytest.raises(ValueError):
+        mtscomp_amd.load_raw_data(p, n_channels=7, dtype=np.int16)
+
+
+def _write(tmp, arr, **kw):
+    raw = tmp / 'data.bin'
+    arr.tofile(raw)
+    codec = kw.pop('codec', None) or OracleCodec()
+    mtscomp_amd.compress(raw, tmp / 'data.cbin', tmp / 'data.ch', sample_rate=1234., n_channels=arr.shape[1],
+                         dtype=arr.dtype, codec=codec, **kw)
+    return mtscomp_amd.decompress(tmp / 'data.cbin', tmp / 'data.ch', codec=codec), codec
+
+
+def test_errors_like_the_reference(tmp_cfg):
+    arr = np.zeros((100, 4), dtype=np.int16)
+    raw = tmp_cfg / 'd.bin'
+    arr.tofile(raw)
+    codec = OracleCodec()
+    with pytest.raises(ValueError):
+        mtscomp_amd.compress(raw, n_channels=4, dtype='int16', codec=codec)                 # no sample rate
+    with pytest.raises(ValueError):
+        mtscomp_amd.compress(raw, sample_rate=100., dtype='int16', codec=codec)             # no n_channels
+    with pytest.raises(ValueError):
+        mtscomp_amd.compress(raw, sample_rate=100., n_channels=4, codec=codec)              # no dtype
+    with pytest.raises(ValueError):
+        mtscomp_amd.compress(raw, sample_rate=100., n_channels=3, dtype='int16', codec=codec)   # bad size
+    (tmp_cfg / 'e.bin').write_bytes(b'')
+    with pytest.raises(Exception):
+        mtscomp_amd.compress(tmp_cfg / 'e.bin', sample_rate=100., n_channels=4, dtype='int16', codec=codec)
+
+
+def test_check_fail_raises_runtime_error(tmp_cfg):
+    # tests.py:345-378: flip bytes of the raw file between write and check
+    arr = (np.random.RandomState(0).randn(5000, 8) * 1000).astype(np.int16)
+    raw = tmp_cfg / 'd.bin'
+    arr.tofile(raw)
+
+    def before_check(w):
+        w.close()
+        with open(raw, 'r+b') as f:
+            f.seek(raw.stat().st_size // 2)
+            f.write(b'\x55' * 8)
+        w.open(raw, sample_rate=1234., n_channels=8, dtype=arr.dtype)
+    w = mtscomp_amd.Writer(before_check=before_check, codec=OracleCodec())
+    w.open(raw, sample_rate=1234., n_channels=8, dtype=arr.dtype)
+    with pytest.raises(RuntimeError):
+        w.write(tmp_cfg / 'd.cbin', tmp_cfg / 'd.ch')
+
+
+def test_reader_indexing_matches_numpy(tmp_cfg):
+    # tests.py:246-342
+    arr = (np.random.RandomState(1).randn(6997, 19) * 3000).astype(np.int16)
+    r, _ = _write(tmp_cfg, arr)
+    N = arr.shape[0]
+    rs = np.random.RandomState(2)
+    items = [slice(a, b, c) for a in (None, 0, 1, -1) for b in (None, 0, 1, -1) for c in (None, 2, 3, N // 2, N)]
+    items += [slice(*map(int, t)) for t in rs.randint(-100, 2 * N, size=(100, 3)) if t[2] > 0]
+    items += [(slice(None),), (slice(None), slice(1, -1, 2)), (slice(None), [1, 5, 3]), (slice(None), 1),
+              (1, slice(None)), (2, 1), 0, 1, N - 2, N - 1, -1, -N]
+    items += rs.randint(-N, N, size=50).tolist()
+    for s in items:
+        got, want = r[s], arr[s]
+        assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), s
+    table = [(-1, 2, 0, 0), (0, 0, 0, 0), (1233, 1233, 0, 0), (1233, 1234, 0, 1), (1234, 1234, 1, 1),
+             (1234, 1235, 1, 1), (-10000, 10000, 0, 5), (1234, 10000, 1, 5), (6996, 10000, 5, 5), (6998, 10000, 5, 5)]
+    for i0, i1, c0, c1 in table:
+        assert r._chunks_for_interval(i0, i1) == (c0, c1)
+    r.close()
+
+
+def test_batched_decode_and_cache(tmp_cfg):
+    arr = (np.random.RandomState(3).randn(6997, 5) * 300).astype(np.int16)
+    r, codec = _write(tmp_cfg, arr, check_after_compress=False)
+    r.set_cache_size(2)
+    codec.calls.clear()
+    d = r.decompress_chunks([0, 1, 2])          # tests.py:413-430
+    assert sorted(d) == [0, 1, 2] and codec.calls == [('decompress', 3)]
+    assert len(r._cache) == 2
+    d = r.decompress_chunks([1, 2, 3], pool=r.start_thread_pool())
+    r.stop_thread_pool()
+    assert sorted(d) == [1, 2, 3] and codec.calls[-1] == ('decompress', 1)      # 1, 2 came from the cache
+    codec.calls.clear()
+    x = r[1000:4000]                            # 3-4 chunks in ONE codec call
+    assert np.array_equal(x, arr[1000:4000]) and len(codec.calls) == 1
+    r.close()
+
+
+def test_corrupt_and_wrong_size_map_to_reference_exceptions(tmp_cfg):
+    arr = (np.random.RandomState(4).randn(3000, 5) * 300).astype(np.int16)
+    r, codec = _write(tmp_cfg, arr)
+    r.close()
+    meta = json.loads((tmp_cfg / 'data.ch').read_text())
+    b = bytearray((tmp_cfg / 'data.cbin').read_bytes())
+    b[meta['chunk_offsets'][1] + 30] ^= 0xff
+    (tmp_cfg / 'data.cbin').write_bytes(bytes(b))
+    r = mtscomp_amd.decompress(tmp_cfg / 'data.cbin', tmp_cfg / 'data.ch', codec=codec)
+    assert np.array_equal(r[:1000], arr[:1000])
+    with pytest.raises(IOError, match='Compressed chunk #1 is corrupted'):
+        r[1300:1400]
+    r.close()
+    meta['chunk_bounds'][-1] -= 1            # valid stream, wrong expected size -> AssertionError (mtscomp.py:628)
+    r = mtscomp_amd.Reader(codec=codec)
+    r.open(tmp_cfg / 'data.cbin', meta)
+    with pytest.raises(AssertionError):
+        r[2500:2600]
+    r.close()
+
+
+@pytest.mark.parametrize('n_devices', [1, 2, 3])
+def test_round_robin_sharding_of_hipcodec(n_devices, monkeypatch):
+    """HipCodec shards chunk i -> device i mod G and reassembles in order (host logic only: the device
+    calls are replaced by the oracle)."""
+    from oracle import oracle as O
+    seen = []
+
+    def fake_compress(data, bounds, flags, level=6, device=0):
+        seen.append((device, len(bounds) - 1))
+        return [O.compress_chunk(np.ascontiguousarray(data[bounds[i]:bounds[i + 1]]), flags, level)
+                for i in range(len(bounds) - 1)]
+    monkeypatch.setattr(hip, 'require_device', lambda: n_devices)
+    monkeypatch.setattr(hip, 'compress_chunks', fake_compress)
+    codec = api.HipCodec()
+    assert codec.devices == list(range(n_devices))
+    x = (np.random.RandomState(5).randn(700, 6) * 100).astype(np.int16)
+    chunks = [x[i * 100:(i + 1) * 100] for i in range(7)]
+    got = codec.compress(chunks, 5, 6)
+    assert got == [O.compress_chunk(c, 5, 6) for c in chunks]
+    assert sorted(seen) == sorted((d, len(range(d, 7, n_devices))) for d in range(n_devices))
+
+
+def test_3d_npy_and_options(tmp_cfg):
+    # tests.py:433-448
+    array = np.random.RandomState(6).randint(-5000, 5000, size=(20, 12, 13), dtype=np.int16)
+    p = tmp_cfg / 't.npy'
+    np.save(p, array)
+    codec = OracleCodec()
+    mtscomp_amd.compress(p, out=tmp_cfg / 't.cnpy', outmeta=tmp_cfg / 't.ch', sample_rate=np.prod(array.shape[1:]),
+                         dtype=array.dtype, do_time_diff=False, codec=codec)
+    d = mtscomp_amd.decompress(tmp_cfg / 't.cnpy', cmeta=tmp_cfg / 't.ch', codec=codec)
+    assert np.array_equal(d[:, :].reshape(d.cmeta.shape), array)
+    d.close()
+
+
+@pytest.mark.parametrize('chunk_duration', [.01, .1, 1., 10.])
+def test_chunk_durations(tmp_cfg, chunk_duration):
+    arr = (np.random.RandomState(7).randn(6997, 3) * 300).astype(np.int16)
+    r, _ = _write(tmp_cfg, arr, chunk_duration=chunk_duration)
+    assert np.array_equal(r[:], arr)
+    r.close()
