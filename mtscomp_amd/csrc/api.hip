@@ -185,8 +185,9 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     // ---- workspace ----
     int rc;
     if (!raw_is_stream) { if ((rc = E.stream.ensure(stream_bytes))) return rc; }
-    if ((rc = E.sort_a.ensure((sorted_off + 64) * 4))) return rc;
-    if ((rc = E.sort_b.ensure((sorted_off + 64) * 4))) return rc;
+    const size_t sort_n = align_up(sorted_off + 64, 64);          // u64 entries followed by u16 hashes
+    if ((rc = E.sort_a.ensure(sort_n * 10))) return rc;
+    if ((rc = E.sort_b.ensure(sort_n * 10))) return rc;
     if ((rc = E.tables.ensure((stream_bytes + 64) * sizeof(uint2)))) return rc;
     if ((rc = E.tokens.ensure((toff + 64) * 4))) return rc;
     if ((rc = E.marks.ensure(stream_bytes / 8 + 256))) return rc;
@@ -264,10 +265,13 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         d_stream = E.stream.as<u8>();
     }
     E.t_mark(st, "delta_transpose");
-    if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), E.sort_a.as<u32>(), E.sort_b.as<u32>()))) return rc;
+    u64 *tmp_e = E.sort_a.as<u64>(), *srt_e = E.sort_b.as<u64>();
+    u16 *tmp_h = (u16 *)(tmp_e + sort_n), *srt_h = (u16 *)(srt_e + sort_n);
+    u16 *srt_nb = tmp_h;           // the chain lengths overwrite the pass-1 hashes (dead after pass 2)
+    if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_e, tmp_h, srt_e, srt_h, srt_nb))) return rc;
     E.t_mark(st, "hash_sort");
     uint2 *d_tables = E.tables.as<uint2>();
-    if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), E.sort_b.as<u32>(), d_tables, cfg))) return rc;
+    if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_e, srt_nb, d_tables, cfg))) return rc;
     E.t_mark(st, "match");
     if ((rc = launch_parse_spec(st, d_tables, d_chunks, pb, (int)nseg, cfg))) return rc;
     int round = 0;
@@ -404,20 +408,19 @@ static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const 
     u64 *d_oo = (u64 *)(dp + o_oo);
     u32 *d_rows = (u32 *)(dp + o_rows);
     int *d_status = (int *)(dp + o_status);
-    // launch_inflate expects [stream offsets (u64) | lengths (u32)] contiguous in its scratch
-    if ((rc = E.inf_scratch.ensure(12 * (size_t)n_chunks + 256))) return rc;
-    u64 *d_so2 = E.inf_scratch.as<u64>();
-    u32 *d_nn2 = (u32 *)(d_so2 + n_chunks);
+    {
+        std::vector<u64> clens(n_chunks);
+        for (int i = 0; i < n_chunks; i++) clens[i] = ic[i].c_len;
+        if ((rc = E.inf_scratch.ensure(inflate_scratch_bytes(n_chunks, clens.data(), nn.data())))) return rc;
+    }
     MTS_HIP(hipMemcpyAsync(d_ic, ic.data(), sizeof(InfChunk) * n_chunks, hipMemcpyHostToDevice, st));
     MTS_HIP(hipMemcpyAsync(d_so, so.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
     MTS_HIP(hipMemcpyAsync(d_nn, nn.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
-    MTS_HIP(hipMemcpyAsync(d_so2, so.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
-    MTS_HIP(hipMemcpyAsync(d_nn2, nn.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
     MTS_HIP(hipMemcpyAsync(d_oo, oo.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
     MTS_HIP(hipMemcpyAsync(d_rows, rows.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
     E.t_begin(st);
-    if ((rc = launch_inflate(st, d_cdata, d_ic, n_chunks, E.stream.as<u8>(), E.tokens.as<u32>(), d_res, E.adler.as<u64>(), max_n,
-                             d_status, E.inf_scratch.p, E.inf_scratch.cap, &E))) return rc;
+    if ((rc = launch_inflate(st, d_cdata, d_ic, ic.data(), n_chunks, E.stream.as<u8>(), E.tokens.as<u32>(), d_res, E.adler.as<u64>(),
+                             max_n, d_status, E.inf_scratch.p, &E))) return rc;
     if (d_out) {
         if ((rc = launch_cumsum_transpose(st, E.stream.p, d_out, d_so, d_oo, d_rows, d_status, n_chunks, max_rows, nc, sz, flags,
                                           E.segsums.p))) return rc;

@@ -113,10 +113,10 @@ int launch_adler_stream(hipStream_t st, const u8 *d_stream, const u64 *d_stream_
                         int n_chunks, u32 max_n, u64 *d_adler_acc);
 
 // deflate.hip
-int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles,
-                     u32 *d_tmp, u32 *d_sorted);
+int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u64 *d_tmp_e,
+                     u16 *d_tmp_h, u64 *d_sorted_e, u16 *d_sorted_h, u16 *d_sorted_nb);
 int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles,
-                 const u32 *d_sorted, uint2 *d_tables, LevelCfg cfg);
+                 const u64 *d_sorted_e, const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg);
 struct ParseBufs {
     u32 *entry, *exit_a, *exit_b, *cnt, *tokbase;   // per segment
     u32 *marks;                                     // 1 bit per stream byte (global stream offsets)
@@ -160,10 +160,10 @@ struct InfResult {
     u32 adler_stored;
     u64 end_bit;
 };
-int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, int n_chunks,
-                   u8 *d_stream, u32 *d_tokens, InfResult *d_res, u64 *d_adler_acc, u32 max_n,
-                   int *d_status_out, void *d_scratch, size_t scratch_bytes, void *engine);
+int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, const InfChunk *h_chunks, int n_chunks,
+                   u8 *d_stream, u32 *d_tokens, InfResult *d_res, u64 *d_adler_acc, u32 max_n, int *d_status_out,
+                   void *d_scratch, void *engine);
+size_t inflate_scratch_bytes(int n_chunks, const u64 *c_lens, const u32 *n_expect);
 void inflate_mark(void *engine, hipStream_t st, const char *name);   // stage timing hook (api.hip)
-size_t inflate_scratch_bytes(int n_chunks, u64 total_cbytes);
 
 }  // namespace mts

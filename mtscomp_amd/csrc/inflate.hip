@@ -11,6 +11,10 @@
 //                     lives in an LDS ring; copies that only need older bytes run in parallel,
 //                     the few that depend on the current step are resolved in lane order.
 // followed by the adler32 reduction over the produced stream.
+#include <stdlib.h>
+
+#include <vector>
+
 #include "common.h"
 
 namespace mts {
@@ -91,23 +95,33 @@ __device__ __forceinline__ int chain_decode(u32 v, const u32 (&lc)[MAXL + 1], u3
     return (int)(so + ((v - lo) >> (MAXL - l_)));
 }
 
-// per-lane LDS scratch, lane interleaved (element k of lane L at k*64 + L): 1 KiB per lane
+// Huffman scratch in LDS.  Element k of a user sits at k*stride + lane: stride 64 = one private table set
+// per lane of a wave (64 independent streams), stride 1 / lane 0 = one table set shared by a wave.
 constexpr int INF_LENS = 320;        // u8 code lengths
 constexpr int INF_CNT = 32;          // u16: [0..15] counts, [16..31] offsets
 constexpr int INF_LSYM = 288;        // u16
 constexpr int INF_DSYM = 32;         // u16
-constexpr int INF_LDS_PER_WAVE = 64 * (INF_LENS + 2 * (INF_CNT + INF_LSYM + INF_DSYM));
+constexpr int INF_SET_BYTES = INF_LENS + 2 * (INF_CNT + INF_LSYM + INF_DSYM);      // 1024
+constexpr int INF_LDS_PER_WAVE = 64 * INF_SET_BYTES;
 
 struct LaneLds {
-    u8 *lens; u16 *cnt; u16 *lsym; u16 *dsym; int lane;
-    __device__ __forceinline__ u8 &len(int k) { return lens[k * 64 + lane]; }
-    __device__ __forceinline__ u16 &c(int k) { return cnt[k * 64 + lane]; }
-    __device__ __forceinline__ u16 &ls(int k) { return lsym[k * 64 + lane]; }
-    __device__ __forceinline__ u16 &ds(int k) { return dsym[k * 64 + lane]; }
+    u8 *lens; u16 *cnt; u16 *lsym; u16 *dsym; int lane; int stride;
+    __device__ __forceinline__ void bind(u8 *base, int stride_, int lane_)
+    {
+        stride = stride_; lane = lane_;
+        lens = base;
+        cnt = (u16 *)(base + stride_ * INF_LENS);
+        lsym = cnt + stride_ * INF_CNT;
+        dsym = lsym + stride_ * INF_LSYM;
+    }
+    __device__ __forceinline__ u8 &len(int k) { return lens[k * stride + lane]; }
+    __device__ __forceinline__ u16 &c(int k) { return cnt[k * stride + lane]; }
+    __device__ __forceinline__ u16 &ls(int k) { return lsym[k * stride + lane]; }
+    __device__ __forceinline__ u16 &ds(int k) { return dsym[k * stride + lane]; }
 };
 
 // Build the compare chain + sorted symbol table for lens[first .. first+nsym).
-// returns 0 complete, 1 incomplete, -1 over-subscribed; *maxlen = longest code
+// returns 0 complete, 1 incomplete, -1 over-subscribed; maxlen = longest code
 template <int MAXL, bool DIST>
 __device__ int build_chain(LaneLds &L, int first, int nsym, u32 (&lc)[MAXL + 1], int &maxlen)
 {
@@ -145,34 +159,9 @@ __device__ int build_chain(LaneLds &L, int first, int nsym, u32 (&lc)[MAXL + 1],
 #define INF_CORRUPT (-1)
 #define INF_TOOLONG (-2)
 
-// decodes one deflate block starting at br.pos (just after nothing: reads BFINAL/BTYPE itself).
-// EMIT: write tokens to tk[ntok...].  out_base + nout = bytes produced before each token.
-// token: literal = byte; match = 1<<31 | (len-3) << 16 | (dist-1)
-template <bool EMIT>
-__device__ int decode_block(BitIn &br, LaneLds &L, const u8 *cbytes, u32 *tk, u32 &ntok, u64 &nout, u64 out_limit,
-                            bool &last)
+// Code tables of a fixed (type 1) or dynamic (type 2) block; br stands right after the 3 header bits.
+__device__ int parse_tables(BitIn &br, LaneLds &L, u32 type, u32 (&LC)[16], u32 (&DC)[16])
 {
-    u32 hdr = br.get(3);
-    last = hdr & 1;
-    const u32 type = hdr >> 1;
-    if (br.pos > br.end) return INF_CORRUPT;
-    if (type == 3) return INF_CORRUPT;
-    if (type == 0) {
-        br.seek((br.pos + 7) & ~7ull);
-        const u32 len = br.get(16), nlen = br.get(16);
-        if (br.pos > br.end) return INF_CORRUPT;
-        if ((len ^ 0xffff) != nlen) return INF_CORRUPT;
-        if (br.pos + 8ull * len > br.end) return INF_CORRUPT;
-        if (nout + len > out_limit) return INF_TOOLONG;
-        // bytes are at absolute bit position br.pos (byte aligned) relative to br.w
-        const u8 *src = (const u8 *)br.w + (br.pos >> 3);
-        if (EMIT) for (u32 i = 0; i < len; i++) tk[ntok + i] = src[i];
-        ntok += len; nout += len;
-        br.seek(br.pos + 8ull * len);
-        (void)cbytes;
-        return INF_OK;
-    }
-    u32 LC[16], DC[16];
     int nlen_codes, ndist_codes;
     if (type == 1) {
         for (int i = 0; i < 144; i++) L.len(i) = 8;
@@ -229,62 +218,562 @@ __device__ int decode_block(BitIn &br, LaneLds &L, const u8 *cbytes, u32 *tk, u3
     if (type == 2 && (e < 0 || (e > 0 && ml != 1))) return INF_CORRUPT;
     e = build_chain<15, true>(L, nlen_codes, ndist_codes, DC, ml);
     if (type == 2 && (e < 0 || (e > 0 && ml > 1))) return INF_CORRUPT;
-    for (;;) {
-        br.refill();
-        u32 cl;
-        int si = chain_decode<15>(__brev(br.peek()) >> 17, LC, cl);
-        if (si < 0) return INF_CORRUPT;
-        u32 sym = L.ls(si);
-        br.skip(cl);
-        if (sym < 256) {
-            if (nout + 1 > out_limit) return INF_TOOLONG;
-            if (EMIT) tk[ntok] = sym;
-            ntok++; nout++;
-        } else if (sym == 256) {
-            if (br.pos > br.end) return INF_CORRUPT;
-            break;
-        } else {
-            sym -= 257;
-            if (sym >= 29) return INF_CORRUPT;
-            u32 eb, lbase;
-            if (sym < 8) { eb = 0; lbase = 3 + sym; }
-            else if (sym == 28) { eb = 0; lbase = 258; }
-            else { eb = (sym - 4) >> 2; lbase = 3 + ((4 + (sym & 3)) << eb); }
-            const u32 length = lbase + br.get(eb);
-            br.refill();
-            si = chain_decode<15>(__brev(br.peek()) >> 17, DC, cl);
-            if (si < 0) return INF_CORRUPT;
-            const u32 dsym = L.ds(si);
-            br.skip(cl);
-            if (dsym >= 30) return INF_CORRUPT;
-            u32 dbase;
-            if (dsym < 4) { eb = 0; dbase = 1 + dsym; }
-            else { eb = (dsym - 2) >> 1; dbase = 1 + ((2 + (dsym & 1)) << eb); }
-            const u32 dist = dbase + br.get(eb);
-            if (br.pos > br.end) return INF_CORRUPT;
-            if ((u64)dist > nout) return INF_CORRUPT;                 // too far back
-            if (nout + length > out_limit) return INF_TOOLONG;
-            if (EMIT) tk[ntok] = 0x80000000u | ((length - 3) << 16) | (dist - 1);
-            ntok++; nout += length;
-        }
+    return INF_OK;
+}
+
+// One token.  Returns 0 literal/match decoded, 1 end of block, <0 error.
+// token: literal = byte; match = 1<<31 | (len-3) << 16 | (dist-1);  *olen = bytes it produces
+__device__ __forceinline__ int decode_token(BitIn &br, LaneLds &L, const u32 (&LC)[16], const u32 (&DC)[16], u32 &tok, u32 &olen)
+{
+    br.refill();
+    u32 cl;
+    int si = chain_decode<15>(__brev(br.peek()) >> 17, LC, cl);
+    if (si < 0) return INF_CORRUPT;
+    u32 sym = L.ls(si);
+    br.skip(cl);
+    if (sym < 256) { tok = sym; olen = 1; return 0; }
+    if (sym == 256) return 1;
+    sym -= 257;
+    if (sym >= 29) return INF_CORRUPT;
+    u32 eb, lbase;
+    if (sym < 8) { eb = 0; lbase = 3 + sym; }
+    else if (sym == 28) { eb = 0; lbase = 258; }
+    else { eb = (sym - 4) >> 2; lbase = 3 + ((4 + (sym & 3)) << eb); }
+    const u32 length = lbase + br.get(eb);
+    br.refill();
+    si = chain_decode<15>(__brev(br.peek()) >> 17, DC, cl);
+    if (si < 0) return INF_CORRUPT;
+    const u32 dsym = L.ds(si);
+    br.skip(cl);
+    if (dsym >= 30) return INF_CORRUPT;
+    u32 dbase;
+    if (dsym < 4) { eb = 0; dbase = 1 + dsym; }
+    else { eb = (dsym - 2) >> 1; dbase = 1 + ((2 + (dsym & 1)) << eb); }
+    const u32 dist = dbase + br.get(eb);
+    tok = 0x80000000u | ((length - 3) << 16) | (dist - 1);
+    olen = length;
+    return 0;
+}
+
+// One whole deflate block, sequentially by one lane, starting at br.pos (reads BFINAL/BTYPE itself).
+// EMIT: write tokens to tk[ntok...].  nout = bytes produced so far in the stream (distance check).
+template <bool EMIT>
+__device__ int decode_block(BitIn &br, LaneLds &L, u32 *tk, u32 &ntok, u64 &nout, u64 out_limit, bool &last)
+{
+    u32 hdr = br.get(3);
+    last = hdr & 1;
+    const u32 type = hdr >> 1;
+    if (br.pos > br.end) return INF_CORRUPT;
+    if (type == 3) return INF_CORRUPT;
+    if (type == 0) {
+        br.seek((br.pos + 7) & ~7ull);
+        const u32 len = br.get(16), nlen = br.get(16);
         if (br.pos > br.end) return INF_CORRUPT;
+        if ((len ^ 0xffff) != nlen) return INF_CORRUPT;
+        if (br.pos + 8ull * len > br.end) return INF_CORRUPT;
+        if (nout + len > out_limit) return INF_TOOLONG;
+        const u8 *src = (const u8 *)br.w + (br.pos >> 3);        // byte aligned
+        if (EMIT) for (u32 i = 0; i < len; i++) tk[ntok + i] = src[i];
+        ntok += len; nout += len;
+        br.seek(br.pos + 8ull * len);
+        return INF_OK;
+    }
+    u32 LC[16], DC[16];
+    const int rc = parse_tables(br, L, type, LC, DC);
+    if (rc != INF_OK) return rc;
+    for (;;) {
+        u32 tok, olen;
+        const int t = decode_token(br, L, LC, DC, tok, olen);
+        if (t < 0) return INF_CORRUPT;
+        if (br.pos > br.end) return INF_CORRUPT;
+        if (t == 1) break;
+        if ((tok >> 31) && (u64)((tok & 0x7fff) + 1) > nout) return INF_CORRUPT;       // too far back
+        if (nout + olen > out_limit) return INF_TOOLONG;
+        if (EMIT) tk[ntok] = tok;
+        ntok++; nout += olen;
     }
     return INF_OK;
 }
 
-// H: one lane per chunk, sequential over the chunk's blocks
+// ================================================================================================
+// Fast path, step 1: find every bit offset that carries a valid dynamic-block header
+// ================================================================================================
+// A DEFLATE stream has no sync points, so block starts are not known without decoding.  They can be
+// guessed, though: test EVERY bit offset for a well-formed dynamic header (BTYPE=10, HLIT/HDIST in range,
+// a complete code-length code, then lit/len + distance code lengths that decode to complete codes with
+// an end-of-block symbol).  Random bits pass the cheap part ~0.08 % of the time and the full check
+// almost never; true block starts always pass.  Candidates are only hints: the chain walk below
+// accepts a block only if the previous block really ends there.
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_SPAN_BITS = SCAN_THREADS * 32;
+constexpr int SCAN_SURV_CAP = 512;
+
+// full validation of the header at absolute bit `o` (BFINAL bit); true if well formed
+__device__ bool validate_dyn_header(const u32 *w, u64 nwords, u64 end, u64 o)
+{
+    BitIn br;
+    br.w = w; br.nwords = nwords; br.end = end;
+    br.seek(o + 3);
+    const int nlen = (int)br.get(5) + 257, ndist = (int)br.get(5) + 1, ncode = (int)br.get(4) + 4;
+    if (nlen > 286 || ndist > 30) return false;
+    // code-length code: lengths packed 3 bits each by symbol
+    const u8 order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    u64 cl = 0;
+    for (int i = 0; i < ncode; i++) cl |= (u64)br.get(3) << (3 * order[i]);
+    // compare chain of the 7-bit code + its sorted symbols packed 5 bits each (two u64)
+    u32 CC[8];
+    u32 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 19; s++) {
+        const u32 l = (u32)(cl >> (3 * s)) & 7;
+#pragma unroll
+        for (int k = 1; k < 8; k++) cnt[k] += (l == (u32)k);
+    }
+    u32 firstc = 0, offs[8], off = 0;
+    int left = 1;
+    CC[0] = 0;
+#pragma unroll
+    for (int l = 1; l <= 7; l++) {
+        left = (left << 1) - (int)cnt[l];
+        offs[l] = off; off += cnt[l];
+        CC[l] = (((firstc + cnt[l]) << (7 - l)) & 0xffff) | (cnt[l] << 16);
+        firstc = (firstc + cnt[l]) << 1;
+    }
+    if (left != 0) return false;
+    u64 t0 = 0, t1 = 0;                   // sorted symbol k at bits 5*(k%12) of t[k/12]
+#pragma unroll
+    for (int l = 1; l <= 7; l++) {
+        u32 o2 = offs[l];
+        for (int s = 0; s < 19; s++) {
+            if (((u32)(cl >> (3 * s)) & 7) == (u32)l) {
+                if (o2 < 12) t0 |= (u64)s << (5 * o2); else t1 |= (u64)s << (5 * (o2 - 12));
+                o2++;
+            }
+        }
+    }
+    const int total = nlen + ndist;
+    int idx = 0, prev = 0, len256 = 0, maxl = 0, maxd = 0;
+    u32 kl = 0, kd = 0;                   // Kraft sums scaled by 2^15
+    while (idx < total) {
+        br.refill();
+        u32 clen;
+        const int si = chain_decode<7>(__brev(br.peek()) >> 25, CC, clen);
+        if (si < 0) return false;
+        const int sym = (int)((si < 12 ? t0 >> (5 * si) : t1 >> (5 * (si - 12))) & 31);
+        br.skip(clen);
+        int rep = 1, val = sym;
+        if (sym >= 16) {
+            if (sym == 16) { if (idx == 0) return false; val = prev; rep = 3 + (int)br.get(2); }
+            else if (sym == 17) { val = 0; rep = 3 + (int)br.get(3); }
+            else { val = 0; rep = 11 + (int)br.get(7); }
+            if (idx + rep > total) return false;
+        }
+        prev = val;
+        if (val) {
+            const int nl = idx >= nlen ? 0 : (idx + rep <= nlen ? rep : nlen - idx);
+            const int nd = rep - nl;
+            kl += (u32)nl * (32768u >> val);
+            kd += (u32)nd * (32768u >> val);
+            if (nl && val > maxl) maxl = val;
+            if (nd && val > maxd) maxd = val;
+            if (idx <= 256 && 256 < idx + rep) len256 = val;
+        }
+        idx += rep;
+        if (br.pos > end) return false;
+    }
+    if (len256 == 0) return false;
+    if (kl > 32768u || (kl < 32768u && maxl != 1)) return false;
+    if (kd > 32768u || (kd < 32768u && maxd > 1)) return false;
+    return true;
+}
+
+struct InfFast {                 // per-chunk bookkeeping of the fast path (device arrays, one entry per chunk)
+    u64 cand_off;                // first slot of this chunk in the candidate arrays
+    u32 cand_cap;
+    u32 true_off;                // first slot in the true-block array
+    u32 true_cap;
+    u32 pad;
+};
+struct CandRes {                 // result of decoding one candidate block (pass A)
+    u64 end_bit;                 // position after the end-of-block symbol
+    u32 ntok, nout, nsub;
+    u32 ok;                      // 1 = decoded to a clean end of block
+    u32 bfinal;
+    u32 pad;
+};
+struct TrueBlk {
+    u64 start_bit;
+    u32 cand;                    // candidate slot, or 0xffffffff = decode sequentially (stored/fixed/unseen block)
+    u32 tok_off;                 // chunk relative
+    u32 ntok;
+    u32 chunk;
+};
+constexpr int SUBCAP = 512;      // sub-sequences recorded per candidate block
+constexpr int SUB_BITS = 2048;   // bits per sub-sequence
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
+                                                           const InfFast *__restrict__ fast, u64 *__restrict__ cand_pos,
+                                                           u32 *__restrict__ cand_cnt)
+{
+    const int ci = blockIdx.y;
+    const InfChunk ch = chunks[ci];
+    if (ch.c_len < 8) return;
+    const u64 a = (u64)(cdata + ch.c_off);
+    const u32 *w = (const u32 *)(a & ~(u64)3);
+    const u64 bit0 = (a & 3) * 8, end = bit0 + 8 * ch.c_len, nwords = (end + 31) >> 5;
+    const u64 span0 = (u64)blockIdx.x * SCAN_SPAN_BITS;        // absolute bit of this workgroup's span
+    if (span0 >= end) return;
+    __shared__ u32 sw[SCAN_THREADS + 8];
+    __shared__ u64 surv[SCAN_SURV_CAP];
+    __shared__ u32 nsurv;
+    const int tid = threadIdx.x;
+    const u64 word0 = span0 >> 5;
+    for (int i = tid; i < SCAN_THREADS + 8; i += SCAN_THREADS) sw[i] = word0 + i < nwords ? w[word0 + i] : 0;
+    if (tid == 0) nsurv = 0;
+    __syncthreads();
+    // phase A: 32 consecutive offsets per thread
+    const u64 lo = (u64)sw[tid] | ((u64)sw[tid + 1] << 32), mid = (u64)sw[tid + 2] | ((u64)sw[tid + 3] << 32);
+    const u64 hi = sw[tid + 4];
+    const u64 first_ok = bit0 + 16;
+    for (int k = 0; k < 32; k++) {
+        const u64 o = span0 + (u64)tid * 32 + k;
+        const u64 v = k ? (lo >> k) | (mid << (64 - k)) : lo;            // 64 bits from o
+        const u32 h = (u32)v;
+        const u32 hlit = (h >> 3) & 31, hdist = (h >> 8) & 31, ncode = ((h >> 13) & 15) + 4;
+        if (((h >> 1) & 3) != 2 || hlit > 29 || hdist > 29) continue;
+        if (o < first_ok || o + 17 + 3 * ncode + 8 > end) continue;
+        const u64 v2 = k ? (mid >> k) | (hi << (64 - k)) : mid;          // bits 64.. from o
+        // Kraft sum of the code-length code (3-bit lengths from bit 17), scaled by 128
+        u32 kraft = 0;
+        for (u32 i = 0; i < ncode; i++) {
+            const u32 b = 17 + 3 * i;
+            // b = 17, 20, ..., 71: the field at b = 62 straddles v / v2
+            const u32 l = (u32)(b < 62 ? v >> b : b == 62 ? (v >> 62) | (v2 << 2) : v2 >> (b - 64)) & 7;
+            kraft += l ? 128u >> l : 0;
+        }
+        if (kraft != 128) continue;
+        const u32 slot = atomicAdd(&nsurv, 1u);
+        if (slot < SCAN_SURV_CAP) surv[slot] = o;
+    }
+    __syncthreads();
+    // phase B: full validation, survivors packed into the first lanes
+    const u32 ns = min(nsurv, (u32)SCAN_SURV_CAP);
+    if ((u32)tid < ns) {
+        const u64 o = surv[tid];
+        if (validate_dyn_header(w, nwords, end, o)) {
+            const InfFast f = fast[ci];
+            const u32 slot = atomicAdd(&cand_cnt[ci], 1u);
+            if (slot < f.cand_cap) cand_pos[f.cand_off + slot] = o;
+        }
+    }
+}
+
+// sort each chunk's candidates by position (rank sort; the lists are short)
+__global__ __launch_bounds__(256) void k_inf_sortc(const InfFast *__restrict__ fast, u64 *__restrict__ cand_pos,
+                                                   u64 *__restrict__ cand_tmp, u32 *__restrict__ cand_cnt)
+{
+    const int ci = blockIdx.x;
+    const InfFast f = fast[ci];
+    const u32 n = min(cand_cnt[ci], f.cand_cap);
+    u64 *p = cand_pos + f.cand_off, *t = cand_tmp + f.cand_off;
+    for (u32 i = threadIdx.x; i < n; i += 256) t[i] = p[i];
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < n; i += 256) {
+        const u64 v = t[i];
+        u32 r = 0;
+        for (u32 j = 0; j < n; j++) r += t[j] < v;
+        p[r] = v;                                   // positions are distinct
+    }
+}
+
+// ================================================================================================
+// Fast path, step 2: wave-per-block self-synchronising Huffman decode
+// ================================================================================================
+// The 64 lanes of a wave decode 64 consecutive SUB_BITS-bit sub-sequences of one block at once.  Only
+// lane 0 starts on a token boundary; the others start mid-token, decode garbage for a while and -- because
+// Huffman streams re-synchronise -- end on true token boundaries.  Each lane then restarts from the exit
+// of its left neighbour; this repeats until every lane's start equals its neighbour's exit, i.e. until
+// the 64 decodes chain exactly like a sequential decode.  Pass A (this kernel) records, per sub-sequence,
+// the start bit and the running token count; pass B re-decodes from those starts and writes the tokens.
+enum { SPAN_CONT = 0, SPAN_EOB = 1, SPAN_ERR = 2 };
+
+template <int MODE>      // 0: find the exit only, 1: count, 2: emit `want` tokens to tk
+__device__ __forceinline__ void decode_span(BitIn &br, LaneLds &L, const u32 (&LC)[16], const u32 (&DC)[16], u64 stop,
+                                            u32 &ntok, u32 &nout, int &flag, u32 *tk, u32 want)
+{
+    flag = SPAN_CONT;
+    ntok = 0; nout = 0;
+    for (;;) {
+        if (MODE == 2) { if (ntok >= want) break; }
+        else if (br.pos >= stop) break;
+        u32 tok, olen;
+        const int t = decode_token(br, L, LC, DC, tok, olen);
+        if (t < 0 || br.pos > br.end) { flag = SPAN_ERR; break; }
+        if (t == 1) { flag = SPAN_EOB; break; }
+        if (MODE == 2) tk[ntok] = tok;
+        ntok++; nout += olen;
+    }
+}
+
+// position of the first lane (>= 1 bit set) in a ballot, or 64
+__device__ __forceinline__ int first_lane(u64 m) { return m ? __ffsll((long long)m) - 1 : 64; }
+
+__global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
+                                                  const InfFast *__restrict__ fast, const u32 *__restrict__ slot_chunk,
+                                                  const u64 *__restrict__ cand_pos, const u32 *__restrict__ cand_cnt,
+                                                  CandRes *__restrict__ cres, uint2 *__restrict__ subs)
+{
+    const u32 slot = blockIdx.x;
+    const u32 ci = slot_chunk[slot];
+    const InfFast f = fast[ci];
+    const u32 k = slot - (u32)f.cand_off;
+    if (k >= min(cand_cnt[ci], f.cand_cap)) return;
+    const InfChunk ch = chunks[ci];
+    __shared__ __attribute__((aligned(16))) u8 tabs[INF_SET_BYTES];
+    LaneLds L;
+    L.bind(tabs, 1, 0);
+    const int lane = threadIdx.x;
+    BitIn br;
+    br.init(cdata, ch.c_off, ch.c_len, 0);
+    const u64 o = cand_pos[slot];
+    br.seek(o);
+    CandRes r;
+    r.end_bit = 0; r.ntok = 0; r.nout = 0; r.nsub = 0; r.ok = 0; r.bfinal = 0; r.pad = 0;
+    const u32 hdr = br.get(3);
+    r.bfinal = hdr & 1;
+    u32 LC[16], DC[16];
+    // every lane parses the header redundantly (identical control flow, identical LDS writes)
+    const int rc = parse_tables(br, L, hdr >> 1, LC, DC);
+    if (rc != INF_OK) { if (lane == 0) cres[slot] = r; return; }
+    __builtin_amdgcn_wave_barrier();
+    uint2 *sub = subs + (u64)slot * SUBCAP;
+    u64 base = br.pos;
+    u32 tot_tok = 0, tot_out = 0, nsub = 0;
+    bool done = false, fail = false;
+    while (!done && !fail) {
+        const u64 stop = base + (u64)(lane + 1) * SUB_BITS;
+        u64 start = base + (u64)lane * SUB_BITS, ex;
+        u32 nt, no; int fl;
+        // speculative pass: exits only
+        br.seek(start);
+        decode_span<0>(br, L, LC, DC, stop, nt, no, fl, nullptr, 0);
+        ex = br.pos;
+        bool counted = false;
+        for (int it = 0; it < 66; it++) {
+            // true start of lane i = exit of lane i-1; lanes after the first EOB/ERR lane are void
+            const u64 pex = __shfl_up(ex, 1, 64);
+            const int pfl = __shfl_up(fl, 1, 64);
+            const u64 want_start = lane == 0 ? base : pex;
+            const u64 stopm = __ballot(fl != SPAN_CONT);
+            const int fstop = first_lane(stopm);              // lanes > fstop are void
+            const bool valid = lane <= fstop;
+            (void)pfl;
+            const bool redo = valid && (!counted || want_start != start);
+            // (a lane that is void now may become valid later only if an earlier lane changes: handled
+            //  because `counted` stays false for lanes that never ran the counting pass)
+            if (!__any(redo)) break;
+            if (redo) {
+                start = want_start;
+                br.seek(start);
+                decode_span<1>(br, L, LC, DC, stop, nt, no, fl, nullptr, 0);
+                ex = br.pos;
+                counted = true;
+            }
+        }
+        // consistent chain: lanes 0..fstop hold the true sub-sequences of this round
+        const u64 stopm = __ballot(fl != SPAN_CONT);
+        const int fstop = first_lane(stopm);
+        const bool valid = lane <= fstop && counted;
+        // verify (a lane could still be inconsistent if the iteration cap was hit)
+        const u64 pex = __shfl_up(ex, 1, 64);
+        const bool bad = valid && lane > 0 && pex != start;
+        if (__any(bad) || __any(lane <= fstop && !counted)) { fail = true; break; }
+        // prefix sums of the token counts
+        u32 x = valid ? nt : 0, y = valid ? no : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 xx = __shfl_up(x, off, 64), yy = __shfl_up(y, off, 64);
+            if (lane >= off) { x += xx; y += yy; }
+        }
+        const int nvalid = fstop < 64 ? fstop + 1 : 64;
+        if (nsub + nvalid > SUBCAP - 1) { fail = true; break; }
+        if (valid) sub[nsub + lane] = make_uint2((u32)(start - o), tot_tok + x - nt);
+        const u32 rt = __shfl(x, nvalid - 1, 64), ro = __shfl(y, nvalid - 1, 64);
+        tot_tok += rt; tot_out += ro;
+        nsub += nvalid;
+        if (fstop < 64) {
+            const int ffl = __shfl(fl, fstop, 64);
+            const u64 fex = __shfl(ex, fstop, 64);
+            if (ffl == SPAN_EOB) { done = true; r.end_bit = fex; }
+            else fail = true;
+        } else base = __shfl(ex, 63, 64);
+    }
+    if (lane == 0) {
+        if (done && !fail) {
+            sub[nsub] = make_uint2(0, tot_tok);
+            r.ok = 1; r.ntok = tot_tok; r.nout = tot_out; r.nsub = nsub;
+        }
+        cres[slot] = r;
+    }
+}
+
+// ================================================================================================
+// Fast path, step 3: chain the blocks of each chunk (one wave per chunk)
+// ================================================================================================
+constexpr int CHAIN_NEED_SEQ = 1;     // value of seq_flag: let the sequential decoder handle the chunk
+
+__global__ __launch_bounds__(64) void k_inf_chain(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
+                                                  const InfFast *__restrict__ fast, const u64 *__restrict__ cand_pos,
+                                                  const u32 *__restrict__ cand_cnt, const CandRes *__restrict__ cres,
+                                                  TrueBlk *__restrict__ tblk, u32 *__restrict__ true_cnt,
+                                                  InfResult *__restrict__ res, int *__restrict__ seq_flag)
+{
+    const int ci = blockIdx.x;
+    const InfChunk ch = chunks[ci];
+    const InfFast f = fast[ci];
+    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) u8 tabs[INF_SET_BYTES];
+    InfResult r;
+    r.status = MTS_CHUNK_OK; r.n_out = 0; r.ntok = 0; r.adler_stored = 0; r.end_bit = 0;
+    // zlib header
+    const u8 *cb = cdata + ch.c_off;
+    bool ok = ch.c_len >= 2;
+    if (ok) {
+        const u32 cmf = cb[0], flg = cb[1];
+        ok = ((cmf << 8) | flg) % 31 == 0 && (cmf & 15) == 8 && (cmf >> 4) <= 7 && !(flg & 0x20);
+    }
+    if (!ok) { if (lane == 0) { r.status = MTS_CHUNK_CORRUPT; res[ci] = r; seq_flag[ci] = 0; true_cnt[ci] = 0; } return; }
+    BitIn br;
+    br.init(cdata, ch.c_off, ch.c_len, 16);
+    const u32 ncand = min(cand_cnt[ci], f.cand_cap);
+    const bool cand_overflow = cand_cnt[ci] > f.cand_cap;
+    const u64 *cp = cand_pos + f.cand_off;
+    u32 cur = 0;                   // candidates below `cur` are behind the walk
+    u64 pos = br.pos;
+    u32 ntok = 0, ntrue = 0;
+    u64 nout = 0;
+    bool last = false, need_seq = cand_overflow;
+    LaneLds L;
+    L.bind(tabs, 1, 0);
+    while (!last && !need_seq) {
+        // find a candidate at exactly `pos` (wave-wide search forward)
+        int found = -1;
+        for (;;) {
+            const u32 i = cur + lane;
+            const u64 v = i < ncand ? cp[i] : ~0ull;
+            const u64 ge = __ballot(v >= pos);
+            if (ge == 0) { cur += 64; if (cur >= ncand) break; continue; }
+            const int fl = first_lane(ge);
+            const u64 fv = __shfl(v, fl, 64);
+            cur += fl;
+            if (fv == pos) found = (int)cur;
+            break;
+        }
+        u32 b_ntok = 0, b_nout = 0, b_cand = 0xffffffffu;
+        u64 b_end = 0;
+        bool b_ok = false;
+        if (found >= 0) {
+            const CandRes c = cres[f.cand_off + found];
+            if (c.ok) { b_ok = true; b_ntok = c.ntok; b_nout = c.nout; b_end = c.end_bit; b_cand = (u32)(f.cand_off + found); last = c.bfinal; }
+        }
+        if (!b_ok) {
+            // stored / fixed / unseen block: count it sequentially (every lane runs the same decode)
+            br.seek(pos);
+            u32 nt = 0; u64 no = nout; bool lst = false;
+            const int st = decode_block<false>(br, L, nullptr, nt, no, ~0ull, lst);
+            if (st != INF_OK) { need_seq = true; break; }
+            b_ntok = nt; b_nout = (u32)(no - nout); b_end = br.pos; last = lst;
+        }
+        if (ntrue >= f.true_cap || (u64)ntok + b_ntok > (u64)ch.n_expect + 1 || nout + b_nout > ch.n_expect) { need_seq = true; break; }
+        if (lane == 0) {
+            TrueBlk tb;
+            tb.start_bit = pos; tb.cand = b_cand; tb.tok_off = ntok; tb.ntok = b_ntok; tb.chunk = (u32)ci;
+            tblk[f.true_off + ntrue] = tb;
+        }
+        ntrue++;
+        ntok += b_ntok; nout += b_nout;
+        pos = b_end;
+    }
+    if (!need_seq) {
+        const u64 tb = (pos + 7) & ~7ull;
+        if (tb + 32 > br.end || nout != ch.n_expect) need_seq = true;        // let the reference path classify
+        else {
+            const u8 *t = (const u8 *)br.w + (tb >> 3);
+            r.adler_stored = ((u32)t[0] << 24) | ((u32)t[1] << 16) | ((u32)t[2] << 8) | t[3];
+            r.end_bit = tb + 32;
+            r.n_out = (u32)nout; r.ntok = ntok;
+        }
+    }
+    if (lane == 0) {
+        res[ci] = r;
+        seq_flag[ci] = need_seq ? CHAIN_NEED_SEQ : 0;
+        true_cnt[ci] = need_seq ? 0 : ntrue;
+    }
+}
+
+// ================================================================================================
+// Fast path, step 4: emit the tokens of every accepted block (one wave per block)
+// ================================================================================================
+__global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
+                                                  const InfFast *__restrict__ fast, const u32 *__restrict__ tslot_chunk,
+                                                  const TrueBlk *__restrict__ tblk, const u32 *__restrict__ true_cnt,
+                                                  const CandRes *__restrict__ cres, const uint2 *__restrict__ subs,
+                                                  u32 *__restrict__ tokens, InfResult *__restrict__ res)
+{
+    const u32 slot = blockIdx.x;
+    const u32 ci = tslot_chunk[slot];
+    const InfFast f = fast[ci];
+    if (slot - f.true_off >= true_cnt[ci]) return;
+    const TrueBlk tb = tblk[slot];
+    const InfChunk ch = chunks[ci];
+    __shared__ __attribute__((aligned(16))) u8 tabs[INF_SET_BYTES];
+    LaneLds L;
+    L.bind(tabs, 1, 0);
+    const int lane = threadIdx.x;
+    BitIn br;
+    br.init(cdata, ch.c_off, ch.c_len, 0);
+    br.seek(tb.start_bit);
+    u32 *tk = tokens + ch.tok_off + tb.tok_off;
+    if (tb.cand == 0xffffffffu) {
+        // sequential block (rare): every lane decodes it, lane 0 writes
+        u32 nt = 0; u64 no = 1ull << 40; bool lst;
+        if (lane == 0) {
+            const int st = decode_block<true>(br, L, tk, nt, no, ~0ull, lst);
+            if (st != INF_OK || nt != tb.ntok) res[ci].status = MTS_CHUNK_CORRUPT;
+        }
+        return;
+    }
+    const u32 hdr = br.get(3);
+    u32 LC[16], DC[16];
+    if (parse_tables(br, L, hdr >> 1, LC, DC) != INF_OK) { if (lane == 0) res[ci].status = MTS_CHUNK_CORRUPT; return; }
+    __builtin_amdgcn_wave_barrier();
+    const u32 nsub = cres[tb.cand].nsub;
+    const uint2 *sub = subs + (u64)tb.cand * SUBCAP;
+    for (u32 j0 = 0; j0 < nsub; j0 += 64) {
+        const u32 j = j0 + lane;
+        if (j < nsub) {
+            const uint2 a = sub[j], b = sub[j + 1];
+            br.seek(tb.start_bit + a.x);
+            u32 nt, no; int fl;
+            decode_span<2>(br, L, LC, DC, 0, nt, no, fl, tk + a.y, b.y - a.y);
+            if (nt != b.y - a.y) res[ci].status = MTS_CHUNK_CORRUPT;
+        }
+    }
+}
+
+// ================================================================================================
+// Reference path: one lane per chunk, sequential (authoritative for anything the fast path declines)
+// ================================================================================================
 __global__ __launch_bounds__(64) void k_inf_decode(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
-                                                   int n_chunks, u32 *__restrict__ tokens, InfResult *__restrict__ res)
+                                                   int n_chunks, u32 *__restrict__ tokens, InfResult *__restrict__ res,
+                                                   const int *__restrict__ seq_flag)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const int ci = blockIdx.x * 64 + threadIdx.x;
     LaneLds L;
-    L.lane = threadIdx.x;
-    L.lens = smem;
-    L.cnt = (u16 *)(smem + 64 * INF_LENS);
-    L.lsym = L.cnt + 64 * INF_CNT;
-    L.dsym = L.lsym + 64 * INF_LSYM;
+    L.bind(smem, 64, threadIdx.x);
     if (ci >= n_chunks) return;
+    if (seq_flag && seq_flag[ci] == 0) return;
     const InfChunk ch = chunks[ci];
     InfResult r;
     r.status = MTS_CHUNK_OK; r.n_out = 0; r.ntok = 0; r.adler_stored = 0; r.end_bit = 0;
@@ -302,7 +791,7 @@ __global__ __launch_bounds__(64) void k_inf_decode(const u8 *__restrict__ cdata,
     u64 nout = 0;
     bool last = false;
     int st = INF_OK;
-    while (!last && st == INF_OK) st = decode_block<true>(br, L, cdata, tk, ntok, nout, (u64)ch.n_expect, last);
+    while (!last && st == INF_OK) st = decode_block<true>(br, L, tk, ntok, nout, (u64)ch.n_expect, last);
     if (st == INF_TOOLONG) {
         // More output than the header promises.  zlib.decompress would carry on: a stream that is valid
         // to its end is a size mismatch (AssertionError, mtscomp.py:628), anything else is corruption
@@ -310,7 +799,7 @@ __global__ __launch_bounds__(64) void k_inf_decode(const u8 *__restrict__ cdata,
         br.init(cdata, ch.c_off, ch.c_len, 16);
         u32 nt2 = 0; u64 no2 = 0;
         last = false; st = INF_OK;
-        while (!last && st == INF_OK) st = decode_block<false>(br, L, cdata, tk, nt2, no2, ~0ull, last);
+        while (!last && st == INF_OK) st = decode_block<false>(br, L, tk, nt2, no2, ~0ull, last);
         const u64 tb = (br.pos + 7) & ~7ull;
         r.status = (st == INF_OK && tb + 32 <= br.end) ? MTS_CHUNK_BADSIZE : MTS_CHUNK_CORRUPT;
     }
@@ -330,56 +819,199 @@ __global__ __launch_bounds__(64) void k_inf_decode(const u8 *__restrict__ cdata,
     res[ci] = r;
 }
 
-// Z: tokens -> bytes
-__global__ __launch_bounds__(64) void k_inf_lz(const u32 *__restrict__ tokens, const InfChunk *__restrict__ chunks,
-                                               const InfResult *__restrict__ res, u8 *__restrict__ stream)
+// ================================================================================================
+// Z: tokens -> bytes (LZ77 resolution)
+// ================================================================================================
+// One workgroup per chunk.  Tokens are taken in groups of 64 (one per lane); LZ_WORKERS waves take the
+// groups round robin, one wave streams finished bytes to HBM.  The 64 KiB of history a copy can reach
+// lives in an LDS ring of 16-bit cells: low byte = data, high byte = lap tag of the position that wrote
+// it.  A copy reads its source cell, and proceeds only if the tag says "written in the lap I expect",
+// so every byte waits for exactly the bytes it depends on (no group-level barrier, no serial commit):
+// the critical path is the copy-of-copy depth of the data, not the number of tokens.
+constexpr int LZ_THREADS = 1024;
+constexpr int LZ_FLUSHERS = 2;                           // waves streaming finished bytes to HBM
+constexpr int LZ_WORKERS = LZ_THREADS / 64 - LZ_FLUSHERS;
+constexpr u32 LZ_RING = 65536;                           // positions held (power of two)
+constexpr u32 LZ_REACH = 32768 + 258;                    // furthest back a copy reads from its own start
+constexpr u32 LZ_FLUSH = 4096;                           // flush granule (bytes)
+constexpr int LZ_LDS = 2 * LZ_RING + 256;
+constexpr u32 LZ_SPIN_MAX = 1u << 20;                     // bound on every wait loop (a stuck kernel must end)
+
+// prefix sums of the output size of each 64-token group: gbase[g] = first output byte of group g
+__global__ __launch_bounds__(1024) void k_inf_gbase(const u32 *__restrict__ tokens, const InfChunk *__restrict__ chunks,
+                                                    const InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
+                                                    u32 *__restrict__ gbase)
+{
+    const int ci = blockIdx.x;
+    const InfResult r = res[ci];
+    if (r.status != MTS_CHUNK_OK) return;
+    const u32 *tk = tokens + chunks[ci].tok_off;
+    u32 *gb = gbase + gb_off[ci];
+    const u32 ntok = r.ntok, ngroups = (ntok + 63) / 64;
+    __shared__ u32 wtot[16];
+    __shared__ u32 carry;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u32 g0 = 0; g0 < ngroups; g0 += 16) {
+        const u32 g = g0 + wave;
+        const u32 i = g * 64 + lane;
+        u32 len = 0;
+        if (g < ngroups && i < ntok) { const u32 t = tk[i]; len = (t >> 31) ? ((t >> 16) & 0xff) + 3 : 1; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) len += __shfl_down(len, off, 64);
+        if (lane == 0) wtot[wave] = len;
+        __syncthreads();
+        if (lane == 0 && g < ngroups) {
+            u32 add = carry;
+            for (int w = 0; w < wave; w++) add += wtot[w];
+            gb[g] = add;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { u32 a = carry; for (int w = 0; w < 16; w++) a += wtot[w]; carry = a; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gb[ngroups] = carry;
+}
+
+__device__ __forceinline__ u32 lz_tag(u32 pos) { return ((pos >> 16) & 0x7f) + 1; }
+
+__global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ tokens, const InfChunk *__restrict__ chunks,
+                                                       InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
+                                                       const u32 *__restrict__ gbase, u8 *__restrict__ stream)
 {
     const int ci = blockIdx.x;
     const InfResult r = res[ci];
     if (r.status != MTS_CHUNK_OK) return;
     const InfChunk ch = chunks[ci];
-    __shared__ __attribute__((aligned(16))) u8 ring[65536];
-    const int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    volatile u16 *ring = (volatile u16 *)smem;                       // LZ_RING cells
+    volatile u32 *prog = (volatile u32 *)(smem + 2 * LZ_RING);       // [w] = groups finished by worker w (count)
+    volatile u32 *fl_next = prog + 16;                               // [k] = first byte flusher k has not streamed out yet
+    volatile u32 *bad_p = prog + 20;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 *tk = tokens + ch.tok_off;
+    const u32 *gb = gbase + gb_off[ci];
     u8 *out = stream + ch.stream_off;
-    const u32 ntok = r.ntok;
-    u32 base = 0, flushed = 0;
-    constexpr u32 M = 65535;
-    for (u32 t0 = 0; t0 < ntok; t0 += 64) {
-        const bool act = t0 + lane < ntok;
-        const u32 t = act ? tk[t0 + lane] : 0;
+    const u32 ntok = r.ntok, ngroups = (ntok + 63) / 64, nout = r.n_out;
+    for (u32 i = threadIdx.x; i < LZ_RING / 2; i += LZ_THREADS) ((volatile u32 *)ring)[i] = 0;      // tag 0 = never written
+    if (threadIdx.x < 24) prog[threadIdx.x] = (threadIdx.x >= 16 && threadIdx.x < 16 + LZ_FLUSHERS) ? (threadIdx.x - 16) * LZ_FLUSH : 0;
+    __syncthreads();
+    // number of leading groups that are completely finished = min over workers of the first group each
+    // has not finished (worker w owns groups w, w+W, w+2W, ...)
+    auto groups_done = [&]() -> u32 {
+        u32 v = 0xffffffffu;
+        if (lane < LZ_WORKERS) { const u32 c = prog[lane]; v = c >= 0x01000000u ? 0xffffffffu : c * LZ_WORKERS + lane; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = min(v, (u32)__shfl_xor(v, off, 64));
+        return v < ngroups ? v : ngroups;
+    };
+    // bytes below this are in HBM already
+    auto flushed = [&]() -> u32 {
+        u32 v = fl_next[0];
+#pragma unroll
+        for (int k = 1; k < LZ_FLUSHERS; k++) v = min(v, fl_next[k]);
+        return v;
+    };
+    if (wave >= LZ_WORKERS) {
+        // ---- flushers: granule q belongs to flusher q % LZ_FLUSHERS; 8 cells -> 8 bytes per lane ----
+        const u32 me = wave - LZ_WORKERS;
+        u32 idle = 0;
+        for (u32 q = me;; q += LZ_FLUSHERS) {
+            const u32 lo = q * LZ_FLUSH;
+            if (lo >= nout) break;
+            const u32 hi = lo + LZ_FLUSH < nout ? lo + LZ_FLUSH : nout;
+            for (;;) {
+                const u32 gd = groups_done();
+                const u32 safe = gd >= ngroups ? nout : gb[gd];          // bytes below `safe` are final
+                if (safe >= hi) break;
+                if (++idle > LZ_SPIN_MAX) { if (lane == 0) { *bad_p = 3; for (int k = 0; k < LZ_FLUSHERS; k++) fl_next[k] = 0xffffffffu; } return; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            idle = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (u32 o = lo + lane * 8; o < hi; o += 512) {
+                const uint4 c = *(const uint4 *)(smem + 2 * (o & (LZ_RING - 1)));
+                const u32 v0 = (c.x & 0xff) | ((c.x >> 8) & 0xff00) | ((c.y & 0xff) << 16) | ((c.y >> 16) << 24);
+                const u32 v1 = (c.z & 0xff) | ((c.z >> 8) & 0xff00) | ((c.w & 0xff) << 16) | ((c.w >> 16) << 24);
+                if (o + 8 <= hi) *(uint2 *)(out + o) = make_uint2(v0, v1);
+                else { const u64 v = (u64)v0 | ((u64)v1 << 32); for (u32 k = 0; o + k < hi; k++) out[o + k] = (u8)(v >> (8 * k)); }
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            if (lane == 0) fl_next[me] = lo + LZ_FLUSHERS * LZ_FLUSH;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) fl_next[me] = 0xffffffffu;
+        return;
+    }
+    // ---- workers ----
+    u32 done_cnt = 0;
+    u32 t_n = 0, base_n = 0, next_n = 0;
+    if ((u32)wave < ngroups) {
+        const u32 i = wave * 64 + lane;
+        t_n = i < ntok ? tk[i] : 0; base_n = gb[wave]; next_n = gb[wave + 1];
+    }
+    for (u32 g = wave; g < ngroups; g += LZ_WORKERS) {
+        const u32 t = t_n, base = base_n, next = next_n;
+        const u32 i = g * 64 + lane;
+        const bool act = i < ntok;
+        // prefetch the next group's tokens while this one is resolved
+        if (g + LZ_WORKERS < ngroups) {
+            const u32 i2 = (g + LZ_WORKERS) * 64 + lane;
+            t_n = i2 < ntok ? tk[i2] : 0; base_n = gb[g + LZ_WORKERS]; next_n = gb[g + LZ_WORKERS + 1];
+        }
+        // ring safety: writing up to `next` destroys positions below next - LZ_RING; every group that may
+        // still read them (groups starting below next - LZ_RING + LZ_REACH) must be finished, and the bytes
+        // must be in HBM
+        if (next > LZ_RING) {
+            const u32 lim = next - LZ_RING;                    // positions below lim get overwritten
+            for (u32 waits = 0;; waits++) {
+                bool ok = flushed() >= lim;
+                if (ok) { const u32 gd = groups_done(); if (gd < g && gb[gd] < lim + LZ_REACH) ok = false; }
+                if (ok) break;
+                if (waits > LZ_SPIN_MAX) { *bad_p = 4; break; }                               // never hang
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
         const bool cp = act && (t >> 31);
         const u32 len = !act ? 0 : cp ? ((t >> 16) & 0xff) + 3 : 1;
         u32 x = len;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
-        const u32 total = __shfl(x, 63, 64);
         const u32 dst = base + x - len;
         const u32 dist = (t & 0x7fff) + 1;
+        bool live = cp;
+        if (cp && dist > dst) { live = false; *bad_p = 1; }              // distance too far back: corrupt
+        if (act && !cp) ring[dst & (LZ_RING - 1)] = (u16)((lz_tag(dst) << 8) | (t & 0xff));
+        // copies: every lane advances byte by byte whenever its next source cell carries the expected tag
+        u32 k = 0;
         const u32 src = dst - dist;
-        if (act && !cp) ring[dst & M] = (u8)t;
-        const bool indep = cp && (src + (len < dist ? len : dist) <= base);
-        if (indep) for (u32 k = 0; k < len; k++) ring[(dst + k) & M] = ring[(src + k) & M];
-        __builtin_amdgcn_wave_barrier();
-        u64 dep = __ballot(cp && !indep);
-        while (dep) {
-            const int Ld = __ffsll((long long)dep) - 1;
-            if (lane == Ld) for (u32 k = 0; k < len; k++) ring[(dst + k) & M] = ring[(src + k) & M];
-            dep &= dep - 1;
-            __builtin_amdgcn_wave_barrier();
-        }
-        base += total;
-        while (flushed + 16384 <= base) {
-            __builtin_amdgcn_wave_barrier();
-            for (u32 i = 0; i < 16; i++) {
-                const u32 o = flushed + i * 1024 + lane * 16;
-                *(uint4 *)(out + o) = *(const uint4 *)(ring + (o & M));
+        u32 spins = 0;
+        while (__any(live && k < len)) {
+            if (live && k < len) {
+                const u32 sp = src + k;
+                const u32 c = ring[sp & (LZ_RING - 1)];
+                if ((c >> 8) == lz_tag(sp)) {
+                    const u32 dp = dst + k;
+                    ring[dp & (LZ_RING - 1)] = (u16)((lz_tag(dp) << 8) | (c & 0xff));
+                    k++;
+                    spins = 0;
+                } else if (++spins > (1u << 22)) { live = false; *bad_p = 2; }       // bounded spin: never hang the GPU
             }
-            flushed += 16384;
         }
+        done_cnt++;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) prog[wave] = done_cnt;
     }
-    __builtin_amdgcn_wave_barrier();
-    for (u32 o = flushed + lane; o < base; o += 64) out[o] = ring[o & M];
+    // workers with no (more) groups count as "finished everything"
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0) prog[wave] = 0x7f000000u;
+    if (wave == 0 && lane == 0) {
+        // wait for the flushers before reporting (same workgroup: they are resident)
+        for (u32 waits = 0; flushed() < nout && waits < 4 * LZ_SPIN_MAX; waits++) __builtin_amdgcn_s_sleep(8);
+        if (*bad_p || flushed() < nout) res[ci].status = MTS_CHUNK_CORRUPT;
+    }
 }
 
 // adler check + final status
@@ -397,33 +1029,116 @@ __global__ __launch_bounds__(64) void k_inf_finish(const InfChunk *__restrict__ 
     status_out[ci] = r.status;
 }
 
-size_t inflate_scratch_bytes(int n_chunks, u64 total_cbytes)
+// ------------------------------------------------------------------------------------------------
+// host side of the inflate pipeline
+// ------------------------------------------------------------------------------------------------
+static inline u32 cand_cap_of(u64 c_len) { return (u32)(c_len / 4096 + 64); }
+
+// scratch layout (all 256-B aligned): [so u64 n][nn u32 n][fast n][cand_cnt n][true_cnt n][seq_flag n]
+//   [slot_chunk total_cand][tslot_chunk total_true][cand_pos][cand_tmp][cres][tblk][subs]
+struct InfLayout {
+    size_t so, nn, fast, cand_cnt, true_cnt, seq_flag, slot_chunk, tslot_chunk, cand_pos, cand_tmp, cres, tblk, subs, gb_off, gbase, end;
+    u32 total_cand, total_true;
+};
+static InfLayout inf_layout(int n_chunks, const u64 *c_lens, const u32 *n_expect)
 {
-    (void)total_cbytes;
-    return (size_t)n_chunks * 32 + 4096;
+    InfLayout l;
+    u64 tc = 0;
+    for (int i = 0; i < n_chunks; i++) tc += cand_cap_of(c_lens[i]);
+    l.total_cand = (u32)tc;
+    l.total_true = (u32)(2 * tc);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t r = o; o += align_up(bytes, 256); return r; };
+    l.so = take(8 * (size_t)n_chunks); l.nn = take(4 * (size_t)n_chunks); l.fast = take(sizeof(InfFast) * (size_t)n_chunks);
+    l.cand_cnt = take(4 * (size_t)n_chunks); l.true_cnt = take(4 * (size_t)n_chunks); l.seq_flag = take(4 * (size_t)n_chunks);
+    l.slot_chunk = take(4 * (size_t)l.total_cand); l.tslot_chunk = take(4 * (size_t)l.total_true);
+    l.cand_pos = take(8 * (size_t)l.total_cand); l.cand_tmp = take(8 * (size_t)l.total_cand);
+    l.cres = take(sizeof(CandRes) * (size_t)l.total_cand); l.tblk = take(sizeof(TrueBlk) * (size_t)l.total_true);
+    l.subs = take(sizeof(uint2) * (size_t)SUBCAP * l.total_cand);
+    l.gb_off = take(8 * (size_t)n_chunks);
+    size_t ng = 0;
+    for (int i = 0; i < n_chunks; i++) ng += ((size_t)n_expect[i] + 2 + 63) / 64 + 2;       // tokens <= bytes + 1
+    l.gbase = take(4 * ng);
+    l.end = o;
+    return l;
 }
 
-int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, int n_chunks, u8 *d_stream,
-                   u32 *d_tokens, InfResult *d_res, u64 *d_adler_acc, u32 max_n, int *d_status_out, void *d_scratch,
-                   size_t scratch_bytes, void *engine)
+size_t inflate_scratch_bytes(int n_chunks, const u64 *c_lens, const u32 *n_expect) { return inf_layout(n_chunks, c_lens, n_expect).end + 256; }
+
+int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, const InfChunk *h_chunks, int n_chunks,
+                   u8 *d_stream, u32 *d_tokens, InfResult *d_res, u64 *d_adler_acc, u32 max_n, int *d_status_out,
+                   void *d_scratch, void *engine)
 {
     if (n_chunks == 0) return MTS_OK;
     static bool attr_set = false;
     if (!attr_set) {
         MTS_HIP(hipFuncSetAttribute((const void *)k_inf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, INF_LDS_PER_WAVE));
+        MTS_HIP(hipFuncSetAttribute((const void *)k_inf_lz, hipFuncAttributeMaxDynamicSharedMemorySize, LZ_LDS));
         attr_set = true;
     }
+    std::vector<u64> lens(n_chunks), so(n_chunks);
+    std::vector<u32> nn(n_chunks);
+    u64 max_clen = 0;
+    for (int i = 0; i < n_chunks; i++) {
+        lens[i] = h_chunks[i].c_len; so[i] = h_chunks[i].stream_off; nn[i] = h_chunks[i].n_expect;
+        if (lens[i] > max_clen) max_clen = lens[i];
+    }
+    const InfLayout l = inf_layout(n_chunks, lens.data(), nn.data());
+    std::vector<u64> gboff(n_chunks);
+    { u64 a = 0; for (int i = 0; i < n_chunks; i++) { gboff[i] = a; a += ((u64)nn[i] + 2 + 63) / 64 + 2; } }
+    u8 *S = (u8 *)d_scratch;
+    std::vector<InfFast> fast(n_chunks);
+    std::vector<u32> slot_chunk(l.total_cand), tslot_chunk(l.total_true);
+    u64 co = 0; u32 to = 0;
+    for (int i = 0; i < n_chunks; i++) {
+        fast[i].cand_off = co; fast[i].cand_cap = cand_cap_of(lens[i]);
+        fast[i].true_off = to; fast[i].true_cap = 2 * fast[i].cand_cap; fast[i].pad = 0;
+        for (u32 k = 0; k < fast[i].cand_cap; k++) slot_chunk[co + k] = (u32)i;
+        for (u32 k = 0; k < fast[i].true_cap; k++) tslot_chunk[to + k] = (u32)i;
+        co += fast[i].cand_cap; to += fast[i].true_cap;
+    }
+    MTS_HIP(hipMemcpyAsync(S + l.so, so.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(S + l.nn, nn.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(S + l.fast, fast.data(), sizeof(InfFast) * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(S + l.slot_chunk, slot_chunk.data(), 4 * (size_t)l.total_cand, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(S + l.tslot_chunk, tslot_chunk.data(), 4 * (size_t)l.total_true, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(S + l.gb_off, gboff.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemsetAsync(S + l.cand_cnt, 0, 4 * (size_t)n_chunks, st));
+    MTS_HIP(hipStreamSynchronize(st));      // the staging vectors above are locals
+    const InfFast *d_fast = (const InfFast *)(S + l.fast);
+    u64 *d_cand_pos = (u64 *)(S + l.cand_pos), *d_cand_tmp = (u64 *)(S + l.cand_tmp);
+    u32 *d_cand_cnt = (u32 *)(S + l.cand_cnt), *d_true_cnt = (u32 *)(S + l.true_cnt);
+    int *d_seq = (int *)(S + l.seq_flag);
+    CandRes *d_cres = (CandRes *)(S + l.cres);
+    TrueBlk *d_tblk = (TrueBlk *)(S + l.tblk);
+    uint2 *d_subs = (uint2 *)(S + l.subs);
+    const bool fast_path = getenv("MTS_INFLATE_SEQ") == nullptr;
+    if (fast_path) {
+        const u64 max_bits = 8 * max_clen + 32;
+        dim3 gscan((unsigned)((max_bits + SCAN_SPAN_BITS - 1) / SCAN_SPAN_BITS), n_chunks);
+        hipLaunchKernelGGL(k_inf_scan, gscan, dim3(SCAN_THREADS), 0, st, d_cdata, d_chunks, d_fast, d_cand_pos, d_cand_cnt);
+        hipLaunchKernelGGL(k_inf_sortc, dim3(n_chunks), dim3(256), 0, st, d_fast, d_cand_pos, d_cand_tmp, d_cand_cnt);
+        inflate_mark(engine, st, "inflate_scan");
+        hipLaunchKernelGGL(k_inf_passA, dim3(l.total_cand), dim3(64), 0, st, d_cdata, d_chunks, d_fast, (const u32 *)(S + l.slot_chunk),
+                           d_cand_pos, d_cand_cnt, d_cres, d_subs);
+        inflate_mark(engine, st, "inflate_passA");
+        hipLaunchKernelGGL(k_inf_chain, dim3(n_chunks), dim3(64), 0, st, d_cdata, d_chunks, d_fast, d_cand_pos, d_cand_cnt, d_cres,
+                           d_tblk, d_true_cnt, d_res, d_seq);
+        inflate_mark(engine, st, "inflate_chain");
+        hipLaunchKernelGGL(k_inf_passB, dim3(l.total_true), dim3(64), 0, st, d_cdata, d_chunks, d_fast, (const u32 *)(S + l.tslot_chunk),
+                           d_tblk, d_true_cnt, d_cres, d_subs, d_tokens, d_res);
+        inflate_mark(engine, st, "inflate_passB");
+    }
     hipLaunchKernelGGL(k_inf_decode, dim3((n_chunks + 63) / 64), dim3(64), INF_LDS_PER_WAVE, st, d_cdata, d_chunks, n_chunks,
-                       d_tokens, d_res);
-    inflate_mark(engine, st, "inflate_huffman");
-    hipLaunchKernelGGL(k_inf_lz, dim3(n_chunks), dim3(64), 0, st, d_tokens, d_chunks, d_res, d_stream);
+                       d_tokens, d_res, fast_path ? d_seq : nullptr);
+    inflate_mark(engine, st, "inflate_seq_fallback");
+    hipLaunchKernelGGL(k_inf_gbase, dim3(n_chunks), dim3(1024), 0, st, d_tokens, d_chunks, d_res, (const u64 *)(S + l.gb_off),
+                       (u32 *)(S + l.gbase));
+    hipLaunchKernelGGL(k_inf_lz, dim3(n_chunks), dim3(LZ_THREADS), LZ_LDS, st, d_tokens, d_chunks, d_res, (const u64 *)(S + l.gb_off),
+                       (const u32 *)(S + l.gbase), d_stream);
     MTS_HIP(hipGetLastError());
     inflate_mark(engine, st, "inflate_lz");
-    // adler32 of the produced streams: per-chunk offset/length tables live in d_scratch
-    u64 *d_so = (u64 *)d_scratch;
-    u32 *d_nn = (u32 *)(d_so + n_chunks);
-    (void)scratch_bytes;
-    int rc = launch_adler_stream(st, d_stream, d_so, d_nn, n_chunks, max_n, d_adler_acc);
+    int rc = launch_adler_stream(st, d_stream, (const u64 *)(S + l.so), (const u32 *)(S + l.nn), n_chunks, max_n, d_adler_acc);
     if (rc) return rc;
     hipLaunchKernelGGL(k_inf_finish, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_chunks, d_res, d_adler_acc, n_chunks,
                        d_status_out);
