@@ -34,19 +34,15 @@ def parse_args():
     p.add_argument('--seconds', type=int, default=60, help='recording length per GPU (1 s chunks)')
     p.add_argument('--channels', type=int, default=385)
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-chunks', type=int, default=0, help='chunks in the CPU baseline sample (0 = 2 per core)')
+    p.add_argument('--cpu-chunks', type=int, default=32, help='chunks in the CPU baseline sample')
     return p.parse_args()
 
 
-def cpu_baseline(nc, rate, n_chunks):
+def cpu_baseline(x, nc, rate, n_chunks):
     """The reference's ThreadPool path restated on numpy + stdlib zlib (oracle.ref_*), timed on this box's
-    host cores over a bounded sample of the same workload."""
-    from mtscomp_amd.synth import synth_int16
+    host cores over a bounded sample of the same workload (the first chunks of the benchmarked recording)."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
-    if n_chunks <= 0:
-        n_chunks = 2 * cores
-    x = synth_int16(0, n_chunks * rate, nc, 0)
+    cores = min(os.cpu_count() or 1, n_chunks)
     bounds = [i * rate for i in range(n_chunks + 1)]
     t0 = time.perf_counter()
     cc = O.ref_compress_array(x, bounds, n_threads=cores)
@@ -57,10 +53,11 @@ def cpu_baseline(nc, rate, n_chunks):
     gb = x.nbytes / 1e9
     return {
         'value': gb / (t2 - t0), 'unit': 'GB/s', 'cores': cores, 'kind': 'port',
-        'sample': '%d chunks of %d ch x %d samples int16 (%.0f MB), numpy diff/tobytes + stdlib zlib %s level 6 + '
-                  'ThreadPool(%d): compress %.3f GB/s, decompress %.3f GB/s'
+        'sample': 'first %d chunks of the benchmarked recording (%d ch x %d samples int16 each, %.0f MB), numpy '
+                  'diff/tobytes + stdlib zlib %s level 6 + ThreadPool(%d) of %d host cpus: compress %.3f GB/s, '
+                  'decompress %.3f GB/s'
                   % (n_chunks, nc, rate, x.nbytes / 1e6, __import__('zlib').ZLIB_RUNTIME_VERSION, cores,
-                     gb / (t1 - t0), gb / (t2 - t1)),
+                     os.cpu_count() or 1, gb / (t1 - t0), gb / (t2 - t1)),
         'compress_gbps': gb / (t1 - t0), 'decompress_gbps': gb / (t2 - t1),
     }
 
@@ -203,7 +200,8 @@ def main():
                          'algorithmic_bytes_per_launch': algo, 'launch_ms': match_ms},
         }
         if not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(nc, rate, args.cpu_chunks)
+            m = max(1, min(args.cpu_chunks, n_chunks))
+            res['cpu_baseline'] = cpu_baseline(raw[:m * rate].cpu().numpy(), nc, rate, m)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

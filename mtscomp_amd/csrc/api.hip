@@ -387,7 +387,7 @@ static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const 
         if (n > max_n) max_n = (u32)n;
         if (n_rows[i] > (long)max_rows) max_rows = (u32)n_rows[i];
         soff += align_up(n + STREAM_PAD, STREAM_ALIGN);
-        toff += n + 2;
+        toff += align_up(n + 2, 4);          // 16-byte aligned token arrays (vector loads)
     }
     int rc;
     if ((rc = E.stream.ensure(soff + STREAM_PAD))) return rc;

@@ -221,6 +221,24 @@ __device__ int parse_tables(BitIn &br, LaneLds &L, u32 type, u32 (&LC)[16], u32 
     return INF_OK;
 }
 
+constexpr u32 LZ_PIECE = 8;          // longest copy handed to one lane of the LZ resolver
+__device__ __forceinline__ u32 lz_pieces(u32 tok, u32 olen) { return (tok >> 31) ? (olen + LZ_PIECE - 1) / LZ_PIECE : 1; }
+__device__ __forceinline__ void lz_emit_pieces(u32 *tk, u32 tok, u32 olen)
+{
+    if (!(tok >> 31) || olen <= LZ_PIECE) { tk[0] = tok; return; }
+    const u32 dist1 = tok & 0x7fff;
+    u32 k = 0;
+    // pieces of LZ_PIECE bytes; a short remainder (< 3 bytes is not encodable as len-3 >= 0) is merged
+    // into the last piece by making the last two pieces share the remainder
+    u32 left = olen;
+    while (left > 0) {
+        u32 l = left > LZ_PIECE ? LZ_PIECE : left;
+        if (left > LZ_PIECE && left - LZ_PIECE < 3) l = left - 3;          // leave >= 3 for the last piece
+        tk[k++] = 0x80000000u | ((l - 3) << 16) | dist1;
+        left -= l;
+    }
+}
+
 // One token.  Returns 0 literal/match decoded, 1 end of block, <0 error.
 // token: literal = byte; match = 1<<31 | (len-3) << 16 | (dist-1);  *olen = bytes it produces
 __device__ __forceinline__ int decode_token(BitIn &br, LaneLds &L, const u32 (&LC)[16], const u32 (&DC)[16], u32 &tok, u32 &olen)
@@ -289,8 +307,8 @@ __device__ int decode_block(BitIn &br, LaneLds &L, u32 *tk, u32 &ntok, u64 &nout
         if (t == 1) break;
         if ((tok >> 31) && (u64)((tok & 0x7fff) + 1) > nout) return INF_CORRUPT;       // too far back
         if (nout + olen > out_limit) return INF_TOOLONG;
-        if (EMIT) tk[ntok] = tok;
-        ntok++; nout += olen;
+        if (EMIT) lz_emit_pieces(tk + ntok, tok, olen);
+        ntok += lz_pieces(tok, olen); nout += olen;
     }
     return INF_OK;
 }
@@ -304,6 +322,16 @@ __device__ int decode_block(BitIn &br, LaneLds &L, u32 *tk, u32 &ntok, u64 &nout
 // an end-of-block symbol).  Random bits pass the cheap part ~0.08 % of the time and the full check
 // almost never; true block starts always pass.  Candidates are only hints: the chain walk below
 // accepts a block only if the previous block really ends there.
+__device__ __forceinline__ u32 wave_excl_scan(u32 v, u32 &total)
+{
+    const int lane = threadIdx.x & 63;
+    u32 x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+    total = x;                     // inclusive value: lane 63 holds the wave total
+    return x - v;
+}
+
 constexpr int SCAN_THREADS = 1024;
 constexpr int SCAN_SPAN_BITS = SCAN_THREADS * 32;
 constexpr int SCAN_SURV_CAP = 512;
@@ -411,6 +439,8 @@ struct TrueBlk {
 constexpr int SUBCAP = 512;      // sub-sequences recorded per candidate block
 constexpr int SUB_BITS = 2048;   // bits per sub-sequence
 
+constexpr int SCAN_L1_CAP = 14336;       // filter-1 survivors kept per workgroup (expected ~7200 of 32768)
+
 __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
                                                            const InfFast *__restrict__ fast, u64 *__restrict__ cand_pos,
                                                            u32 *__restrict__ cand_cnt)
@@ -424,42 +454,83 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
     const u64 span0 = (u64)blockIdx.x * SCAN_SPAN_BITS;        // absolute bit of this workgroup's span
     if (span0 >= end) return;
     __shared__ u32 sw[SCAN_THREADS + 8];
-    __shared__ u64 surv[SCAN_SURV_CAP];
+    __shared__ u16 l1[SCAN_L1_CAP];
+    __shared__ u32 surv[SCAN_SURV_CAP];
+    __shared__ u32 wsum[16];
     __shared__ u32 nsurv;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const u64 word0 = span0 >> 5;
     for (int i = tid; i < SCAN_THREADS + 8; i += SCAN_THREADS) sw[i] = word0 + i < nwords ? w[word0 + i] : 0;
     if (tid == 0) nsurv = 0;
     __syncthreads();
-    // phase A: 32 consecutive offsets per thread
-    const u64 lo = (u64)sw[tid] | ((u64)sw[tid + 1] << 32), mid = (u64)sw[tid + 2] | ((u64)sw[tid + 3] << 32);
-    const u64 hi = sw[tid + 4];
-    const u64 first_ok = bit0 + 16;
+    // phase A1: the 3 header fields at each of this thread's 32 offsets (BTYPE == 2, HLIT <= 29, HDIST <= 29)
+    const u32 w0 = sw[tid], w1 = sw[tid + 1];
+    u32 m = 0;
+#pragma unroll
     for (int k = 0; k < 32; k++) {
-        const u64 o = span0 + (u64)tid * 32 + k;
-        const u64 v = k ? (lo >> k) | (mid << (64 - k)) : lo;            // 64 bits from o
-        const u32 h = (u32)v;
-        const u32 hlit = (h >> 3) & 31, hdist = (h >> 8) & 31, ncode = ((h >> 13) & 15) + 4;
-        if (((h >> 1) & 3) != 2 || hlit > 29 || hdist > 29) continue;
-        if (o < first_ok || o + 17 + 3 * ncode + 8 > end) continue;
-        const u64 v2 = k ? (mid >> k) | (hi << (64 - k)) : mid;          // bits 64.. from o
-        // Kraft sum of the code-length code (3-bit lengths from bit 17), scaled by 128
-        u32 kraft = 0;
-        for (u32 i = 0; i < ncode; i++) {
-            const u32 b = 17 + 3 * i;
-            // b = 17, 20, ..., 71: the field at b = 62 straddles v / v2
-            const u32 l = (u32)(b < 62 ? v >> b : b == 62 ? (v >> 62) | (v2 << 2) : v2 >> (b - 64)) & 7;
-            kraft += l ? 128u >> l : 0;
+        const u32 h = __builtin_amdgcn_alignbit(w1, w0, k);
+        const bool ok = ((h >> 1) & 3) == 2 && ((h >> 3) & 31) <= 29 && ((h >> 8) & 31) <= 29;
+        m |= (u32)ok << k;
+    }
+    // keep only offsets inside the stream
+    {
+        const u64 o0 = span0 + (u64)tid * 32;
+        const u64 first_ok = bit0 + 16;
+        if (o0 + 32 <= first_ok || o0 + 100 > end) {
+            u32 keep = 0;
+            for (int k = 0; k < 32; k++) if (o0 + k >= first_ok && o0 + k + 100 <= end) keep |= 1u << k;
+            m &= keep;
+        } else if (o0 < first_ok) m &= ~0u << (u32)(first_ok - o0);
+    }
+    // compact the survivors of the workgroup
+    const u32 cntm = __popc(m);
+    u32 tot;
+    u32 ex = wave_excl_scan(cntm, tot);
+    if (lane == 63) wsum[wave] = tot;
+    __syncthreads();
+    u32 base = 0, n1 = 0;
+    for (int q = 0; q < 16; q++) { if (q < wave) base += wsum[q]; n1 += wsum[q]; }
+    n1 = n1 < (u32)SCAN_L1_CAP ? n1 : (u32)SCAN_L1_CAP;
+    {
+        u32 slot = base + ex, mm = m;
+        while (mm) {
+            const int k = __ffs(mm) - 1;
+            mm &= mm - 1;
+            if (slot < (u32)SCAN_L1_CAP) l1[slot] = (u16)(tid * 32 + k);
+            slot++;
         }
-        if (kraft != 128) continue;
-        const u32 slot = atomicAdd(&nsurv, 1u);
-        if (slot < SCAN_SURV_CAP) surv[slot] = o;
+    }
+    __syncthreads();
+    // phase A2: Kraft sum of the code-length code (3-bit lengths from bit 17), all lanes busy
+    for (u32 it = tid; it < n1; it += SCAN_THREADS) {
+        const u32 rel = l1[it];
+        const u32 wi = rel >> 5, k = rel & 31;
+        const u32 x0 = sw[wi], x1 = sw[wi + 1], x2 = sw[wi + 2], x3 = sw[wi + 3];
+        const u32 f0 = __builtin_amdgcn_alignbit(x1, x0, k), f1 = __builtin_amdgcn_alignbit(x2, x1, k),
+                  f2 = __builtin_amdgcn_alignbit(x3, x2, k);
+        const u32 ncode = ((f0 >> 13) & 15) + 4;
+        // bits 17.. of the stream at this offset: g0 = fields 0..9 (+2 bits of field 10), g1 = rest
+        const u32 g0 = __builtin_amdgcn_alignbit(f1, f0, 17), g1 = __builtin_amdgcn_alignbit(f2, f1, 17);
+        u32 kraft = 0;
+#pragma unroll
+        for (u32 i = 0; i < 19; i++) {
+            u32 l;
+            if (i < 10) l = (g0 >> (3 * i)) & 7;
+            else if (i == 10) l = ((g0 >> 30) | (g1 << 2)) & 7;
+            else l = (g1 >> (3 * i - 32)) & 7;
+            const u32 c = (0x80u >> l) & 0x7f;                    // 128 >> l, 0 for l == 0
+            kraft += i < ncode ? c : 0;
+        }
+        if (kraft == 128) {
+            const u32 slot = atomicAdd(&nsurv, 1u);
+            if (slot < SCAN_SURV_CAP) surv[slot] = rel;
+        }
     }
     __syncthreads();
     // phase B: full validation, survivors packed into the first lanes
     const u32 ns = min(nsurv, (u32)SCAN_SURV_CAP);
     if ((u32)tid < ns) {
-        const u64 o = surv[tid];
+        const u64 o = span0 + surv[tid];
         if (validate_dyn_header(w, nwords, end, o)) {
             const InfFast f = fast[ci];
             const u32 slot = atomicAdd(&cand_cnt[ci], 1u);
@@ -510,8 +581,11 @@ __device__ __forceinline__ void decode_span(BitIn &br, LaneLds &L, const u32 (&L
         const int t = decode_token(br, L, LC, DC, tok, olen);
         if (t < 0 || br.pos > br.end) { flag = SPAN_ERR; break; }
         if (t == 1) { flag = SPAN_EOB; break; }
-        if (MODE == 2) tk[ntok] = tok;
-        ntok++; nout += olen;
+        // a copy longer than LZ_PIECE bytes is written as several copies with the same distance (byte k of
+        // a copy reads dst - dist whatever piece it is in), so no lane of the resolver owns a long run
+        const u32 np = lz_pieces(tok, olen);
+        if (MODE == 2) lz_emit_pieces(tk + ntok, tok, olen);
+        ntok += np; nout += olen;
     }
 }
 
@@ -837,48 +911,81 @@ constexpr u32 LZ_FLUSH = 4096;                           // flush granule (bytes
 constexpr int LZ_LDS = 2 * LZ_RING + 256;
 constexpr u32 LZ_SPIN_MAX = 1u << 20;                     // bound on every wait loop (a stuck kernel must end)
 
-// prefix sums of the output size of each 64-token group: gbase[g] = first output byte of group g
-__global__ __launch_bounds__(1024) void k_inf_gbase(const u32 *__restrict__ tokens, const InfChunk *__restrict__ chunks,
-                                                    const InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
-                                                    u32 *__restrict__ gbase)
+// Output offset of every 64-token group, as a two-level scan:
+//   k_inf_gsum   one thread per group sums the bytes its 64 tokens produce; a 256-thread workgroup scans its
+//                256 groups (a "tile") -> gbase[g] = offset inside the tile, tile_tot[tile]
+//   k_inf_gscan  one wave per chunk scans the tile totals -> tile_base[tile]
+// group g starts at tile_base[g >> 8] + gbase[g].
+constexpr int GS_TILE = 256;
+
+__global__ __launch_bounds__(GS_TILE) void k_inf_gsum(const u32 *__restrict__ tokens, const InfChunk *__restrict__ chunks,
+                                                      const InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
+                                                      const u64 *__restrict__ tb_off, u32 *__restrict__ gbase,
+                                                      u32 *__restrict__ tile_base)
+{
+    const int ci = blockIdx.y;
+    const InfResult r = res[ci];
+    if (r.status != MTS_CHUNK_OK) return;
+    const u32 ntok = r.ntok, ngroups = (ntok + 63) / 64;
+    const u32 g = blockIdx.x * GS_TILE + threadIdx.x;
+    if (blockIdx.x * GS_TILE >= ngroups && !(blockIdx.x == 0)) return;
+    const u32 *tk = tokens + chunks[ci].tok_off;
+    u32 sum = 0;
+    if (g < ngroups) {
+        const u32 t0 = g * 64;
+        if (t0 + 64 <= ntok) {
+            const uint4 *q = (const uint4 *)(tk + t0);              // tok_off and t0 are multiples of... see note
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint4 v = q[k];
+                sum += (v.x >> 31) ? ((v.x >> 16) & 0xff) + 3 : 1;
+                sum += (v.y >> 31) ? ((v.y >> 16) & 0xff) + 3 : 1;
+                sum += (v.z >> 31) ? ((v.z >> 16) & 0xff) + 3 : 1;
+                sum += (v.w >> 31) ? ((v.w >> 16) & 0xff) + 3 : 1;
+            }
+        } else {
+            for (u32 i = t0; i < ntok; i++) { const u32 t = tk[i]; sum += (t >> 31) ? ((t >> 16) & 0xff) + 3 : 1; }
+        }
+    }
+    __shared__ u32 wtot[GS_TILE / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32 x = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+    if (lane == 63) wtot[wave] = x;
+    __syncthreads();
+    u32 add = 0, tot = 0;
+    for (int w = 0; w < GS_TILE / 64; w++) { if (w < wave) add += wtot[w]; tot += wtot[w]; }
+    if (g < ngroups) gbase[gb_off[ci] + g] = add + x - sum;
+    if (threadIdx.x == 0) tile_base[tb_off[ci] + blockIdx.x] = tot;          // totals; scanned in place next
+}
+
+__global__ __launch_bounds__(64) void k_inf_gscan(const InfResult *__restrict__ res, const u64 *__restrict__ tb_off,
+                                                  u32 *__restrict__ tile_base)
 {
     const int ci = blockIdx.x;
     const InfResult r = res[ci];
     if (r.status != MTS_CHUNK_OK) return;
-    const u32 *tk = tokens + chunks[ci].tok_off;
-    u32 *gb = gbase + gb_off[ci];
-    const u32 ntok = r.ntok, ngroups = (ntok + 63) / 64;
-    __shared__ u32 wtot[16];
-    __shared__ u32 carry;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (u32 g0 = 0; g0 < ngroups; g0 += 16) {
-        const u32 g = g0 + wave;
-        const u32 i = g * 64 + lane;
-        u32 len = 0;
-        if (g < ngroups && i < ntok) { const u32 t = tk[i]; len = (t >> 31) ? ((t >> 16) & 0xff) + 3 : 1; }
+    const u32 ngroups = (r.ntok + 63) / 64, ntiles = (ngroups + GS_TILE - 1) / GS_TILE;
+    u32 *tb = tile_base + tb_off[ci];
+    const int lane = threadIdx.x;
+    u32 carry = 0;
+    for (u32 t0 = 0; t0 < ntiles; t0 += 64) {
+        const u32 v = t0 + lane < ntiles ? tb[t0 + lane] : 0;
+        u32 x = v;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) len += __shfl_down(len, off, 64);
-        if (lane == 0) wtot[wave] = len;
-        __syncthreads();
-        if (lane == 0 && g < ngroups) {
-            u32 add = carry;
-            for (int w = 0; w < wave; w++) add += wtot[w];
-            gb[g] = add;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) { u32 a = carry; for (int w = 0; w < 16; w++) a += wtot[w]; carry = a; }
-        __syncthreads();
+        for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+        if (t0 + lane < ntiles) tb[t0 + lane] = carry + x - v;
+        carry += __shfl(x, 63, 64);
     }
-    if (threadIdx.x == 0) gb[ngroups] = carry;
 }
 
 __device__ __forceinline__ u32 lz_tag(u32 pos) { return ((pos >> 16) & 0x7f) + 1; }
 
 __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ tokens, const InfChunk *__restrict__ chunks,
                                                        InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
-                                                       const u32 *__restrict__ gbase, u8 *__restrict__ stream)
+                                                       const u64 *__restrict__ tb_off, const u32 *__restrict__ gbase,
+                                                       const u32 *__restrict__ tile_base, u8 *__restrict__ stream)
 {
     const int ci = blockIdx.x;
     const InfResult r = res[ci];
@@ -891,22 +998,33 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
     volatile u32 *bad_p = prog + 20;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 *tk = tokens + ch.tok_off;
-    const u32 *gb = gbase + gb_off[ci];
+    const u32 *gbl = gbase + gb_off[ci];
+    const u32 *tbs = tile_base + tb_off[ci];
     u8 *out = stream + ch.stream_off;
     const u32 ntok = r.ntok, ngroups = (ntok + 63) / 64, nout = r.n_out;
+    auto gb = [&](u32 g) -> u32 { return g >= ngroups ? nout : tbs[g / GS_TILE] + gbl[g]; };   // first output byte of group g
     for (u32 i = threadIdx.x; i < LZ_RING / 2; i += LZ_THREADS) ((volatile u32 *)ring)[i] = 0;      // tag 0 = never written
     if (threadIdx.x < 24) prog[threadIdx.x] = (threadIdx.x >= 16 && threadIdx.x < 16 + LZ_FLUSHERS) ? (threadIdx.x - 16) * LZ_FLUSH : 0;
     __syncthreads();
-    // number of leading groups that are completely finished = min over workers of the first group each
-    // has not finished (worker w owns groups w, w+W, w+2W, ...)
-    auto groups_done = [&]() -> u32 {
-        u32 v = 0xffffffffu;
-        if (lane < LZ_WORKERS) { const u32 c = prog[lane]; v = c >= 0x01000000u ? 0xffffffffu : c * LZ_WORKERS + lane; }
+    // every worker publishes the base of its first group before anyone looks at the progress words
+    u32 t_n = 0, base_n = 0, next_n = 0;
+    if (wave < LZ_WORKERS) {
+        if ((u32)wave < ngroups) {
+            const u32 i = wave * 64 + lane;
+            t_n = i < ntok ? tk[i] : 0; base_n = gb(wave); next_n = gb(wave + 1);
+        }
+        if (lane == 0) prog[wave] = (u32)wave < ngroups ? base_n : 0xffffffffu;
+    }
+    __syncthreads();
+    // bytes below this are final: the smallest start offset among the groups the workers are still on
+    // (each worker publishes the base of its current group in prog[w]; 0xffffffff when it has no more)
+    auto safe_bytes = [&]() -> u32 {
+        u32 v = lane < LZ_WORKERS ? prog[lane] : 0xffffffffu;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v = min(v, (u32)__shfl_xor(v, off, 64));
-        return v < ngroups ? v : ngroups;
+        return v < nout ? v : nout;
     };
-    // bytes below this are in HBM already
+    // bytes below this are in HBM already (or at least in registers on their way there)
     auto flushed = [&]() -> u32 {
         u32 v = fl_next[0];
 #pragma unroll
@@ -921,12 +1039,9 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
             const u32 lo = q * LZ_FLUSH;
             if (lo >= nout) break;
             const u32 hi = lo + LZ_FLUSH < nout ? lo + LZ_FLUSH : nout;
-            for (;;) {
-                const u32 gd = groups_done();
-                const u32 safe = gd >= ngroups ? nout : gb[gd];          // bytes below `safe` are final
-                if (safe >= hi) break;
+            while (safe_bytes() < hi) {
                 if (++idle > LZ_SPIN_MAX) { if (lane == 0) { *bad_p = 3; for (int k = 0; k < LZ_FLUSHERS; k++) fl_next[k] = 0xffffffffu; } return; }
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(2);
             }
             idle = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -937,40 +1052,35 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
                 if (o + 8 <= hi) *(uint2 *)(out + o) = make_uint2(v0, v1);
                 else { const u64 v = (u64)v0 | ((u64)v1 << 32); for (u32 k = 0; o + k < hi; k++) out[o + k] = (u8)(v >> (8 * k)); }
             }
-            __builtin_amdgcn_s_waitcnt(0);
+            // the stores above already consumed the LDS data: the ring space can be reused now
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) fl_next[me] = lo + LZ_FLUSHERS * LZ_FLUSH;
         }
-        __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0) fl_next[me] = 0xffffffffu;
         return;
     }
     // ---- workers ----
-    u32 done_cnt = 0;
-    u32 t_n = 0, base_n = 0, next_n = 0;
-    if ((u32)wave < ngroups) {
-        const u32 i = wave * 64 + lane;
-        t_n = i < ntok ? tk[i] : 0; base_n = gb[wave]; next_n = gb[wave + 1];
-    }
     for (u32 g = wave; g < ngroups; g += LZ_WORKERS) {
         const u32 t = t_n, base = base_n, next = next_n;
         const u32 i = g * 64 + lane;
         const bool act = i < ntok;
+        if (lane == 0) prog[wave] = base;            // groups below `base` owned by this worker are done
         // prefetch the next group's tokens while this one is resolved
         if (g + LZ_WORKERS < ngroups) {
             const u32 i2 = (g + LZ_WORKERS) * 64 + lane;
-            t_n = i2 < ntok ? tk[i2] : 0; base_n = gb[g + LZ_WORKERS]; next_n = gb[g + LZ_WORKERS + 1];
+            t_n = i2 < ntok ? tk[i2] : 0; base_n = gb(g + LZ_WORKERS); next_n = gb(g + LZ_WORKERS + 1);
         }
-        // ring safety: writing up to `next` destroys positions below next - LZ_RING; every group that may
-        // still read them (groups starting below next - LZ_RING + LZ_REACH) must be finished, and the bytes
-        // must be in HBM
+        // ring safety: writing up to `next` destroys positions below next - LZ_RING; they must be in HBM,
+        // and every group that may still read them (groups starting below next - LZ_RING + LZ_REACH) must
+        // be finished
         if (next > LZ_RING) {
             const u32 lim = next - LZ_RING;                    // positions below lim get overwritten
             for (u32 waits = 0;; waits++) {
                 bool ok = flushed() >= lim;
-                if (ok) { const u32 gd = groups_done(); if (gd < g && gb[gd] < lim + LZ_REACH) ok = false; }
+                if (ok) { const u32 sb = safe_bytes(); if (sb < base && sb < lim + LZ_REACH) ok = false; }
                 if (ok) break;
                 if (waits > LZ_SPIN_MAX) { *bad_p = 4; break; }                               // never hang
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
         }
         const bool cp = act && (t >> 31);
@@ -987,26 +1097,35 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
         u32 k = 0;
         const u32 src = dst - dist;
         u32 spins = 0;
+        const bool wide = dist >= 4;             // 4 source bytes never include this lane's own pending writes
         while (__any(live && k < len)) {
             if (live && k < len) {
                 const u32 sp = src + k;
-                const u32 c = ring[sp & (LZ_RING - 1)];
-                if ((c >> 8) == lz_tag(sp)) {
-                    const u32 dp = dst + k;
-                    ring[dp & (LZ_RING - 1)] = (u16)((lz_tag(dp) << 8) | (c & 0xff));
-                    k++;
-                    spins = 0;
-                } else if (++spins > (1u << 22)) { live = false; *bad_p = 2; }       // bounded spin: never hang the GPU
+                // up to 4 cells in flight; commit the longest valid prefix
+                const u32 c0 = ring[sp & (LZ_RING - 1)];
+                const u32 c1 = ring[(sp + 1) & (LZ_RING - 1)];
+                const u32 c2 = ring[(sp + 2) & (LZ_RING - 1)];
+                const u32 c3 = ring[(sp + 3) & (LZ_RING - 1)];
+                const bool v0 = (c0 >> 8) == lz_tag(sp);
+                const bool v1 = v0 && wide && k + 1 < len && (c1 >> 8) == lz_tag(sp + 1);
+                const bool v2 = v1 && k + 2 < len && (c2 >> 8) == lz_tag(sp + 2);
+                const bool v3 = v2 && k + 3 < len && (c3 >> 8) == lz_tag(sp + 3);
+                const u32 dp = dst + k;
+                if (v0) ring[dp & (LZ_RING - 1)] = (u16)((lz_tag(dp) << 8) | (c0 & 0xff));
+                if (v1) ring[(dp + 1) & (LZ_RING - 1)] = (u16)((lz_tag(dp + 1) << 8) | (c1 & 0xff));
+                if (v2) ring[(dp + 2) & (LZ_RING - 1)] = (u16)((lz_tag(dp + 2) << 8) | (c2 & 0xff));
+                if (v3) ring[(dp + 3) & (LZ_RING - 1)] = (u16)((lz_tag(dp + 3) << 8) | (c3 & 0xff));
+                const u32 adv = (u32)v0 + (u32)v1 + (u32)v2 + (u32)v3;
+                k += adv;
+                if (adv) spins = 0;
+                else if (++spins > (1u << 22)) { live = false; *bad_p = 2; }       // bounded spin: never hang the GPU
             }
         }
-        done_cnt++;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-        if (lane == 0) prog[wave] = done_cnt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // ring writes before the next progress update
     }
-    // workers with no (more) groups count as "finished everything"
-    __builtin_amdgcn_s_waitcnt(0);
-    if (lane == 0) prog[wave] = 0x7f000000u;
+    // no more groups for this worker
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) prog[wave] = 0xffffffffu;
     if (wave == 0 && lane == 0) {
         // wait for the flushers before reporting (same workgroup: they are resident)
         for (u32 waits = 0; flushed() < nout && waits < 4 * LZ_SPIN_MAX; waits++) __builtin_amdgcn_s_sleep(8);
@@ -1037,7 +1156,7 @@ static inline u32 cand_cap_of(u64 c_len) { return (u32)(c_len / 4096 + 64); }
 // scratch layout (all 256-B aligned): [so u64 n][nn u32 n][fast n][cand_cnt n][true_cnt n][seq_flag n]
 //   [slot_chunk total_cand][tslot_chunk total_true][cand_pos][cand_tmp][cres][tblk][subs]
 struct InfLayout {
-    size_t so, nn, fast, cand_cnt, true_cnt, seq_flag, slot_chunk, tslot_chunk, cand_pos, cand_tmp, cres, tblk, subs, gb_off, gbase, end;
+    size_t so, nn, fast, cand_cnt, true_cnt, seq_flag, slot_chunk, tslot_chunk, cand_pos, cand_tmp, cres, tblk, subs, gb_off, gbase, tb_off, tile_base, end;
     u32 total_cand, total_true;
 };
 static InfLayout inf_layout(int n_chunks, const u64 *c_lens, const u32 *n_expect)
@@ -1059,6 +1178,8 @@ static InfLayout inf_layout(int n_chunks, const u64 *c_lens, const u32 *n_expect
     size_t ng = 0;
     for (int i = 0; i < n_chunks; i++) ng += ((size_t)n_expect[i] + 2 + 63) / 64 + 2;       // tokens <= bytes + 1
     l.gbase = take(4 * ng);
+    l.tb_off = take(8 * (size_t)n_chunks);
+    l.tile_base = take(4 * (ng / GS_TILE + 2 * (size_t)n_chunks + 16));
     l.end = o;
     return l;
 }
@@ -1084,8 +1205,15 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
         if (lens[i] > max_clen) max_clen = lens[i];
     }
     const InfLayout l = inf_layout(n_chunks, lens.data(), nn.data());
-    std::vector<u64> gboff(n_chunks);
-    { u64 a = 0; for (int i = 0; i < n_chunks; i++) { gboff[i] = a; a += ((u64)nn[i] + 2 + 63) / 64 + 2; } }
+    std::vector<u64> gboff(n_chunks), tboff(n_chunks);
+    {
+        u64 a = 0, b2 = 0;
+        for (int i = 0; i < n_chunks; i++) {
+            const u64 ng1 = ((u64)nn[i] + 2 + 63) / 64 + 2;
+            gboff[i] = a; a += ng1;
+            tboff[i] = b2; b2 += ng1 / GS_TILE + 2;
+        }
+    }
     u8 *S = (u8 *)d_scratch;
     std::vector<InfFast> fast(n_chunks);
     std::vector<u32> slot_chunk(l.total_cand), tslot_chunk(l.total_true);
@@ -1103,6 +1231,7 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
     MTS_HIP(hipMemcpyAsync(S + l.slot_chunk, slot_chunk.data(), 4 * (size_t)l.total_cand, hipMemcpyHostToDevice, st));
     MTS_HIP(hipMemcpyAsync(S + l.tslot_chunk, tslot_chunk.data(), 4 * (size_t)l.total_true, hipMemcpyHostToDevice, st));
     MTS_HIP(hipMemcpyAsync(S + l.gb_off, gboff.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(S + l.tb_off, tboff.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
     MTS_HIP(hipMemsetAsync(S + l.cand_cnt, 0, 4 * (size_t)n_chunks, st));
     MTS_HIP(hipStreamSynchronize(st));      // the staging vectors above are locals
     const InfFast *d_fast = (const InfFast *)(S + l.fast);
@@ -1132,10 +1261,17 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
     hipLaunchKernelGGL(k_inf_decode, dim3((n_chunks + 63) / 64), dim3(64), INF_LDS_PER_WAVE, st, d_cdata, d_chunks, n_chunks,
                        d_tokens, d_res, fast_path ? d_seq : nullptr);
     inflate_mark(engine, st, "inflate_seq_fallback");
-    hipLaunchKernelGGL(k_inf_gbase, dim3(n_chunks), dim3(1024), 0, st, d_tokens, d_chunks, d_res, (const u64 *)(S + l.gb_off),
-                       (u32 *)(S + l.gbase));
+    {
+        u32 max_groups = 1;
+        for (int i = 0; i < n_chunks; i++) { const u32 gmax = (u32)(((u64)nn[i] + 2 + 63) / 64); if (gmax > max_groups) max_groups = gmax; }
+        dim3 gg((max_groups + GS_TILE - 1) / GS_TILE, n_chunks);
+        hipLaunchKernelGGL(k_inf_gsum, gg, dim3(GS_TILE), 0, st, d_tokens, d_chunks, d_res, (const u64 *)(S + l.gb_off),
+                           (const u64 *)(S + l.tb_off), (u32 *)(S + l.gbase), (u32 *)(S + l.tile_base));
+        hipLaunchKernelGGL(k_inf_gscan, dim3(n_chunks), dim3(64), 0, st, d_res, (const u64 *)(S + l.tb_off), (u32 *)(S + l.tile_base));
+    }
+    inflate_mark(engine, st, "inflate_offsets");
     hipLaunchKernelGGL(k_inf_lz, dim3(n_chunks), dim3(LZ_THREADS), LZ_LDS, st, d_tokens, d_chunks, d_res, (const u64 *)(S + l.gb_off),
-                       (const u32 *)(S + l.gbase), d_stream);
+                       (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base), d_stream);
     MTS_HIP(hipGetLastError());
     inflate_mark(engine, st, "inflate_lz");
     int rc = launch_adler_stream(st, d_stream, (const u64 *)(S + l.so), (const u32 *)(S + l.nn), n_chunks, max_n, d_adler_acc);
