@@ -18,6 +18,8 @@
 //                      build_tree / gen_bitlen / scan_tree by one lane; stored/fixed/dynamic choice.
 //   L  k_block_layout  per chunk: bit offsets of the blocks, stream size, adler32.
 //   B  k_block_pack    per block: canonical codes -> bitstream (each lane packs a run of tokens).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mts {
@@ -159,7 +161,10 @@ __device__ __forceinline__ void radix_pass(const u8 *__restrict__ s, const u64 *
 }
 
 // third phase: hashes (now sorted) -> number of same-hash predecessors of each slot, capped at 65535
-__device__ __forceinline__ void chain_lengths(const u16 *__restrict__ sh, u16 *__restrict__ nb, u32 wlen, u32 *wmax, u32 *carry_p)
+// and the two filter keys of the match stage: k3 = byte 3, k34 = a mix of bytes 3 and 4 (equal bytes =>
+// equal mix; the mix only ever causes a candidate to be scored that need not have been)
+__device__ __forceinline__ void chain_lengths(const u16 *__restrict__ sh, const u64 *__restrict__ se, u16 *__restrict__ nb,
+                                              u8 *__restrict__ k3, u8 *__restrict__ k34, u32 wlen, u32 *wmax, u32 *carry_p)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) *carry_p = 0;
@@ -180,7 +185,13 @@ __device__ __forceinline__ void chain_lengths(const u16 *__restrict__ sh, u16 *_
         v = max(v, pre);
         __syncthreads();
         if (threadIdx.x == 1023) *carry_p = v;
-        if (act) { const u32 c = i + 1 - v; nb[i] = (u16)(c < 65535u ? c : 65535u); }
+        if (act) {
+            const u32 c = i + 1 - v;
+            nb[i] = (u16)(c < 65535u ? c : 65535u);
+            const u32 w1 = (u32)(se[i] >> 32), b3 = w1 & 0xff, b4 = (w1 >> 8) & 0xff;
+            k3[i] = (u8)b3;
+            k34[i] = (u8)(b4 ^ ((b3 << 3) | (b3 >> 5)));
+        }
         __syncthreads();
     }
 }
@@ -188,7 +199,8 @@ __device__ __forceinline__ void chain_lengths(const u16 *__restrict__ sh, u16 *_
 __global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
                                                     u64 *__restrict__ tmp_e, u16 *__restrict__ tmp_h,
                                                     u64 *__restrict__ sorted_e, u16 *__restrict__ sorted_h,
-                                                    u16 *__restrict__ sorted_nb)
+                                                    u16 *__restrict__ sorted_nb, u8 *__restrict__ sorted_k3,
+                                                    u8 *__restrict__ sorted_k34)
 {
     const TileDesc td = tiles[blockIdx.x];
     __shared__ u32 cnt[16][256];
@@ -198,15 +210,16 @@ __global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ strea
     radix_pass<8, true>(s, nullptr, nullptr, tmp_e + td.sorted_off, tmp_h + td.sorted_off, td.wlen, cnt, tot);   // low 8 hash bits
     radix_pass<7, false>(s, tmp_e + td.sorted_off, tmp_h + td.sorted_off, sorted_e + td.sorted_off, sorted_h + td.sorted_off,
                          td.wlen, cnt, tot);                                                                      // high 7 bits
-    chain_lengths(sorted_h + td.sorted_off, sorted_nb + td.sorted_off, td.wlen, tot, tot + 32);
+    chain_lengths(sorted_h + td.sorted_off, sorted_e + td.sorted_off, sorted_nb + td.sorted_off, sorted_k3 + td.sorted_off,
+                  sorted_k34 + td.sorted_off, td.wlen, tot, tot + 32);
 }
 
 int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u64 *d_tmp_e, u16 *d_tmp_h,
-                     u64 *d_sorted_e, u16 *d_sorted_h, u16 *d_sorted_nb)
+                     u64 *d_sorted_e, u16 *d_sorted_h, u16 *d_sorted_nb, u8 *d_sorted_k3, u8 *d_sorted_k34)
 {
     if (n_tiles == 0) return MTS_OK;
     hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(1024), 0, st, d_stream, d_tiles, d_tmp_e, d_tmp_h, d_sorted_e, d_sorted_h,
-                       d_sorted_nb);
+                       d_sorted_nb, d_sorted_k3, d_sorted_k34);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
@@ -347,16 +360,189 @@ __global__ __launch_bounds__(1024) void k_match(const u8 *__restrict__ stream, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// M, filtered walk (default).  Same result as k_match above, far fewer candidates scored:
+// a candidate can only replace the current best if it can be LONGER than it.  Its length is bounded from
+// the two byte keys alone: byte 3 differs -> at most 3, byte 3 equal but the (3,4) mix differs -> at most
+// 4.  So once best >= 3 only byte-3-equal candidates are scored, once best >= 4 only mix-equal ones; all
+// others are skipped -- which changes nothing, because zlib's walk would have compared and rejected them
+// (they still count against the chain budget: budgets are positions in the run, not candidates scored).
+// The keys of 8 candidates are tested per LDS read with SWAR byte compares.
+// ------------------------------------------------------------------------------------------------
+constexpr int WINB4 = WIN + 288;
+constexpr int ST4_N = 192;                          // entries staged per wave: slots i0-128 .. i0+63
+constexpr int ST4_BYTES = ST4_N * 8 + 2 * ST4_N;    // entries + two key arrays
+constexpr int MATCH4_LDS = WINB4 + 16 * ST4_BYTES;
+
+// bit k of the result = byte k of v is zero (k = 0..3)
+__device__ __forceinline__ u32 zero_bytes4(u32 v)
+{
+    const u32 t = ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v | 0x7f7f7f7fu;      // bit 7 of a byte clear iff the byte is 0
+    return ((((~t) >> 7) & 0x01010101u) * 0x01020408u) >> 24;
+}
+__device__ __forceinline__ u32 zero_bytes8(u64 v) { return zero_bytes4((u32)v) | (zero_bytes4((u32)(v >> 32)) << 4); }
+// bits [lo, hi] (inclusive, may lie outside 0..31) of a 32-bit word
+__device__ __forceinline__ u32 bit_range(int lo, int hi)
+{
+    if (hi < 0 || lo > 31 || hi < lo) return 0;
+    const u32 l = lo < 0 ? 0 : (u32)lo, h = hi > 31 ? 31 : (u32)hi;
+    return (0xffffffffu >> (31 - h)) & (0xffffffffu << l);
+}
+
+__global__ __launch_bounds__(1024) void k_match4(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
+                                                 const u64 *__restrict__ sorted_e, const u16 *__restrict__ sorted_nb,
+                                                 const u8 *__restrict__ sorted_k3, const u8 *__restrict__ sorted_k34,
+                                                 uint2 *__restrict__ tables, LevelCfg cfg)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const TileDesc td = tiles[blockIdx.x];
+    u32 *win = (u32 *)smem;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u8 *wbase = smem + WINB4 + wave * ST4_BYTES;
+    u64 *SE = (u64 *)wbase;
+    u64 *SK3 = (u64 *)(wbase + ST4_N * 8);
+    u64 *SK34 = (u64 *)(wbase + ST4_N * 8 + ST4_N);
+    uint2 *T = tables + td.stream_off;
+    if (threadIdx.x < 2) {
+        const u32 hashed_end = td.w + td.wlen;
+        const u32 p = hashed_end + threadIdx.x;
+        if (p >= td.a && p < td.own_end) T[p] = make_uint2(0, 0);
+    }
+    if (td.wlen == 0) return;
+    {
+        const u32 nbytes = (td.own_end - td.w) + 288;
+        const uint4 *src = (const uint4 *)(stream + td.stream_off + td.w);
+        uint4 *dst = (uint4 *)win;
+        const u32 nvec = (nbytes + 15) / 16;
+        for (u32 i = threadIdx.x; i < nvec; i += 1024) dst[i] = src[i];
+    }
+    __syncthreads();
+    const u64 *se = sorted_e + td.sorted_off;
+    const u16 *snb = sorted_nb + td.sorted_off;
+    const u32 *k3w = (const u32 *)(sorted_k3 + td.sorted_off);
+    const u32 *k34w = (const u32 *)(sorted_k34 + td.sorted_off);
+    const u32 wlen = td.wlen, n = td.n;
+    const u32 wlen_pad = (wlen + 63) & ~63u;
+    const u32 ngroups = (wlen + 63) / 64;
+    const u32 halo = td.a - td.w;
+    const u32 chain = (u32)cfg.chain, qchain = (u32)cfg.chain >> 2;
+    const int r8 = lane & 7, g8 = lane >> 3;
+    for (u32 g = wave; g < ngroups; g += 16) {
+        const u32 i0 = g * 64, i = i0 + lane;
+        const u64 e = i < wlen ? se[i] : ~0ull;
+        const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
+        const u32 rel_p = e0 & REL_MASK;
+        const bool own = i < wlen && rel_p >= halo;
+        if (!__any(own)) continue;
+        const u32 p_abs = td.w + rel_p;
+        const u32 look = n - p_abs;
+        const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
+        const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
+        const int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
+        const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
+        u32 nbv = own ? (u32)snb[i] : 0;
+        nbv = nbv < chain ? nbv : chain;
+        const u32 rep3 = (e1 & 0xff) * 0x01010101u;
+        const u32 b3 = e1 & 0xff, b4 = (e1 >> 8) & 0xff;
+        const u32 rep34 = ((b4 ^ ((b3 << 3) | (b3 >> 5))) & 0xff) * 0x01010101u;
+        u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
+        bool stop = false, qtaken = false;
+        const u32 jmax = __reduce_max_sync_u32(nbv);
+        for (u32 jbase = 0; jbase < jmax; jbase += 128) {
+            // stage slots i0 - jbase - 128 + k, k in [0, 192)
+            const int sb = (int)i0 - (int)jbase - 128;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int idx = sb + lane + 64 * k;
+                SE[lane + 64 * k] = (idx >= 0 && (u32)idx < wlen) ? se[idx] : ~0ull;
+            }
+            if (lane < 48) {
+                const int idx = sb + 4 * lane;                       // 4 keys per lane
+                const bool in = idx >= 0 && (u32)idx + 4 <= wlen_pad;
+                ((u32 *)SK3)[lane] = in ? k3w[idx >> 2] : 0;
+                ((u32 *)SK34)[lane] = in ? k34w[idx >> 2] : 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const u32 nbl = nbv > jbase ? (nbv - jbase < 128 ? nbv - jbase : 128) : 0;      // candidates of this lane in the block
+            // candidate jj (1 = newest) of this lane sits in stage slot 128 + lane - jj = 8*g8 + m with
+            // m = 128 + r8 - jj; the masks below are indexed by m (5 words), scanned from high m to low
+            const int lo_m = 128 + r8 - (int)nbl, hi_m = 127 + r8;
+#pragma unroll
+            for (int w = 4; w >= 0; w--) {
+                const u32 V = bit_range(lo_m - 32 * w, hi_m - 32 * w);
+                u32 M8 = 0, M5 = 0;
+#pragma unroll
+                for (int tt = 0; tt < 4; tt++) {
+                    const int t = 4 * w + tt;
+                    if (t > 16) continue;
+                    const u64 a3 = SK3[g8 + t], a34 = SK34[g8 + t];
+                    const u32 z3 = zero_bytes8(a3 ^ ((u64)rep3 | ((u64)rep3 << 32)));
+                    const u32 z34 = zero_bytes8(a34 ^ ((u64)rep34 | ((u64)rep34 << 32)));
+                    M8 |= z3 << (8 * tt);
+                    M5 |= (z3 & z34) << (8 * tt);
+                }
+                M8 &= V; M5 &= V;
+                u32 el = stop ? 0 : (best < 3 ? V : best < 4 ? M8 : M5);
+                while (__any(el != 0)) {
+                    if (el) {
+                        const u32 b = 31 - __builtin_clz(el);
+                        el &= ~(1u << b);
+                        const int m = 32 * w + (int)b;
+                        const u32 j = jbase + (u32)(128 + r8 - m);
+                        const u64 c = SE[8 * g8 + m];
+                        const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
+                        const u32 rel_c = c0 & REL_MASK;
+                        if (!qtaken && j > qchain) { qbest = best; qdist = bdist; qtaken = true; }
+                        if ((int)rel_c > (j == 1 ? lim1 : limn)) {
+                            const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
+                            if ((x0 & 0x1ff) == 0) {
+                                u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
+                                if (x1 == 0 && (x0 >> 9) == 0) {
+                                    while (len < maxlen) {
+                                        const u32 x = lds_u32(win, rel_c + len) ^ lds_u32(win, rel_p + len);
+                                        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+                                        len += 4;
+                                    }
+                                }
+                                len = len < maxlen ? len : maxlen;
+                                if (len > best) {
+                                    best = len; bdist = rel_p - rel_c;
+                                    if (len >= nice) stop = true;
+                                    // fewer candidates can still win now
+                                    el &= best < 4 ? M8 : M5;
+                                }
+                            }
+                        } else stop = true;                 // out of range: so is everything older
+                        if (stop) el = 0;
+                    }
+                }
+            }
+            if (!__any(!stop && nbv > jbase + 128)) break;
+        }
+        if (!qtaken) { qbest = best; qdist = bdist; }
+        if (own) T[p_abs] = make_uint2(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0);
+    }
+}
+
 int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u64 *d_sorted_e,
-                 const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg)
+                 const u16 *d_sorted_nb, const u8 *d_sorted_k3, const u8 *d_sorted_k34, uint2 *d_tables, LevelCfg cfg)
 {
     if (n_tiles == 0) return MTS_OK;
     static bool attr_set = false;
+    static bool use_v3 = false;
     if (!attr_set) {
         MTS_HIP(hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS));
+        MTS_HIP(hipFuncSetAttribute((const void *)k_match4, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH4_LDS));
+        const char *e = getenv("MTS_MATCH");
+        use_v3 = e && e[0] == '3';              // unfiltered walk, kept for A/B measurements
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_match, dim3(n_tiles), dim3(1024), MATCH_LDS, st, d_stream, d_tiles, d_sorted_e, d_sorted_nb, d_tables, cfg);
+    if (use_v3)
+        hipLaunchKernelGGL(k_match, dim3(n_tiles), dim3(1024), MATCH_LDS, st, d_stream, d_tiles, d_sorted_e, d_sorted_nb, d_tables, cfg);
+    else
+        hipLaunchKernelGGL(k_match4, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted_e, d_sorted_nb,
+                           d_sorted_k3, d_sorted_k34, d_tables, cfg);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }

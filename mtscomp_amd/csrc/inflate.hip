@@ -985,7 +985,7 @@ __device__ __forceinline__ u32 lz_tag(u32 pos) { return ((pos >> 16) & 0x7f) + 1
 __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ tokens, const InfChunk *__restrict__ chunks,
                                                        InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
                                                        const u64 *__restrict__ tb_off, const u32 *__restrict__ gbase,
-                                                       const u32 *__restrict__ tile_base, u8 *__restrict__ stream)
+                                                       const u32 *__restrict__ tile_base, u8 *__restrict__ stream, int n_workers)
 {
     const int ci = blockIdx.x;
     const InfResult r = res[ci];
@@ -1008,7 +1008,8 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
     __syncthreads();
     // every worker publishes the base of its first group before anyone looks at the progress words
     u32 t_n = 0, base_n = 0, next_n = 0;
-    if (wave < LZ_WORKERS) {
+    const int LZW = n_workers;          // decoding waves actually used (<= LZ_WORKERS)
+    if (wave < LZW) {
         if ((u32)wave < ngroups) {
             const u32 i = wave * 64 + lane;
             t_n = i < ntok ? tk[i] : 0; base_n = gb(wave); next_n = gb(wave + 1);
@@ -1019,7 +1020,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
     // bytes below this are final: the smallest start offset among the groups the workers are still on
     // (each worker publishes the base of its current group in prog[w]; 0xffffffff when it has no more)
     auto safe_bytes = [&]() -> u32 {
-        u32 v = lane < LZ_WORKERS ? prog[lane] : 0xffffffffu;
+        u32 v = lane < LZW ? prog[lane] : 0xffffffffu;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v = min(v, (u32)__shfl_xor(v, off, 64));
         return v < nout ? v : nout;
@@ -1060,15 +1061,16 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
         return;
     }
     // ---- workers ----
-    for (u32 g = wave; g < ngroups; g += LZ_WORKERS) {
+    if (wave >= LZW) return;
+    for (u32 g = wave; g < ngroups; g += LZW) {
         const u32 t = t_n, base = base_n, next = next_n;
         const u32 i = g * 64 + lane;
         const bool act = i < ntok;
         if (lane == 0) prog[wave] = base;            // groups below `base` owned by this worker are done
         // prefetch the next group's tokens while this one is resolved
-        if (g + LZ_WORKERS < ngroups) {
-            const u32 i2 = (g + LZ_WORKERS) * 64 + lane;
-            t_n = i2 < ntok ? tk[i2] : 0; base_n = gb(g + LZ_WORKERS); next_n = gb(g + LZ_WORKERS + 1);
+        if (g + LZW < ngroups) {
+            const u32 i2 = (g + LZW) * 64 + lane;
+            t_n = i2 < ntok ? tk[i2] : 0; base_n = gb(g + LZW); next_n = gb(g + LZW + 1);
         }
         // ring safety: writing up to `next` destroys positions below next - LZ_RING; they must be in HBM,
         // and every group that may still read them (groups starting below next - LZ_RING + LZ_REACH) must
@@ -1102,19 +1104,21 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
             if (live && k < len) {
                 const u32 sp = src + k;
                 // up to 4 cells in flight; commit the longest valid prefix
-                const u32 c0 = ring[sp & (LZ_RING - 1)];
-                const u32 c1 = ring[(sp + 1) & (LZ_RING - 1)];
-                const u32 c2 = ring[(sp + 2) & (LZ_RING - 1)];
-                const u32 c3 = ring[(sp + 3) & (LZ_RING - 1)];
+                // relaxed atomic loads: re-read every iteration like volatile, but the four may be in flight together
+                u16 *rg = (u16 *)smem;
+                const u32 c0 = __hip_atomic_load(rg + (sp & (LZ_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const u32 c1 = __hip_atomic_load(rg + ((sp + 1) & (LZ_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const u32 c2 = __hip_atomic_load(rg + ((sp + 2) & (LZ_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const u32 c3 = __hip_atomic_load(rg + ((sp + 3) & (LZ_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const bool v0 = (c0 >> 8) == lz_tag(sp);
                 const bool v1 = v0 && wide && k + 1 < len && (c1 >> 8) == lz_tag(sp + 1);
                 const bool v2 = v1 && k + 2 < len && (c2 >> 8) == lz_tag(sp + 2);
                 const bool v3 = v2 && k + 3 < len && (c3 >> 8) == lz_tag(sp + 3);
                 const u32 dp = dst + k;
-                if (v0) ring[dp & (LZ_RING - 1)] = (u16)((lz_tag(dp) << 8) | (c0 & 0xff));
-                if (v1) ring[(dp + 1) & (LZ_RING - 1)] = (u16)((lz_tag(dp + 1) << 8) | (c1 & 0xff));
-                if (v2) ring[(dp + 2) & (LZ_RING - 1)] = (u16)((lz_tag(dp + 2) << 8) | (c2 & 0xff));
-                if (v3) ring[(dp + 3) & (LZ_RING - 1)] = (u16)((lz_tag(dp + 3) << 8) | (c3 & 0xff));
+                if (v0) __hip_atomic_store(rg + (dp & (LZ_RING - 1)), (u16)((lz_tag(dp) << 8) | (c0 & 0xff)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (v1) __hip_atomic_store(rg + ((dp + 1) & (LZ_RING - 1)), (u16)((lz_tag(dp + 1) << 8) | (c1 & 0xff)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (v2) __hip_atomic_store(rg + ((dp + 2) & (LZ_RING - 1)), (u16)((lz_tag(dp + 2) << 8) | (c2 & 0xff)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (v3) __hip_atomic_store(rg + ((dp + 3) & (LZ_RING - 1)), (u16)((lz_tag(dp + 3) << 8) | (c3 & 0xff)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const u32 adv = (u32)v0 + (u32)v1 + (u32)v2 + (u32)v3;
                 k += adv;
                 if (adv) spins = 0;
@@ -1242,6 +1246,8 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
     TrueBlk *d_tblk = (TrueBlk *)(S + l.tblk);
     uint2 *d_subs = (uint2 *)(S + l.subs);
     const bool fast_path = getenv("MTS_INFLATE_SEQ") == nullptr;
+    int lz_workers = LZ_WORKERS;
+    if (const char *e = getenv("MTS_LZ_WORKERS")) { lz_workers = atoi(e); if (lz_workers < 1) lz_workers = 1; if (lz_workers > LZ_WORKERS) lz_workers = LZ_WORKERS; }
     if (fast_path) {
         const u64 max_bits = 8 * max_clen + 32;
         dim3 gscan((unsigned)((max_bits + SCAN_SPAN_BITS - 1) / SCAN_SPAN_BITS), n_chunks);
@@ -1271,7 +1277,7 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
     }
     inflate_mark(engine, st, "inflate_offsets");
     hipLaunchKernelGGL(k_inf_lz, dim3(n_chunks), dim3(LZ_THREADS), LZ_LDS, st, d_tokens, d_chunks, d_res, (const u64 *)(S + l.gb_off),
-                       (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base), d_stream);
+                       (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base), d_stream, lz_workers);
     MTS_HIP(hipGetLastError());
     inflate_mark(engine, st, "inflate_lz");
     int rc = launch_adler_stream(st, d_stream, (const u64 *)(S + l.so), (const u32 *)(S + l.nn), n_chunks, max_n, d_adler_acc);
