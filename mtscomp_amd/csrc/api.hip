@@ -185,9 +185,9 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     // ---- workspace ----
     int rc;
     if (!raw_is_stream) { if ((rc = E.stream.ensure(stream_bytes))) return rc; }
-    const size_t sort_n = align_up(sorted_off + 64, 64);          // u64 entries followed by u16 hashes
-    if ((rc = E.sort_a.ensure(sort_n * 10))) return rc;
-    if ((rc = E.sort_b.ensure(sort_n * 12))) return rc;           // + two u8 filter-key arrays
+    const size_t sort_n = align_up(sorted_off + 64, 64);          // 32-bit keys; sort_a also holds the u16 chain lengths
+    if ((rc = E.sort_a.ensure(sort_n * 6))) return rc;
+    if ((rc = E.sort_b.ensure(sort_n * 4))) return rc;
     if ((rc = E.tables.ensure((stream_bytes + 64) * sizeof(uint2)))) return rc;
     if ((rc = E.tokens.ensure((toff + 64) * 4))) return rc;
     if ((rc = E.marks.ensure(stream_bytes / 8 + 256))) return rc;
@@ -265,14 +265,12 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         d_stream = E.stream.as<u8>();
     }
     E.t_mark(st, "delta_transpose");
-    u64 *tmp_e = E.sort_a.as<u64>(), *srt_e = E.sort_b.as<u64>();
-    u16 *tmp_h = (u16 *)(tmp_e + sort_n), *srt_h = (u16 *)(srt_e + sort_n);
-    u16 *srt_nb = tmp_h;           // the chain lengths overwrite the pass-1 hashes (dead after pass 2)
-    u8 *srt_k3 = (u8 *)(srt_h + sort_n), *srt_k34 = srt_k3 + sort_n;
-    if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_e, tmp_h, srt_e, srt_h, srt_nb, srt_k3, srt_k34))) return rc;
+    u32 *tmp_k = E.sort_a.as<u32>(), *srt_k = E.sort_b.as<u32>();
+    u16 *srt_nb = (u16 *)(tmp_k + sort_n);
+    if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, srt_nb))) return rc;
     E.t_mark(st, "hash_sort");
     uint2 *d_tables = E.tables.as<uint2>();
-    if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_e, srt_nb, srt_k3, srt_k34, d_tables, cfg))) return rc;
+    if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, srt_nb, d_tables, cfg))) return rc;
     E.t_mark(st, "match");
     if ((rc = launch_parse_spec(st, d_tables, d_chunks, pb, (int)nseg, cfg))) return rc;
     int round = 0;

@@ -113,12 +113,10 @@ int launch_adler_stream(hipStream_t st, const u8 *d_stream, const u64 *d_stream_
                         int n_chunks, u32 max_n, u64 *d_adler_acc);
 
 // deflate.hip
-int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u64 *d_tmp_e,
-                     u16 *d_tmp_h, u64 *d_sorted_e, u16 *d_sorted_h, u16 *d_sorted_nb, u8 *d_sorted_k3,
-                     u8 *d_sorted_k34);
+int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp,
+                     u32 *d_sorted, u16 *d_sorted_nb);
 int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles,
-                 const u64 *d_sorted_e, const u16 *d_sorted_nb, const u8 *d_sorted_k3, const u8 *d_sorted_k34,
-                 uint2 *d_tables, LevelCfg cfg);
+                 const u32 *d_sorted, const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg);
 struct ParseBufs {
     u32 *entry, *exit_a, *exit_b, *cnt, *tokbase;   // per segment
     u32 *marks;                                     // 1 bit per stream byte (global stream offsets)

@@ -75,30 +75,11 @@ __device__ __forceinline__ u32 __reduce_max_sync_u32(u32 v)
 // ================================================================================================
 // S: hash sort
 // ================================================================================================
-// A sorted entry carries everything the match stage needs to score a candidate without touching the
-// window bytes.  Two 32-bit words:
-//   w0 [16:0]  rel   window-relative position
-//      [25:17] d     9 bits that, TOGETHER WITH AN EQUAL 15-BIT HASH, prove bytes 0..2 equal:
-//                    h = (b0<<10 ^ b1<<5 ^ b2) & 0x7fff exposes b0[4:3], b1[4:3], b2[4:0] directly and
-//                    b0[2:0]^b1[7:5], b1[2:0]^b2[7:5]; b0[7:5] not at all.  d = b0[7:5] : b0[2:0] : b1[2:0].
-//      [31:26] low 6 bits of byte 7
-//   w1         bytes 3..6
-// so the common prefix of two same-hash positions is known exactly up to 7 bytes from the entries alone;
-// only longer matches read the window.  A parallel u16 array first carries the hash (sort key) and ends
-// up holding, per sorted slot, the number of same-hash predecessors (the length of the chain behind it).
-__device__ __forceinline__ u64 make_entry(u32 rel, u32 lo, u32 hi)       // lo = bytes 0..3, hi = bytes 4..7
-{
-    const u32 b0 = lo & 0xff, b1 = (lo >> 8) & 0xff;
-    const u32 d = ((b0 >> 5) << 6) | ((b0 & 7) << 3) | (b1 & 7);
-    const u32 w0 = rel | (d << REL_BITS) | (((hi >> 24) & 0x3f) << 26);
-    const u32 w1 = (lo >> 24) | (hi << 8);
-    return (u64)w0 | ((u64)w1 << 32);
-}
-
+// The radix passes move 32-bit keys  (hash << 17) | window-relative position.  Everything else the match
+// stage wants about a position (its bytes 0..7) is read from the window, which that kernel keeps in LDS.
 template <int NB, bool FIRST>
-__device__ __forceinline__ void radix_pass(const u8 *__restrict__ s, const u64 *__restrict__ src_e, const u16 *__restrict__ src_h,
-                                           u64 *__restrict__ dst_e, u16 *__restrict__ dst_h, u32 wlen, u32 (*cnt)[256],
-                                           u32 *tot)
+__device__ __forceinline__ void radix_pass(const u8 *__restrict__ s, const u32 *__restrict__ src, u32 *__restrict__ dst, u32 wlen,
+                                           u32 (*cnt)[256], u32 *tot)
 {
     constexpr int NBIN = 1 << NB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -108,7 +89,7 @@ __device__ __forceinline__ void radix_pass(const u8 *__restrict__ s, const u64 *
     __syncthreads();
     for (u32 i = beg + lane; i < end; i += 64) {
         u32 d;
-        if (FIRST) d = hash_of(gld_u32_unaligned(s, i)) & 255; else d = src_h[i] >> 8;
+        if (FIRST) d = hash_of(gld_u32_unaligned(s, i)) & 255; else d = src[i] >> 25;
         atomicAdd(&cnt[wave][d], 1u);
     }
     __syncthreads();
@@ -133,17 +114,19 @@ __device__ __forceinline__ void radix_pass(const u8 *__restrict__ s, const u64 *
         for (int w = 0; w < 16; w++) cnt[w][threadIdx.x] += base;
     }
     __syncthreads();
+    // ranking: the next step's key is fetched while this step is ranked (the loop is latency bound)
+    auto fetch = [&](u32 i) -> u32 {
+        if (i >= end) return 0;
+        if (FIRST) return (hash_of(gld_u32_unaligned(s, i)) << REL_BITS) | i;
+        return src[i];
+    };
+    u32 key_n = fetch(beg + lane);
     for (u32 base = beg; base < end; base += 64) {
         const u32 i = base + lane;
         const bool act = i < end;
-        u64 ent = 0;
-        u32 h = 0, d = 0;
-        if (act) {
-            if (FIRST) {
-                const u32 lo = gld_u32_unaligned(s, i), hi = gld_u32_unaligned(s, (u64)i + 4);
-                h = hash_of(lo); ent = make_entry(i, lo, hi); d = h & 255;
-            } else { ent = src_e[i]; h = src_h[i]; d = h >> 8; }
-        }
+        const u32 key = key_n;
+        key_n = fetch(i + 64);
+        const u32 d = FIRST ? (key >> REL_BITS) & 255 : key >> 25;
         const u64 actm = __ballot(act);
         const u64 m = match_digit<NB>(d, actm);
         const u32 rank = __popcll(m & lanemask_lt()), count = __popcll(m);
@@ -151,8 +134,7 @@ __device__ __forceinline__ void radix_pass(const u8 *__restrict__ s, const u64 *
         if (act) off = cnt[wave][d];
         __builtin_amdgcn_wave_barrier();
         if (act) {
-            dst_e[off + rank] = ent;
-            dst_h[off + rank] = (u16)h;
+            dst[off + rank] = key;
             if (rank == count - 1) cnt[wave][d] = off + count;
         }
         __builtin_amdgcn_wave_barrier();
@@ -160,11 +142,8 @@ __device__ __forceinline__ void radix_pass(const u8 *__restrict__ s, const u64 *
     __syncthreads();
 }
 
-// third phase: hashes (now sorted) -> number of same-hash predecessors of each slot, capped at 65535
-// and the two filter keys of the match stage: k3 = byte 3, k34 = a mix of bytes 3 and 4 (equal bytes =>
-// equal mix; the mix only ever causes a candidate to be scored that need not have been)
-__device__ __forceinline__ void chain_lengths(const u16 *__restrict__ sh, const u64 *__restrict__ se, u16 *__restrict__ nb,
-                                              u8 *__restrict__ k3, u8 *__restrict__ k34, u32 wlen, u32 *wmax, u32 *carry_p)
+// third phase: sorted keys -> number of same-hash predecessors of each slot (the chain behind it), capped
+__device__ __forceinline__ void chain_lengths(const u32 *__restrict__ sk, u16 *__restrict__ nb, u32 wlen, u32 *wmax, u32 *carry_p)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) *carry_p = 0;
@@ -172,8 +151,8 @@ __device__ __forceinline__ void chain_lengths(const u16 *__restrict__ sh, const 
     for (u32 base = 0; base < wlen; base += 1024) {
         const u32 i = base + threadIdx.x;
         const bool act = i < wlen;
-        const u32 h = act ? sh[i] : 0xffffu;
-        const u32 hprev = (act && i > 0) ? sh[i - 1] : 0xfffeu;
+        const u32 h = act ? sk[i] >> REL_BITS : 0xffffu;
+        const u32 hprev = (act && i > 0) ? sk[i - 1] >> REL_BITS : 0xfffeu;
         // bucket start index + 1 where a bucket starts here, else 0; running max = start of my bucket
         u32 v = (act && h != hprev) ? i + 1 : 0;
 #pragma unroll
@@ -185,41 +164,29 @@ __device__ __forceinline__ void chain_lengths(const u16 *__restrict__ sh, const 
         v = max(v, pre);
         __syncthreads();
         if (threadIdx.x == 1023) *carry_p = v;
-        if (act) {
-            const u32 c = i + 1 - v;
-            nb[i] = (u16)(c < 65535u ? c : 65535u);
-            const u32 w1 = (u32)(se[i] >> 32), b3 = w1 & 0xff, b4 = (w1 >> 8) & 0xff;
-            k3[i] = (u8)b3;
-            k34[i] = (u8)(b4 ^ ((b3 << 3) | (b3 >> 5)));
-        }
+        if (act) { const u32 c = i + 1 - v; nb[i] = (u16)(c < 65535u ? c : 65535u); }
         __syncthreads();
     }
 }
 
 __global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
-                                                    u64 *__restrict__ tmp_e, u16 *__restrict__ tmp_h,
-                                                    u64 *__restrict__ sorted_e, u16 *__restrict__ sorted_h,
-                                                    u16 *__restrict__ sorted_nb, u8 *__restrict__ sorted_k3,
-                                                    u8 *__restrict__ sorted_k34)
+                                                    u32 *__restrict__ tmp, u32 *__restrict__ sorted, u16 *__restrict__ sorted_nb)
 {
     const TileDesc td = tiles[blockIdx.x];
     __shared__ u32 cnt[16][256];
     __shared__ u32 tot[256];
     if (td.wlen == 0) return;
     const u8 *s = stream + td.stream_off + td.w;
-    radix_pass<8, true>(s, nullptr, nullptr, tmp_e + td.sorted_off, tmp_h + td.sorted_off, td.wlen, cnt, tot);   // low 8 hash bits
-    radix_pass<7, false>(s, tmp_e + td.sorted_off, tmp_h + td.sorted_off, sorted_e + td.sorted_off, sorted_h + td.sorted_off,
-                         td.wlen, cnt, tot);                                                                      // high 7 bits
-    chain_lengths(sorted_h + td.sorted_off, sorted_e + td.sorted_off, sorted_nb + td.sorted_off, sorted_k3 + td.sorted_off,
-                  sorted_k34 + td.sorted_off, td.wlen, tot, tot + 32);
+    radix_pass<8, true>(s, nullptr, tmp + td.sorted_off, td.wlen, cnt, tot);                        // low 8 hash bits
+    radix_pass<7, false>(s, tmp + td.sorted_off, sorted + td.sorted_off, td.wlen, cnt, tot);        // high 7 bits
+    chain_lengths(sorted + td.sorted_off, sorted_nb + td.sorted_off, td.wlen, tot, tot + 32);
 }
 
-int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u64 *d_tmp_e, u16 *d_tmp_h,
-                     u64 *d_sorted_e, u16 *d_sorted_h, u16 *d_sorted_nb, u8 *d_sorted_k3, u8 *d_sorted_k34)
+int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp, u32 *d_sorted,
+                     u16 *d_sorted_nb)
 {
     if (n_tiles == 0) return MTS_OK;
-    hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(1024), 0, st, d_stream, d_tiles, d_tmp_e, d_tmp_h, d_sorted_e, d_sorted_h,
-                       d_sorted_nb, d_sorted_k3, d_sorted_k34);
+    hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(1024), 0, st, d_stream, d_tiles, d_tmp, d_sorted, d_sorted_nb);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
@@ -227,141 +194,31 @@ int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles
 // ================================================================================================
 // M: per-position best matches (t_full, t_quarter) -- orc_match_tables() is the oracle
 // ================================================================================================
-constexpr int WINB = WIN + 320;                   // window bytes kept in LDS (+ MAX_MATCH over-read)
-constexpr int STAGE_N = 128;                      // per wave: sorted entries being walked
-constexpr int MATCH_LDS = WINB + 16 * STAGE_N * 8;
-
+// The kernel scores a candidate from a 64-bit "entry" built (from the LDS window) for every staged slot:
+//   w0 [16:0]  rel   window-relative position
+//      [25:17] d     9 bits that, TOGETHER WITH AN EQUAL 15-BIT HASH, prove bytes 0..2 equal:
+//                    h = (b0<<10 ^ b1<<5 ^ b2) & 0x7fff exposes b0[4:3], b1[4:3], b2[4:0] directly and
+//                    b0[2:0]^b1[7:5], b1[2:0]^b2[7:5]; b0[7:5] not at all.  d = b0[7:5] : b0[2:0] : b1[2:0].
+//      [31:26] low 6 bits of byte 7
+//   w1         bytes 3..6
+// so the common prefix of two same-hash positions is known exactly up to 7 bytes from the entries alone;
+// only longer matches go back to the window bytes.
+__device__ __forceinline__ u64 make_entry(u32 rel, u32 lo, u32 hi)       // lo = bytes 0..3, hi = bytes 4..7
+{
+    const u32 b0 = lo & 0xff, b1 = (lo >> 8) & 0xff;
+    const u32 d = ((b0 >> 5) << 6) | ((b0 & 7) << 3) | (b1 & 7);
+    const u32 w0 = rel | (d << REL_BITS) | (((hi >> 24) & 0x3f) << 26);
+    const u32 w1 = (lo >> 24) | (hi << 8);
+    return (u64)w0 | ((u64)w1 << 32);
+}
 __device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
 {
     const u32 a = addr >> 2;
     return alignbyte(win[a + 1], win[a], addr & 3);
 }
 
-// state of one lane's chain walk
-struct Walk {
-    u32 e0, e1;          // own entry
-    u32 rel_p, maxlen, nice;
-    int lim;             // a candidate is in range iff (int)rel_c > lim   (lim1 for the first, limn after)
-    int limn;
-    u32 nb;              // candidates available (same-hash predecessors, capped by the chain budget)
-    u32 best, bdist;
-    bool stop;           // chain ended (out of range / nice length reached)
-};
-
-// score candidate number j (entry c); branch free except for the >= 7 byte path
-__device__ __forceinline__ void walk_step(Walk &w, const u32 *win, u64 c, u32 j)
-{
-    const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
-    const u32 rel_c = c0 & REL_MASK;
-    const bool act = !w.stop && j <= w.nb;
-    const bool inlim = (int)rel_c > w.lim;
-    w.lim = w.limn;
-    w.stop = w.stop || (act && !inlim);
-    const bool use = act && inlim;
-    const u32 x0 = (c0 ^ w.e0) >> REL_BITS;                 // d (9 bits), then byte-7 bits (6 bits)
-    const u32 x1 = c1 ^ w.e1;                               // bytes 3..6
-    const bool m3 = (x0 & 0x1ff) == 0;
-    u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
-    const bool deep = use && m3 && x1 == 0 && (x0 >> 9) == 0;   // bytes 0..6 equal and byte 7 not yet different
-    if (__any(deep)) {
-        if (deep) {
-            // byte 7's low 6 bits are equal too: continue in the window from byte 7
-            while (len < w.maxlen) {
-                const u32 x = lds_u32(win, rel_c + len) ^ lds_u32(win, w.rel_p + len);
-                if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
-                len += 4;
-            }
-        }
-    }
-    len = len < w.maxlen ? len : w.maxlen;
-    const bool upd = use && m3 && len > w.best;
-    w.best = upd ? len : w.best;
-    w.bdist = upd ? w.rel_p - rel_c : w.bdist;
-    w.stop = w.stop || (upd && len >= w.nice);
-}
-
-__global__ __launch_bounds__(1024) void k_match(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
-                                                const u64 *__restrict__ sorted_e, const u16 *__restrict__ sorted_nb,
-                                                uint2 *__restrict__ tables, LevelCfg cfg)
-{
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const TileDesc td = tiles[blockIdx.x];
-    u32 *win = (u32 *)smem;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    u64 *stage = (u64 *)(smem + WINB) + wave * STAGE_N;
-    uint2 *T = tables + td.stream_off;
-    // positions past the last hashed one have no candidates
-    if (threadIdx.x < 2) {
-        const u32 hashed_end = td.w + td.wlen;                 // first owned position without a hash
-        const u32 p = hashed_end + threadIdx.x;
-        if (p >= td.a && p < td.own_end) T[p] = make_uint2(0, 0);
-    }
-    if (td.wlen == 0) return;
-    // window bytes -> LDS (only matches longer than 7 bytes read them)
-    {
-        const u32 nbytes = (td.own_end - td.w) + 288;
-        const uint4 *src = (const uint4 *)(stream + td.stream_off + td.w);
-        uint4 *dst = (uint4 *)win;
-        const u32 nvec = (nbytes + 15) / 16;
-        for (u32 i = threadIdx.x; i < nvec; i += 1024) dst[i] = src[i];
-    }
-    __syncthreads();
-    const u64 *se = sorted_e + td.sorted_off;
-    const u16 *snb = sorted_nb + td.sorted_off;
-    const u32 wlen = td.wlen, n = td.n;
-    const u32 ngroups = (wlen + 63) / 64;
-    const u32 halo = td.a - td.w;
-    const u32 chain = (u32)cfg.chain, qchain = (u32)cfg.chain >> 2;
-    for (u32 g = wave; g < ngroups; g += 16) {
-        const u32 i0 = g * 64, i = i0 + lane;
-        const u64 e = i < wlen ? se[i] : ~0ull;
-        Walk w;
-        w.e0 = (u32)e; w.e1 = (u32)(e >> 32);
-        w.rel_p = w.e0 & REL_MASK;
-        const bool own = i < wlen && w.rel_p >= halo;
-        if (!__any(own)) continue;
-        const u32 p_abs = td.w + w.rel_p;
-        const u32 look = n - p_abs;
-        w.maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
-        w.nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
-        // candidate j is usable iff its absolute position exceeds a limit (first candidate: dist <= MAX_DIST
-        // and position != 0; later ones: > strstart - MAX_DIST, zlib's `limit`); window relative, signed
-        w.lim = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
-        w.limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
-        u32 nbv = own ? (u32)snb[i] : 0;
-        w.nb = nbv < chain ? nbv : chain;
-        w.best = 2; w.bdist = 0; w.stop = false;
-        u32 qbest = 2, qdist = 0;
-        bool qsnap = false;                                      // wave uniform
-        const u32 jmax = __reduce_max_sync_u32(w.nb);
-        for (u32 jb = 0; jb < jmax; jb += 64) {
-            // entries i0 - jb - 64 + k, k in [0, 128)
-            const int s0 = (int)i0 - (int)jb - 64 + lane;
-            __builtin_amdgcn_wave_barrier();
-            stage[lane] = s0 >= 0 ? se[s0] : ~0ull;
-            stage[lane + 64] = (s0 + 64 >= 0 && (u32)(s0 + 64) < wlen) ? se[s0 + 64] : ~0ull;
-            __builtin_amdgcn_wave_barrier();
-            bool live = true;
-            for (u32 jj = 1; jj <= 64 && live; jj += 4) {
-                const u64 c0 = stage[lane + 64 - jj], c1 = stage[lane + 63 - jj], c2 = stage[lane + 62 - jj], c3 = stage[lane + 61 - jj];
-                const u32 j = jb + jj;
-                walk_step(w, win, c0, j);
-                walk_step(w, win, c1, j + 1);
-                walk_step(w, win, c2, j + 2);
-                walk_step(w, win, c3, j + 3);
-                if (j + 3 == qchain) { qbest = w.best; qdist = w.bdist; qsnap = true; }
-                live = __any(!w.stop && j + 3 < w.nb);
-            }
-            if (!live) break;
-        }
-        // every lane finished before candidate number qchain: the quarter-budget result is the final one
-        if (!qsnap) { qbest = w.best; qdist = w.bdist; }
-        if (own) T[p_abs] = make_uint2(w.best >= 3 ? (w.best << 16) | w.bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// M, filtered walk (default).  Same result as k_match above, far fewer candidates scored:
+// The walk is filtered: it produces exactly what the plain newest-first walk produces, scoring far fewer candidates:
 // a candidate can only replace the current best if it can be LONGER than it.  Its length is bounded from
 // the two byte keys alone: byte 3 differs -> at most 3, byte 3 equal but the (3,4) mix differs -> at most
 // 4.  So once best >= 3 only byte-3-equal candidates are scored, once best >= 4 only mix-equal ones; all
@@ -390,8 +247,7 @@ __device__ __forceinline__ u32 bit_range(int lo, int hi)
 }
 
 __global__ __launch_bounds__(1024) void k_match4(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
-                                                 const u64 *__restrict__ sorted_e, const u16 *__restrict__ sorted_nb,
-                                                 const u8 *__restrict__ sorted_k3, const u8 *__restrict__ sorted_k34,
+                                                 const u32 *__restrict__ sorted, const u16 *__restrict__ sorted_nb,
                                                  uint2 *__restrict__ tables, LevelCfg cfg)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -402,6 +258,7 @@ __global__ __launch_bounds__(1024) void k_match4(const u8 *__restrict__ stream, 
     u64 *SE = (u64 *)wbase;
     u64 *SK3 = (u64 *)(wbase + ST4_N * 8);
     u64 *SK34 = (u64 *)(wbase + ST4_N * 8 + ST4_N);
+    u8 *SK3b = (u8 *)SK3, *SK34b = (u8 *)SK34;
     uint2 *T = tables + td.stream_off;
     if (threadIdx.x < 2) {
         const u32 hashed_end = td.w + td.wlen;
@@ -417,23 +274,20 @@ __global__ __launch_bounds__(1024) void k_match4(const u8 *__restrict__ stream, 
         for (u32 i = threadIdx.x; i < nvec; i += 1024) dst[i] = src[i];
     }
     __syncthreads();
-    const u64 *se = sorted_e + td.sorted_off;
+    const u32 *sk = sorted + td.sorted_off;
     const u16 *snb = sorted_nb + td.sorted_off;
-    const u32 *k3w = (const u32 *)(sorted_k3 + td.sorted_off);
-    const u32 *k34w = (const u32 *)(sorted_k34 + td.sorted_off);
     const u32 wlen = td.wlen, n = td.n;
-    const u32 wlen_pad = (wlen + 63) & ~63u;
     const u32 ngroups = (wlen + 63) / 64;
     const u32 halo = td.a - td.w;
     const u32 chain = (u32)cfg.chain, qchain = (u32)cfg.chain >> 2;
     const int r8 = lane & 7, g8 = lane >> 3;
     for (u32 g = wave; g < ngroups; g += 16) {
         const u32 i0 = g * 64, i = i0 + lane;
-        const u64 e = i < wlen ? se[i] : ~0ull;
-        const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
-        const u32 rel_p = e0 & REL_MASK;
+        const u32 rel_p = i < wlen ? sk[i] & REL_MASK : 0;
         const bool own = i < wlen && rel_p >= halo;
         if (!__any(own)) continue;
+        const u64 e = make_entry(rel_p, lds_u32(win, rel_p), lds_u32(win, rel_p + 4));
+        const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
         const u32 p_abs = td.w + rel_p;
         const u32 look = n - p_abs;
         const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
@@ -454,14 +308,20 @@ __global__ __launch_bounds__(1024) void k_match4(const u8 *__restrict__ stream, 
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < 3; k++) {
+                // slot -> position -> its 8 bytes (from the window) -> entry + the two filter keys
                 const int idx = sb + lane + 64 * k;
-                SE[lane + 64 * k] = (idx >= 0 && (u32)idx < wlen) ? se[idx] : ~0ull;
-            }
-            if (lane < 48) {
-                const int idx = sb + 4 * lane;                       // 4 keys per lane
-                const bool in = idx >= 0 && (u32)idx + 4 <= wlen_pad;
-                ((u32 *)SK3)[lane] = in ? k3w[idx >> 2] : 0;
-                ((u32 *)SK34)[lane] = in ? k34w[idx >> 2] : 0;
+                u64 ce = ~0ull;
+                u32 k3 = 0, k34 = 0;
+                if (idx >= 0 && (u32)idx < wlen) {
+                    const u32 rc = sk[idx] & REL_MASK;
+                    const u32 lo = lds_u32(win, rc), hi = lds_u32(win, rc + 4);
+                    ce = make_entry(rc, lo, hi);
+                    k3 = lo >> 24;
+                    k34 = ((hi & 0xff) ^ ((k3 << 3) | (k3 >> 5))) & 0xff;
+                }
+                SE[lane + 64 * k] = ce;
+                SK3b[lane + 64 * k] = (u8)k3;
+                SK34b[lane + 64 * k] = (u8)k34;
             }
             __builtin_amdgcn_wave_barrier();
             const u32 nbl = nbv > jbase ? (nbv - jbase < 128 ? nbv - jbase : 128) : 0;      // candidates of this lane in the block
@@ -525,24 +385,16 @@ __global__ __launch_bounds__(1024) void k_match4(const u8 *__restrict__ stream, 
     }
 }
 
-int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u64 *d_sorted_e,
-                 const u16 *d_sorted_nb, const u8 *d_sorted_k3, const u8 *d_sorted_k34, uint2 *d_tables, LevelCfg cfg)
+int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted,
+                 const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg)
 {
     if (n_tiles == 0) return MTS_OK;
     static bool attr_set = false;
-    static bool use_v3 = false;
     if (!attr_set) {
-        MTS_HIP(hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS));
         MTS_HIP(hipFuncSetAttribute((const void *)k_match4, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH4_LDS));
-        const char *e = getenv("MTS_MATCH");
-        use_v3 = e && e[0] == '3';              // unfiltered walk, kept for A/B measurements
         attr_set = true;
     }
-    if (use_v3)
-        hipLaunchKernelGGL(k_match, dim3(n_tiles), dim3(1024), MATCH_LDS, st, d_stream, d_tiles, d_sorted_e, d_sorted_nb, d_tables, cfg);
-    else
-        hipLaunchKernelGGL(k_match4, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted_e, d_sorted_nb,
-                           d_sorted_k3, d_sorted_k34, d_tables, cfg);
+    hipLaunchKernelGGL(k_match4, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
