@@ -190,8 +190,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     if ((rc = E.sort_b.ensure(sort_n * 4))) return rc;
     if ((rc = E.tables.ensure((stream_bytes + 64) * sizeof(uint2)))) return rc;
     if ((rc = E.tokens.ensure((toff + 64) * 4))) return rc;
-    if ((rc = E.marks.ensure(stream_bytes / 8 + 256))) return rc;
-    if ((rc = E.segbuf.ensure((size_t)(nseg + 64) * 4 * 7 + 256))) return rc;
+    if ((rc = E.segbuf.ensure((size_t)(nseg + 64) * 4 * (7 + 16) + 256))) return rc;
     if ((rc = E.blk.ensure((size_t)(nblk + 1) * (sizeof(BlockRec) + 8) + 256))) return rc;
     if ((rc = E.blkcodes.ensure((size_t)(nblk + 1) * BLK_CODE_WORDS * 4))) return rc;
     if ((rc = E.blkhdr.ensure((size_t)(nblk + 1) * BLK_HDR_WORDS * 4))) return rc;
@@ -211,7 +210,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     const size_t SN = nseg + 64;
     pb.entry = sg; pb.exit_a = sg + SN; pb.exit_b = sg + 2 * SN; pb.cnt = sg + 3 * SN; pb.tokbase = sg + 4 * SN;
     pb.seg_chunk = sg + 5 * SN; pb.seg_start = sg + 6 * SN;
-    pb.marks = E.marks.as<u32>();
+    pb.cp = sg + 7 * SN;
     pb.changed = (int *)(E.adler.as<u8>() + sizeof(u64) * 2 * n_chunks);
     // block arrays
     BlockRec *d_blocks = E.blk.as<BlockRec>();
@@ -231,7 +230,6 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     }
     MTS_HIP(hipMemcpyAsync(d_blk_chunk, h_blk_chunk.data(), 4 * (size_t)nblk, hipMemcpyHostToDevice, st));
     MTS_HIP(hipMemsetAsync(d_cout, 0, sizeof(ChunkOut) * n_chunks, st));
-    MTS_HIP(hipMemsetAsync(pb.marks, 0, stream_bytes / 8 + 256, st));
     MTS_HIP(hipMemsetAsync(pb.changed, 0, 4, st));
     // zero the output slots (the packer ORs bits into them)
     {
@@ -288,7 +286,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     E.t_mark(st, "parse_fixpoint");
     if ((rc = launch_parse_count(st, d_tables, d_chunks, pb, (int)nseg, n_chunks, cfg, d_cout))) return rc;
     u32 *d_tokens = E.tokens.as<u32>();
-    if ((rc = launch_parse_emit(st, d_stream, d_tables, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start))) return rc;
+    if ((rc = launch_parse_emit(st, d_stream, d_tables, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start, d_cout))) return rc;
     E.t_mark(st, "parse_emit");
     if ((rc = launch_block_trees(st, d_chunks, d_blk_chunk, (int)nblk, d_tokens, d_blk_in_start, d_cout, d_blocks,
                                  E.blkcodes.as<u32>(), E.blkhdr.as<u32>()))) return rc;

@@ -119,7 +119,7 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
                  const u32 *d_sorted, const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg);
 struct ParseBufs {
     u32 *entry, *exit_a, *exit_b, *cnt, *tokbase;   // per segment
-    u32 *marks;                                     // 1 bit per stream byte (global stream offsets)
+    u32 *cp;                                        // per segment 16 words: 7 checkpoint positions, 7 token counts
     u32 *seg_chunk, *seg_start;                     // per segment: owning chunk / start position
     int *changed;                                   // device flag
 };
@@ -131,7 +131,7 @@ int launch_parse_count(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d
                        int n_segs, int n_chunks, LevelCfg cfg, ChunkOut *d_cout);
 int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables,
                       const ChunkDesc *d_chunks, ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens,
-                      u32 *d_blk_in_start);
+                      u32 *d_blk_in_start, ChunkOut *d_cout);
 int launch_block_trees(hipStream_t st, const ChunkDesc *d_chunks, const u32 *d_blk_chunk, int total_blk_cap,
                        const u32 *d_tokens, const u32 *d_blk_in_start, const ChunkOut *d_cout,
                        BlockRec *d_blocks, u32 *d_blk_codes, u32 *d_blk_hdr);

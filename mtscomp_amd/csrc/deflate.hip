@@ -426,8 +426,11 @@ __device__ __forceinline__ u32 lazy_step(const uint2 *__restrict__ T, u32 p0, u3
     return p + len;
 }
 
-__device__ __forceinline__ bool mark_test(const u32 *marks, u64 bit) { return (marks[bit >> 5] >> (bit & 31)) & 1; }
-__device__ __forceinline__ void mark_set(u32 *marks, u64 bit) { marks[bit >> 5] |= 1u << (bit & 31); }
+// Speculative walk of one segment from `entry`.  Besides the exit (first base position at or beyond the
+// segment end) and the token count it records checkpoints: the first base position at or beyond
+// s + k * PARSE_CP (k = 1..7) and the tokens emitted before it.  A later walk from a corrected entry only
+// has to run until it lands on a recorded checkpoint: from there on the two walks are the same walk.
+constexpr int PARSE_CP = SEG / 8;
 
 __global__ __launch_bounds__(64) void k_parse_spec(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
                                                    ParseBufs pb, int n_segs, LevelCfg cfg)
@@ -438,11 +441,18 @@ __global__ __launch_bounds__(64) void k_parse_spec(const uint2 *__restrict__ tab
     const u32 s = pb.seg_start[g], n = ch.n;
     const u32 segend = min(s + (u32)SEG, n);
     const uint2 *T = tables + ch.stream_off;
-    u32 *marks = pb.marks;          // segments own whole mark words (SEG and stream_off are multiples of 32)
-    u32 pos = s, mp, ml, md;
-    while (pos < segend) { mark_set(marks, ch.stream_off + pos); pos = lazy_step(T, pos, n, cfg, mp, ml, md); }
+    u32 *cp = pb.cp + (u64)g * 16;
+    u32 pos = s, mp, ml, md, cnt = 0, k = 1;
+    while (pos < segend) {
+        while (k < 8 && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++; }
+        const u32 p0 = pos;
+        pos = lazy_step(T, pos, n, cfg, mp, ml, md);
+        cnt += mp - p0 + 1;
+    }
+    for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }      // checkpoints past the exit
     pb.entry[g] = s;
     pb.exit_a[g] = pos;
+    pb.cnt[g] = cnt;
 }
 
 __global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
@@ -462,48 +472,31 @@ __global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tabl
     const u32 s = pb.seg_start[g], n = ch.n;
     const u32 segend = min(s + (u32)SEG, n);
     const uint2 *T = tables + ch.stream_off;
-    u32 *marks = pb.marks;
-    u32 pos = ne, mp, ml, md;
-    bool merged = false;
+    u32 *cp = pb.cp + (u64)g * 16;
+    const u32 old_cnt = pb.cnt[g];
+    u32 pos = ne, mp, ml, md, cnt = 0, k = 1;
     while (pos < segend) {
-        if (mark_test(marks, ch.stream_off + pos)) { merged = true; break; }
-        pos = lazy_step(T, pos, n, cfg, mp, ml, md);
-    }
-    if (merged) {
-        // same tail as before: keep the exit, add the new prefix to the marks
-        const u32 pm = pos;
-        pos = ne;
-        while (pos < pm) { mark_set(marks, ch.stream_off + pos); pos = lazy_step(T, pos, n, cfg, mp, ml, md); }
-        exit_out[g] = old_exit;
-        return;
-    }
-    // a different exit: the old marks no longer lead to it -> rebuild this segment's marks
-    exit_out[g] = pos;
-    if (pos != old_exit) *pb.changed = 1;
-    const u64 w0 = (ch.stream_off + s) >> 5, w1 = (ch.stream_off + segend + 31) >> 5;
-    for (u64 w = w0; w < w1; w++) marks[w] = 0;
-    pos = ne;
-    while (pos < segend) { mark_set(marks, ch.stream_off + pos); pos = lazy_step(T, pos, n, cfg, mp, ml, md); }
-}
-
-__global__ __launch_bounds__(64) void k_parse_count(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
-                                                    ParseBufs pb, int n_segs, LevelCfg cfg, ChunkOut *cout)
-{
-    const int g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= n_segs) return;
-    const u32 ci = pb.seg_chunk[g];
-    const ChunkDesc ch = chunks[ci];
-    const u32 s = pb.seg_start[g], n = ch.n;
-    const u32 segend = min(s + (u32)SEG, n);
-    const uint2 *T = tables + ch.stream_off;
-    u32 pos = pb.entry[g], mp, ml, md, cnt = 0;
-    while (pos < segend) {
+        bool merged = false;
+        while (k < 8 && pos >= s + k * PARSE_CP) {
+            if (cp[k - 1] == pos) { merged = true; break; }
+            cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++;               // this walk's own checkpoint
+        }
+        if (merged) {
+            // same walk from here on: keep the exit, shift the counts of the remaining checkpoints
+            const u32 at_old = cp[8 + k - 1];
+            for (u32 q = k; q < 8; q++) cp[8 + q - 1] = cp[8 + q - 1] - at_old + cnt;
+            pb.cnt[g] = cnt + (old_cnt - at_old);
+            exit_out[g] = old_exit;
+            return;
+        }
         const u32 p0 = pos;
         pos = lazy_step(T, pos, n, cfg, mp, ml, md);
         cnt += mp - p0 + 1;
-        if (pos >= n) cout[ci].trailing = (ml == 0) ? 1u : 0u;      // last token of the chunk
     }
+    for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }
+    exit_out[g] = pos;
     pb.cnt[g] = cnt;
+    if (pos != old_exit) *pb.changed = 1;
 }
 
 // exclusive scan of the per-segment token counts of each chunk (one workgroup per chunk)
@@ -537,7 +530,8 @@ __global__ __launch_bounds__(256) void k_seg_scan(const ChunkDesc *__restrict__ 
 
 __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream, const uint2 *__restrict__ tables,
                                                    const ChunkDesc *__restrict__ chunks, ParseBufs pb, int n_segs,
-                                                   LevelCfg cfg, u32 *__restrict__ tokens, u32 *__restrict__ blk_in_start)
+                                                   LevelCfg cfg, u32 *__restrict__ tokens, u32 *__restrict__ blk_in_start,
+                                                   ChunkOut *__restrict__ cout)
 {
     const int g = blockIdx.x * 64 + threadIdx.x;
     if (g >= n_segs) return;
@@ -552,6 +546,7 @@ __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream
     while (pos < segend) {
         const u32 p0 = pos;
         pos = lazy_step(T, pos, n, cfg, mp, ml, md);
+        if (pos >= n) cout[pb.seg_chunk[g]].trailing = (ml == 0) ? 1u : 0u;       // last token of the chunk
         const u32 nlit = ml ? mp - p0 : 1;
         for (u32 q = 0; q < nlit; q++, k++) {
             if (k % BLOCK_TOKENS == 0) bis[k / BLOCK_TOKENS] = p0 + q;
@@ -583,18 +578,17 @@ int launch_parse_fix(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_c
 int launch_parse_count(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs,
                        int n_chunks, LevelCfg cfg, ChunkOut *d_cout)
 {
-    if (n_segs)
-        hipLaunchKernelGGL(k_parse_count, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_tables, d_chunks, pb, n_segs, cfg, d_cout);
+    (void)d_tables; (void)n_segs; (void)cfg;      // the counts come out of the spec/fix walks
     hipLaunchKernelGGL(k_seg_scan, dim3(n_chunks), dim3(256), 0, st, d_chunks, pb, d_cout);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
 int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables, const ChunkDesc *d_chunks,
-                      ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start)
+                      ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start, ChunkOut *d_cout)
 {
     if (n_segs == 0) return MTS_OK;
     hipLaunchKernelGGL(k_parse_emit, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_stream, d_tables, d_chunks, pb, n_segs,
-                       cfg, d_tokens, d_blk_in_start);
+                       cfg, d_tokens, d_blk_in_start, d_cout);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
