@@ -246,7 +246,9 @@ __device__ __forceinline__ u32 bit_range(int lo, int hi)
     return (0xffffffffu >> (31 - h)) & (0xffffffffu << l);
 }
 
-__global__ __launch_bounds__(1024) void k_match4(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
+// WLDS: window bytes staged in LDS (1 workgroup per CU) or read from HBM/L2 where needed (2 per CU)
+template <bool WLDS>
+__global__ __launch_bounds__(1024, WLDS ? 1 : 2) void k_match4(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
                                                  const u32 *__restrict__ sorted, const u16 *__restrict__ sorted_nb,
                                                  uint2 *__restrict__ tables, LevelCfg cfg)
 {
@@ -254,7 +256,9 @@ __global__ __launch_bounds__(1024) void k_match4(const u8 *__restrict__ stream, 
     const TileDesc td = tiles[blockIdx.x];
     u32 *win = (u32 *)smem;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    u8 *wbase = smem + WINB4 + wave * ST4_BYTES;
+    u8 *wbase = smem + (WLDS ? WINB4 : 0) + wave * ST4_BYTES;
+    const u8 *gwin = stream + td.stream_off + td.w;
+    auto wread = [&](u32 addr) -> u32 { return WLDS ? lds_u32(win, addr) : gld_u32_unaligned(gwin, addr); };
     u64 *SE = (u64 *)wbase;
     u64 *SK3 = (u64 *)(wbase + ST4_N * 8);
     u64 *SK34 = (u64 *)(wbase + ST4_N * 8 + ST4_N);
@@ -266,14 +270,14 @@ __global__ __launch_bounds__(1024) void k_match4(const u8 *__restrict__ stream, 
         if (p >= td.a && p < td.own_end) T[p] = make_uint2(0, 0);
     }
     if (td.wlen == 0) return;
-    {
+    if (WLDS) {
         const u32 nbytes = (td.own_end - td.w) + 288;
         const uint4 *src = (const uint4 *)(stream + td.stream_off + td.w);
         uint4 *dst = (uint4 *)win;
         const u32 nvec = (nbytes + 15) / 16;
         for (u32 i = threadIdx.x; i < nvec; i += 1024) dst[i] = src[i];
+        __syncthreads();
     }
-    __syncthreads();
     const u32 *sk = sorted + td.sorted_off;
     const u16 *snb = sorted_nb + td.sorted_off;
     const u32 wlen = td.wlen, n = td.n;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(1024) void k_match4(const u8 *__restrict__ stream, 
         const u32 rel_p = i < wlen ? sk[i] & REL_MASK : 0;
         const bool own = i < wlen && rel_p >= halo;
         if (!__any(own)) continue;
-        const u64 e = make_entry(rel_p, lds_u32(win, rel_p), lds_u32(win, rel_p + 4));
+        const u64 e = make_entry(rel_p, wread(rel_p), wread(rel_p + 4));
         const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
         const u32 p_abs = td.w + rel_p;
         const u32 look = n - p_abs;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(1024) void k_match4(const u8 *__restrict__ stream, 
                 u32 k3 = 0, k34 = 0;
                 if (idx >= 0 && (u32)idx < wlen) {
                     const u32 rc = sk[idx] & REL_MASK;
-                    const u32 lo = lds_u32(win, rc), hi = lds_u32(win, rc + 4);
+                    const u32 lo = wread(rc), hi = wread(rc + 4);
                     ce = make_entry(rc, lo, hi);
                     k3 = lo >> 24;
                     k34 = ((hi & 0xff) ^ ((k3 << 3) | (k3 >> 5))) & 0xff;
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(1024) void k_match4(const u8 *__restrict__ stream, 
                                 u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
                                 if (x1 == 0 && (x0 >> 9) == 0) {
                                     while (len < maxlen) {
-                                        const u32 x = lds_u32(win, rel_c + len) ^ lds_u32(win, rel_p + len);
+                                        const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
                                         if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
                                         len += 4;
                                     }
@@ -389,12 +393,18 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
                  const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg)
 {
     if (n_tiles == 0) return MTS_OK;
-    static bool attr_set = false;
+    static bool attr_set = false, win_global = false;
     if (!attr_set) {
-        MTS_HIP(hipFuncSetAttribute((const void *)k_match4, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH4_LDS));
+        MTS_HIP(hipFuncSetAttribute((const void *)k_match4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH4_LDS));
+        // default: window bytes come from HBM/L2 (two workgroups per CU); MTS_MATCH_WIN=lds stages them in LDS
+        const char *e = getenv("MTS_MATCH_WIN");
+        win_global = !(e && e[0] == 'l');
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_match4, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
+    if (win_global)
+        hipLaunchKernelGGL(k_match4<false>, dim3(n_tiles), dim3(1024), 16 * ST4_BYTES, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
+    else
+        hipLaunchKernelGGL(k_match4<true>, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
