@@ -226,10 +226,9 @@ __device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
 // (they still count against the chain budget: budgets are positions in the run, not candidates scored).
 // The keys of 8 candidates are tested per LDS read with SWAR byte compares.
 // ------------------------------------------------------------------------------------------------
-constexpr int WINB4 = WIN + 288;
-constexpr int ST4_N = 192;                          // entries staged per wave: slots i0-128 .. i0+63
+constexpr int ST4_N = 256;                          // slots staged per wave (ring)
 constexpr int ST4_BYTES = ST4_N * 8 + 2 * ST4_N;    // entries + two key arrays
-constexpr int MATCH4_LDS = WINB4 + 16 * ST4_BYTES;
+constexpr int MATCH4_LDS = 16 * ST4_BYTES;
 
 // bit k of the result = byte k of v is zero (k = 0..3)
 __device__ __forceinline__ u32 zero_bytes4(u32 v)
@@ -246,19 +245,20 @@ __device__ __forceinline__ u32 bit_range(int lo, int hi)
     return (0xffffffffu >> (31 - h)) & (0xffffffffu << l);
 }
 
-// WLDS: window bytes staged in LDS (1 workgroup per CU) or read from HBM/L2 where needed (2 per CU)
-template <bool WLDS>
-__global__ __launch_bounds__(1024, WLDS ? 1 : 2) void k_match4(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
-                                                 const u32 *__restrict__ sorted, const u16 *__restrict__ sorted_nb,
-                                                 uint2 *__restrict__ tables, LevelCfg cfg)
+// SLIDE (chain budget <= 128): a wave owns a contiguous range of 64-slot groups and keeps the last 192
+// slots it needs in a 256-slot ring, so every slot's entry is built exactly once per wave (the window
+// bytes come from L2).  Larger budgets restage 192 slots per 128 candidates.
+template <bool SLIDE>
+__global__ __launch_bounds__(1024, 2) void k_match4(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
+                                                    const u32 *__restrict__ sorted, const u16 *__restrict__ sorted_nb,
+                                                    uint2 *__restrict__ tables, LevelCfg cfg)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const TileDesc td = tiles[blockIdx.x];
-    u32 *win = (u32 *)smem;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    u8 *wbase = smem + (WLDS ? WINB4 : 0) + wave * ST4_BYTES;
+    u8 *wbase = smem + wave * ST4_BYTES;
     const u8 *gwin = stream + td.stream_off + td.w;
-    auto wread = [&](u32 addr) -> u32 { return WLDS ? lds_u32(win, addr) : gld_u32_unaligned(gwin, addr); };
+    auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
     u64 *SE = (u64 *)wbase;
     u64 *SK3 = (u64 *)(wbase + ST4_N * 8);
     u64 *SK34 = (u64 *)(wbase + ST4_N * 8 + ST4_N);
@@ -270,14 +270,6 @@ __global__ __launch_bounds__(1024, WLDS ? 1 : 2) void k_match4(const u8 *__restr
         if (p >= td.a && p < td.own_end) T[p] = make_uint2(0, 0);
     }
     if (td.wlen == 0) return;
-    if (WLDS) {
-        const u32 nbytes = (td.own_end - td.w) + 288;
-        const uint4 *src = (const uint4 *)(stream + td.stream_off + td.w);
-        uint4 *dst = (uint4 *)win;
-        const u32 nvec = (nbytes + 15) / 16;
-        for (u32 i = threadIdx.x; i < nvec; i += 1024) dst[i] = src[i];
-        __syncthreads();
-    }
     const u32 *sk = sorted + td.sorted_off;
     const u16 *snb = sorted_nb + td.sorted_off;
     const u32 wlen = td.wlen, n = td.n;
@@ -285,13 +277,39 @@ __global__ __launch_bounds__(1024, WLDS ? 1 : 2) void k_match4(const u8 *__restr
     const u32 halo = td.a - td.w;
     const u32 chain = (u32)cfg.chain, qchain = (u32)cfg.chain >> 2;
     const int r8 = lane & 7, g8 = lane >> 3;
-    for (u32 g = wave; g < ngroups; g += 16) {
+    // slot -> position -> its 8 bytes -> entry + the two filter keys, written to stage index `at`
+    auto build = [&](int idx, int at) -> u64 {
+        u64 ce = ~0ull;
+        u32 k3 = 0, k34 = 0;
+        if (idx >= 0 && (u32)idx < wlen) {
+            const u32 rc = sk[idx] & REL_MASK;
+            const u32 lo = wread(rc), hi = wread(rc + 4);
+            ce = make_entry(rc, lo, hi);
+            k3 = lo >> 24;
+            k34 = ((hi & 0xff) ^ ((k3 << 3) | (k3 >> 5))) & 0xff;
+        }
+        SE[at] = ce;
+        SK3b[at] = (u8)k3;
+        SK34b[at] = (u8)k34;
+        return ce;
+    };
+    const u32 gpw = SLIDE ? (ngroups + 15) / 16 : 1;
+    const u32 g_begin = SLIDE ? wave * gpw : wave, g_end = SLIDE ? min(ngroups, g_begin + gpw) : ngroups;
+    const u32 g_step = SLIDE ? 1 : 16;
+    if (SLIDE && g_begin < g_end) {
+        const int i0 = (int)g_begin * 64;
+        build(i0 - 128 + lane, (i0 - 128 + lane) & 255);
+        build(i0 - 64 + lane, (i0 - 64 + lane) & 255);
+    }
+    for (u32 g = g_begin; g < g_end; g += g_step) {
         const u32 i0 = g * 64, i = i0 + lane;
-        const u32 rel_p = i < wlen ? sk[i] & REL_MASK : 0;
+        u64 e;
+        if (SLIDE) { __builtin_amdgcn_wave_barrier(); e = build((int)i, (int)(i & 255)); __builtin_amdgcn_wave_barrier(); }
+        else { const u32 rp = i < wlen ? sk[i] & REL_MASK : 0; e = make_entry(rp, wread(rp), wread(rp + 4)); }
+        const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
+        const u32 rel_p = e0 & REL_MASK;
         const bool own = i < wlen && rel_p >= halo;
         if (!__any(own)) continue;
-        const u64 e = make_entry(rel_p, wread(rel_p), wread(rel_p + 4));
-        const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
         const u32 p_abs = td.w + rel_p;
         const u32 look = n - p_abs;
         const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
@@ -307,29 +325,17 @@ __global__ __launch_bounds__(1024, WLDS ? 1 : 2) void k_match4(const u8 *__restr
         bool stop = false, qtaken = false;
         const u32 jmax = __reduce_max_sync_u32(nbv);
         for (u32 jbase = 0; jbase < jmax; jbase += 128) {
-            // stage slots i0 - jbase - 128 + k, k in [0, 192)
+            // the candidates of this block live in slots sb .. sb + 191
             const int sb = (int)i0 - (int)jbase - 128;
-            __builtin_amdgcn_wave_barrier();
+            if (!SLIDE) {
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                // slot -> position -> its 8 bytes (from the window) -> entry + the two filter keys
-                const int idx = sb + lane + 64 * k;
-                u64 ce = ~0ull;
-                u32 k3 = 0, k34 = 0;
-                if (idx >= 0 && (u32)idx < wlen) {
-                    const u32 rc = sk[idx] & REL_MASK;
-                    const u32 lo = wread(rc), hi = wread(rc + 4);
-                    ce = make_entry(rc, lo, hi);
-                    k3 = lo >> 24;
-                    k34 = ((hi & 0xff) ^ ((k3 << 3) | (k3 >> 5))) & 0xff;
-                }
-                SE[lane + 64 * k] = ce;
-                SK3b[lane + 64 * k] = (u8)k3;
-                SK34b[lane + 64 * k] = (u8)k34;
+                for (int k = 0; k < 3; k++) build(sb + lane + 64 * k, lane + 64 * k);
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
+            const int gbase = SLIDE ? (sb >> 3) : 0;                         // 8-slot key group of slot sb in the stage
             const u32 nbl = nbv > jbase ? (nbv - jbase < 128 ? nbv - jbase : 128) : 0;      // candidates of this lane in the block
-            // candidate jj (1 = newest) of this lane sits in stage slot 128 + lane - jj = 8*g8 + m with
+            // candidate jj (1 = newest) of this lane sits in slot sb + 128 + lane - jj = sb + 8*g8 + m with
             // m = 128 + r8 - jj; the masks below are indexed by m (5 words), scanned from high m to low
             const int lo_m = 128 + r8 - (int)nbl, hi_m = 127 + r8;
 #pragma unroll
@@ -340,7 +346,8 @@ __global__ __launch_bounds__(1024, WLDS ? 1 : 2) void k_match4(const u8 *__restr
                 for (int tt = 0; tt < 4; tt++) {
                     const int t = 4 * w + tt;
                     if (t > 16) continue;
-                    const u64 a3 = SK3[g8 + t], a34 = SK34[g8 + t];
+                    const int G = SLIDE ? ((gbase + g8 + t) & 31) : (g8 + t);
+                    const u64 a3 = SK3[G], a34 = SK34[G];
                     const u32 z3 = zero_bytes8(a3 ^ ((u64)rep3 | ((u64)rep3 << 32)));
                     const u32 z34 = zero_bytes8(a34 ^ ((u64)rep34 | ((u64)rep34 << 32)));
                     M8 |= z3 << (8 * tt);
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(1024, WLDS ? 1 : 2) void k_match4(const u8 *__restr
                         el &= ~(1u << b);
                         const int m = 32 * w + (int)b;
                         const u32 j = jbase + (u32)(128 + r8 - m);
-                        const u64 c = SE[8 * g8 + m];
+                        const u64 c = SE[SLIDE ? ((sb + 8 * g8 + m) & 255) : (8 * g8 + m)];
                         const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                         const u32 rel_c = c0 & REL_MASK;
                         if (!qtaken && j > qchain) { qbest = best; qdist = bdist; qtaken = true; }
@@ -393,18 +400,10 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
                  const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg)
 {
     if (n_tiles == 0) return MTS_OK;
-    static bool attr_set = false, win_global = false;
-    if (!attr_set) {
-        MTS_HIP(hipFuncSetAttribute((const void *)k_match4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH4_LDS));
-        // default: window bytes come from HBM/L2 (two workgroups per CU); MTS_MATCH_WIN=lds stages them in LDS
-        const char *e = getenv("MTS_MATCH_WIN");
-        win_global = !(e && e[0] == 'l');
-        attr_set = true;
-    }
-    if (win_global)
-        hipLaunchKernelGGL(k_match4<false>, dim3(n_tiles), dim3(1024), 16 * ST4_BYTES, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
-    else
+    if (cfg.chain <= 128)
         hipLaunchKernelGGL(k_match4<true>, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
+    else
+        hipLaunchKernelGGL(k_match4<false>, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
