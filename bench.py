@@ -62,6 +62,16 @@ def cpu_baseline(x, nc, rate, n_chunks):
     }
 
 
+def measured_traffic(n_chunks, nc):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r1_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this script).  Only valid for the profiled
+    workload (60 chunks x 385 ch); null otherwise."""
+    p = ROOT / 'profiles' / 'r1_traffic.json'
+    if not p.exists() or n_chunks != 60 or nc != 385:
+        return None
+    return json.loads(p.read_text())['traffic_bytes_per_launch']
+
+
 def main():
     args = parse_args()
     import torch
@@ -195,8 +205,8 @@ def main():
             'decompress_gbps': raw_bytes * world * args.steps / t_d / 1e9,
             'ratio': csize / raw_bytes, 'byte_identical_chunk0': ok_oracle,
             'stage_ms': {k: float(np.mean(v)) for k, v in stage.items()},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_match', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+            'roofline': {'bound': 'hbm', 'kernel': 'k_match4', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': measured_traffic(n_chunks, nc),
                          'algorithmic_bytes_per_launch': algo, 'launch_ms': match_ms},
         }
         if not args.no_cpu_baseline:
