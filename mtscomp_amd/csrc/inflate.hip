@@ -335,6 +335,7 @@ __device__ __forceinline__ u32 wave_excl_scan(u32 v, u32 &total)
 constexpr int SCAN_THREADS = 1024;
 constexpr int SCAN_SPAN_BITS = SCAN_THREADS * 32;
 constexpr int SCAN_SURV_CAP = 512;
+constexpr int SCAN_TAIL = 88;            // words staged past the span: a dynamic header is < 2560 bits long
 
 // full validation of the header at absolute bit `o` (BFINAL bit); true if well formed
 __device__ bool validate_dyn_header(const u32 *w, u64 nwords, u64 end, u64 o)
@@ -443,7 +444,8 @@ constexpr int SCAN_L1_CAP = 14336;       // filter-1 survivors kept per workgrou
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
                                                            const InfFast *__restrict__ fast, u64 *__restrict__ cand_pos,
-                                                           u32 *__restrict__ cand_cnt)
+                                                           u32 *__restrict__ cand_cnt, u64 *__restrict__ surv_list,
+                                                           u32 *__restrict__ surv_cnt, u32 surv_cap)
 {
     const int ci = blockIdx.y;
     const InfChunk ch = chunks[ci];
@@ -453,25 +455,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
     const u64 bit0 = (a & 3) * 8, end = bit0 + 8 * ch.c_len, nwords = (end + 31) >> 5;
     const u64 span0 = (u64)blockIdx.x * SCAN_SPAN_BITS;        // absolute bit of this workgroup's span
     if (span0 >= end) return;
-    __shared__ u32 sw[SCAN_THREADS + 8];
+    __shared__ u32 sw[SCAN_THREADS + SCAN_TAIL];
     __shared__ u16 l1[SCAN_L1_CAP];
     __shared__ u32 surv[SCAN_SURV_CAP];
     __shared__ u32 wsum[16];
     __shared__ u32 nsurv;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const u64 word0 = span0 >> 5;
-    for (int i = tid; i < SCAN_THREADS + 8; i += SCAN_THREADS) sw[i] = word0 + i < nwords ? w[word0 + i] : 0;
+    for (int i = tid; i < SCAN_THREADS + SCAN_TAIL; i += SCAN_THREADS) sw[i] = word0 + i < nwords ? w[word0 + i] : 0;
     if (tid == 0) nsurv = 0;
     __syncthreads();
-    // phase A1: the 3 header fields at each of this thread's 32 offsets (BTYPE == 2, HLIT <= 29, HDIST <= 29)
+    // phase A1: the 3 header fields at each of this thread's 32 offsets, all 32 at once (bit k of S(j) is
+    // stream bit o_k + j):  BTYPE == 2 <=> bit1 = 0, bit2 = 1;  HLIT <= 29 <=> not (bits 4..7 all set);
+    // HDIST <= 29 <=> not (bits 9..12 all set)
     const u32 w0 = sw[tid], w1 = sw[tid + 1];
-    u32 m = 0;
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        const u32 h = __builtin_amdgcn_alignbit(w1, w0, k);
-        const bool ok = ((h >> 1) & 3) == 2 && ((h >> 3) & 31) <= 29 && ((h >> 8) & 31) <= 29;
-        m |= (u32)ok << k;
-    }
+#define S_(j) __builtin_amdgcn_alignbit(w1, w0, j)
+    u32 m = ~S_(1) & S_(2);
+    m &= ~(S_(4) & S_(5) & S_(6) & S_(7));
+    m &= ~(S_(9) & S_(10) & S_(11) & S_(12));
+#undef S_
     // keep only offsets inside the stream
     {
         const u64 o0 = span0 + (u64)tid * 32;
@@ -527,15 +529,35 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
         }
     }
     __syncthreads();
-    // phase B: full validation, survivors packed into the first lanes
+    // the survivors go to a global list; their full validation is a separate, fully occupied launch
+    // (it is a long serial decode per survivor: latency bound, so it wants many waves in flight)
     const u32 ns = min(nsurv, (u32)SCAN_SURV_CAP);
-    if ((u32)tid < ns) {
-        const u64 o = span0 + surv[tid];
-        if (validate_dyn_header(w, nwords, end, o)) {
-            const InfFast f = fast[ci];
-            const u32 slot = atomicAdd(&cand_cnt[ci], 1u);
-            if (slot < f.cand_cap) cand_pos[f.cand_off + slot] = o;
-        }
+    __shared__ u32 gbase_s;
+    if (tid == 0) gbase_s = ns ? atomicAdd(surv_cnt, ns) : 0;
+    __syncthreads();
+    if ((u32)tid < ns && gbase_s + tid < surv_cap) surv_list[gbase_s + tid] = ((u64)ci << 40) | (span0 + surv[tid]);
+    (void)fast; (void)cand_pos; (void)cand_cnt;
+}
+
+__global__ __launch_bounds__(256) void k_inf_validate(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
+                                                      const InfFast *__restrict__ fast, const u64 *__restrict__ surv_list,
+                                                      const u32 *__restrict__ surv_cnt, u32 surv_cap,
+                                                      u64 *__restrict__ cand_pos, u32 *__restrict__ cand_cnt)
+{
+    const u32 idx = blockIdx.x * 256 + threadIdx.x;
+    const u32 n = min(*surv_cnt, surv_cap);
+    if (idx >= n) return;
+    const u64 v = surv_list[idx];
+    const u32 ci = (u32)(v >> 40);
+    const u64 o = v & ((1ull << 40) - 1);
+    const InfChunk ch = chunks[ci];
+    const u64 a = (u64)(cdata + ch.c_off);
+    const u32 *w = (const u32 *)(a & ~(u64)3);
+    const u64 bit0 = (a & 3) * 8, end = bit0 + 8 * ch.c_len, nwords = (end + 31) >> 5;
+    if (validate_dyn_header(w, nwords, end, o)) {
+        const InfFast f = fast[ci];
+        const u32 slot = atomicAdd(&cand_cnt[ci], 1u);
+        if (slot < f.cand_cap) cand_pos[f.cand_off + slot] = o;
     }
 }
 
@@ -1160,8 +1182,8 @@ static inline u32 cand_cap_of(u64 c_len) { return (u32)(c_len / 4096 + 64); }
 // scratch layout (all 256-B aligned): [so u64 n][nn u32 n][fast n][cand_cnt n][true_cnt n][seq_flag n]
 //   [slot_chunk total_cand][tslot_chunk total_true][cand_pos][cand_tmp][cres][tblk][subs]
 struct InfLayout {
-    size_t so, nn, fast, cand_cnt, true_cnt, seq_flag, slot_chunk, tslot_chunk, cand_pos, cand_tmp, cres, tblk, subs, gb_off, gbase, tb_off, tile_base, end;
-    u32 total_cand, total_true;
+    size_t so, nn, fast, cand_cnt, true_cnt, seq_flag, slot_chunk, tslot_chunk, cand_pos, cand_tmp, cres, tblk, subs, gb_off, gbase, tb_off, tile_base, surv, surv_cnt, end;
+    u32 total_cand, total_true, surv_cap;
 };
 static InfLayout inf_layout(int n_chunks, const u64 *c_lens, const u32 *n_expect)
 {
@@ -1184,6 +1206,11 @@ static InfLayout inf_layout(int n_chunks, const u64 *c_lens, const u32 *n_expect
     l.gbase = take(4 * ng);
     l.tb_off = take(8 * (size_t)n_chunks);
     l.tile_base = take(4 * (ng / GS_TILE + 2 * (size_t)n_chunks + 16));
+    u64 cbits = 0;
+    for (int i = 0; i < n_chunks; i++) cbits += 8 * c_lens[i];
+    l.surv_cap = (u32)(cbits / 256 + 65536);          // ~0.1 % of the bit offsets pass the cheap filters
+    l.surv = take(8 * (size_t)l.surv_cap);
+    l.surv_cnt = take(256);
     l.end = o;
     return l;
 }
@@ -1251,7 +1278,13 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
     if (fast_path) {
         const u64 max_bits = 8 * max_clen + 32;
         dim3 gscan((unsigned)((max_bits + SCAN_SPAN_BITS - 1) / SCAN_SPAN_BITS), n_chunks);
-        hipLaunchKernelGGL(k_inf_scan, gscan, dim3(SCAN_THREADS), 0, st, d_cdata, d_chunks, d_fast, d_cand_pos, d_cand_cnt);
+        u64 *d_surv = (u64 *)(S + l.surv);
+        u32 *d_surv_cnt = (u32 *)(S + l.surv_cnt);
+        MTS_HIP(hipMemsetAsync(d_surv_cnt, 0, 4, st));
+        hipLaunchKernelGGL(k_inf_scan, gscan, dim3(SCAN_THREADS), 0, st, d_cdata, d_chunks, d_fast, d_cand_pos, d_cand_cnt, d_surv,
+                           d_surv_cnt, l.surv_cap);
+        hipLaunchKernelGGL(k_inf_validate, dim3((l.surv_cap + 255) / 256), dim3(256), 0, st, d_cdata, d_chunks, d_fast, d_surv,
+                           d_surv_cnt, l.surv_cap, d_cand_pos, d_cand_cnt);
         hipLaunchKernelGGL(k_inf_sortc, dim3(n_chunks), dim3(256), 0, st, d_fast, d_cand_pos, d_cand_tmp, d_cand_cnt);
         inflate_mark(engine, st, "inflate_scan");
         hipLaunchKernelGGL(k_inf_passA, dim3(l.total_cand), dim3(64), 0, st, d_cdata, d_chunks, d_fast, (const u32 *)(S + l.slot_chunk),
