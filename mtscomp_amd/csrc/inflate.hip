@@ -919,18 +919,33 @@ __global__ __launch_bounds__(64) void k_inf_decode(const u8 *__restrict__ cdata,
 // Z: tokens -> bytes (LZ77 resolution)
 // ================================================================================================
 // One workgroup per chunk.  Tokens are taken in groups of 64 (one per lane); LZ_WORKERS waves take the
-// groups round robin, one wave streams finished bytes to HBM.  The 64 KiB of history a copy can reach
-// lives in an LDS ring of 16-bit cells: low byte = data, high byte = lap tag of the position that wrote
-// it.  A copy reads its source cell, and proceeds only if the tag says "written in the lap I expect",
-// so every byte waits for exactly the bytes it depends on (no group-level barrier, no serial commit):
-// the critical path is the copy-of-copy depth of the data, not the number of tokens.
+// groups round robin, LZ_FLUSHERS waves stream finished bytes to HBM.  The 64 KiB of history a copy can
+// reach lives in LDS as a byte ring plus one "written" bit per byte.  A copy piece (3..8 bytes) reads
+// the bits and the bytes of its source and commits when every byte it needs is written, so every piece
+// waits for exactly the bytes it depends on (no group-level barrier, no serial commit): the critical
+// path is the copy-of-copy depth of the data, not the number of tokens.
+//
+// The DS unit of gfx950 executes a misaligned access one lane per clock (measured: 64 cycles per
+// ds_read_b64 against 4-8 aligned), so every access here is dword aligned: a source window is three
+// aligned dwords funnel-shifted in registers, and a destination is written by OR-ing the shifted bytes
+// into ring slots that are known to be zero (LDS atomics, no return).  The flushers re-zero a ring slot
+// (bytes and bits) LZ_ZLAG granules after streaming it out, when no copy can reach it any more; a
+// worker runs at most LZ_AHEAD bytes past what the flushers have processed, which is exactly the
+// zeroed part of the ring.  Ordering relies on the LDS executing one wave's instructions in issue
+// order: writers OR data then bits, readers load bits then data.
 constexpr int LZ_THREADS = 1024;
 constexpr int LZ_FLUSHERS = 2;                           // waves streaming finished bytes to HBM
 constexpr int LZ_WORKERS = LZ_THREADS / 64 - LZ_FLUSHERS;
 constexpr u32 LZ_RING = 65536;                           // positions held (power of two)
 constexpr u32 LZ_REACH = 32768 + 258;                    // furthest back a copy reads from its own start
 constexpr u32 LZ_FLUSH = 4096;                           // flush granule (bytes)
-constexpr int LZ_LDS = 2 * LZ_RING + 256;
+constexpr u32 LZ_ZLAG = 10;                              // a granule's ring slot is zeroed when the granule LZ_ZLAG later is flushed
+constexpr u32 LZ_AHEAD = LZ_RING - LZ_ZLAG * LZ_FLUSH;   // a worker may write this far past flushed()
+static_assert(LZ_REACH <= (LZ_ZLAG - 1) * LZ_FLUSH, "a slot must be out of every copy's reach before it is zeroed");
+constexpr u32 LZ_BITS_OFF = LZ_RING;                     // LDS layout: bytes, bits (+ one pad dword), control words
+constexpr u32 LZ_CTL_OFF = LZ_RING + LZ_RING / 8 + 16;
+constexpr int LZ_LDS = LZ_CTL_OFF + 256;
+constexpr u32 LZ_EDGE = LZ_RING - 12;                    // windows starting above this ring offset go byte by byte
 constexpr u32 LZ_SPIN_MAX = 1u << 20;                     // bound on every wait loop (a stuck kernel must end)
 
 // Output offset of every 64-token group, as a two-level scan:
@@ -1002,60 +1017,124 @@ __global__ __launch_bounds__(64) void k_inf_gscan(const InfResult *__restrict__ 
     }
 }
 
-__device__ __forceinline__ u32 lz_tag(u32 pos) { return ((pos >> 16) & 0x7f) + 1; }
+// inclusive wave scan on the DPP network (row shifts, then the two row broadcasts of gfx9)
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 x)
+{
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);     // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);     // row_shr:8
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+// LDS accesses of the resolver, in program order (see the note on ordering above); addresses are LDS byte
+// offsets, dword aligned
+__device__ __forceinline__ void lz_load_window(u32 bits_addr, u32 data_addr, u32 &b0, u32 &b1, u32 &d0, u32 &d1, u32 &d2)
+{
+    u32x2 b, d;
+    asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %4 offset1:1\n\tds_read_b32 %2, %4 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(b), "=&v"(d), "=&v"(d2) : "v"(bits_addr), "v"(data_addr) : "memory");
+    b0 = b.x; b1 = b.y; d0 = d.x; d1 = d.y;
+}
+__device__ __forceinline__ void lz_or_window(u32 data_addr, u32 w0, u32 w1, u32 w2, u32 bits_addr, u32 m0, u32 m1)
+{
+    asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4\n\tds_or_b32 %0, %3 offset:8\n\tds_or_b32 %4, %5\n\tds_or_b32 %4, %6 offset:4"
+                 :: "v"(data_addr), "v"(w0), "v"(w1), "v"(w2), "v"(bits_addr), "v"(m0), "v"(m1) : "memory");
+}
+__device__ __forceinline__ void lz_or_byte(u32 data_addr, u32 w, u32 bits_addr, u32 m)
+{
+    asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %2, %3" :: "v"(data_addr), "v"(w), "v"(bits_addr), "v"(m) : "memory");
+}
+__device__ __forceinline__ void lz_load_byte(u32 bits_addr, u32 data_addr, u32 &bits, u32 &data)
+{
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_u8 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bits), "=&v"(data) : "v"(bits_addr), "v"(data_addr) : "memory");
+}
+__device__ __forceinline__ void lds_zero16(u32 addr)
+{
+    const u32x4 z = {0, 0, 0, 0};
+    asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(z) : "memory");
+}
+
+// control words of the resolver, addressed as LDS byte offsets (explicit DS instructions: a volatile
+// pointer into dynamic LDS would be accessed with flat loads)
+__device__ __forceinline__ u32 lds_ld(u32 addr)
+{
+    u32 v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_st(u32 addr, u32 v) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
+// minimum over lanes 0..15 (row 0 of the wave), wave-uniform result
+__device__ __forceinline__ u32 row0_min_dpp(u32 x)
+{
+    x = min(x, (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x111, 0xf, 0xf, false));
+    x = min(x, (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x112, 0xf, 0xf, false));
+    x = min(x, (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x114, 0xf, 0xf, false));
+    x = min(x, (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x118, 0xf, 0xf, false));
+    return (u32)__builtin_amdgcn_readlane((int)x, 15);
+}
 
 __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ tokens, const InfChunk *__restrict__ chunks,
                                                        InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
                                                        const u64 *__restrict__ tb_off, const u32 *__restrict__ gbase,
-                                                       const u32 *__restrict__ tile_base, u8 *__restrict__ stream, int n_workers)
+                                                       const u32 *__restrict__ tile_base, u8 *__restrict__ stream, int n_workers,
+                                                       u64 *__restrict__ prof)
 {
     const int ci = blockIdx.x;
     const InfResult r = res[ci];
     if (r.status != MTS_CHUNK_OK) return;
     const InfChunk ch = chunks[ci];
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    volatile u16 *ring = (volatile u16 *)smem;                       // LZ_RING cells
-    volatile u32 *prog = (volatile u32 *)(smem + 2 * LZ_RING);       // [w] = groups finished by worker w (count)
-    volatile u32 *fl_next = prog + 16;                               // [k] = first byte flusher k has not streamed out yet
-    volatile u32 *bad_p = prog + 20;
+    const u32 lds_data = (u32)(uintptr_t)smem;                       // LDS byte offsets of the byte ring, the bit ring, ...
+    const u32 lds_bits = lds_data + LZ_BITS_OFF;
+    const u32 lds_prog = lds_data + LZ_CTL_OFF;                      // [w] = first byte of the group worker w is on
+    const u32 lds_flnext = lds_prog + 64;                            // [k] = first byte of the next granule of flusher k
+    const u32 lds_bad = lds_prog + 80;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 *tk = tokens + ch.tok_off;
     const u32 *gbl = gbase + gb_off[ci];
     const u32 *tbs = tile_base + tb_off[ci];
     u8 *out = stream + ch.stream_off;
     const u32 ntok = r.ntok, ngroups = (ntok + 63) / 64, nout = r.n_out;
-    auto gb = [&](u32 g) -> u32 { return g >= ngroups ? nout : tbs[g / GS_TILE] + gbl[g]; };   // first output byte of group g
-    for (u32 i = threadIdx.x; i < LZ_RING / 2; i += LZ_THREADS) ((volatile u32 *)ring)[i] = 0;      // tag 0 = never written
-    if (threadIdx.x < 24) prog[threadIdx.x] = (threadIdx.x >= 16 && threadIdx.x < 16 + LZ_FLUSHERS) ? (threadIdx.x - 16) * LZ_FLUSH : 0;
+    if (ntok == 0) return;                                           // nothing to resolve (k_inf_finish checks the size)
+    for (u32 i = threadIdx.x * 16; i < LZ_CTL_OFF; i += LZ_THREADS * 16) lds_zero16(lds_data + i);     // bytes and bits start at zero
+    if (threadIdx.x < 24) lds_st(lds_prog + 4 * threadIdx.x, (threadIdx.x >= 16 && threadIdx.x < 16 + LZ_FLUSHERS) ? (threadIdx.x - 16) * LZ_FLUSH : 0);
     __syncthreads();
-    // every worker publishes the base of its first group before anyone looks at the progress words
-    u32 t_n = 0, base_n = 0, next_n = 0;
+    // the next group's token and its output range are fetched one group ahead; the loaded words are only
+    // combined when the group starts, so the loads stay in flight while the current group is resolved
+    u32 t_n = 0, tb0_n = 0, gl0_n = 0, tb1_n = 0, gl1_n = 0;
     const int LZW = n_workers;          // decoding waves actually used (<= LZ_WORKERS)
+    auto prefetch = [&](u32 h) {
+        const u32 h0 = h < ngroups ? h : ngroups - 1, h1 = h + 1 < ngroups ? h + 1 : ngroups - 1;
+        const u32 i2 = h0 * 64 + lane;
+        t_n = tk[i2 < ntok ? i2 : ntok - 1];
+        tb0_n = tbs[h0 / GS_TILE]; gl0_n = gbl[h0]; tb1_n = tbs[h1 / GS_TILE]; gl1_n = gbl[h1];
+    };
+    // every worker publishes the base of its first group before anyone looks at the progress words
     if (wave < LZW) {
-        if ((u32)wave < ngroups) {
-            const u32 i = wave * 64 + lane;
-            t_n = i < ntok ? tk[i] : 0; base_n = gb(wave); next_n = gb(wave + 1);
-        }
-        if (lane == 0) prog[wave] = (u32)wave < ngroups ? base_n : 0xffffffffu;
+        prefetch(wave);
+        if (lane == 0) lds_st(lds_prog + 4 * wave, (u32)wave < ngroups ? tb0_n + gl0_n : 0xffffffffu);
     }
     __syncthreads();
     // bytes below this are final: the smallest start offset among the groups the workers are still on
     // (each worker publishes the base of its current group in prog[w]; 0xffffffff when it has no more)
     auto safe_bytes = [&]() -> u32 {
-        u32 v = lane < LZW ? prog[lane] : 0xffffffffu;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v = min(v, (u32)__shfl_xor(v, off, 64));
+        const u32 v = row0_min_dpp(lane < LZW ? lds_ld(lds_prog + 4 * lane) : 0xffffffffu);
         return v < nout ? v : nout;
     };
-    // bytes below this are in HBM already (or at least in registers on their way there)
+    // every granule below this has been streamed out, and the ring slot LZ_ZLAG granules behind it zeroed
     auto flushed = [&]() -> u32 {
-        u32 v = fl_next[0];
+        u32 v = lds_ld(lds_flnext);
 #pragma unroll
-        for (int k = 1; k < LZ_FLUSHERS; k++) v = min(v, fl_next[k]);
+        for (int k = 1; k < LZ_FLUSHERS; k++) v = min(v, lds_ld(lds_flnext + 4 * k));
         return v;
     };
     if (wave >= LZ_WORKERS) {
-        // ---- flushers: granule q belongs to flusher q % LZ_FLUSHERS; 8 cells -> 8 bytes per lane ----
+        // ---- flushers: granule q belongs to flusher q % LZ_FLUSHERS; 16 bytes per lane and step ----
         const u32 me = wave - LZ_WORKERS;
         u32 idle = 0;
         for (u32 q = me;; q += LZ_FLUSHERS) {
@@ -1063,103 +1142,123 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
             if (lo >= nout) break;
             const u32 hi = lo + LZ_FLUSH < nout ? lo + LZ_FLUSH : nout;
             while (safe_bytes() < hi) {
-                if (++idle > LZ_SPIN_MAX) { if (lane == 0) { *bad_p = 3; for (int k = 0; k < LZ_FLUSHERS; k++) fl_next[k] = 0xffffffffu; } return; }
+                if (++idle > LZ_SPIN_MAX) { if (lane == 0) { lds_st(lds_bad, 3); for (int k = 0; k < LZ_FLUSHERS; k++) lds_st(lds_flnext + 4 * k, 0xffffffffu); } return; }
                 __builtin_amdgcn_s_sleep(2);
             }
             idle = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            for (u32 o = lo + lane * 8; o < hi; o += 512) {
-                const uint4 c = *(const uint4 *)(smem + 2 * (o & (LZ_RING - 1)));
-                const u32 v0 = (c.x & 0xff) | ((c.x >> 8) & 0xff00) | ((c.y & 0xff) << 16) | ((c.y >> 16) << 24);
-                const u32 v1 = (c.z & 0xff) | ((c.z >> 8) & 0xff00) | ((c.w & 0xff) << 16) | ((c.w >> 16) << 24);
-                if (o + 8 <= hi) *(uint2 *)(out + o) = make_uint2(v0, v1);
-                else { const u64 v = (u64)v0 | ((u64)v1 << 32); for (u32 k = 0; o + k < hi; k++) out[o + k] = (u8)(v >> (8 * k)); }
+#pragma unroll
+            for (u32 o = lo + lane * 16; o < lo + LZ_FLUSH; o += 1024) {
+                if (o < hi) {
+                    u32x4 c;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(c) : "v"(lds_data + (o & (LZ_RING - 1))) : "memory");
+                    if (o + 16 <= hi) *(u32x4 *)(out + o) = c;
+                    else { const u32 cw[4] = {c.x, c.y, c.z, c.w}; for (u32 k = 0; o + k < hi; k++) out[o + k] = (u8)(cw[k >> 2] >> (8 * (k & 3))); }
+                }
             }
-            // the stores above already consumed the LDS data: the ring space can be reused now
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) fl_next[me] = lo + LZ_FLUSHERS * LZ_FLUSH;
+            // every running group starts at or above `hi`, so nothing reaches the granule LZ_ZLAG back any more:
+            // clear its slot (bytes and bits) for the lap that comes next
+            if (q >= LZ_ZLAG) {
+                const u32 zo = ((q - LZ_ZLAG) * LZ_FLUSH) & (LZ_RING - 1);
+#pragma unroll
+                for (u32 o = lane * 16; o < LZ_FLUSH; o += 1024) lds_zero16(lds_data + zo + o);
+                if (lane < (int)(LZ_FLUSH / 8 / 16)) lds_zero16(lds_bits + zo / 8 + lane * 16);
+            }
+            if (lane == 0) lds_st(lds_flnext + 4 * me, lo + LZ_FLUSHERS * LZ_FLUSH);
         }
-        if (lane == 0) fl_next[me] = 0xffffffffu;
+        if (lane == 0) lds_st(lds_flnext + 4 * me, 0xffffffffu);
         return;
     }
     // ---- workers ----
     if (wave >= LZW) return;
+    u64 pc_vm = 0, pc_sleeps = 0, pc_wait = 0, pc_pre = 0, pc_loop = 0, pc_iter = 0, pc_groups = 0, pc_t0 = prof ? __builtin_readcyclecounter() : 0;
+    u32 fl_seen = 0;                     // last value read of flushed(): it only grows
     for (u32 g = wave; g < ngroups; g += LZW) {
-        const u32 t = t_n, base = base_n, next = next_n;
+        u64 c0_ = prof ? __builtin_readcyclecounter() : 0;
+        const u32 t = t_n, base = tb0_n + gl0_n, next = g + 1 < ngroups ? tb1_n + gl1_n : nout;
         const u32 i = g * 64 + lane;
         const bool act = i < ntok;
-        if (lane == 0) prog[wave] = base;            // groups below `base` owned by this worker are done
-        // prefetch the next group's tokens while this one is resolved
-        if (g + LZW < ngroups) {
-            const u32 i2 = (g + LZW) * 64 + lane;
-            t_n = i2 < ntok ? tk[i2] : 0; base_n = gb(g + LZW); next_n = gb(g + LZW + 1);
-        }
-        // ring safety: writing up to `next` destroys positions below next - LZ_RING; they must be in HBM,
-        // and every group that may still read them (groups starting below next - LZ_RING + LZ_REACH) must
-        // be finished
-        if (next > LZ_RING) {
-            const u32 lim = next - LZ_RING;                    // positions below lim get overwritten
-            for (u32 waits = 0;; waits++) {
-                bool ok = flushed() >= lim;
-                if (ok) { const u32 sb = safe_bytes(); if (sb < base && sb < lim + LZ_REACH) ok = false; }
-                if (ok) break;
-                if (waits > LZ_SPIN_MAX) { *bad_p = 4; break; }                               // never hang
+        if (lane == 0) lds_st(lds_prog + 4 * wave, base);            // groups below `base` owned by this worker are done
+        prefetch(g + LZW);
+        u64 cv_ = 0;
+        if (prof) { asm volatile("" :: "v"(next), "v"(t)); cv_ = __builtin_readcyclecounter(); pc_vm += cv_ - c0_; }
+        // ring safety: this group writes up to `next`; only the slots below flushed() + LZ_AHEAD are zeroed
+        if (next > LZ_AHEAD) {
+            const u32 lim = next - LZ_AHEAD;
+            for (u32 waits = 0; fl_seen < lim; waits++) {
+                if (prof && waits) pc_sleeps++;
+                fl_seen = flushed();
+                if (fl_seen >= lim) break;
+                if (waits > LZ_SPIN_MAX) { lds_st(lds_bad, 4); break; }                       // never hang
                 __builtin_amdgcn_s_sleep(1);
             }
         }
+        u64 c1_ = prof ? __builtin_readcyclecounter() : 0;
         const bool cp = act && (t >> 31);
         const u32 len = !act ? 0 : cp ? ((t >> 16) & 0xff) + 3 : 1;
-        u32 x = len;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
-        const u32 dst = base + x - len;
+        const u32 dst = base + wave_incl_scan_dpp(len) - len;
         const u32 dist = (t & 0x7fff) + 1;
-        bool live = cp;
-        if (cp && dist > dst) { live = false; *bad_p = 1; }              // distance too far back: corrupt
-        if (act && !cp) ring[dst & (LZ_RING - 1)] = (u16)((lz_tag(dst) << 8) | (t & 0xff));
-        // copies: every lane advances byte by byte whenever its next source cell carries the expected tag
-        u32 k = 0;
         const u32 src = dst - dist;
-        u32 spins = 0;
-        const bool wide = dist >= 4;             // 4 source bytes never include this lane's own pending writes
-        while (__any(live && k < len)) {
-            if (live && k < len) {
-                const u32 sp = src + k;
-                // up to 4 cells in flight; commit the longest valid prefix
-                // relaxed atomic loads: re-read every iteration like volatile, but the four may be in flight together
-                u16 *rg = (u16 *)smem;
-                const u32 c0 = __hip_atomic_load(rg + (sp & (LZ_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const u32 c1 = __hip_atomic_load(rg + ((sp + 1) & (LZ_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const u32 c2 = __hip_atomic_load(rg + ((sp + 2) & (LZ_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const u32 c3 = __hip_atomic_load(rg + ((sp + 3) & (LZ_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const bool v0 = (c0 >> 8) == lz_tag(sp);
-                const bool v1 = v0 && wide && k + 1 < len && (c1 >> 8) == lz_tag(sp + 1);
-                const bool v2 = v1 && k + 2 < len && (c2 >> 8) == lz_tag(sp + 2);
-                const bool v3 = v2 && k + 3 < len && (c3 >> 8) == lz_tag(sp + 3);
-                const u32 dp = dst + k;
-                if (v0) __hip_atomic_store(rg + (dp & (LZ_RING - 1)), (u16)((lz_tag(dp) << 8) | (c0 & 0xff)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (v1) __hip_atomic_store(rg + ((dp + 1) & (LZ_RING - 1)), (u16)((lz_tag(dp + 1) << 8) | (c1 & 0xff)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (v2) __hip_atomic_store(rg + ((dp + 2) & (LZ_RING - 1)), (u16)((lz_tag(dp + 2) << 8) | (c2 & 0xff)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (v3) __hip_atomic_store(rg + ((dp + 3) & (LZ_RING - 1)), (u16)((lz_tag(dp + 3) << 8) | (c3 & 0xff)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const u32 adv = (u32)v0 + (u32)v1 + (u32)v2 + (u32)v3;
-                k += adv;
-                if (adv) spins = 0;
-                else if (++spins > (1u << 22)) { live = false; *bad_p = 2; }       // bounded spin: never hang the GPU
+        const u32 dofs = dst & (LZ_RING - 1), sofs = src & (LZ_RING - 1);
+        bool pend = cp;
+        if (cp && (dist > dst || len > 8)) { pend = false; lds_st(lds_bad, 1); }      // distance too far back (or a piece this kernel never makes): corrupt
+        if (act && !cp) lz_or_byte(lds_data + (dofs & ~3u), (t & 0xff) << (8 * (dofs & 3)), lds_bits + ((dofs >> 5) << 2), 1u << (dofs & 31));
+        // a piece whose source or destination window would run past the ring end goes byte by byte
+        const bool slow = pend && (sofs > LZ_EDGE || dofs > LZ_EDGE);
+        const u32 need = len < dist ? len : dist;                       // source bytes that are not this piece's own output
+        const u32 nbits = (1u << need) - 1;
+        const u32 ba = lds_bits + ((sofs >> 5) << 2), da = lds_data + (sofs & ~3u);
+        const u32 wa = lds_data + (dofs & ~3u), wba = lds_bits + ((dofs >> 5) << 2);
+        const u64 wbits = (u64)((1u << len) - 1) << (dofs & 31);
+        const u64 lmask = len >= 8 ? ~0ull : (1ull << (8 * len)) - 1;
+        const u32 wsh = 8 * (dofs & 3);
+        u32 spins = 0, k = 0;
+        u64 c2_ = prof ? __builtin_readcyclecounter() : 0;
+        while (__any(pend)) {
+            if (prof) pc_iter++;
+            if (pend && !slow) {
+                u32 b0, b1, x0, x1, x2;
+                lz_load_window(ba, da, b0, b1, x0, x1, x2);
+                if ((__builtin_amdgcn_alignbit(b1, b0, sofs & 31) & nbits) == nbits) {
+                    u64 v = (u64)__builtin_amdgcn_alignbyte(x1, x0, sofs & 3) | ((u64)__builtin_amdgcn_alignbyte(x2, x1, sofs & 3) << 32);
+                    if (dist < 8) {                                   // overlapping copy: the piece repeats its first `dist` bytes
+                        v &= (1ull << (8 * dist)) - 1;
+                        v |= v << (8 * dist);
+                        if (dist < 4) v |= v << (16 * dist);
+                        if (dist < 2) v |= v << 32;
+                    }
+                    v &= lmask;
+                    const u64 w01 = v << wsh;
+                    const u32 w2 = (u32)(((v >> 32) << wsh) >> 32);
+                    lz_or_window(wa, (u32)w01, (u32)(w01 >> 32), w2, wba, (u32)wbits, (u32)(wbits >> 32));
+                    pend = false;
+                } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }       // bounded spin: never hang the GPU
+            } else if (pend) {
+                // byte-wise path (window across the ring end): one byte per round
+                const u32 so = (src + k) & (LZ_RING - 1), dd = (dst + k) & (LZ_RING - 1);
+                u32 bw, dv;
+                lz_load_byte(lds_bits + ((so >> 5) << 2), lds_data + so, bw, dv);
+                if ((bw >> (so & 31)) & 1) {
+                    lz_or_byte(lds_data + (dd & ~3u), dv << (8 * (dd & 3)), lds_bits + ((dd >> 5) << 2), 1u << (dd & 31));
+                    if (++k == len) pend = false;
+                    spins = 0;
+                } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // ring writes before the next progress update
+        if (prof) { const u64 c3_ = __builtin_readcyclecounter(); pc_wait += c1_ - c0_; pc_pre += c2_ - c1_; pc_loop += c3_ - c2_; pc_groups++; }
+    }
+    if (prof && lane == 0) {
+        u64 *q = prof + ((u64)ci * 16 + wave) * 8;
+        q[0] = __builtin_readcyclecounter() - pc_t0; q[1] = pc_wait; q[2] = pc_pre; q[3] = pc_loop; q[4] = pc_iter; q[5] = pc_groups; q[6] = pc_vm; q[7] = pc_sleeps;
     }
     // no more groups for this worker
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) prog[wave] = 0xffffffffu;
-    if (wave == 0 && lane == 0) {
+    if (lane == 0) lds_st(lds_prog + 4 * wave, 0xffffffffu);
+    if (wave == 0) {
         // wait for the flushers before reporting (same workgroup: they are resident)
         for (u32 waits = 0; flushed() < nout && waits < 4 * LZ_SPIN_MAX; waits++) __builtin_amdgcn_s_sleep(8);
-        if (*bad_p || flushed() < nout) res[ci].status = MTS_CHUNK_CORRUPT;
+        if (lane == 0 && (lds_ld(lds_bad) || flushed() < nout)) res[ci].status = MTS_CHUNK_CORRUPT;
     }
 }
 
-// adler check + final status
 __global__ __launch_bounds__(64) void k_inf_finish(const InfChunk *__restrict__ chunks, InfResult *__restrict__ res,
                                                    const u64 *__restrict__ adler_acc, int n_chunks, int *__restrict__ status_out)
 {
@@ -1309,9 +1408,22 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
         hipLaunchKernelGGL(k_inf_gscan, dim3(n_chunks), dim3(64), 0, st, d_res, (const u64 *)(S + l.tb_off), (u32 *)(S + l.tile_base));
     }
     inflate_mark(engine, st, "inflate_offsets");
+    u64 *d_prof = nullptr;                   // MTS_LZ_PROF=1: per-wave cycle counters of the resolver, printed to stderr
+    if (getenv("MTS_LZ_PROF")) { MTS_HIP(hipMalloc(&d_prof, (size_t)n_chunks * 16 * 8 * 8)); MTS_HIP(hipMemsetAsync(d_prof, 0, (size_t)n_chunks * 16 * 8 * 8, st)); }
     hipLaunchKernelGGL(k_inf_lz, dim3(n_chunks), dim3(LZ_THREADS), LZ_LDS, st, d_tokens, d_chunks, d_res, (const u64 *)(S + l.gb_off),
-                       (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base), d_stream, lz_workers);
+                       (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base), d_stream, lz_workers,
+                       d_prof);
     MTS_HIP(hipGetLastError());
+    if (d_prof) {
+        std::vector<u64> hp((size_t)n_chunks * 16 * 8);
+        MTS_HIP(hipStreamSynchronize(st));
+        MTS_HIP(hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost));
+        MTS_HIP(hipFree(d_prof));
+        u64 a[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nw = 0;
+        for (int c = 0; c < n_chunks; c++) for (int w = 0; w < 16; w++) { const u64 *q = &hp[((size_t)c * 16 + w) * 8]; if (!q[5]) continue; nw++; for (int k = 0; k < 8; k++) a[k] += q[k]; }
+        if (nw) fprintf(stderr, "[lz prof] waves %d  per wave: total %.0f  wait %.0f  pre %.0f  loop %.0f cycles; groups %.0f  iters/group %.2f  cycles/group %.0f  vmwait %.0f  sleeps %.0f\n", nw,
+                        (double)a[0] / nw, (double)a[1] / nw, (double)a[2] / nw, (double)a[3] / nw, (double)a[5] / nw, (double)a[4] / a[5], (double)a[0] / a[5], (double)a[6] / nw, (double)a[7] / nw);
+    }
     inflate_mark(engine, st, "inflate_lz");
     int rc = launch_adler_stream(st, d_stream, (const u64 *)(S + l.so), (const u32 *)(S + l.nn), n_chunks, max_n, d_adler_acc);
     if (rc) return rc;
