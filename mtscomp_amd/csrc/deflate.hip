@@ -396,11 +396,170 @@ __global__ __launch_bounds__(1024, 2) void k_match4(const u8 *__restrict__ strea
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_match5 (chain budget <= 128): the same filtered walk, but the filter masks are not computed by comparing
+// keys -- they are looked up.  Every wave keeps, next to its 256-slot ring of entries, two tables of
+// 64 rows x 256 bits: row k of T3 has bit r set iff the slot at ring position r has 6-bit key k3 = k,
+// T34 likewise for the (byte 3, byte 4) key.  A slot entering the ring clears the bit of the slot it
+// replaces and sets its own (4 LDS atomics per 64 slots).  A lane then reads the row of its OWN key and
+// funnel-shifts out the 128 bits of the slots before it: that is the mask of candidates with an equal
+// key.  6-bit keys make the masks supersets of "byte 3 equal" / "bytes 3,4 equal", which is all the
+// filter needs: a candidate that passes is scored exactly, one that fails could not have been longer.
+// ------------------------------------------------------------------------------------------------
+constexpr int M5_WAVES = 8;
+constexpr int M5_RING = 256;
+constexpr int M5_ROWS = 64;
+constexpr int M5_WAVE_LDS = M5_RING * 8 + 2 * M5_RING + 2 * M5_ROWS * (M5_RING / 8);     // 6656
+constexpr int MATCH5_LDS = M5_WAVES * M5_WAVE_LDS;
+
+__device__ __forceinline__ u32 m5_key3(u32 b3) { return (b3 ^ (b3 >> 6)) & 63; }
+__device__ __forceinline__ u32 m5_key34(u32 b3, u32 b4) { return (b4 ^ (b4 >> 6) ^ (b3 << 2) ^ (b3 >> 5)) & 63; }
+
+__global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
+                                                          const u32 *__restrict__ sorted, const u16 *__restrict__ sorted_nb,
+                                                          uint2 *__restrict__ tables, LevelCfg cfg)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const TileDesc td = tiles[blockIdx.x];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u8 *wbase = smem + wave * M5_WAVE_LDS;
+    const u8 *gwin = stream + td.stream_off + td.w;
+    auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
+    u64 *SE = (u64 *)wbase;
+    u8 *K3 = wbase + M5_RING * 8, *K34 = K3 + M5_RING;
+    u32 *T3 = (u32 *)(K34 + M5_RING), *T34 = T3 + M5_ROWS * 8;
+    uint2 *T = tables + td.stream_off;
+    if (threadIdx.x < 2) {
+        const u32 hashed_end = td.w + td.wlen;
+        const u32 p = hashed_end + threadIdx.x;
+        if (p >= td.a && p < td.own_end) T[p] = make_uint2(0, 0);
+    }
+    if (td.wlen == 0) return;
+    const u32 *sk = sorted + td.sorted_off;
+    const u16 *snb = sorted_nb + td.sorted_off;
+    const u32 wlen = td.wlen, n = td.n;
+    const u32 ngroups = (wlen + 63) / 64;
+    const u32 halo = td.a - td.w;
+    const u32 chain = (u32)cfg.chain, qchain = (u32)cfg.chain >> 2;
+    const u32 gpw = (ngroups + M5_WAVES - 1) / M5_WAVES;
+    const u32 g_begin = wave * gpw, g_end = min(ngroups, g_begin + gpw);
+    if (g_begin >= g_end) return;
+    // tables and key rings start empty
+    for (int k = lane; k < (M5_WAVE_LDS - M5_RING * 8) / 16; k += 64) ((uint4 *)(wbase + M5_RING * 8))[k] = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+    // slot idx -> position -> its 8 bytes -> entry; enters the ring at idx & 255, replacing slot idx - 256
+    auto stage = [&](int idx) -> u64 {
+        const u32 rp = (u32)idx & (M5_RING - 1), word = rp >> 5, bit = 1u << (rp & 31);
+        u64 ce = ~0ull;
+        u32 k3 = 0, k34 = 0;
+        const bool valid = idx >= 0 && (u32)idx < wlen;
+        if (valid) {
+            const u32 rc = sk[idx] & REL_MASK;
+            const u32 lo = wread(rc), hi = wread(rc + 4);
+            ce = make_entry(rc, lo, hi);
+            k3 = m5_key3(lo >> 24);
+            k34 = m5_key34(lo >> 24, hi & 0xff);
+        }
+        const u32 o3 = K3[rp], o34 = K34[rp];
+        atomicAnd(&T3[o3 * 8 + word], ~bit);
+        atomicAnd(&T34[o34 * 8 + word], ~bit);
+        if (valid) { atomicOr(&T3[k3 * 8 + word], bit); atomicOr(&T34[k34 * 8 + word], bit); }
+        SE[rp] = ce;
+        K3[rp] = (u8)k3;
+        K34[rp] = (u8)k34;
+        return ce;
+    };
+    {
+        const int i0 = (int)g_begin * 64;
+        stage(i0 - 128 + lane);
+        stage(i0 - 64 + lane);
+    }
+    for (u32 g = g_begin; g < g_end; g++) {
+        const u32 i0 = g * 64, i = i0 + lane;
+        __builtin_amdgcn_wave_barrier();
+        const u64 e = stage((int)i);
+        __builtin_amdgcn_wave_barrier();
+        const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
+        const u32 rel_p = e0 & REL_MASK;
+        const bool own = i < wlen && rel_p >= halo;
+        if (!__any(own)) continue;
+        const u32 p_abs = td.w + rel_p;
+        const u32 look = n - p_abs;
+        const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
+        const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
+        const int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
+        const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
+        u32 nbv = own ? (u32)snb[i] : 0;
+        nbv = nbv < chain ? nbv : chain;
+        // the 128 slots before this lane's own are ring positions lo .. lo + 127 (mod 256); candidate j
+        // (1 = newest) is bit 128 - j of the masks
+        const u32 b3 = e1 & 0xff, b4 = (e1 >> 8) & 0xff;
+        const u32 lo = (i + 128) & (M5_RING - 1), w0 = lo >> 5, sh = lo & 31;
+        const u32 *r3 = T3 + m5_key3(b3) * 8, *r34 = T34 + m5_key34(b3, b4) * 8;
+        u32 W3[5], W34[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { const u32 o = (w0 + k) & 7; W3[k] = r3[o]; W34[k] = r34[o]; }
+        u32 M8[4], M5[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            M8[k] = __builtin_amdgcn_alignbit(W3[k + 1], W3[k], sh);
+            M5[k] = M8[k] & __builtin_amdgcn_alignbit(W34[k + 1], W34[k], sh);
+        }
+        u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
+        bool stop = nbv == 0, qtaken = false;
+#pragma unroll
+        for (int w = 3; w >= 0; w--) {
+            u32 el = stop ? 0 : (best < 3 ? 0xffffffffu : best < 4 ? M8[w] : M5[w]);
+            while (__any(el != 0)) {
+                if (el) {
+                    const u32 b = 31 - __builtin_clz(el);
+                    el &= ~(1u << b);
+                    const u32 t = 32 * w + b;
+                    const u32 j = 128 - t;
+                    if (j > nbv) { stop = true; el = 0; }           // past this lane's chain budget: so is everything older
+                    else {
+                        const u64 c = SE[(lo + t) & (M5_RING - 1)];
+                        const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
+                        const u32 rel_c = c0 & REL_MASK;
+                        if (!qtaken && j > qchain) { qbest = best; qdist = bdist; qtaken = true; }
+                        if ((int)rel_c > (j == 1 ? lim1 : limn)) {
+                            const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
+                            if ((x0 & 0x1ff) == 0) {
+                                u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
+                                if (x1 == 0 && (x0 >> 9) == 0) {
+                                    while (len < maxlen) {
+                                        const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
+                                        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+                                        len += 4;
+                                    }
+                                }
+                                len = len < maxlen ? len : maxlen;
+                                if (len > best) {
+                                    best = len; bdist = rel_p - rel_c;
+                                    if (len >= nice) stop = true;
+                                    // fewer candidates can still win now
+                                    el &= best < 4 ? M8[w] : M5[w];
+                                }
+                            }
+                        } else stop = true;                 // out of range: so is everything older
+                        if (stop) el = 0;
+                    }
+                }
+            }
+        }
+        if (!qtaken) { qbest = best; qdist = bdist; }
+        if (own) T[p_abs] = make_uint2(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0);
+    }
+}
+
 int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted,
                  const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg)
 {
     if (n_tiles == 0) return MTS_OK;
-    if (cfg.chain <= 128)
+    static const bool use4 = getenv("MTS_MATCH_V4") != nullptr;       // A/B switch for measurements
+    if (cfg.chain <= 128 && !use4)
+        hipLaunchKernelGGL(k_match5, dim3(n_tiles), dim3(M5_WAVES * 64), MATCH5_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
+    else if (cfg.chain <= 128)
         hipLaunchKernelGGL(k_match4<true>, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
     else
         hipLaunchKernelGGL(k_match4<false>, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
