@@ -398,22 +398,33 @@ __global__ __launch_bounds__(1024, 2) void k_match4(const u8 *__restrict__ strea
 
 // ------------------------------------------------------------------------------------------------
 // k_match5 (chain budget <= 128): the same filtered walk, but the filter masks are not computed by comparing
-// keys -- they are looked up.  Every wave keeps, next to its 256-slot ring of entries, two tables of
-// 64 rows x 256 bits: row k of T3 has bit r set iff the slot at ring position r has 6-bit key k3 = k,
-// T34 likewise for the (byte 3, byte 4) key.  A slot entering the ring clears the bit of the slot it
-// replaces and sets its own (4 LDS atomics per 64 slots).  A lane then reads the row of its OWN key and
-// funnel-shifts out the 128 bits of the slots before it: that is the mask of candidates with an equal
-// key.  6-bit keys make the masks supersets of "byte 3 equal" / "bytes 3,4 equal", which is all the
-// filter needs: a candidate that passes is scored exactly, one that fails could not have been longer.
+// keys -- they are looked up, and they go deeper.  Every wave keeps, next to its 256-slot ring of
+// entries, four tables of 32 rows x 256 bits: row k of table d (d = 4..7) has bit r set iff the slot at
+// ring position r has key_d = k, where key_d is a 5-bit hash of bytes 3 .. d-1 of the slot's string.  A
+// slot entering the ring clears the bits of the slot it replaces and sets its own (8 LDS atomics per 64
+// slots).  A lane reads the rows of its OWN keys and funnel-shifts out the 128 bits of the slots before
+// it: M_d = candidates whose first d bytes may equal its own (hash + bytes 3..d-1; a superset, which is
+// all the filter needs: a candidate that passes is scored exactly, one that fails cannot be longer than
+// d-1).  With best length L the walk only pops candidates of M_(L+1) (M_7 from 6 on), so the number of
+// scored candidates is about the number of times the best length improves.
 // ------------------------------------------------------------------------------------------------
 constexpr int M5_WAVES = 8;
 constexpr int M5_RING = 256;
-constexpr int M5_ROWS = 64;
-constexpr int M5_WAVE_LDS = M5_RING * 8 + 2 * M5_RING + 2 * M5_ROWS * (M5_RING / 8);     // 6656
+constexpr int M5_ROWS = 32;
+constexpr int M5_LEVELS = 4;                         // tables for prefix lengths 4, 5, 6, 7
+constexpr int M5_TABLE = M5_ROWS * (M5_RING / 8);    // bytes per table
+constexpr int M5_WAVE_LDS = M5_RING * 8 + M5_LEVELS * M5_RING + M5_LEVELS * M5_TABLE;     // 7168
 constexpr int MATCH5_LDS = M5_WAVES * M5_WAVE_LDS;
 
-__device__ __forceinline__ u32 m5_key3(u32 b3) { return (b3 ^ (b3 >> 6)) & 63; }
-__device__ __forceinline__ u32 m5_key34(u32 b3, u32 b4) { return (b4 ^ (b4 >> 6) ^ (b3 << 2) ^ (b3 >> 5)) & 63; }
+// 5-bit keys of the prefixes (b3), (b3,b4), (b3..b5), (b3..b6) of e1 = bytes 3..6
+__device__ __forceinline__ u32 m5_hash24(u32 x) { return (__umul24(x, 0x9E3779u) >> 19) & 31; }
+__device__ __forceinline__ void m5_keys(u32 e1, u32 (&k)[M5_LEVELS])
+{
+    k[0] = m5_hash24(e1 & 0xff);
+    k[1] = m5_hash24(e1 & 0xffff);
+    k[2] = m5_hash24(e1 & 0xffffff);
+    k[3] = m5_hash24((e1 ^ (e1 >> 11)) & 0xffffff);
+}
 
 __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
                                                           const u32 *__restrict__ sorted, const u16 *__restrict__ sorted_nb,
@@ -426,8 +437,8 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     const u8 *gwin = stream + td.stream_off + td.w;
     auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
     u64 *SE = (u64 *)wbase;
-    u8 *K3 = wbase + M5_RING * 8, *K34 = K3 + M5_RING;
-    u32 *T3 = (u32 *)(K34 + M5_RING), *T34 = T3 + M5_ROWS * 8;
+    u8 *KR = wbase + M5_RING * 8;                                  // [level][ring position]
+    u32 *TB = (u32 *)(KR + M5_LEVELS * M5_RING);                   // [level][row][8 words]
     uint2 *T = tables + td.stream_off;
     if (threadIdx.x < 2) {
         const u32 hashed_end = td.w + td.wlen;
@@ -448,36 +459,38 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     for (int k = lane; k < (M5_WAVE_LDS - M5_RING * 8) / 16; k += 64) ((uint4 *)(wbase + M5_RING * 8))[k] = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_wave_barrier();
     // slot idx -> position -> its 8 bytes -> entry; enters the ring at idx & 255, replacing slot idx - 256
-    auto stage = [&](int idx) -> u64 {
+    auto stage = [&](int idx, u32 (&key)[M5_LEVELS]) -> u64 {
         const u32 rp = (u32)idx & (M5_RING - 1), word = rp >> 5, bit = 1u << (rp & 31);
         u64 ce = ~0ull;
-        u32 k3 = 0, k34 = 0;
         const bool valid = idx >= 0 && (u32)idx < wlen;
         if (valid) {
             const u32 rc = sk[idx] & REL_MASK;
             const u32 lo = wread(rc), hi = wread(rc + 4);
             ce = make_entry(rc, lo, hi);
-            k3 = m5_key3(lo >> 24);
-            k34 = m5_key34(lo >> 24, hi & 0xff);
         }
-        const u32 o3 = K3[rp], o34 = K34[rp];
-        atomicAnd(&T3[o3 * 8 + word], ~bit);
-        atomicAnd(&T34[o34 * 8 + word], ~bit);
-        if (valid) { atomicOr(&T3[k3 * 8 + word], bit); atomicOr(&T34[k34 * 8 + word], bit); }
+        m5_keys((u32)(ce >> 32), key);
+#pragma unroll
+        for (int d = 0; d < M5_LEVELS; d++) {
+            u32 *tb = TB + d * (M5_TABLE / 4);
+            const u32 old = KR[d * M5_RING + rp];
+            atomicAnd(&tb[old * 8 + word], ~bit);
+            if (valid) atomicOr(&tb[key[d] * 8 + word], bit);
+            KR[d * M5_RING + rp] = (u8)key[d];
+        }
         SE[rp] = ce;
-        K3[rp] = (u8)k3;
-        K34[rp] = (u8)k34;
         return ce;
     };
     {
         const int i0 = (int)g_begin * 64;
-        stage(i0 - 128 + lane);
-        stage(i0 - 64 + lane);
+        u32 kk[M5_LEVELS];
+        stage(i0 - 128 + lane, kk);
+        stage(i0 - 64 + lane, kk);
     }
     for (u32 g = g_begin; g < g_end; g++) {
         const u32 i0 = g * 64, i = i0 + lane;
+        u32 key[M5_LEVELS];
         __builtin_amdgcn_wave_barrier();
-        const u64 e = stage((int)i);
+        const u64 e = stage((int)i, key);
         __builtin_amdgcn_wave_barrier();
         const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
         const u32 rel_p = e0 & REL_MASK;
@@ -492,62 +505,82 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         u32 nbv = own ? (u32)snb[i] : 0;
         nbv = nbv < chain ? nbv : chain;
         // the 128 slots before this lane's own are ring positions lo .. lo + 127 (mod 256); candidate j
-        // (1 = newest) is bit 128 - j of the masks
-        const u32 b3 = e1 & 0xff, b4 = (e1 >> 8) & 0xff;
+        // (1 = newest) is bit 128 - j of the masks.  V = the candidates inside this lane's chain budget.
         const u32 lo = (i + 128) & (M5_RING - 1), w0 = lo >> 5, sh = lo & 31;
-        const u32 *r3 = T3 + m5_key3(b3) * 8, *r34 = T34 + m5_key34(b3, b4) * 8;
-        u32 W3[5], W34[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) { const u32 o = (w0 + k) & 7; W3[k] = r3[o]; W34[k] = r34[o]; }
-        u32 M8[4], M5[4];
+        u32 V[4], A4[4], A5[4], A6[4], A7[4];                     // V = inside the budget; A_d = V & "first d bytes may match"
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            M8[k] = __builtin_amdgcn_alignbit(W3[k + 1], W3[k], sh);
-            M5[k] = M8[k] & __builtin_amdgcn_alignbit(W34[k + 1], W34[k], sh);
+            const int s = 32 * k + (int)nbv - 96;               // candidates of word k: bits >= 32 - s
+            V[k] = s <= 0 ? 0u : s >= 32 ? 0xffffffffu : 0xffffffffu << (32 - s);
         }
-        u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
-        bool stop = nbv == 0, qtaken = false;
-#pragma unroll
-        for (int w = 3; w >= 0; w--) {
-            u32 el = stop ? 0 : (best < 3 ? 0xffffffffu : best < 4 ? M8[w] : M5[w]);
+        auto rowmask = [&](const int d, const u32 (&in)[4], u32 (&out)[4]) __attribute__((always_inline)) {
+            const u32 *row = TB + d * (M5_TABLE / 4) + key[d] * 8;
+            const u32 W0 = row[w0 & 7], W1 = row[(w0 + 1) & 7], W2 = row[(w0 + 2) & 7], W3 = row[(w0 + 3) & 7], W4 = row[(w0 + 4) & 7];
+            out[0] = in[0] & __builtin_amdgcn_alignbit(W1, W0, sh);
+            out[1] = in[1] & __builtin_amdgcn_alignbit(W2, W1, sh);
+            out[2] = in[2] & __builtin_amdgcn_alignbit(W3, W2, sh);
+            out[3] = in[3] & __builtin_amdgcn_alignbit(W4, W3, sh);
+        };
+        rowmask(0, V, A4);
+        rowmask(1, A4, A5);
+        rowmask(2, A5, A6);
+        rowmask(3, A6, A7);
+        u32 best = 2, bdist = 0;
+        bool stop = false;
+        // candidates of word w restricted to `part`, newest first
+        auto walk = [&](const u32 tb, const u32 m0, const u32 m1, const u32 m2, const u32 m3, const u32 m4, const u32 part) __attribute__((always_inline)) {
+            // (the empty asm statements keep the compiler from turning the select chain into a table in scratch memory)
+            auto pick = [&]() -> u32 {
+                u32 r = best >= 3 ? m1 : m0;
+                asm volatile("" : "+v"(r));
+                r = best >= 4 ? m2 : r;
+                asm volatile("" : "+v"(r));
+                r = best >= 5 ? m3 : r;
+                asm volatile("" : "+v"(r));
+                return best >= 6 ? m4 : r;
+            };
+            u32 el = stop ? 0 : pick() & part;
             while (__any(el != 0)) {
                 if (el) {
                     const u32 b = 31 - __builtin_clz(el);
                     el &= ~(1u << b);
-                    const u32 t = 32 * w + b;
-                    const u32 j = 128 - t;
-                    if (j > nbv) { stop = true; el = 0; }           // past this lane's chain budget: so is everything older
-                    else {
-                        const u64 c = SE[(lo + t) & (M5_RING - 1)];
-                        const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
-                        const u32 rel_c = c0 & REL_MASK;
-                        if (!qtaken && j > qchain) { qbest = best; qdist = bdist; qtaken = true; }
-                        if ((int)rel_c > (j == 1 ? lim1 : limn)) {
-                            const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
-                            if ((x0 & 0x1ff) == 0) {
-                                u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
-                                if (x1 == 0 && (x0 >> 9) == 0) {
-                                    while (len < maxlen) {
-                                        const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
-                                        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
-                                        len += 4;
-                                    }
-                                }
-                                len = len < maxlen ? len : maxlen;
-                                if (len > best) {
-                                    best = len; bdist = rel_p - rel_c;
-                                    if (len >= nice) stop = true;
-                                    // fewer candidates can still win now
-                                    el &= best < 4 ? M8[w] : M5[w];
+                    const u32 t = tb + b;
+                    const u64 c = SE[(lo + t) & (M5_RING - 1)];
+                    const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
+                    const u32 rel_c = c0 & REL_MASK;
+                    if ((int)rel_c > (t == 127 ? lim1 : limn)) {
+                        const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
+                        if ((x0 & 0x1ff) == 0) {
+                            u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
+                            if (x1 == 0 && (x0 >> 9) == 0) {
+                                while (len < maxlen) {
+                                    const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
+                                    if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+                                    len += 4;
                                 }
                             }
-                        } else stop = true;                 // out of range: so is everything older
-                        if (stop) el = 0;
-                    }
+                            len = len < maxlen ? len : maxlen;
+                            if (len > best) {
+                                best = len; bdist = rel_p - rel_c;
+                                if (len >= nice) stop = true;
+                                el &= pick();                       // fewer candidates can still win now
+                            }
+                        }
+                    } else stop = true;                 // out of range: so is everything older
+                    if (stop) el = 0;
                 }
             }
-        }
-        if (!qtaken) { qbest = best; qdist = bdist; }
+        };
+        // candidates 1 .. qchain first: what the walk holds then is the quarter-budget result
+        const u32 qpart = qchain >= 32 ? 0xffffffffu : ~(0xffffffffu >> qchain);        // qchain <= 32 (chain <= 128)
+#define MTS_WALK(w, part) walk(32 * (w), V[w], A4[w], A5[w], A6[w], A7[w], part)
+        MTS_WALK(3, qpart);
+        const u32 qbest = best, qdist = bdist;
+        if (qpart != 0xffffffffu) MTS_WALK(3, ~qpart);
+        MTS_WALK(2, 0xffffffffu);
+        MTS_WALK(1, 0xffffffffu);
+        MTS_WALK(0, 0xffffffffu);
+#undef MTS_WALK
         if (own) T[p_abs] = make_uint2(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0);
     }
 }
