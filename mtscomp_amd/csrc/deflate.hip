@@ -458,16 +458,12 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     // tables and key rings start empty
     for (int k = lane; k < (M5_WAVE_LDS - M5_RING * 8) / 16; k += 64) ((uint4 *)(wbase + M5_RING * 8))[k] = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_wave_barrier();
-    // slot idx -> position -> its 8 bytes -> entry; enters the ring at idx & 255, replacing slot idx - 256
-    auto stage = [&](int idx, u32 (&key)[M5_LEVELS]) -> u64 {
+    // slot idx -> position -> its 8 bytes -> entry; enters the ring at idx & 255, replacing slot idx - 256.
+    // The window words of a slot are loaded one group ahead (the loads stay in flight during the walk).
+    auto commit = [&](int idx, u32 rc, u32 lo, u32 hi, u32 (&key)[M5_LEVELS]) -> u64 {
         const u32 rp = (u32)idx & (M5_RING - 1), word = rp >> 5, bit = 1u << (rp & 31);
-        u64 ce = ~0ull;
         const bool valid = idx >= 0 && (u32)idx < wlen;
-        if (valid) {
-            const u32 rc = sk[idx] & REL_MASK;
-            const u32 lo = wread(rc), hi = wread(rc + 4);
-            ce = make_entry(rc, lo, hi);
-        }
+        const u64 ce = valid ? make_entry(rc, lo, hi) : ~0ull;
         m5_keys((u32)(ce >> 32), key);
 #pragma unroll
         for (int d = 0; d < M5_LEVELS; d++) {
@@ -480,18 +476,31 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         SE[rp] = ce;
         return ce;
     };
+    auto slot_rel = [&](int idx) -> u32 { return sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1] & REL_MASK; };
+    const int i_first = (int)g_begin * 64 + lane;
     {
-        const int i0 = (int)g_begin * 64;
         u32 kk[M5_LEVELS];
-        stage(i0 - 128 + lane, kk);
-        stage(i0 - 64 + lane, kk);
+        const u32 ra = slot_rel(i_first - 128), rb = slot_rel(i_first - 64);
+        const u32 la = wread(ra), ha = wread(ra + 4), lb = wread(rb), hb = wread(rb + 4);
+        commit(i_first - 128, ra, la, ha, kk);
+        commit(i_first - 64, rb, lb, hb, kk);
     }
+    // pipeline: (rc, lo, hi, nb) of the group about to be walked, rc of the one after
+    u32 rc_c = slot_rel(i_first), rc_n = slot_rel(i_first + 64);
+    u32 lo_c = wread(rc_c), hi_c = wread(rc_c + 4);
+    u32 nb_c = snb[(u32)i_first < wlen ? (u32)i_first : wlen - 1];
     for (u32 g = g_begin; g < g_end; g++) {
         const u32 i0 = g * 64, i = i0 + lane;
         u32 key[M5_LEVELS];
         __builtin_amdgcn_wave_barrier();
-        const u64 e = stage((int)i, key);
+        const u64 e = commit((int)i, rc_c, lo_c, hi_c, key);
         __builtin_amdgcn_wave_barrier();
+        const u32 nb_raw = nb_c;
+        // next group's words, and the position of the one after
+        rc_c = rc_n;
+        lo_c = wread(rc_c); hi_c = wread(rc_c + 4);
+        nb_c = snb[i + 64 < wlen ? i + 64 : wlen - 1];
+        rc_n = slot_rel((int)i + 128);
         const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
         const u32 rel_p = e0 & REL_MASK;
         const bool own = i < wlen && rel_p >= halo;
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
         const int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
         const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
-        u32 nbv = own ? (u32)snb[i] : 0;
+        u32 nbv = own ? nb_raw : 0;
         nbv = nbv < chain ? nbv : chain;
         // the 128 slots before this lane's own are ring positions lo .. lo + 127 (mod 256); candidate j
         // (1 = newest) is bit 128 - j of the masks.  V = the candidates inside this lane's chain budget.
@@ -590,9 +599,11 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
 {
     if (n_tiles == 0) return MTS_OK;
     static const bool use4 = getenv("MTS_MATCH_V4") != nullptr;       // A/B switch for measurements
-    if (cfg.chain <= 128 && !use4)
+    if (cfg.chain <= 128 && !use4) {
+        static bool attr_done = false;
+        if (!attr_done && MATCH5_LDS > 65536) { MTS_HIP(hipFuncSetAttribute((const void *)k_match5, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH5_LDS)); attr_done = true; }
         hipLaunchKernelGGL(k_match5, dim3(n_tiles), dim3(M5_WAVES * 64), MATCH5_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
-    else if (cfg.chain <= 128)
+    } else if (cfg.chain <= 128)
         hipLaunchKernelGGL(k_match4<true>, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
     else
         hipLaunchKernelGGL(k_match4<false>, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
