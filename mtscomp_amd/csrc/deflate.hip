@@ -413,7 +413,7 @@ constexpr int M5_RING = 256;
 constexpr int M5_ROWS = 32;
 constexpr int M5_LEVELS = 4;                         // tables for prefix lengths 4, 5, 6, 7
 constexpr int M5_TABLE = M5_ROWS * (M5_RING / 8);    // bytes per table
-constexpr int M5_WAVE_LDS = M5_RING * 8 + M5_LEVELS * M5_TABLE;     // 6144
+constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_LEVELS * M5_TABLE;     // 8192: entries, bytes 7..14, tables
 // requested LDS is padded so that TWO workgroups share a CU, not three: every workgroup reads its own 128 KiB
 // window through L2, and three per CU (12 MiB per XCD against 4 MiB of L2) measured 10 % slower than two
 constexpr int MATCH5_LDS = M5_WAVES * M5_WAVE_LDS > 56 * 1024 ? M5_WAVES * M5_WAVE_LDS : 56 * 1024;
@@ -439,7 +439,8 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     const u8 *gwin = stream + td.stream_off + td.w;
     auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
     u64 *SE = (u64 *)wbase;
-    u32 *TB = (u32 *)(wbase + M5_RING * 8);                        // [level][row][8 words]
+    u64 *SX = SE + M5_RING;                                        // bytes 7..14 of every slot: matches up to 15 never leave the LDS
+    u32 *TB = (u32 *)(wbase + 2 * M5_RING * 8);                    // [level][row][8 words]
     uint2 *T = tables + td.stream_off;
     if (threadIdx.x < 2) {
         const u32 hashed_end = td.w + td.wlen;
@@ -458,11 +459,11 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     if (g_begin >= g_end) return;
     // the tables start empty (the entry ring may hold anything: the bits of a ring position are only ever
     // set by the slot that is there, so clearing the bits of a stale or invalid entry clears nothing)
-    for (int k = lane; k < (M5_WAVE_LDS - M5_RING * 8) / 16; k += 64) ((uint4 *)(wbase + M5_RING * 8))[k] = make_uint4(0, 0, 0, 0);
+    for (int k = lane; k < (M5_WAVE_LDS - 2 * M5_RING * 8) / 16; k += 64) ((uint4 *)(wbase + 2 * M5_RING * 8))[k] = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_wave_barrier();
     // slot idx -> position -> its 8 bytes -> entry; enters the ring at idx & 255, replacing slot idx - 256.
     // The window words of a slot are loaded one group ahead (the loads stay in flight during the walk).
-    auto commit = [&](int idx, u32 rc, u32 lo, u32 hi, u32 (&key)[M5_LEVELS]) -> u64 {
+    auto commit = [&](int idx, u32 rc, u32 lo, u32 hi, u64 x, u32 (&key)[M5_LEVELS]) -> u64 {
         const u32 rp = (u32)idx & (M5_RING - 1), word = rp >> 5, bit = 1u << (rp & 31);
         const bool valid = idx >= 0 && (u32)idx < wlen;
         const u64 ce = valid ? make_entry(rc, lo, hi) : ~0ull;
@@ -476,31 +477,37 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
             if (valid) atomicOr(&tb[key[d] * 8 + word], bit);
         }
         SE[rp] = ce;
+        SX[rp] = x;
         return ce;
     };
+    // bytes 7..14 of the string at window offset r, given its bytes 4..7
+    auto ext_bytes = [&](u32 r, u32 hi) -> u64 { return (u64)(hi >> 24) | ((u64)wread(r + 8) << 8) | ((u64)(wread(r + 12) & 0xffffffu) << 40); };
     auto slot_rel = [&](int idx) -> u32 { return sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1] & REL_MASK; };
     const int i_first = (int)g_begin * 64 + lane;
     {
         u32 kk[M5_LEVELS];
         const u32 ra = slot_rel(i_first - 128), rb = slot_rel(i_first - 64);
         const u32 la = wread(ra), ha = wread(ra + 4), lb = wread(rb), hb = wread(rb + 4);
-        commit(i_first - 128, ra, la, ha, kk);
-        commit(i_first - 64, rb, lb, hb, kk);
+        commit(i_first - 128, ra, la, ha, ext_bytes(ra, ha), kk);
+        commit(i_first - 64, rb, lb, hb, ext_bytes(rb, hb), kk);
     }
     // pipeline: (rc, lo, hi, nb) of the group about to be walked, rc of the one after
     u32 rc_c = slot_rel(i_first), rc_n = slot_rel(i_first + 64);
     u32 lo_c = wread(rc_c), hi_c = wread(rc_c + 4);
+    u64 x_c = ext_bytes(rc_c, hi_c);
     u32 nb_c = snb[(u32)i_first < wlen ? (u32)i_first : wlen - 1];
     for (u32 g = g_begin; g < g_end; g++) {
         const u32 i0 = g * 64, i = i0 + lane;
         u32 key[M5_LEVELS];
         __builtin_amdgcn_wave_barrier();
-        const u64 e = commit((int)i, rc_c, lo_c, hi_c, key);
+        const u64 e = commit((int)i, rc_c, lo_c, hi_c, x_c, key);
+        const u64 ex = x_c;
         __builtin_amdgcn_wave_barrier();
         const u32 nb_raw = nb_c;
         // next group's words, and the position of the one after
         rc_c = rc_n;
         lo_c = wread(rc_c); hi_c = wread(rc_c + 4);
+        x_c = ext_bytes(rc_c, hi_c);
         nb_c = snb[i + 64 < wlen ? i + 64 : wlen - 1];
         rc_n = slot_rel((int)i + 128);
         const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
@@ -556,7 +563,8 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                     const u32 b = 31 - __builtin_clz(el);
                     el &= ~(1u << b);
                     const u32 t = tb + b;
-                    const u64 c = SE[(lo + t) & (M5_RING - 1)];
+                    const u32 slot = (lo + t) & (M5_RING - 1);
+                    const u64 c = SE[slot];
                     const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                     const u32 rel_c = c0 & REL_MASK;
                     if ((int)rel_c > (t == 127 ? lim1 : limn)) {
@@ -564,10 +572,15 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                         if ((x0 & 0x1ff) == 0) {
                             u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
                             if (x1 == 0 && (x0 >> 9) == 0) {
-                                while (len < maxlen) {
-                                    const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
-                                    if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
-                                    len += 4;
+                                const u64 y = SX[slot] ^ ex;
+                                if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
+                                else {
+                                    len = 15;
+                                    while (len < maxlen) {
+                                        const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
+                                        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+                                        len += 4;
+                                    }
                                 }
                             }
                             len = len < maxlen ? len : maxlen;
