@@ -632,18 +632,18 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
 // One step of the state machine from a base state (no pending match) at p0.  Emits the literals
 // b[p0 .. mpos-1] followed by match (mlen, mdist) at mpos, or the single literal b[p0] when mlen == 0.
 // Returns the next base position.
-__device__ __forceinline__ u32 lazy_step(const uint2 *__restrict__ T, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos,
-                                         u32 &mlen, u32 &mdist)
+template <class RD>
+__device__ __forceinline__ u32 lazy_step(RD &&rd, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos, u32 &mlen, u32 &mdist)
 {
     u32 p = p0;
-    const u32 c = T[p].x;
+    const u32 c = rd(p).x;
     u32 len = c >> 16, dist = c & 0xffff;
     if (len == MIN_MATCH && dist > (u32)TOO_FAR) len = 0;
     if (len < MIN_MATCH) { mpos = p0; mlen = 0; mdist = 0; return p0 + 1; }
     for (;;) {
         const u32 q = p + 1;
         if (q < n && len < (u32)cfg.lazy) {
-            const uint2 d2 = T[q];
+            const uint2 d2 = rd(q);
             const u32 d = len >= (u32)cfg.good ? d2.y : d2.x;
             if ((d >> 16) > len) { p = q; len = d >> 16; dist = d & 0xffff; continue; }
         }
@@ -651,6 +651,11 @@ __device__ __forceinline__ u32 lazy_step(const uint2 *__restrict__ T, u32 p0, u3
     }
     mpos = p; mlen = len; mdist = dist;
     return p + len;
+}
+
+__device__ __forceinline__ u64 readlane_u64(u64 v, int k)
+{
+    return (u64)(u32)__builtin_amdgcn_readlane((int)(u32)v, k) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), k) << 32);
 }
 
 // Speculative walk of one segment from `entry`.  Besides the exit (first base position at or beyond the
@@ -668,12 +673,13 @@ __global__ __launch_bounds__(64) void k_parse_spec(const uint2 *__restrict__ tab
     const u32 s = pb.seg_start[g], n = ch.n;
     const u32 segend = min(s + (u32)SEG, n);
     const uint2 *T = tables + ch.stream_off;
+    auto rd = [&](u32 q) -> uint2 { return T[q]; };
     u32 *cp = pb.cp + (u64)g * 16;
     u32 pos = s, mp, ml, md, cnt = 0, k = 1;
     while (pos < segend) {
         while (k < 8 && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++; }
         const u32 p0 = pos;
-        pos = lazy_step(T, pos, n, cfg, mp, ml, md);
+        pos = lazy_step(rd, pos, n, cfg, mp, ml, md);
         cnt += mp - p0 + 1;
     }
     for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }      // checkpoints past the exit
@@ -699,6 +705,7 @@ __global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tabl
     const u32 s = pb.seg_start[g], n = ch.n;
     const u32 segend = min(s + (u32)SEG, n);
     const uint2 *T = tables + ch.stream_off;
+    auto rd = [&](u32 q) -> uint2 { return T[q]; };
     u32 *cp = pb.cp + (u64)g * 16;
     const u32 old_cnt = pb.cnt[g];
     u32 pos = ne, mp, ml, md, cnt = 0, k = 1;
@@ -717,7 +724,7 @@ __global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tabl
             return;
         }
         const u32 p0 = pos;
-        pos = lazy_step(T, pos, n, cfg, mp, ml, md);
+        pos = lazy_step(rd, pos, n, cfg, mp, ml, md);
         cnt += mp - p0 + 1;
     }
     for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }
@@ -755,34 +762,68 @@ __global__ __launch_bounds__(256) void k_seg_scan(const ChunkDesc *__restrict__ 
     }
 }
 
+// The final walk.  A lane's tokens go to consecutive addresses, but the 64 lanes of a wave are in 64 different
+// segments: stored one by one, every token would be a 4-byte partial write.  So the tokens of a round are
+// collected in a short LDS row per lane and the rows are written out one after the other (consecutive
+// lanes write consecutive tokens of ONE segment).
+constexpr int PTCAP = 32;                  // tokens buffered per lane and round
+constexpr int PTROW = PTCAP + 1;
+
 __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream, const uint2 *__restrict__ tables,
                                                    const ChunkDesc *__restrict__ chunks, ParseBufs pb, int n_segs,
                                                    LevelCfg cfg, u32 *__restrict__ tokens, u32 *__restrict__ blk_in_start,
                                                    ChunkOut *__restrict__ cout)
 {
-    const int g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= n_segs) return;
-    const ChunkDesc ch = chunks[pb.seg_chunk[g]];
-    const u32 s = pb.seg_start[g], n = ch.n;
+    __shared__ u32 tokb[64 * PTROW];
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x * 64 + lane;
+    const bool valid = g < n_segs;
+    const int gc = valid ? g : n_segs - 1;
+    const u32 ci = pb.seg_chunk[gc];
+    const ChunkDesc ch = chunks[ci];
+    const u32 s = pb.seg_start[gc], n = ch.n;
     const u32 segend = min(s + (u32)SEG, n);
     const uint2 *T = tables + ch.stream_off;
     const u8 *b = stream + ch.stream_off;
     u32 *tk = tokens + ch.tok_off;
     u32 *bis = blk_in_start + ch.blk0;
-    u32 pos = pb.entry[g], mp, ml, md, k = pb.tokbase[g];
-    while (pos < segend) {
-        const u32 p0 = pos;
-        pos = lazy_step(T, pos, n, cfg, mp, ml, md);
-        if (pos >= n) cout[pb.seg_chunk[g]].trailing = (ml == 0) ? 1u : 0u;       // last token of the chunk
-        const u32 nlit = ml ? mp - p0 : 1;
-        for (u32 q = 0; q < nlit; q++, k++) {
-            if (k % BLOCK_TOKENS == 0) bis[k / BLOCK_TOKENS] = p0 + q;
-            tk[k] = (u32)b[p0 + q] << 16;
+    auto rd = [&](u32 q) -> uint2 { return T[q]; };
+    u32 pos = pb.entry[gc], mp, ml, md, k = pb.tokbase[gc];
+    for (;;) {
+        const bool act = valid && pos < segend;
+        if (!__any(act)) break;
+        const u32 k0 = k;
+        auto put = [&](u32 v, u32 at) {
+            if (k % BLOCK_TOKENS == 0) bis[k / BLOCK_TOKENS] = at;
+            const u32 j = k - k0;
+            if (j < (u32)PTCAP) tokb[lane * PTROW + j] = v; else tk[k] = v;      // (a step longer than the row: straight to memory)
+            k++;
+        };
+        while (act && pos < segend && k - k0 < (u32)PTCAP) {
+            const u32 p0 = pos;
+            pos = lazy_step(rd, pos, n, cfg, mp, ml, md);
+            if (pos >= n) cout[ci].trailing = (ml == 0) ? 1u : 0u;       // last token of the chunk
+            const u32 nlit = ml ? mp - p0 : 1;
+            for (u32 q = 0; q < nlit; q++) put((u32)b[p0 + q] << 16, p0 + q);
+            if (ml) put(((ml - MIN_MATCH) << 16) | md, mp);
         }
-        if (ml) {
-            if (k % BLOCK_TOKENS == 0) bis[k / BLOCK_TOKENS] = mp;
-            tk[k++] = ((ml - MIN_MATCH) << 16) | md;
+        __builtin_amdgcn_wave_barrier();
+        const u32 nloc = min(k - k0, (u32)PTCAP);
+        const int sub = lane & 31, half = lane >> 5;
+#pragma unroll 1
+        for (int rb = 0; rb < 64; rb += 16) {                   // two rows per store: lanes 0..31 one row, 32..63 the next
+            u32 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = tokb[(rb + 2 * j + half) * PTROW + sub];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int r0 = rb + 2 * j;
+                u32 *d0 = (u32 *)readlane_u64((u64)(tk + k0), r0), *d1 = (u32 *)readlane_u64((u64)(tk + k0), r0 + 1);
+                const u32 c0 = (u32)__builtin_amdgcn_readlane((int)nloc, r0), c1 = (u32)__builtin_amdgcn_readlane((int)nloc, r0 + 1);
+                if ((u32)sub < (half ? c1 : c0)) (half ? d1 : d0)[sub] = v[j];
+            }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
