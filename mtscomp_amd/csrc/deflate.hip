@@ -1245,8 +1245,30 @@ __device__ __forceinline__ void token_put(Sink &s, u32 t, const u32 *lc_tab, con
     s.put((c & 0xffff) | (((dist - 1) & ((1u << ed) - 1)) << (c >> 16)), (int)((c >> 16) + ed));
 }
 
+// code bits of one token, LSB first: <= 48 bits (15 + 5 length, 15 + 13 distance)
+__device__ __forceinline__ u64 token_code(u32 t, const u32 *lc_tab, const u32 *dc_tab, u32 &nb)
+{
+    const u32 dist = t & 0xffff, lc = t >> 16;
+    if (dist == 0) { const u32 c = lc_tab[lc]; nb = c >> 16; return c & 0xffff; }
+    u32 el, ed;
+    const u32 lcode = len_code(lc, el), dcode = dist_code(dist - 1, ed);
+    const u32 c = lc_tab[257 + lcode], d = dc_tab[dcode];
+    const u32 n1 = (c >> 16) + el, n2 = (d >> 16) + ed;
+    const u64 v1 = (c & 0xffff) | ((lc & ((1u << el) - 1)) << (c >> 16));
+    const u64 v2 = (d & 0xffff) | (((dist - 1) & ((1u << ed) - 1)) << (d >> 16));
+    nb = n1 + n2;
+    return v1 | (v2 << n1);
+}
+
+// One workgroup per block.  The bits of the block are assembled in LDS and leave as whole words, coalesced:
+// a wave owns 4096 consecutive tokens and takes them 64 at a time (one coalesced load), a wave scan of
+// the code lengths gives every token its bit position, and the code is OR-ed into the (zeroed) LDS image.
+// Only the first and the last word of the image can be shared with the neighbouring blocks: those two are
+// OR-ed into the (zeroed) output, the rest is stored.  A block too large for the image (it holds 16 bits
+// per token; zlib needs 9-10 on this kind of data) ORs the overhang straight into the output.
 constexpr int PACK_THREADS = 256;
-constexpr int PACK_RUN = (BLOCK_TOKENS + PACK_THREADS - 1) / PACK_THREADS;   // 64 tokens per lane
+constexpr int PACK_WTOK = 4096;                 // token indices per wave (4 x 4096 >= 16383 tokens + end-of-block)
+constexpr int PACK_IMG_WORDS = 8192;
 
 __global__ __launch_bounds__(PACK_THREADS) void k_block_pack(const u8 *__restrict__ stream, const ChunkDesc *__restrict__ chunks,
                                                              const u32 *__restrict__ blk_chunk, int total_blk_cap,
@@ -1265,10 +1287,11 @@ __global__ __launch_bounds__(PACK_THREADS) void k_block_pack(const u8 *__restric
     u32 *out = (u32 *)(outb + ch.out_off);
     __shared__ u32 codes[BLK_CODE_WORDS];
     __shared__ u32 wsum[PACK_THREADS / 64];
+    __shared__ u32 img[PACK_IMG_WORDS];
     const int tid = threadIdx.x;
-    Sink sk;
     if (r.btype == 0) {
         // stored: [3 bits][pad][LEN][NLEN][bytes]
+        Sink sk;
         const u64 hdr_bit = r.bit_start;
         const u64 pay_bit = ((hdr_bit + 3 + 7) & ~7ull) + 32;
         if (tid == 0) {
@@ -1296,42 +1319,70 @@ __global__ __launch_bounds__(PACK_THREADS) void k_block_pack(const u8 *__restric
         }
         return;
     }
+    // the image starts at the output word holding the first bit of the block (block 0: the zlib header)
+    const u64 first_bit = bi == 0 ? 0 : r.bit_start;
+    const u64 word0 = first_bit >> 5;
+    const u64 end_bit = r.last ? ((r.bit_start + r.nbits + 7) & ~7ull) + 32 : r.bit_start + r.nbits;
+    const u32 nwords = (u32)(((end_bit + 31) >> 5) - word0);
+    const u32 nimg = nwords < (u32)PACK_IMG_WORDS ? nwords : (u32)PACK_IMG_WORDS;
     for (int i = tid; i < BLK_CODE_WORDS; i += PACK_THREADS) codes[i] = i < L_CODES + D_CODES ? blk_codes[(u64)b * BLK_CODE_WORDS + i] : 0;
+    for (u32 i = tid; i < nimg; i += PACK_THREADS) img[i] = 0;
     __syncthreads();
+    // nb bits of v at absolute bit position `at`
+    auto or_bits = [&](u64 at, u64 v, u32 nb) {
+        if (nb == 0) return;
+        const u32 rel = (u32)(at - (word0 << 5)), w = rel >> 5, sh = rel & 31;
+        const u64 lo = v << sh;
+        const u32 x[3] = {(u32)lo, (u32)(lo >> 32), sh ? (u32)(v >> (64 - sh)) : 0u};
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (x[j]) { if (w + j < (u32)PACK_IMG_WORDS) atomicOr(&img[w + j], x[j]); else atomicOr(&out[word0 + w + j], x[j]); }
+    };
     const u32 *lc_tab = codes, *dc_tab = codes + L_CODES;
     const u32 *tk = tokens + ch.tok_off + r.tok0;
-    const u32 t0 = min((u32)tid * PACK_RUN, r.ntok), t1 = min(t0 + PACK_RUN, r.ntok);
-    // bits this lane writes: (lane 0: stream header + block header + trees) + its tokens + (EOB for the owner of the end)
-    const bool owns_end = (r.ntok == 0) ? tid == 0 : (t1 == r.ntok && t0 < r.ntok);
-    u32 nbits = 0;
-    for (u32 i = t0; i < t1; i++) nbits += token_bits(tk[i], lc_tab, dc_tab);
-    if (owns_end) nbits += lc_tab[256] >> 16;
-    const u32 pre = tid == 0 ? 3 + r.hdr_bits : 0;
-    nbits += pre;
-    u32 wtot;
-    u32 ex = wave_excl_scan_u32(nbits, wtot);
-    if ((tid & 63) == 0) wsum[tid >> 6] = wtot;
-    __syncthreads();
-    for (int w = 0; w < (tid >> 6); w++) ex += wsum[w];
-    u64 bitpos = r.bit_start + ex;
+    const int wave = tid >> 6, lane = tid & 63;
+    // token index ntok is the end-of-block symbol
+    const u32 i_beg = (u32)wave * PACK_WTOK, i_end = min(i_beg + (u32)PACK_WTOK, r.ntok + 1);
+    auto code_at = [&](u32 i, u32 &nb) -> u64 {
+        if (i < r.ntok) return token_code(tk[i], lc_tab, dc_tab, nb);
+        if (i == r.ntok) { const u32 c = lc_tab[256]; nb = c >> 16; return c & 0xffff; }
+        nb = 0;
+        return 0;
+    };
+    u32 mybits = 0;
+    for (u32 i = i_beg + lane; i < i_end; i += 64) { u32 nb; code_at(i, nb); mybits += nb; }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) mybits += __shfl_xor(mybits, o, 64);
+    if (lane == 0) wsum[wave] = mybits;
+    // zlib header, block header, code-length header
     if (tid == 0) {
-        if (bi == 0) { sk.init(out, 0); sk.put(zhdr, 16); } else sk.init(out, bitpos);
-        sk.put(r.last | (r.btype << 1), 3);
-        if (r.btype == 2) {
-            const u32 *hw = blk_hdr + (u64)b * BLK_HDR_WORDS;
-            u32 left = r.hdr_bits, k = 0;
-            while (left >= 32) { const u32 w = hw[k++]; sk.put(w & 0xffff, 16); sk.put(w >> 16, 16); left -= 32; }
-            if (left) { const u32 w = hw[k]; if (left > 16) { sk.put(w & 0xffff, 16); sk.put((w >> 16) & ((1u << (left - 16)) - 1), (int)left - 16); } else sk.put(w & ((1u << left) - 1), (int)left); }
+        if (bi == 0) or_bits(0, zhdr, 16);
+        or_bits(r.bit_start, r.last | (r.btype << 1), 3);
+        if (r.last) or_bits(end_bit - 32, __builtin_bswap32(co.adler), 32);           // adler32, big-endian
+    }
+    if (r.btype == 2) {
+        const u32 *hw = blk_hdr + (u64)b * BLK_HDR_WORDS;
+        for (u32 k = tid; 32 * k < r.hdr_bits; k += PACK_THREADS) {
+            const u32 left = r.hdr_bits - 32 * k;
+            or_bits(r.bit_start + 3 + 32 * k, left >= 32 ? hw[k] : hw[k] & ((1u << left) - 1), left >= 32 ? 32 : left);
         }
-    } else sk.init(out, bitpos);
-    for (u32 i = t0; i < t1; i++) token_put(sk, tk[i], lc_tab, dc_tab);
-    if (owns_end) { const u32 c = lc_tab[256]; sk.put(c & 0xffff, (int)(c >> 16)); }
-    sk.flush();
-    if (r.last && owns_end) {
-        const u64 endbit = (r.bit_start + r.nbits + 7) & ~7ull;
-        sk.init(out, endbit);
-        sk.put(__builtin_bswap32(co.adler), 32);      // adler32 big-endian
-        sk.flush();
+    }
+    __syncthreads();
+    u64 pos = r.bit_start + 3 + r.hdr_bits;
+    for (int w = 0; w < wave; w++) pos += wsum[w];
+    for (u32 i0 = i_beg; i0 < i_end; i0 += 64) {
+        u32 nb;
+        const u64 v = code_at(i0 + lane, nb);
+        u32 x = nb;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        or_bits(pos + x - nb, v, nb);
+        pos += __shfl(x, 63, 64);
+    }
+    __syncthreads();
+    for (u32 j = tid; j < nimg; j += PACK_THREADS) {
+        const u32 v = img[j];
+        if (j == 0 || j == nwords - 1) { if (v) atomicOr(&out[word0 + j], v); } else out[word0 + j] = v;
     }
 }
 
