@@ -53,6 +53,18 @@ def repeats(n, seed):
     return bytes(out[:n])
 
 
+def farcopies(n, seed):
+    """Nothing but short copies from 16-32 KiB back: every token costs ~20 bits (13 of them distance extra
+    bits), more than the 16 bits per token the block-pack kernel's LDS image is sized for."""
+    r = _rng(seed)
+    out = bytearray(r.randint(0, 256, size=33000).astype(np.uint8).tobytes())
+    while len(out) < n:
+        d = r.randint(16385, 32000)
+        s = len(out) - d
+        out += out[s:s + r.randint(4, 40)]
+    return bytes(out[:n])
+
+
 def cases_small():
     r = _rng(1)
     c = {
@@ -68,6 +80,7 @@ def cases_small():
         'rand4_50k': r.randint(0, 4, size=50000).astype(np.uint8).tobytes(),
         'text_100k': textlike(100000, 2),
         'repeats_200k': repeats(200000, 3),
+        'farcopies_900k': farcopies(900000, 5),
         'first50': (lambda b: b + b)(r.randint(0, 256, size=50).astype(np.uint8).tobytes()),
         'ar1_8ch': ar1_stream(3000, 8),
         'ar1_64ch_4k': ar1_stream(4000, 64),
