@@ -77,22 +77,12 @@ __device__ __forceinline__ u32 __reduce_max_sync_u32(u32 v)
 // ================================================================================================
 // The radix passes move 32-bit keys  (hash << 17) | window-relative position.  Everything else the match
 // stage wants about a position (its bytes 0..7) is read from the window, which that kernel keeps in LDS.
-template <int NB, bool FIRST>
-__device__ __forceinline__ void radix_pass(const u8 *__restrict__ s, const u32 *__restrict__ src, u32 *__restrict__ dst, u32 wlen,
-                                           u32 (*cnt)[256], u32 *tot)
+// per-(wave, digit) counts -> where each wave's keys of each digit start (digit-major, wave-minor: stable)
+template <int NB>
+__device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
 {
     constexpr int NBIN = 1 << NB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 per = (((wlen + 15) / 16) + 63) & ~63u;
-    const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
-    for (int i = threadIdx.x; i < 16 * 256; i += 1024) (&cnt[0][0])[i] = 0;
-    __syncthreads();
-    for (u32 i = beg + lane; i < end; i += 64) {
-        u32 d;
-        if (FIRST) d = hash_of(gld_u32_unaligned(s, i)) & 255; else d = src[i] >> 25;
-        atomicAdd(&cnt[wave][d], 1u);
-    }
-    __syncthreads();
     if (threadIdx.x < NBIN) {
         u32 run = 0;
         for (int w = 0; w < 16; w++) { const u32 c = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += c; }
@@ -114,7 +104,19 @@ __device__ __forceinline__ void radix_pass(const u8 *__restrict__ s, const u32 *
         for (int w = 0; w < 16; w++) cnt[w][threadIdx.x] += base;
     }
     __syncthreads();
-    // ranking: the next step's key is fetched while this step is ranked (the loop is latency bound)
+}
+
+// One stable counting-sort pass over the tile: wave w owns keys [w * per, (w + 1) * per) and ranks them 64 at a
+// time with wave ballots.  The first pass makes the keys from the stream and, while it scatters them,
+// counts the SECOND pass's digits per second-pass wave (a key's destination says which wave will own it),
+// so the second pass needs no counting loop of its own.
+template <int NB, bool FIRST>
+__device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *__restrict__ src, u32 *__restrict__ dst, u32 wlen,
+                                          u32 per, u32 (*cnt)[256], u32 (*cnt2)[128], u32 per_magic)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
+    // the next step's key is fetched while this step is ranked
     auto fetch = [&](u32 i) -> u32 {
         if (i >= end) return 0;
         if (FIRST) return (hash_of(gld_u32_unaligned(s, i)) << REL_BITS) | i;
@@ -136,6 +138,7 @@ __device__ __forceinline__ void radix_pass(const u8 *__restrict__ s, const u32 *
         if (act) {
             dst[off + rank] = key;
             if (rank == count - 1) cnt[wave][d] = off + count;
+            if (FIRST) atomicAdd(&cnt2[__umulhi(off + rank, per_magic)][key >> 25], 1u);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -174,12 +177,35 @@ __global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ strea
 {
     const TileDesc td = tiles[blockIdx.x];
     __shared__ u32 cnt[16][256];
+    __shared__ u32 cnt2[16][128];
     __shared__ u32 tot[256];
     if (td.wlen == 0) return;
     const u8 *s = stream + td.stream_off + td.w;
-    radix_pass<8, true>(s, nullptr, tmp + td.sorted_off, td.wlen, cnt, tot);                        // low 8 hash bits
-    radix_pass<7, false>(s, tmp + td.sorted_off, sorted + td.sorted_off, td.wlen, cnt, tot);        // high 7 bits
-    chain_lengths(sorted + td.sorted_off, sorted_nb + td.sorted_off, td.wlen, tot, tot + 32);
+    const u32 wlen = td.wlen;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 per = (((wlen + 15) / 16) + 63) & ~63u;              // keys per wave (both passes)
+    const u32 per_magic = 0xffffffffu / per + 1;                    // __umulhi(x, magic) == x / per for x < 2^17 (per < 2^15)
+    for (int i = threadIdx.x; i < 16 * 256; i += 1024) (&cnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 16 * 128; i += 1024) (&cnt2[0][0])[i] = 0;
+    __syncthreads();
+    {   // digits of the first pass: 4 positions per lane and step, so four loads are in flight
+        const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
+        for (u32 i0 = beg + lane; i0 < end; i0 += 256) {
+            u32 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = gld_u32_unaligned(s, min(i0 + 64 * k, end - 1));
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (i0 + 64 * k < end) atomicAdd(&cnt[wave][hash_of(v[k]) & 255], 1u);
+        }
+    }
+    __syncthreads();
+    bin_offsets<8>(cnt, tot);
+    rank_pass<8, true>(s, nullptr, tmp + td.sorted_off, wlen, per, cnt, cnt2, per_magic);                  // low 8 hash bits
+    for (int i = threadIdx.x; i < 16 * 128; i += 1024) cnt[i >> 7][i & 127] = cnt2[i >> 7][i & 127];
+    __syncthreads();
+    bin_offsets<7>(cnt, tot);
+    rank_pass<7, false>(s, tmp + td.sorted_off, sorted + td.sorted_off, wlen, per, cnt, cnt2, per_magic);  // high 7 bits
+    chain_lengths(sorted + td.sorted_off, sorted_nb + td.sorted_off, wlen, tot, tot + 32);
 }
 
 int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp, u32 *d_sorted,
