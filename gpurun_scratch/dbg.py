@@ -10,4 +10,4 @@ b=np.arange(n+1,dtype=np.int64)*rate; sl=np.arange(n,dtype=np.int64)*bound; sz=n
 lp=lambda a:a.ctypes.data_as(C.POINTER(C.c_long))
 rc=L.mts_dev_compress_chunks(0,None,C.c_void_p(raw.data_ptr()),nc,2,lp(b),n,5,6,C.c_void_p(cbuf.data_ptr()),lp(sl),lp(sz))
 h=(C.c_ulonglong*16)(); L.mts_dbg_read(h)
-g=h[0]; print("groups",g,"iters/group",h[1]/g,"pops/lane",h[2]/g/64,"maxpops/group",h[3]/g,"ext/lane",h[4]/g/64)
+g=h[0]; print("groups",g,"iters/group",h[1]/g,"pops/lane",h[2]/g/64,"maxpops/group",h[3]/g,"improvements/lane",h[4]/g/64)

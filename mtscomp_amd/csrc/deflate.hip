@@ -116,18 +116,19 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
-    // the next step's key is fetched while this step is ranked
+    // keys are fetched two steps ahead of their ranking
     auto fetch = [&](u32 i) -> u32 {
         if (i >= end) return 0;
         if (FIRST) return (hash_of(gld_u32_unaligned(s, i)) << REL_BITS) | i;
         return src[i];
     };
-    u32 key_n = fetch(beg + lane);
+    u32 key_n = fetch(beg + lane), key_nn = fetch(beg + lane + 64);
     for (u32 base = beg; base < end; base += 64) {
         const u32 i = base + lane;
         const bool act = i < end;
         const u32 key = key_n;
-        key_n = fetch(i + 64);
+        key_n = key_nn;
+        key_nn = fetch(i + 128);
         const u32 d = FIRST ? (key >> REL_BITS) & 255 : key >> 25;
         const u64 actm = __ballot(act);
         const u64 m = match_digit<NB>(d, actm);

@@ -31,6 +31,9 @@ struct BitIn {
     u32 nextw;
     u64 pos;           // bits consumed so far (relative to w)
     u64 end;           // first bit past the compressed data
+    const u32 *lw = nullptr;   // optional LDS copy of words [lw0, lw0 + lwn) (staged by the caller with coalesced loads)
+    u64 lw0 = 0;
+    u32 lwn = 0;
     __device__ __forceinline__ void init(const u8 *base, u64 byte_off, u64 byte_len, u64 start_bit)
     {
         const u64 a = (u64)(base + byte_off);
@@ -40,7 +43,12 @@ struct BitIn {
         nwords = (end + 31) >> 5;
         seek(bit0 + start_bit);
     }
-    __device__ __forceinline__ u32 word(u64 i) const { return i < nwords ? w[i] : 0u; }
+    __device__ __forceinline__ u32 word(u64 i) const
+    {
+        const u64 o = i - lw0;
+        if (o < lwn) return lw[o];
+        return i < nwords ? w[i] : 0u;
+    }
     __device__ __forceinline__ void seek(u64 p)
     {
         pos = p;
@@ -437,6 +445,7 @@ struct TrueBlk {
     u32 ntok;
     u32 chunk;
 };
+constexpr int PASSB_STAGE_WORDS = 6144;   // LDS copy of the 64 sub-sequences a wave decodes in one step (~4096 words + slack)
 constexpr int SUBCAP = 512;      // sub-sequences recorded per candidate block
 constexpr int SUB_BITS = 2048;   // bits per sub-sequence
 
@@ -845,8 +854,22 @@ __global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, 
     __builtin_amdgcn_wave_barrier();
     const u32 nsub = cres[tb.cand].nsub;
     const uint2 *sub = subs + (u64)tb.cand * SUBCAP;
+    // every lane reads its own sub-sequence word by word: straight from memory that is one dependent, uncoalesced
+    // load per ~3 tokens.  The 64 sub-sequences of a step are one contiguous piece of the stream (~16 KiB):
+    // it is copied to LDS with coalesced loads first.
+    __shared__ u32 stage[PASSB_STAGE_WORDS];
     for (u32 j0 = 0; j0 < nsub; j0 += 64) {
         const u32 j = j0 + lane;
+        const u32 jl = min(j0 + 64, nsub);
+        const u64 wlo = (tb.start_bit + sub[j0].x) >> 5, whi = ((tb.start_bit + sub[jl].x) >> 5) + 3;
+        __builtin_amdgcn_wave_barrier();
+        br.lwn = 0;
+        if (whi - wlo < (u64)PASSB_STAGE_WORDS) {
+            const u32 nw = (u32)(whi - wlo) + 1;
+            for (u32 k = lane; k < nw; k += 64) stage[k] = br.word(wlo + k);
+            br.lw = stage; br.lw0 = wlo; br.lwn = nw;
+        }
+        __builtin_amdgcn_wave_barrier();
         if (j < nsub) {
             const uint2 a = sub[j], b = sub[j + 1];
             br.seek(tb.start_bit + a.x);
