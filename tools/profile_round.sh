@@ -1,0 +1,43 @@
+#!/bin/bash
+# Everything profiles/ holds for one round, from a 1-GPU box:  tools/profile_round.sh r1
+#   <tag>_bench_default.jsonl      the default bench line
+#   <tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command (per-kernel totals / averages)
+#   <tag>_bench_pmc_hbm_bytes.csv  FETCH_SIZE / WRITE_SIZE per kernel (two separate --pmc passes, no trace domains)
+#   <tag>_traffic.json             HBM bytes per launch of the dominant kernel, read by bench.py
+tag=${1:-r1}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+out=$R/gpurun_out/profile_$tag
+rm -rf $out; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+cd $R
+python3 bench.py > $out/${tag}_bench_default.jsonl 2> $out/bench_stderr.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline > $out/stats_stdout.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $out/pmc_fetch_stdout.txt 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $out/pmc_write_stdout.txt 2>&1
+python3 - <<PY
+import csv, glob, json, collections
+out, tag = "$out", "$tag"
+f = glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)
+if f:
+    open(out + "/%s_bench_kernel_stats.csv" % tag, "w").write(open(f[0]).read())
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.Counter())
+for name, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    for fn in glob.glob(out + "/%s/**/*counter_collection.csv" % d, recursive=True):
+        for r in csv.DictReader(open(fn)):
+            if r["Counter_Name"] != name: continue
+            k = r["Kernel_Name"].split("(")[0]
+            agg[k][name] += float(r["Counter_Value"]); n[k][name] += 1
+with open(out + "/%s_bench_pmc_hbm_bytes.csv" % tag, "w") as w:
+    w.write("kernel,launches,FETCH_SIZE_KB_total,WRITE_SIZE_KB_total\n")
+    for k in sorted(agg, key=lambda k: -(agg[k]["FETCH_SIZE"] + agg[k]["WRITE_SIZE"])):
+        w.write("%s,%d,%.3f,%.3f\n" % (k.replace(",", ";"), max(n[k].values()), agg[k]["FETCH_SIZE"], agg[k]["WRITE_SIZE"]))
+dom = [k for k in agg if "k_match5" in k]
+if dom:
+    k = dom[0]; L = max(n[k].values())
+    fe, wr = agg[k]["FETCH_SIZE"] / L, agg[k]["WRITE_SIZE"] / L
+    json.dump({"kernel": "k_match5", "fetch_size_kb": fe, "write_size_kb": wr, "traffic_bytes_per_launch": (fe + wr) * 1024,
+               "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py (60 x 23.1 MB chunks); FETCH not doubled: the kernel's window reads are 4-16 B per lane scattered, not wide coalesced",
+               "source": "profiles/%s_bench_pmc_hbm_bytes.csv" % tag}, open(out + "/%s_traffic.json" % tag, "w"), indent=1)
+print(open(out + "/%s_bench_default.jsonl" % tag).read()[:600])
+PY
+ls -la $out | head -20
