@@ -2,6 +2,8 @@
 //   K1 replaces diff_along_axis + ndarray.tobytes       (/root/reference/mtscomp.py:143-159, :381-394)
 //   K2 replaces reshape(order) + cumsum_along_axis + ascontiguousarray       (mtscomp.py:622-635)
 // Integer items of 1/2/4/8 bytes; arithmetic wraps in the item width like numpy's.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mts {
@@ -95,6 +97,122 @@ __global__ __launch_bounds__(256) void k_delta_transpose(const u8 *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-tile variants for the layout the reference actually uses (time difference, channel-major stream,
+// no spatial difference; items of 1, 2 or 4 bytes).  A workgroup owns TT consecutive rows of ALL channels:
+// on the C-order side that is one contiguous piece of memory (read or written as whole dwords, fully
+// coalesced), on the stream side TT consecutive items of every channel.  The transpose goes through LDS
+// with a row pitch of an odd number of dwords.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 wave_incl_scan_dpp32(u32 x)
+{
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);     // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);     // row_shr:8
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);     // row_bcast:15
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);     // row_bcast:31
+    return x;
+}
+// LDS row pitch in items: at least nc, an odd number of dwords
+__host__ __device__ inline int rows_pitch(int nc, int itemsize)
+{
+    const int per = 4 / itemsize;                       // items per dword (itemsize 1, 2, 4)
+    int dw = (nc + per - 1) / per;
+    if (!(dw & 1)) dw++;
+    return dw * per;
+}
+// largest tile height whose LDS image ((TT + 1) rows) stays within 64 KiB
+static int rows_tile(int nc, int itemsize)
+{
+    const long pitch_b = (long)rows_pitch(nc, itemsize) * itemsize;
+    for (int tt = 64; tt >= 16; tt >>= 1)
+        if ((tt + 1) * pitch_b <= 64 * 1024) return tt;
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_delta_rows(const u8 *__restrict__ raw, u8 *__restrict__ stream,
+                                                    const ChunkDesc *__restrict__ chunks, int nc, int tt_rows, int pitch,
+                                                    u32 nc_magic, u64 *adler_acc)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem_rows[];
+    T *tile = (T *)smem_rows;                                   // [tt_rows + 1][pitch]; row 0 = t0 - 1
+    __shared__ u64 red[8];
+    const ChunkDesc ch = chunks[blockIdx.y];
+    const long nt = ch.n_rows;
+    const long t0 = (long)blockIdx.x * tt_rows;
+    if (t0 >= nt) return;
+    constexpr int EPD = 4 / (int)sizeof(T);
+    const T *x = (const T *)(raw + ch.raw_off);
+    const int nrow = (int)min((long)tt_rows, nt - t0);
+    // tile row 0 = row t0 - 1 (zeros before the chunk's first row), item by item
+    for (int c = threadIdx.x; c < nc; c += 256) tile[c] = t0 > 0 ? x[(t0 - 1) * nc + c] : (T)0;
+    // rows t0 .. : one contiguous piece of memory, copied a dword (EPD items) per lane
+    const T *xs = x + t0 * nc;
+    const long e_n = (long)nrow * nc;
+    if ((((u64)xs) & 3) == 0) {
+        const u32 *xd = (const u32 *)xs;
+        for (long i = threadIdx.x; i * EPD < e_n; i += 256) {
+            u32 v = 0;
+            if ((i + 1) * EPD <= e_n) v = xd[i];
+            else for (int j = 0; (long)i * EPD + j < e_n; j++) v |= (u32)xs[i * EPD + j] << (8 * sizeof(T) * j);      // ragged end: never read past the rows
+#pragma unroll
+            for (int j = 0; j < EPD; j++) {
+                const u32 e = (u32)i * EPD + j;
+                if (e < e_n) {
+                    const u32 r = __umulhi(e, nc_magic), c = e - r * nc;
+                    tile[(r + 1) * pitch + c] = (T)(v >> (8 * sizeof(T) * j));
+                }
+            }
+        }
+    } else {
+        for (long i = threadIdx.x; i < e_n; i += 256) {
+            const u32 r = __umulhi((u32)i, nc_magic), c = (u32)i - r * nc;
+            tile[(r + 1) * pitch + c] = xs[i];
+        }
+    }
+    __syncthreads();
+    T *out = (T *)(stream + ch.stream_off);
+    const u64 nbytes = (u64)nt * nc * sizeof(T);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u64 sa = 0, sb = 0;
+    for (int tb = 0; tb < tt_rows; tb += 64) {
+        const int tt = tb + lane;
+        const long t = t0 + tt;
+        const bool ok = tt < tt_rows && t < nt;
+        for (int c = wave; c < nc; c += 4) {
+            if (ok) {
+                const T d = (T)(tile[(tt + 1) * pitch + c] - tile[tt * pitch + c]);
+                const u64 I = (u64)c * nt + t;
+                out[I] = d;
+                u32 bs = 0, bw = 0;                              // sum of the item's bytes, sum of k * byte_k
+#pragma unroll
+                for (int k = 0; k < (int)sizeof(T); k++) { const u32 b = ((u32)d >> (8 * k)) & 0xff; bs += b; bw += k * b; }
+                sa += bs;
+                sb += (nbytes - I * sizeof(T)) * bs - bw;
+            }
+        }
+    }
+    block_sum2(sa, sb, red);
+    if (threadIdx.x == 0) {
+        atomicAdd((unsigned long long *)&adler_acc[2 * blockIdx.y], (unsigned long long)(sa % 65521u));
+        atomicAdd((unsigned long long *)&adler_acc[2 * blockIdx.y + 1], (unsigned long long)(sb % 65521u));
+    }
+}
+
+template <typename T>
+static void run_delta_rows(hipStream_t st, const u8 *raw, u8 *stream, const ChunkDesc *d_chunks, int n_chunks, u32 max_rows,
+                           int nc, u64 *d_adler_acc)
+{
+    const int tt = rows_tile(nc, (int)sizeof(T)), pitch = rows_pitch(nc, (int)sizeof(T));
+    const size_t lds = (size_t)(tt + 1) * pitch * sizeof(T);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_delta_rows<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }
+    dim3 grid((max_rows + tt - 1) / tt, n_chunks);
+    hipLaunchKernelGGL(k_delta_rows<T>, grid, dim3(256), lds, st, raw, stream, d_chunks, nc, tt, pitch, 0xffffffffu / (u32)nc + 1, d_adler_acc);
+}
+
 int launch_delta_transpose(hipStream_t st, const void *d_raw, void *d_stream, const ChunkDesc *d_chunks,
                            int n_chunks, u32 max_rows, int n_channels, int itemsize, int flags,
                            u64 *d_adler_acc)
@@ -104,6 +222,15 @@ int launch_delta_transpose(hipStream_t st, const void *d_raw, void *d_stream, co
     dim3 grid((max_rows + 63) / 64, (n_channels + 63) / 64, n_chunks), block(256);
     const u8 *raw = (const u8 *)d_raw;
     u8 *stream = (u8 *)d_stream;
+    if (flags == (MTS_FLAG_TIME_DIFF | MTS_FLAG_ORDER_F) && itemsize <= 4 && n_channels >= 2 && rows_tile(n_channels, itemsize) && !getenv("MTS_K12_GENERIC")) {
+        switch (itemsize) {
+        case 1: run_delta_rows<u8>(st, raw, stream, d_chunks, n_chunks, max_rows, n_channels, d_adler_acc); break;
+        case 2: run_delta_rows<u16>(st, raw, stream, d_chunks, n_chunks, max_rows, n_channels, d_adler_acc); break;
+        default: run_delta_rows<u32>(st, raw, stream, d_chunks, n_chunks, max_rows, n_channels, d_adler_acc); break;
+        }
+        MTS_HIP(hipGetLastError());
+        return MTS_OK;
+    }
     switch (itemsize) {
     case 1: hipLaunchKernelGGL(k_delta_transpose<u8>, grid, block, 0, st, raw, stream, d_chunks, n_channels, flags, d_adler_acc); break;
     case 2: hipLaunchKernelGGL(k_delta_transpose<u16>, grid, block, 0, st, raw, stream, d_chunks, n_channels, flags, d_adler_acc); break;
@@ -308,12 +435,126 @@ static int run_cumsum(hipStream_t st, const u8 *stream, u8 *out, const u64 *d_st
     return MTS_OK;
 }
 
+// K2, row-tile variant: (1) per (tile, channel) sums, (2) exclusive scan of the sums over the tiles of a chunk,
+// (3) scan inside the tile with the carry and write whole C-order rows.
+template <typename T>
+__global__ __launch_bounds__(256) void k_rows_sums(const u8 *__restrict__ stream, const u64 *__restrict__ stream_off,
+                                                   const u32 *__restrict__ rows, const int *__restrict__ status,
+                                                   int nc, int tt_rows, int ntile_max, u32 *__restrict__ sums)
+{
+    const int chunk = blockIdx.y;
+    if (status && status[chunk] != 0) return;
+    const long nt = rows[chunk];
+    const long t0 = (long)blockIdx.x * tt_rows;
+    if (t0 >= nt) return;
+    const T *d = (const T *)(stream + stream_off[chunk]);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32 *o = sums + ((u64)chunk * ntile_max + blockIdx.x) * nc;
+    for (int c = wave; c < nc; c += 4) {
+        u32 v = 0;
+        for (int tt = lane; tt < tt_rows; tt += 64)
+            if (t0 + tt < nt) v += (u32)d[(u64)c * nt + t0 + tt];
+        v = wave_incl_scan_dpp32(v);
+        if (lane == 63) o[c] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_rows_scan(const u32 *__restrict__ rows, const int *__restrict__ status, int nc,
+                                                   int tt_rows, int ntile_max, u32 *__restrict__ sums)
+{
+    const int chunk = blockIdx.y;
+    if (status && status[chunk] != 0) return;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nc) return;
+    const int ntile = (int)((rows[chunk] + tt_rows - 1) / tt_rows);
+    u32 *p = sums + (u64)chunk * ntile_max * nc + c;
+    u32 run = 0;
+    for (int k0 = 0; k0 < ntile; k0 += 8) {
+        u32 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = k0 + j < ntile ? p[(u64)(k0 + j) * nc] : 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { if (k0 + j < ntile) p[(u64)(k0 + j) * nc] = run; run += v[j]; }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_cumsum_rows(const u8 *__restrict__ stream, u8 *__restrict__ outb,
+                                                     const u64 *__restrict__ stream_off, const u64 *__restrict__ out_off,
+                                                     const u32 *__restrict__ rows, const int *__restrict__ status,
+                                                     int nc, int tt_rows, int pitch, u32 nc_magic, int ntile_max,
+                                                     const u32 *__restrict__ sums)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem_rows[];
+    T *tile = (T *)smem_rows;                                   // [tt_rows][pitch]
+    const int chunk = blockIdx.y;
+    if (status && status[chunk] != 0) return;
+    const long nt = rows[chunk];
+    const long t0 = (long)blockIdx.x * tt_rows;
+    if (t0 >= nt) return;
+    constexpr int EPD = 4 / (int)sizeof(T);
+    const T *d = (const T *)(stream + stream_off[chunk]);
+    const u32 *carry = sums + ((u64)chunk * ntile_max + blockIdx.x) * nc;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = wave; c < nc; c += 4) {
+        u32 run = carry[c];
+        for (int tb = 0; tb < tt_rows; tb += 64) {
+            const int tt = tb + lane;
+            const u32 v = (tt < tt_rows && t0 + tt < nt) ? (u32)d[(u64)c * nt + t0 + tt] : 0u;
+            const u32 x = wave_incl_scan_dpp32(v) + run;
+            if (tt < tt_rows) tile[tt * pitch + c] = (T)x;
+            run = (u32)__builtin_amdgcn_readlane((int)x, 63);
+        }
+    }
+    __syncthreads();
+    const int nrow = (int)min((long)tt_rows, nt - t0);
+    T *out = (T *)(outb + out_off[chunk]) + t0 * nc;
+    const long e_n = (long)nrow * nc;
+    if ((((u64)out) & 3) == 0) {
+        // the rows of the tile are one contiguous piece of memory: whole dwords (EPD items), except a ragged end
+        u32 *od = (u32 *)out;
+        for (long i = threadIdx.x; i * EPD < e_n; i += 256) {
+            u32 v = 0;
+            bool full = true;
+#pragma unroll
+            for (int j = 0; j < EPD; j++) {
+                const u32 e = (u32)i * EPD + j;
+                if (e < e_n) {
+                    const u32 r = __umulhi(e, nc_magic), c = e - r * nc;
+                    v |= (u32)tile[r * pitch + c] << (8 * sizeof(T) * j);
+                } else full = false;
+            }
+            if (full) od[i] = v;
+            else for (int j = 0; j < EPD; j++) if ((long)i * EPD + j < e_n) out[i * EPD + j] = (T)(v >> (8 * sizeof(T) * j));
+        }
+    } else {
+        for (long i = threadIdx.x; i < e_n; i += 256) {
+            const u32 r = __umulhi((u32)i, nc_magic), c = (u32)i - r * nc;
+            out[i] = tile[r * pitch + c];
+        }
+    }
+}
+
+template <typename T>
+static void run_cumsum_rows(hipStream_t st, const u8 *stream, u8 *out, const u64 *d_stream_off, const u64 *d_out_off,
+                            const u32 *d_rows, const int *d_status, int n_chunks, u32 max_rows, int nc, u32 *sums)
+{
+    const int tt = rows_tile(nc, (int)sizeof(T)), pitch = rows_pitch(nc, (int)sizeof(T));
+    const size_t lds = (size_t)tt * pitch * sizeof(T);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_cumsum_rows<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }
+    const int ntile = (max_rows + tt - 1) / tt;
+    dim3 grid(ntile, n_chunks);
+    hipLaunchKernelGGL(k_rows_sums<T>, grid, dim3(256), 0, st, stream, d_stream_off, d_rows, d_status, nc, tt, ntile, sums);
+    hipLaunchKernelGGL(k_rows_scan, dim3((nc + 255) / 256, n_chunks), dim3(256), 0, st, d_rows, d_status, nc, tt, ntile, sums);
+    hipLaunchKernelGGL(k_cumsum_rows<T>, grid, dim3(256), lds, st, stream, out, d_stream_off, d_out_off, d_rows, d_status, nc, tt, pitch,
+                       0xffffffffu / (u32)nc + 1, ntile, sums);
+}
+
 static int segr_for(int itemsize) { return itemsize <= 2 ? 256 : itemsize == 4 ? 128 : 64; }
 
 size_t cumsum_scratch_bytes(int n_chunks, u32 max_rows, int n_channels)
 {
-    // worst case SEGR = 64
-    return (size_t)n_chunks * ((max_rows + 63) / 64) * n_channels * sizeof(u64) + 256;
+    // worst case SEGR = 64 (u64 sums), or row tiles of 16 (u32 sums)
+    return (size_t)n_chunks * ((max_rows + 63) / 64 + 1) * n_channels * sizeof(u64) + 256;
 }
 
 int launch_cumsum_transpose(hipStream_t st, const void *d_stream, void *d_out, const u64 *d_stream_off,
@@ -325,6 +566,15 @@ int launch_cumsum_transpose(hipStream_t st, const void *d_stream, void *d_out, c
     u8 *o = (u8 *)d_out;
     u64 *ss = (u64 *)d_segsums;
     (void)segr_for;
+    if (flags == (MTS_FLAG_TIME_DIFF | MTS_FLAG_ORDER_F) && itemsize <= 4 && n_channels >= 2 && rows_tile(n_channels, itemsize) && !getenv("MTS_K12_GENERIC")) {
+        switch (itemsize) {
+        case 1: run_cumsum_rows<u8>(st, s, o, d_stream_off, d_out_off, d_rows, d_status, n_chunks, max_rows, n_channels, (u32 *)ss); break;
+        case 2: run_cumsum_rows<u16>(st, s, o, d_stream_off, d_out_off, d_rows, d_status, n_chunks, max_rows, n_channels, (u32 *)ss); break;
+        default: run_cumsum_rows<u32>(st, s, o, d_stream_off, d_out_off, d_rows, d_status, n_chunks, max_rows, n_channels, (u32 *)ss); break;
+        }
+        MTS_HIP(hipGetLastError());
+        return MTS_OK;
+    }
     switch (itemsize) {
     case 1: return run_cumsum<u8, 256>(st, s, o, d_stream_off, d_out_off, d_rows, d_status, n_chunks, max_rows, n_channels, flags, ss);
     case 2: return run_cumsum<u16, 256>(st, s, o, d_stream_off, d_out_off, d_rows, d_status, n_chunks, max_rows, n_channels, flags, ss);
