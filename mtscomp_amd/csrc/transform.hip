@@ -151,19 +151,19 @@ __global__ __launch_bounds__(256) void k_delta_rows(const u8 *__restrict__ raw, 
     // rows t0 .. : one contiguous piece of memory, copied a dword (EPD items) per lane
     const T *xs = x + t0 * nc;
     const long e_n = (long)nrow * nc;
-    if ((((u64)xs) & 3) == 0) {
-        const u32 *xd = (const u32 *)xs;
-        for (long i = threadIdx.x; i * EPD < e_n; i += 256) {
-            u32 v = 0;
-            if ((i + 1) * EPD <= e_n) v = xd[i];
-            else for (int j = 0; (long)i * EPD + j < e_n; j++) v |= (u32)xs[i * EPD + j] << (8 * sizeof(T) * j);      // ragged end: never read past the rows
+    if ((((u64)xs) & 15) == 0) {
+        // 16 bytes (VW items) per lane and step
+        constexpr int VW = 16 / (int)sizeof(T);
+        const uint4 *xq = (const uint4 *)xs;
+        for (long i = threadIdx.x; i * VW < e_n; i += 256) {
+            u32 w[4] = {0, 0, 0, 0};
+            if ((i + 1) * VW <= e_n) { const uint4 q = xq[i]; w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; }
+            else for (int j = 0; (long)i * VW + j < e_n; j++) w[j / EPD] |= (u32)xs[i * VW + j] << (8 * sizeof(T) * (j % EPD));      // ragged end: never read past the rows
+            u32 r = __umulhi((u32)i * VW, nc_magic), c = (u32)i * VW - r * nc;
 #pragma unroll
-            for (int j = 0; j < EPD; j++) {
-                const u32 e = (u32)i * EPD + j;
-                if (e < e_n) {
-                    const u32 r = __umulhi(e, nc_magic), c = e - r * nc;
-                    tile[(r + 1) * pitch + c] = (T)(v >> (8 * sizeof(T) * j));
-                }
+            for (int j = 0; j < VW; j++) {
+                if ((long)i * VW + j < e_n) tile[(r + 1) * pitch + c] = (T)(w[j / EPD] >> (8 * sizeof(T) * (j % EPD)));
+                if (++c == (u32)nc) { c = 0; r++; }
             }
         }
     } else {
@@ -177,20 +177,51 @@ __global__ __launch_bounds__(256) void k_delta_rows(const u8 *__restrict__ raw, 
     const u64 nbytes = (u64)nt * nc * sizeof(T);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u64 sa = 0, sb = 0;
-    for (int tb = 0; tb < tt_rows; tb += 64) {
-        const int tt = tb + lane;
-        const long t = t0 + tt;
-        const bool ok = tt < tt_rows && t < nt;
-        for (int c = wave; c < nc; c += 4) {
-            if (ok) {
-                const T d = (T)(tile[(tt + 1) * pitch + c] - tile[tt * pitch + c]);
-                const u64 I = (u64)c * nt + t;
-                out[I] = d;
-                u32 bs = 0, bw = 0;                              // sum of the item's bytes, sum of k * byte_k
+    auto adler_item = [&](T d, u64 I) {
+        u32 bs = 0, bw = 0;                                      // sum of the item's bytes, sum of k * byte_k
 #pragma unroll
-                for (int k = 0; k < (int)sizeof(T); k++) { const u32 b = ((u32)d >> (8 * k)) & 0xff; bs += b; bw += k * b; }
-                sa += bs;
-                sb += (nbytes - I * sizeof(T)) * bs - bw;
+        for (int k = 0; k < (int)sizeof(T); k++) { const u32 b = ((u32)d >> (8 * k)) & 0xff; bs += b; bw += k * b; }
+        sa += bs;
+        sb += (nbytes - I * sizeof(T)) * bs - bw;
+    };
+    constexpr int IPL = 8 / (int)sizeof(T);                      // items per lane on the stream side (8 bytes)
+    if (tt_rows % IPL == 0 && ((u64)nt * sizeof(T)) % 8 == 0 && (((u64)out) & 7) == 0 && ((u64)t0 * sizeof(T)) % 8 == 0) {
+        // a lane owns IPL consecutive items of one channel; 64 / (tt_rows / IPL) channels per wave and step
+        const int lpc = tt_rows / IPL, cpw = 64 / lpc;           // lanes per channel (8 or 16 or ...), channels per wave step
+        const int q = lane % lpc, cc = lane / lpc;
+        for (int c0 = wave * cpw; c0 < nc; c0 += 4 * cpw) {
+            const int c = c0 + cc;
+            const int tt = q * IPL;
+            if (cc < cpw && c < nc && t0 + tt < nt) {
+                u32 w[2] = {0, 0};
+                T prev = tile[tt * pitch + c];
+#pragma unroll
+                for (int j = 0; j < IPL; j++) {
+                    const T cur = tile[(tt + j + 1) * pitch + c];
+                    const T d = (T)(cur - prev);
+                    prev = cur;
+                    if (t0 + tt + j < nt) {
+                        w[j / EPD] |= (u32)d << (8 * sizeof(T) * (j % EPD));
+                        adler_item(d, (u64)c * nt + t0 + tt + j);
+                    }
+                }
+                const u64 I = (u64)c * nt + t0 + tt;
+                if (t0 + tt + IPL <= nt) *(uint2 *)&out[I] = make_uint2(w[0], w[1]);
+                else for (int j = 0; t0 + tt + j < nt; j++) out[I + j] = (T)(w[j / EPD] >> (8 * sizeof(T) * (j % EPD)));
+            }
+        }
+    } else {
+        for (int tb = 0; tb < tt_rows; tb += 64) {
+            const int tt = tb + lane;
+            const long t = t0 + tt;
+            const bool ok = tt < tt_rows && t < nt;
+            for (int c = wave; c < nc; c += 4) {
+                if (ok) {
+                    const T d = (T)(tile[(tt + 1) * pitch + c] - tile[tt * pitch + c]);
+                    const u64 I = (u64)c * nt + t;
+                    out[I] = d;
+                    adler_item(d, I);
+                }
             }
         }
     }
@@ -450,12 +481,30 @@ __global__ __launch_bounds__(256) void k_rows_sums(const u8 *__restrict__ stream
     const T *d = (const T *)(stream + stream_off[chunk]);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32 *o = sums + ((u64)chunk * ntile_max + blockIdx.x) * nc;
-    for (int c = wave; c < nc; c += 4) {
-        u32 v = 0;
-        for (int tt = lane; tt < tt_rows; tt += 64)
-            if (t0 + tt < nt) v += (u32)d[(u64)c * nt + t0 + tt];
-        v = wave_incl_scan_dpp32(v);
-        if (lane == 63) o[c] = v;
+    constexpr int EPD = 4 / (int)sizeof(T), IPL = 8 / (int)sizeof(T);
+    if (tt_rows % IPL == 0 && ((u64)nt * sizeof(T)) % 8 == 0 && (((u64)d) & 7) == 0 && ((u64)t0 * sizeof(T)) % 8 == 0 && t0 + tt_rows <= nt) {
+        // a lane reads IPL consecutive items (8 bytes) of one channel; the lanes of a channel are neighbours
+        const int lpc = tt_rows / IPL, cpw = 64 / lpc;
+        const int q = lane % lpc, cc = lane / lpc;
+        for (int c0 = wave * cpw; c0 < nc; c0 += 4 * cpw) {
+            const int c = min(c0 + cc, nc - 1);
+            const uint2 w = *(const uint2 *)&d[(u64)c * nt + t0 + q * IPL];
+            const u32 ww[2] = {w.x, w.y};
+            u32 v = 0;
+#pragma unroll
+            for (int j = 0; j < IPL; j++) v += (u32)(T)(ww[j / EPD] >> (8 * sizeof(T) * (j % EPD)));
+            v = wave_incl_scan_dpp32(v);
+            const u32 before = (u32)__shfl((int)v, (lane - q - 1) & 63, 64);   // total of the lanes before this channel's
+            if (q == lpc - 1 && c0 + cc < nc) o[c] = v - (lane - q ? before : 0u);
+        }
+    } else {
+        for (int c = wave; c < nc; c += 4) {
+            u32 v = 0;
+            for (int tt = lane; tt < tt_rows; tt += 64)
+                if (t0 + tt < nt) v += (u32)d[(u64)c * nt + t0 + tt];
+            v = wave_incl_scan_dpp32(v);
+            if (lane == 63) o[c] = v;
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_rows_scan(const u32 *__restrict__ rows, const int *__restrict__ status, int nc,
@@ -494,14 +543,36 @@ __global__ __launch_bounds__(256) void k_cumsum_rows(const u8 *__restrict__ stre
     const T *d = (const T *)(stream + stream_off[chunk]);
     const u32 *carry = sums + ((u64)chunk * ntile_max + blockIdx.x) * nc;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int c = wave; c < nc; c += 4) {
-        u32 run = carry[c];
-        for (int tb = 0; tb < tt_rows; tb += 64) {
-            const int tt = tb + lane;
-            const u32 v = (tt < tt_rows && t0 + tt < nt) ? (u32)d[(u64)c * nt + t0 + tt] : 0u;
-            const u32 x = wave_incl_scan_dpp32(v) + run;
-            if (tt < tt_rows) tile[tt * pitch + c] = (T)x;
-            run = (u32)__builtin_amdgcn_readlane((int)x, 63);
+    constexpr int IPL = 8 / (int)sizeof(T);
+    if (tt_rows % IPL == 0 && ((u64)nt * sizeof(T)) % 8 == 0 && (((u64)d) & 7) == 0 && ((u64)t0 * sizeof(T)) % 8 == 0 && t0 + tt_rows <= nt) {
+        const int lpc = tt_rows / IPL, cpw = 64 / lpc;
+        const int q = lane % lpc, cc = lane / lpc;
+        for (int c0 = wave * cpw; c0 < nc; c0 += 4 * cpw) {
+            const int c = min(c0 + cc, nc - 1);
+            const uint2 w = *(const uint2 *)&d[(u64)c * nt + t0 + q * IPL];
+            const u32 ww[2] = {w.x, w.y};
+            u32 x[IPL], tot = 0;
+#pragma unroll
+            for (int j = 0; j < IPL; j++) { tot += (u32)(T)(ww[j / EPD] >> (8 * sizeof(T) * (j % EPD))); x[j] = tot; }
+            const u32 v = wave_incl_scan_dpp32(tot);
+            const u32 prev = (u32)__shfl((int)v, (lane - q - 1) & 63, 64);      // (unconditional: a shuffle cannot read a lane that is masked off)
+            const u32 before = (lane - q) ? prev : 0u;                          // total of the lanes of the channels before this one
+            const u32 add = carry[c] + v - tot - before;
+            if (c0 + cc < nc) {
+#pragma unroll
+                for (int j = 0; j < IPL; j++) tile[(q * IPL + j) * pitch + c] = (T)(x[j] + add);
+            }
+        }
+    } else {
+        for (int c = wave; c < nc; c += 4) {
+            u32 run = carry[c];
+            for (int tb = 0; tb < tt_rows; tb += 64) {
+                const int tt = tb + lane;
+                const u32 v = (tt < tt_rows && t0 + tt < nt) ? (u32)d[(u64)c * nt + t0 + tt] : 0u;
+                const u32 x = wave_incl_scan_dpp32(v) + run;
+                if (tt < tt_rows) tile[tt * pitch + c] = (T)x;
+                run = (u32)__builtin_amdgcn_readlane((int)x, 63);
+            }
         }
     }
     __syncthreads();
