@@ -112,16 +112,37 @@ __device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
 // so the second pass needs no counting loop of its own.
 template <int NB, bool FIRST>
 __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *__restrict__ src, u32 *__restrict__ dst, u32 wlen,
-                                          u32 per, u32 (*cnt)[256], u32 (*cnt2)[128], u32 per_magic)
+                                          u32 per, u32 (*cnt)[256], u32 (*cnt2)[128], u32 per_magic, int lane_ordered)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
-    // keys are fetched two steps ahead of their ranking
     auto fetch = [&](u32 i) -> u32 {
         if (i >= end) return 0;
         if (FIRST) return (hash_of(gld_u32_unaligned(s, i)) << REL_BITS) | i;
         return src[i];
     };
+    if (lane_ordered) {
+        // The LDS retires the same-address atomics of one wave instruction in lane order (probed at start-up, see
+        // k_probe_lds_order): the value returned by the add IS the stable destination -- no ballots, no barriers.
+        // Four steps are in flight: their instructions are issued in position order, and so are they executed.
+        for (u32 base = beg; base < end; base += 256) {
+            u32 key[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) key[k] = fetch(base + 64 * k + lane);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (base + 64 * k + lane < end) {
+                    const u32 d = FIRST ? (key[k] >> REL_BITS) & 255 : key[k] >> 25;
+                    const u32 at = atomicAdd(&cnt[wave][d], 1u);
+                    dst[at] = key[k];
+                    if (FIRST) atomicAdd(&cnt2[__umulhi(at, per_magic)][key[k] >> 25], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    // keys are fetched two steps ahead of their ranking
     u32 key_n = fetch(beg + lane), key_nn = fetch(beg + lane + 64);
     for (u32 base = beg; base < end; base += 64) {
         const u32 i = base + lane;
@@ -144,6 +165,26 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+}
+
+// Start-up probe for the property the fast ranking relies on: 64 lanes add 1 to counters picked at random (many
+// lanes per counter); in lane order every lane must get back the number of lower lanes that picked its counter.
+__global__ __launch_bounds__(1024) void k_probe_lds_order(u32 *bad, int iters)
+{
+    __shared__ u32 cnt[16][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32 x = (blockIdx.x * 1024 + threadIdx.x) * 2654435761u + 99u, nbad = 0;
+    for (int it = 0; it < iters; it++) {
+        for (int i = lane; i < 256; i += 64) cnt[wave][i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        x = x * 1664525u + 1013904223u;
+        const u32 d = (x >> 13) & (0xffu >> (it & 7));                  // 256, 128, ... 2 counters
+        const u32 got = atomicAdd(&cnt[wave][d], 1u);
+        const u64 m = match_digit<8>(d, ~0ull);
+        if (got != (u32)__popcll(m & lanemask_lt())) nbad++;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (nbad) atomicAdd(bad, nbad);
 }
 
 // third phase: sorted keys -> number of same-hash predecessors of each slot (the chain behind it), capped
@@ -174,7 +215,7 @@ __device__ __forceinline__ void chain_lengths(const u32 *__restrict__ sk, u16 *_
 }
 
 __global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
-                                                    u32 *__restrict__ tmp, u32 *__restrict__ sorted, u16 *__restrict__ sorted_nb)
+                                                    u32 *__restrict__ tmp, u32 *__restrict__ sorted, u16 *__restrict__ sorted_nb, int lane_ordered)
 {
     const TileDesc td = tiles[blockIdx.x];
     __shared__ u32 cnt[16][256];
@@ -201,19 +242,40 @@ __global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ strea
     }
     __syncthreads();
     bin_offsets<8>(cnt, tot);
-    rank_pass<8, true>(s, nullptr, tmp + td.sorted_off, wlen, per, cnt, cnt2, per_magic);                  // low 8 hash bits
+    rank_pass<8, true>(s, nullptr, tmp + td.sorted_off, wlen, per, cnt, cnt2, per_magic, lane_ordered);                  // low 8 hash bits
     for (int i = threadIdx.x; i < 16 * 128; i += 1024) cnt[i >> 7][i & 127] = cnt2[i >> 7][i & 127];
     __syncthreads();
     bin_offsets<7>(cnt, tot);
-    rank_pass<7, false>(s, tmp + td.sorted_off, sorted + td.sorted_off, wlen, per, cnt, cnt2, per_magic);  // high 7 bits
+    rank_pass<7, false>(s, tmp + td.sorted_off, sorted + td.sorted_off, wlen, per, cnt, cnt2, per_magic, lane_ordered);  // high 7 bits
     chain_lengths(sorted + td.sorted_off, sorted_nb + td.sorted_off, wlen, tot, tot + 32);
+}
+
+// 1 if this device's LDS retires same-address atomics of a wave instruction in lane order (probed once per device)
+static int lds_lane_ordered()
+{
+    static int cached[64];
+    static bool init = false;
+    if (!init) { for (int i = 0; i < 64; i++) cached[i] = -1; init = true; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cached[dev] >= 0) return cached[dev];
+    u32 *d_bad = nullptr, h_bad = 1;
+    if (hipMalloc(&d_bad, 4) != hipSuccess) return 0;
+    if (hipMemset(d_bad, 0, 4) == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_lds_order, dim3(64), dim3(1024), 0, 0, d_bad, 512);
+        if (hipMemcpy(&h_bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) h_bad = 1;
+    }
+    (void)hipFree(d_bad);
+    cached[dev] = h_bad == 0 ? 1 : 0;
+    return cached[dev];
 }
 
 int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp, u32 *d_sorted,
                      u16 *d_sorted_nb)
 {
     if (n_tiles == 0) return MTS_OK;
-    hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(1024), 0, st, d_stream, d_tiles, d_tmp, d_sorted, d_sorted_nb);
+    const int ordered = getenv("MTS_SORT_BALLOT") ? 0 : lds_lane_ordered();      // MTS_SORT_BALLOT=1: force the ballot ranking (tests)
+    hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(1024), 0, st, d_stream, d_tiles, d_tmp, d_sorted, d_sorted_nb, ordered);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }

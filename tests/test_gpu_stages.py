@@ -97,6 +97,15 @@ def test_deflate_bytes_levels(level):
         assert hip.debug_deflate(data, level) == zlib.compress(data, level), name
 
 
+def test_deflate_bytes_ballot_sort(monkeypatch):
+    """The hash sort ranks with LDS atomics when the start-up probe finds them lane ordered; MTS_SORT_BALLOT=1
+    forces the ballot ranking that is used otherwise.  Both must give zlib's bytes."""
+    monkeypatch.setenv('MTS_SORT_BALLOT', '1')
+    for name in ('text_100k', 'ar1_64ch_4k', 'repeats_200k', 'rand4_50k'):
+        data = CASES[name]
+        assert hip.debug_deflate(data, 6) == zlib.compress(data, 6), name
+
+
 def test_deflate_block_boundaries():
     r = np.random.RandomState(7)
     base = r.randint(0, 256, size=16383 * 2 + 40).astype(np.uint8).tobytes()
