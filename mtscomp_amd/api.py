@@ -376,22 +376,33 @@ class Writer:
         if not outmeta:
             outmeta = self.data_path.with_suffix('.ch')
         Path(out).parent.mkdir(exist_ok=True, parents=True)
-        offset = 0
         self.chunk_offsets = [0]
         logger.info("Starting compression on %s.", getattr(self.codec, 'name', 'codec'))
-        with open(out, 'wb') as fb:
+        # The two SHA-1s and the file write are host work in file order (mtscomp.py:477-483); they run on one
+        # background thread while the devices compress the next batch (hashlib and ctypes both release the GIL).
+        state = {'offset': 0}
+
+        def consume(done):
+            for idx in sorted(done.keys()):                     # strictly in file order
+                raw_chunk, cbuf = done[idx]
+                fb.write(cbuf)
+                state['offset'] += len(cbuf)
+                self.chunk_offsets.append(state['offset'])
+                self.sha1_uncompressed.update(np.ascontiguousarray(raw_chunk))
+                self.sha1_compressed.update(cbuf)
+
+        with open(out, 'wb') as fb, ThreadPool(1) as sink:
+            pending = None
             for batch in range(self.n_batches):
                 first = self.batch_size * batch
                 last = min(self.batch_size * (batch + 1), self.n_chunks)
                 done = self.compress_batch(first, last)
                 assert set(done.keys()) <= set(range(first, last))
-                for idx in sorted(done.keys()):                 # strictly in file order
-                    raw_chunk, cbuf = done[idx]
-                    fb.write(cbuf)
-                    offset += len(cbuf)
-                    self.chunk_offsets.append(offset)
-                    self.sha1_uncompressed.update(np.ascontiguousarray(raw_chunk))
-                    self.sha1_compressed.update(cbuf)
+                if pending is not None:
+                    pending.get()                               # keep at most one batch in flight behind the devices
+                pending = sink.apply_async(consume, (done,))
+            if pending is not None:
+                pending.get()
             csize = fb.tell()
         assert self.chunk_offsets[-1] == csize
         ratio = csize / self.file_size
