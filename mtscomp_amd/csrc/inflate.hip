@@ -971,6 +971,23 @@ constexpr int LZ_LDS = LZ_CTL_OFF + 256;
 constexpr u32 LZ_EDGE = LZ_RING - 12;                    // windows starting above this ring offset go byte by byte
 constexpr u32 LZ_SPIN_MAX = 1u << 20;                     // bound on every wait loop (a stuck kernel must end)
 
+// A chunk is one serial dependency chain for the resolver, and one workgroup resolves ~2.6 GB/s: with fewer
+// chunks than CUs most of the chip would idle.  So a chunk's groups are cut into up to LZ_MAXSEG segments
+// resolved by different workgroups (k_inf_lz_seg).  A segment does not know the 32 KiB before its first byte,
+// so it works on 16-bit cells: 0..255 = a byte, 256 + i = "byte i of my unknown window".  The cells leave
+// as they are; k_inf_windows then makes the real windows one after the other (window k = the last 32 KiB
+// of segment k-1, translated with window k-1) and k_inf_translate turns every cell into a byte.
+constexpr int LZ_MAXSEG = 8;
+constexpr u32 LZ_WIN = 32768;
+struct LzPlan {
+    u32 nseg;                          // 1: the whole chunk by k_inf_lz (bytes)
+    u32 g0[LZ_MAXSEG + 1];             // first group of segment k (g0[nseg] = number of groups)
+    u32 b0[LZ_MAXSEG + 1];             // first output byte of segment k (b0[nseg] = output size)
+};
+constexpr u32 LZ2_BITS_OFF = 2 * LZ_RING;                // segment kernel: 16-bit cells, bits (+ pad), control words
+constexpr u32 LZ2_CTL_OFF = LZ2_BITS_OFF + LZ_RING / 8 + 16;
+constexpr int LZ2_LDS = LZ2_CTL_OFF + 256;
+
 // Output offset of every 64-token group, as a two-level scan:
 //   k_inf_gsum   one thread per group sums the bytes its 64 tokens produce; a 256-thread workgroup scans its
 //                256 groups (a "tile") -> gbase[g] = offset inside the tile, tile_tot[tile]
@@ -1105,11 +1122,12 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
                                                        InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
                                                        const u64 *__restrict__ tb_off, const u32 *__restrict__ gbase,
                                                        const u32 *__restrict__ tile_base, u8 *__restrict__ stream, int n_workers,
-                                                       u64 *__restrict__ prof)
+                                                       u64 *__restrict__ prof, const LzPlan *__restrict__ plan)
 {
     const int ci = blockIdx.x;
     const InfResult r = res[ci];
     if (r.status != MTS_CHUNK_OK) return;
+    if (plan[ci].nseg != 1) return;                                  // cut into segments: k_inf_lz_seg
     const InfChunk ch = chunks[ci];
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lds_data = (u32)(uintptr_t)smem;                       // LDS byte offsets of the byte ring, the bit ring, ...
@@ -1282,6 +1300,289 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
     }
 }
 
+// ---- segment resolver (16-bit cells) -------------------------------------------------------------
+// window of 8 cells (16 bytes at a 2-byte boundary) = five aligned dwords
+__device__ __forceinline__ void lz2_load_window(u32 bits_addr, u32 data_addr, u32 &b0, u32 &b1, u32 (&x)[5])
+{
+    u32x2 b, p, q;
+    asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2_b32 %1, %5 offset1:1\n\tds_read2_b32 %2, %5 offset0:2 offset1:3\n\t"
+                 "ds_read_b32 %3, %5 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(b), "=&v"(p), "=&v"(q), "=&v"(x[4]) : "v"(bits_addr), "v"(data_addr) : "memory");
+    b0 = b.x; b1 = b.y; x[0] = p.x; x[1] = p.y; x[2] = q.x; x[3] = q.y;
+}
+__device__ __forceinline__ void lz2_or_window(u32 data_addr, const u32 (&o)[5], u32 bits_addr, u32 m0, u32 m1)
+{
+    asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4\n\tds_or_b32 %0, %3 offset:8\n\tds_or_b32 %0, %4 offset:12\n\t"
+                 "ds_or_b32 %0, %5 offset:16\n\tds_or_b32 %6, %7\n\tds_or_b32 %6, %8 offset:4"
+                 :: "v"(data_addr), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(bits_addr), "v"(m0), "v"(m1) : "memory");
+}
+__device__ __forceinline__ void lz2_load_cell(u32 bits_addr, u32 data_addr, u32 &bits, u32 &data)
+{
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_u16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bits), "=&v"(data) : "v"(bits_addr), "v"(data_addr) : "memory");
+}
+
+// how a chunk is cut (one thread per chunk)
+__global__ __launch_bounds__(64) void k_inf_plan(const InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
+                                                 const u64 *__restrict__ tb_off, const u32 *__restrict__ gbase,
+                                                 const u32 *__restrict__ tile_base, int n_chunks, int nseg_req, LzPlan *__restrict__ plan)
+{
+    const int ci = blockIdx.x * 64 + threadIdx.x;
+    if (ci >= n_chunks) return;
+    const InfResult r = res[ci];
+    LzPlan p;
+    p.nseg = 1;
+    for (int k = 0; k <= LZ_MAXSEG; k++) { p.g0[k] = 0; p.b0[k] = 0; }
+    if (r.status == MTS_CHUNK_OK && r.ntok) {
+        const u32 ngroups = (r.ntok + 63) / 64;
+        const u32 *gbl = gbase + gb_off[ci];
+        const u32 *tbs = tile_base + tb_off[ci];
+        auto gb = [&](u32 g) -> u32 { return g >= ngroups ? r.n_out : tbs[g / GS_TILE] + gbl[g]; };
+        p.g0[1] = ngroups; p.b0[1] = r.n_out;
+        if (nseg_req > 1) {
+            const u32 per = (ngroups + nseg_req - 1) / nseg_req;
+            bool ok = per > 0;
+            u32 g0[LZ_MAXSEG + 1], b0[LZ_MAXSEG + 1];
+            for (int k = 0; k <= nseg_req; k++) { g0[k] = min((u32)k * per, ngroups); b0[k] = gb(g0[k]); }
+            // every segment but the last must produce a whole window; every segment must have work
+            for (int k = 0; k < nseg_req; k++) {
+                if (g0[k + 1] <= g0[k]) ok = false;
+                if (k + 1 < nseg_req && b0[k + 1] - b0[k] < LZ_WIN + 512) ok = false;
+            }
+            if (ok) { p.nseg = (u32)nseg_req; for (int k = 0; k <= nseg_req; k++) { p.g0[k] = g0[k]; p.b0[k] = b0[k]; } }
+        }
+    }
+    plan[ci] = p;
+}
+
+__global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict__ tokens, const InfChunk *__restrict__ chunks,
+                                                           InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
+                                                           const u64 *__restrict__ tb_off, const u32 *__restrict__ gbase,
+                                                           const u32 *__restrict__ tile_base, const LzPlan *__restrict__ plan,
+                                                           u16 *__restrict__ sym, int n_workers)
+{
+    const int ci = blockIdx.y, seg = blockIdx.x;
+    const InfResult r = res[ci];
+    if (r.status != MTS_CHUNK_OK) return;
+    const LzPlan pl = plan[ci];
+    if (pl.nseg < 2 || (u32)seg >= pl.nseg) return;
+    const InfChunk ch = chunks[ci];
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const u32 lds_data = (u32)(uintptr_t)smem;                       // LDS byte offsets of the cell ring, the bit ring, ...
+    const u32 lds_bits = lds_data + LZ2_BITS_OFF;
+    const u32 lds_prog = lds_data + LZ2_CTL_OFF;                     // [w] = first byte of the group worker w is on
+    const u32 lds_flnext = lds_prog + 64;                            // [k] = first byte of the next granule of flusher k
+    const u32 lds_bad = lds_prog + 80;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 *tk = tokens + ch.tok_off;
+    const u32 *gbl = gbase + gb_off[ci];
+    const u32 *tbs = tile_base + tb_off[ci];
+    u16 *out = sym + ch.stream_off;                                  // cells of this chunk (same offsets as the stream, in cells)
+    const u32 ntok = r.ntok, ngroups = (ntok + 63) / 64;
+    const u32 g_lo = pl.g0[seg], g_hi = pl.g0[seg + 1], B = pl.b0[seg], Bend = pl.b0[seg + 1];
+    for (u32 i = threadIdx.x * 16; i < LZ2_CTL_OFF; i += LZ_THREADS * 16) lds_zero16(lds_data + i);     // cells and bits start at zero
+    const u32 q0 = B / LZ_FLUSH;
+    if (threadIdx.x < 24) {
+        u32 v = 0;
+        if (threadIdx.x >= 16 && threadIdx.x < 16 + LZ_FLUSHERS) { const u32 k = threadIdx.x - 16; v = (q0 + ((k - q0) & (LZ_FLUSHERS - 1))) * LZ_FLUSH; }
+        lds_st(lds_prog + 4 * threadIdx.x, v);
+    }
+    __syncthreads();
+    // the unknown window: cell 256 + i at position B - LZ_WIN + i, marked written (segment 0 has none)
+    if (seg > 0) {
+        for (u32 i = threadIdx.x; i < LZ_WIN; i += LZ_THREADS) {
+            const u32 ro = (B - LZ_WIN + i) & (LZ_RING - 1);
+            lz_or_byte(lds_data + ((2 * ro) & ~3u), (256 + i) << (16 * (ro & 1)), lds_bits + ((ro >> 5) << 2), 1u << (ro & 31));
+        }
+    }
+    u32 t_n = 0, tb0_n = 0, gl0_n = 0, tb1_n = 0, gl1_n = 0;
+    const int LZW = n_workers;
+    auto prefetch = [&](u32 h) {
+        const u32 h0 = h < g_hi ? h : g_hi - 1, h1 = h + 1 < ngroups ? h + 1 : ngroups - 1;
+        const u32 i2 = h0 * 64 + lane;
+        t_n = tk[i2 < ntok ? i2 : ntok - 1];
+        tb0_n = tbs[h0 / GS_TILE]; gl0_n = gbl[h0]; tb1_n = tbs[h1 / GS_TILE]; gl1_n = gbl[h1];
+    };
+    if (wave < LZW) {
+        prefetch(g_lo + wave);
+        if (lane == 0) lds_st(lds_prog + 4 * wave, g_lo + (u32)wave < g_hi ? tb0_n + gl0_n : 0xffffffffu);
+    }
+    __syncthreads();
+    auto safe_bytes = [&]() -> u32 {
+        const u32 v = row0_min_dpp(lane < LZW ? lds_ld(lds_prog + 4 * lane) : 0xffffffffu);
+        return v < Bend ? v : Bend;
+    };
+    auto flushed = [&]() -> u32 {
+        u32 v = lds_ld(lds_flnext);
+#pragma unroll
+        for (int k = 1; k < LZ_FLUSHERS; k++) v = min(v, lds_ld(lds_flnext + 4 * k));
+        return v;
+    };
+    if (wave >= LZ_WORKERS) {
+        // ---- flushers: granule q belongs to flusher q % LZ_FLUSHERS; 8 cells (16 bytes) per lane and step ----
+        const u32 me = wave - LZ_WORKERS;
+        u32 idle = 0;
+        for (u32 q = q0 + ((me - q0) & (LZ_FLUSHERS - 1));; q += LZ_FLUSHERS) {
+            const u32 lo = q * LZ_FLUSH;
+            if (lo >= Bend) break;
+            const u32 hi = lo + LZ_FLUSH < Bend ? lo + LZ_FLUSH : Bend;
+            while (safe_bytes() < hi) {
+                if (++idle > LZ_SPIN_MAX) { if (lane == 0) { lds_st(lds_bad, 3); for (int k = 0; k < LZ_FLUSHERS; k++) lds_st(lds_flnext + 4 * k, 0xffffffffu); } return; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            idle = 0;
+#pragma unroll
+            for (u32 o = lo + lane * 8; o < lo + LZ_FLUSH; o += 512) {
+                if (o < hi && o + 8 > B) {
+                    u32x4 c;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(c) : "v"(lds_data + 2 * (o & (LZ_RING - 1))) : "memory");
+                    if (o >= B && o + 8 <= hi) *(u32x4 *)(out + o) = c;
+                    else { const u32 cw[4] = {c.x, c.y, c.z, c.w}; for (u32 k = 0; k < 8; k++) if (o + k >= B && o + k < hi) out[o + k] = (u16)(cw[k >> 1] >> (16 * (k & 1))); }
+                }
+            }
+            if (q >= LZ_ZLAG) {
+                const u32 zo = ((q - LZ_ZLAG) * LZ_FLUSH) & (LZ_RING - 1);
+#pragma unroll
+                for (u32 o = lane * 16; o < 2 * LZ_FLUSH; o += 1024) lds_zero16(lds_data + 2 * zo + o);
+                if (lane < (int)(LZ_FLUSH / 8 / 16)) lds_zero16(lds_bits + zo / 8 + lane * 16);
+            }
+            if (lane == 0) lds_st(lds_flnext + 4 * me, lo + LZ_FLUSHERS * LZ_FLUSH);
+        }
+        if (lane == 0) lds_st(lds_flnext + 4 * me, 0xffffffffu);
+        return;
+    }
+    // ---- workers ----
+    if (wave >= LZW) return;
+    u32 fl_seen = 0;
+    for (u32 g = g_lo + wave; g < g_hi; g += LZW) {
+        const u32 t = t_n, base = tb0_n + gl0_n, next = g + 1 < ngroups ? tb1_n + gl1_n : r.n_out;
+        const u32 i = g * 64 + lane;
+        const bool act = i < ntok;
+        if (lane == 0) lds_st(lds_prog + 4 * wave, base);
+        prefetch(g + LZW);
+        if (next > LZ_AHEAD) {
+            const u32 lim = next - LZ_AHEAD;
+            for (u32 waits = 0; fl_seen < lim; waits++) {
+                fl_seen = flushed();
+                if (fl_seen >= lim) break;
+                if (waits > LZ_SPIN_MAX) { lds_st(lds_bad, 4); break; }                       // never hang
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        const bool cp = act && (t >> 31);
+        const u32 len = !act ? 0 : cp ? ((t >> 16) & 0xff) + 3 : 1;
+        const u32 dst = base + wave_incl_scan_dpp(len) - len;
+        const u32 dist = (t & 0x7fff) + 1;
+        const u32 src = dst - dist;
+        const u32 dofs = dst & (LZ_RING - 1), sofs = src & (LZ_RING - 1);
+        bool pend = cp;
+        if (cp && (dist > dst || len > 8)) { pend = false; lds_st(lds_bad, 1); }
+        if (act && !cp) lz_or_byte(lds_data + ((2 * dofs) & ~3u), (t & 0xff) << (16 * (dofs & 1)), lds_bits + ((dofs >> 5) << 2), 1u << (dofs & 31));
+        // cell by cell: windows that would run past the ring end, and overlapping copies (dist < len)
+        const bool slow = pend && (sofs > LZ_EDGE || dofs > LZ_EDGE || dist < len);
+        const u32 nbits = (1u << len) - 1;
+        const u32 ba = lds_bits + ((sofs >> 5) << 2), da = lds_data + ((2 * sofs) & ~3u);
+        const u32 wa = lds_data + ((2 * dofs) & ~3u), wba = lds_bits + ((dofs >> 5) << 2);
+        const u64 wbits = (u64)nbits << (dofs & 31);
+        u32 spins = 0, k = 0;
+        while (__any(pend)) {
+            if (pend && !slow) {
+                u32 b0, b1, x[5];
+                lz2_load_window(ba, da, b0, b1, x);
+                if ((__builtin_amdgcn_alignbit(b1, b0, sofs & 31) & nbits) == nbits) {
+                    const u32 ssh = 16 * (sofs & 1);
+                    u32 w[4], o[5];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        w[j] = __builtin_amdgcn_alignbit(x[j + 1], x[j], ssh);
+                        const int c0 = 2 * j, c1 = 2 * j + 1;                       // cells of this dword: keep those below len
+                        w[j] &= ((u32)c0 < len ? 0xffffu : 0u) | ((u32)c1 < len ? 0xffff0000u : 0u);
+                    }
+                    const bool odd = dofs & 1;
+                    o[0] = odd ? w[0] << 16 : w[0];
+#pragma unroll
+                    for (int j = 1; j < 4; j++) o[j] = odd ? __builtin_amdgcn_alignbit(w[j], w[j - 1], 16) : w[j];
+                    o[4] = odd ? w[3] >> 16 : 0u;
+                    lz2_or_window(wa, o, wba, (u32)wbits, (u32)(wbits >> 32));
+                    pend = false;
+                } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
+            } else if (pend) {
+                const u32 so = (src + k) & (LZ_RING - 1), dd = (dst + k) & (LZ_RING - 1);
+                u32 bw, dv;
+                lz2_load_cell(lds_bits + ((so >> 5) << 2), lds_data + 2 * so, bw, dv);
+                if ((bw >> (so & 31)) & 1) {
+                    lz_or_byte(lds_data + ((2 * dd) & ~3u), dv << (16 * (dd & 1)), lds_bits + ((dd >> 5) << 2), 1u << (dd & 31));
+                    if (++k == len) pend = false;
+                    spins = 0;
+                } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
+            }
+        }
+    }
+    if (lane == 0) lds_st(lds_prog + 4 * wave, 0xffffffffu);
+    if (wave == 0) {
+        for (u32 waits = 0; flushed() < Bend && waits < 4 * LZ_SPIN_MAX; waits++) __builtin_amdgcn_s_sleep(8);
+        if (lane == 0 && (lds_ld(lds_bad) || flushed() < Bend)) res[ci].status = MTS_CHUNK_CORRUPT;
+    }
+}
+
+// the real window of every segment, one after the other (one workgroup per chunk)
+__global__ __launch_bounds__(1024) void k_inf_windows(const InfChunk *__restrict__ chunks, const InfResult *__restrict__ res,
+                                                      const LzPlan *__restrict__ plan, const u16 *__restrict__ sym, u8 *__restrict__ win)
+{
+    const int ci = blockIdx.x;
+    if (res[ci].status != MTS_CHUNK_OK) return;
+    const LzPlan pl = plan[ci];
+    if (pl.nseg < 2) return;
+    const u16 *cells = sym + chunks[ci].stream_off;
+    u8 *W = win + (size_t)ci * LZ_MAXSEG * LZ_WIN;                  // W[k] = window of segment k
+    for (u32 k = 1; k < pl.nseg; k++) {
+        const u32 p0 = pl.b0[k] - LZ_WIN;                           // >= b0[k - 1]: segments are at least a window long
+        const u8 *prev = W + (size_t)(k - 1) * LZ_WIN;
+        for (u32 i = threadIdx.x; i < LZ_WIN; i += 1024) {
+            const u32 c = cells[p0 + i];
+            W[(size_t)k * LZ_WIN + i] = (u8)(c < 256 ? c : prev[(c - 256) & (LZ_WIN - 1)]);
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+// cells -> bytes: 16 cells per lane
+__global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restrict__ chunks, const InfResult *__restrict__ res,
+                                                       const LzPlan *__restrict__ plan, const u16 *__restrict__ sym,
+                                                       const u8 *__restrict__ win, u8 *__restrict__ stream)
+{
+    const int ci = blockIdx.y;
+    const InfResult r = res[ci];
+    if (r.status != MTS_CHUNK_OK) return;
+    const LzPlan pl = plan[ci];
+    if (pl.nseg < 2) return;
+    const u32 p = (blockIdx.x * 256 + threadIdx.x) * 16;
+    if (p >= r.n_out) return;
+    const u16 *cells = sym + chunks[ci].stream_off;
+    u8 *out = stream + chunks[ci].stream_off;
+    const u8 *W = win + (size_t)ci * LZ_MAXSEG * LZ_WIN;
+    auto seg_of = [&](u32 q) -> u32 { u32 k = 0; while (k + 1 < pl.nseg && q >= pl.b0[k + 1]) k++; return k; };
+    if (p + 16 <= r.n_out) {
+        const uint4 a = *(const uint4 *)(cells + p), b = *(const uint4 *)(cells + p + 8);
+        const u32 cw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const u32 k_lo = seg_of(p), k_hi = seg_of(p + 15);
+        u32 ow[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const u32 c = (cw[j >> 1] >> (16 * (j & 1))) & 0xffff;
+            u32 v = c;
+            if (c >= 256) { const u32 k = (k_lo == k_hi) ? k_lo : seg_of(p + j); v = W[(size_t)k * LZ_WIN + ((c - 256) & (LZ_WIN - 1))]; }
+            ow[j >> 2] |= (v & 0xff) << (8 * (j & 3));
+        }
+        *(uint4 *)(out + p) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    } else {
+        for (u32 q = p; q < r.n_out; q++) {
+            const u32 c = cells[q];
+            out[q] = (u8)(c < 256 ? c : W[(size_t)seg_of(q) * LZ_WIN + ((c - 256) & (LZ_WIN - 1))]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_inf_finish(const InfChunk *__restrict__ chunks, InfResult *__restrict__ res,
                                                    const u64 *__restrict__ adler_acc, int n_chunks, int *__restrict__ status_out)
 {
@@ -1304,8 +1605,9 @@ static inline u32 cand_cap_of(u64 c_len) { return (u32)(c_len / 4096 + 64); }
 // scratch layout (all 256-B aligned): [so u64 n][nn u32 n][fast n][cand_cnt n][true_cnt n][seq_flag n]
 //   [slot_chunk total_cand][tslot_chunk total_true][cand_pos][cand_tmp][cres][tblk][subs]
 struct InfLayout {
-    size_t so, nn, fast, cand_cnt, true_cnt, seq_flag, slot_chunk, tslot_chunk, cand_pos, cand_tmp, cres, tblk, subs, gb_off, gbase, tb_off, tile_base, surv, surv_cnt, end;
+    size_t so, nn, fast, cand_cnt, true_cnt, seq_flag, slot_chunk, tslot_chunk, cand_pos, cand_tmp, cres, tblk, subs, gb_off, gbase, tb_off, tile_base, surv, surv_cnt, plan, win, sym, end;
     u32 total_cand, total_true, surv_cap;
+    int nseg;                // segments the resolver cuts every chunk into (1: none)
 };
 static InfLayout inf_layout(int n_chunks, const u64 *c_lens, const u32 *n_expect)
 {
@@ -1333,6 +1635,15 @@ static InfLayout inf_layout(int n_chunks, const u64 *c_lens, const u32 *n_expect
     l.surv_cap = (u32)(cbits / 256 + 65536);          // ~0.1 % of the bit offsets pass the cheap filters
     l.surv = take(8 * (size_t)l.surv_cap);
     l.surv_cnt = take(256);
+    // LZ resolver: with fewer chunks than CUs a chunk is cut into segments (see LzPlan); cells and windows live here
+    l.nseg = 1;
+    if (n_chunks < 128) { l.nseg = 256 / n_chunks; if (l.nseg > LZ_MAXSEG) l.nseg = LZ_MAXSEG; }
+    if (const char *e = getenv("MTS_LZ_SEGS")) { l.nseg = atoi(e); if (l.nseg < 1) l.nseg = 1; if (l.nseg > LZ_MAXSEG) l.nseg = LZ_MAXSEG; }
+    l.plan = take(sizeof(LzPlan) * (size_t)n_chunks);
+    l.win = take(l.nseg > 1 ? (size_t)n_chunks * LZ_MAXSEG * LZ_WIN : 0);
+    size_t cells = 0;
+    for (int i = 0; i < n_chunks; i++) cells += align_up((u64)n_expect[i] + STREAM_PAD, STREAM_ALIGN);
+    l.sym = take(l.nseg > 1 ? 2 * cells + 4096 : 0);
     l.end = o;
     return l;
 }
@@ -1348,6 +1659,7 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
     if (!attr_set) {
         MTS_HIP(hipFuncSetAttribute((const void *)k_inf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, INF_LDS_PER_WAVE));
         MTS_HIP(hipFuncSetAttribute((const void *)k_inf_lz, hipFuncAttributeMaxDynamicSharedMemorySize, LZ_LDS));
+        MTS_HIP(hipFuncSetAttribute((const void *)k_inf_lz_seg, hipFuncAttributeMaxDynamicSharedMemorySize, LZ2_LDS));
         attr_set = true;
     }
     std::vector<u64> lens(n_chunks), so(n_chunks);
@@ -1429,13 +1741,24 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
         hipLaunchKernelGGL(k_inf_gsum, gg, dim3(GS_TILE), 0, st, d_tokens, d_chunks, d_res, (const u64 *)(S + l.gb_off),
                            (const u64 *)(S + l.tb_off), (u32 *)(S + l.gbase), (u32 *)(S + l.tile_base));
         hipLaunchKernelGGL(k_inf_gscan, dim3(n_chunks), dim3(64), 0, st, d_res, (const u64 *)(S + l.tb_off), (u32 *)(S + l.tile_base));
+        hipLaunchKernelGGL(k_inf_plan, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_res, (const u64 *)(S + l.gb_off), (const u64 *)(S + l.tb_off),
+                           (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base), n_chunks, l.nseg, (LzPlan *)(S + l.plan));
     }
     inflate_mark(engine, st, "inflate_offsets");
     u64 *d_prof = nullptr;                   // MTS_LZ_PROF=1: per-wave cycle counters of the resolver, printed to stderr
     if (getenv("MTS_LZ_PROF")) { MTS_HIP(hipMalloc(&d_prof, (size_t)n_chunks * 16 * 8 * 8)); MTS_HIP(hipMemsetAsync(d_prof, 0, (size_t)n_chunks * 16 * 8 * 8, st)); }
     hipLaunchKernelGGL(k_inf_lz, dim3(n_chunks), dim3(LZ_THREADS), LZ_LDS, st, d_tokens, d_chunks, d_res, (const u64 *)(S + l.gb_off),
                        (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base), d_stream, lz_workers,
-                       d_prof);
+                       d_prof, (const LzPlan *)(S + l.plan));
+    if (l.nseg > 1 && max_n > 0) {
+        hipLaunchKernelGGL(k_inf_lz_seg, dim3(l.nseg, n_chunks), dim3(LZ_THREADS), LZ2_LDS, st, d_tokens, d_chunks, d_res,
+                           (const u64 *)(S + l.gb_off), (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base),
+                           (const LzPlan *)(S + l.plan), (u16 *)(S + l.sym), lz_workers);
+        hipLaunchKernelGGL(k_inf_windows, dim3(n_chunks), dim3(1024), 0, st, d_chunks, d_res, (const LzPlan *)(S + l.plan),
+                           (const u16 *)(S + l.sym), (u8 *)(S + l.win));
+        hipLaunchKernelGGL(k_inf_translate, dim3((max_n + 4095) / 4096, n_chunks), dim3(256), 0, st, d_chunks, d_res,
+                           (const LzPlan *)(S + l.plan), (const u16 *)(S + l.sym), (const u8 *)(S + l.win), d_stream);
+    }
     MTS_HIP(hipGetLastError());
     if (d_prof) {
         std::vector<u64> hp((size_t)n_chunks * 16 * 8);

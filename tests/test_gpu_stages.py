@@ -8,6 +8,7 @@ import pytest
 
 from mtscomp_amd import hip
 from oracle import oracle as O
+from tests import inputs
 from tests.inputs import cases_small, ar1_stream, repeats
 
 pytestmark = pytest.mark.gpu
@@ -133,6 +134,18 @@ def test_inflate(name):
         assert st == 0 and out == data, (level, st, _first_diff(np.frombuffer(out, np.uint8), np.frombuffer(data, np.uint8)))
     st, out = hip.debug_inflate(zlib.compress(data) + b'trailing', len(data))
     assert st == 0 and out == data
+
+
+@pytest.mark.parametrize('nseg', [2, 3, 4, 8])
+def test_inflate_segmented_resolver(monkeypatch, nseg):
+    """With few chunks in a batch the LZ resolver cuts a chunk into segments resolved by different workgroups on
+    symbolic 16-bit cells (unknown 32 KiB window), then translates.  MTS_LZ_SEGS forces the cut."""
+    monkeypatch.setenv('MTS_LZ_SEGS', str(nseg))
+    big = inputs.repeats(700000, 11) + inputs.textlike(300000, 12) + inputs.farcopies(400000, 13)
+    for data in (CASES['repeats_200k'], CASES['text_100k'], CASES['farcopies_900k'], big, inputs.ar1_stream(3000, 64)):
+        for level in (1, 6):
+            st, out = hip.debug_inflate(zlib.compress(data, level), len(data))
+            assert st == 0 and out == data, (len(data), level, st, _first_diff(np.frombuffer(out, np.uint8), np.frombuffer(data, np.uint8)))
 
 
 def test_inflate_other_encoders():
