@@ -281,6 +281,66 @@ __device__ __forceinline__ int decode_token(BitIn &br, LaneLds &L, const u32 (&L
     return 0;
 }
 
+// Wave-shared lookup tables for the kernels in which all 64 lanes decode the SAME block: the next LUT_LBITS
+// (LUT_DBITS) stream bits index a u16 = symbol << 4 | code length; 0 = the code is longer (or invalid): those
+// go through the compare chain.  The tables are filled by decoding every index with the compare chain once.
+constexpr int LUT_LBITS = 10, LUT_DBITS = 8;
+constexpr int LUT_BYTES = 2 * ((1 << LUT_LBITS) + (1 << LUT_DBITS));
+__device__ __forceinline__ void build_luts(LaneLds &L, const u32 (&LC)[16], const u32 (&DC)[16], u16 *lutl, u16 *lutd, int lane)
+{
+    for (u32 e = lane; e < (1u << LUT_LBITS); e += 64) {
+        u32 cl;
+        const int si = chain_decode<15>(__brev(e) >> 17, LC, cl);
+        lutl[e] = (si >= 0 && cl <= (u32)LUT_LBITS) ? (u16)(((u32)L.ls(si) << 4) | cl) : (u16)0;
+    }
+    for (u32 e = lane; e < (1u << LUT_DBITS); e += 64) {
+        u32 cl;
+        const int si = chain_decode<15>(__brev(e) >> 17, DC, cl);
+        lutd[e] = (si >= 0 && cl <= (u32)LUT_DBITS) ? (u16)(((u32)L.ds(si) << 4) | cl) : (u16)0;
+    }
+}
+__device__ __forceinline__ int decode_token_lut(BitIn &br, LaneLds &L, const u32 (&LC)[16], const u32 (&DC)[16],
+                                                const u16 *lutl, const u16 *lutd, u32 &tok, u32 &olen)
+{
+    br.refill();
+    u32 cl, sym;
+    const u32 e = lutl[br.peek() & ((1u << LUT_LBITS) - 1)];
+    if (e) { cl = e & 15; sym = e >> 4; }
+    else {
+        const int si = chain_decode<15>(__brev(br.peek()) >> 17, LC, cl);
+        if (si < 0) return INF_CORRUPT;
+        sym = L.ls(si);
+    }
+    br.skip(cl);
+    if (sym < 256) { tok = sym; olen = 1; return 0; }
+    if (sym == 256) return 1;
+    sym -= 257;
+    if (sym >= 29) return INF_CORRUPT;
+    u32 eb, lbase;
+    if (sym < 8) { eb = 0; lbase = 3 + sym; }
+    else if (sym == 28) { eb = 0; lbase = 258; }
+    else { eb = (sym - 4) >> 2; lbase = 3 + ((4 + (sym & 3)) << eb); }
+    const u32 length = lbase + br.get(eb);
+    br.refill();
+    u32 dsym;
+    const u32 d = lutd[br.peek() & ((1u << LUT_DBITS) - 1)];
+    if (d) { cl = d & 15; dsym = d >> 4; }
+    else {
+        const int si = chain_decode<15>(__brev(br.peek()) >> 17, DC, cl);
+        if (si < 0) return INF_CORRUPT;
+        dsym = L.ds(si);
+    }
+    br.skip(cl);
+    if (dsym >= 30) return INF_CORRUPT;
+    u32 dbase;
+    if (dsym < 4) { eb = 0; dbase = 1 + dsym; }
+    else { eb = (dsym - 2) >> 1; dbase = 1 + ((2 + (dsym & 1)) << eb); }
+    const u32 dist = dbase + br.get(eb);
+    tok = 0x80000000u | ((length - 3) << 16) | (dist - 1);
+    olen = length;
+    return 0;
+}
+
 // One whole deflate block, sequentially by one lane, starting at br.pos (reads BFINAL/BTYPE itself).
 // EMIT: write tokens to tk[ntok...].  nout = bytes produced so far in the stream (distance check).
 template <bool EMIT>
@@ -600,8 +660,8 @@ __global__ __launch_bounds__(256) void k_inf_sortc(const InfFast *__restrict__ f
 enum { SPAN_CONT = 0, SPAN_EOB = 1, SPAN_ERR = 2 };
 
 template <int MODE>      // 0: find the exit only, 1: count, 2: emit `want` tokens to tk
-__device__ __forceinline__ void decode_span(BitIn &br, LaneLds &L, const u32 (&LC)[16], const u32 (&DC)[16], u64 stop,
-                                            u32 &ntok, u32 &nout, int &flag, u32 *tk, u32 want)
+__device__ __forceinline__ void decode_span(BitIn &br, LaneLds &L, const u32 (&LC)[16], const u32 (&DC)[16], const u16 *lutl,
+                                            const u16 *lutd, u64 stop, u32 &ntok, u32 &nout, int &flag, u32 *tk, u32 want)
 {
     flag = SPAN_CONT;
     ntok = 0; nout = 0;
@@ -609,7 +669,7 @@ __device__ __forceinline__ void decode_span(BitIn &br, LaneLds &L, const u32 (&L
         if (MODE == 2) { if (ntok >= want) break; }
         else if (br.pos >= stop) break;
         u32 tok, olen;
-        const int t = decode_token(br, L, LC, DC, tok, olen);
+        const int t = decode_token_lut(br, L, LC, DC, lutl, lutd, tok, olen);
         if (t < 0 || br.pos > br.end) { flag = SPAN_ERR; break; }
         if (t == 1) { flag = SPAN_EOB; break; }
         // a copy longer than LZ_PIECE bytes is written as several copies with the same distance (byte k of
@@ -651,6 +711,10 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     const int rc = parse_tables(br, L, hdr >> 1, LC, DC);
     if (rc != INF_OK) { if (lane == 0) cres[slot] = r; return; }
     __builtin_amdgcn_wave_barrier();
+    __shared__ u16 lut_s[LUT_BYTES / 2];
+    u16 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
+    build_luts(L, LC, DC, lutl, lutd, lane);
+    __builtin_amdgcn_wave_barrier();
     uint2 *sub = subs + (u64)slot * SUBCAP;
     u64 base = br.pos;
     u32 tot_tok = 0, tot_out = 0, nsub = 0;
@@ -661,7 +725,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
         u32 nt, no; int fl;
         // speculative pass: exits only
         br.seek(start);
-        decode_span<0>(br, L, LC, DC, stop, nt, no, fl, nullptr, 0);
+        decode_span<0>(br, L, LC, DC, lutl, lutd, stop, nt, no, fl, nullptr, 0);
         ex = br.pos;
         bool counted = false;
         for (int it = 0; it < 66; it++) {
@@ -680,7 +744,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
             if (redo) {
                 start = want_start;
                 br.seek(start);
-                decode_span<1>(br, L, LC, DC, stop, nt, no, fl, nullptr, 0);
+                decode_span<1>(br, L, LC, DC, lutl, lutd, stop, nt, no, fl, nullptr, 0);
                 ex = br.pos;
                 counted = true;
             }
@@ -852,6 +916,10 @@ __global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, 
     u32 LC[16], DC[16];
     if (parse_tables(br, L, hdr >> 1, LC, DC) != INF_OK) { if (lane == 0) res[ci].status = MTS_CHUNK_CORRUPT; return; }
     __builtin_amdgcn_wave_barrier();
+    __shared__ u16 lut_s[LUT_BYTES / 2];
+    u16 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
+    build_luts(L, LC, DC, lutl, lutd, lane);
+    __builtin_amdgcn_wave_barrier();
     const u32 nsub = cres[tb.cand].nsub;
     const uint2 *sub = subs + (u64)tb.cand * SUBCAP;
     // every lane reads its own sub-sequence word by word: straight from memory that is one dependent, uncoalesced
@@ -874,7 +942,7 @@ __global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, 
             const uint2 a = sub[j], b = sub[j + 1];
             br.seek(tb.start_bit + a.x);
             u32 nt, no; int fl;
-            decode_span<2>(br, L, LC, DC, 0, nt, no, fl, tk + a.y, b.y - a.y);
+            decode_span<2>(br, L, LC, DC, lutl, lutd, 0, nt, no, fl, tk + a.y, b.y - a.y);
             if (nt != b.y - a.y) res[ci].status = MTS_CHUNK_CORRUPT;
         }
     }
