@@ -505,9 +505,9 @@ struct TrueBlk {
     u32 ntok;
     u32 chunk;
 };
-constexpr int PASSB_STAGE_WORDS = 6144;   // LDS copy of the 64 sub-sequences a wave decodes in one step (~4096 words + slack)
+constexpr int PASSB_STAGE_WORDS = 3072;   // LDS copy of the 64 sub-sequences a wave decodes in one step (~2048 words + slack)
 constexpr int SUBCAP = 512;      // sub-sequences recorded per candidate block
-constexpr int SUB_BITS = 2048;   // bits per sub-sequence
+constexpr u32 SUB_BITS = 1024;   // bits per sub-sequence (measured 1024 .. 3072: shorter is faster, the lanes' serial chains dominate)
 
 constexpr int SCAN_L1_CAP = 14336;       // filter-1 survivors kept per workgroup (expected ~7200 of 32768)
 
@@ -1370,19 +1370,19 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
 
 // ---- segment resolver (16-bit cells) -------------------------------------------------------------
 // window of 8 cells (16 bytes at a 2-byte boundary) = five aligned dwords
-__device__ __forceinline__ void lz2_load_window(u32 bits_addr, u32 data_addr, u32 &b0, u32 &b1, u32 (&x)[5])
+__device__ __forceinline__ void lz2_load_window(u32 bits_addr, u32 data_addr, u32 &b0, u32 &b1, u32 &x0, u32 &x1, u32 &x2, u32 &x3, u32 &x4)
 {
     u32x2 b, p, q;
     asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2_b32 %1, %5 offset1:1\n\tds_read2_b32 %2, %5 offset0:2 offset1:3\n\t"
                  "ds_read_b32 %3, %5 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(b), "=&v"(p), "=&v"(q), "=&v"(x[4]) : "v"(bits_addr), "v"(data_addr) : "memory");
-    b0 = b.x; b1 = b.y; x[0] = p.x; x[1] = p.y; x[2] = q.x; x[3] = q.y;
+                 : "=&v"(b), "=&v"(p), "=&v"(q), "=&v"(x4) : "v"(bits_addr), "v"(data_addr) : "memory");
+    b0 = b.x; b1 = b.y; x0 = p.x; x1 = p.y; x2 = q.x; x3 = q.y;
 }
-__device__ __forceinline__ void lz2_or_window(u32 data_addr, const u32 (&o)[5], u32 bits_addr, u32 m0, u32 m1)
+__device__ __forceinline__ void lz2_or_window(u32 data_addr, u32 o0, u32 o1, u32 o2, u32 o3, u32 o4, u32 bits_addr, u32 m0, u32 m1)
 {
     asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4\n\tds_or_b32 %0, %3 offset:8\n\tds_or_b32 %0, %4 offset:12\n\t"
                  "ds_or_b32 %0, %5 offset:16\n\tds_or_b32 %6, %7\n\tds_or_b32 %6, %8 offset:4"
-                 :: "v"(data_addr), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(bits_addr), "v"(m0), "v"(m1) : "memory");
+                 :: "v"(data_addr), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(o4), "v"(bits_addr), "v"(m0), "v"(m1) : "memory");
 }
 __device__ __forceinline__ void lz2_load_cell(u32 bits_addr, u32 data_addr, u32 &bits, u32 &data)
 {
@@ -1431,8 +1431,8 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
     const int ci = blockIdx.y, seg = blockIdx.x;
     const InfResult r = res[ci];
     if (r.status != MTS_CHUNK_OK) return;
-    const LzPlan pl = plan[ci];
-    if (pl.nseg < 2 || (u32)seg >= pl.nseg) return;
+    const LzPlan *pl = plan + ci;
+    if (pl->nseg < 2 || (u32)seg >= pl->nseg) return;
     const InfChunk ch = chunks[ci];
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 lds_data = (u32)(uintptr_t)smem;                       // LDS byte offsets of the cell ring, the bit ring, ...
@@ -1446,7 +1446,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
     const u32 *tbs = tile_base + tb_off[ci];
     u16 *out = sym + ch.stream_off;                                  // cells of this chunk (same offsets as the stream, in cells)
     const u32 ntok = r.ntok, ngroups = (ntok + 63) / 64;
-    const u32 g_lo = pl.g0[seg], g_hi = pl.g0[seg + 1], B = pl.b0[seg], Bend = pl.b0[seg + 1];
+    const u32 g_lo = pl->g0[seg], g_hi = pl->g0[seg + 1], B = pl->b0[seg], Bend = pl->b0[seg + 1];
     for (u32 i = threadIdx.x * 16; i < LZ2_CTL_OFF; i += LZ_THREADS * 16) lds_zero16(lds_data + i);     // cells and bits start at zero
     const u32 q0 = B / LZ_FLUSH;
     if (threadIdx.x < 24) {
@@ -1554,23 +1554,19 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
         u32 spins = 0, k = 0;
         while (__any(pend)) {
             if (pend && !slow) {
-                u32 b0, b1, x[5];
-                lz2_load_window(ba, da, b0, b1, x);
+                u32 b0, b1, x0, x1, x2, x3, x4;
+                lz2_load_window(ba, da, b0, b1, x0, x1, x2, x3, x4);
                 if ((__builtin_amdgcn_alignbit(b1, b0, sofs & 31) & nbits) == nbits) {
                     const u32 ssh = 16 * (sofs & 1);
-                    u32 w[4], o[5];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        w[j] = __builtin_amdgcn_alignbit(x[j + 1], x[j], ssh);
-                        const int c0 = 2 * j, c1 = 2 * j + 1;                       // cells of this dword: keep those below len
-                        w[j] &= ((u32)c0 < len ? 0xffffu : 0u) | ((u32)c1 < len ? 0xffff0000u : 0u);
-                    }
+                    // the 8 cells, two per dword; cells at or beyond len are dropped
+                    const u32 w0 = __builtin_amdgcn_alignbit(x1, x0, ssh) & (len > 1 ? 0xffffffffu : 0xffffu);
+                    const u32 w1 = __builtin_amdgcn_alignbit(x2, x1, ssh) & (len > 3 ? 0xffffffffu : len > 2 ? 0xffffu : 0u);
+                    const u32 w2 = __builtin_amdgcn_alignbit(x3, x2, ssh) & (len > 5 ? 0xffffffffu : len > 4 ? 0xffffu : 0u);
+                    const u32 w3 = __builtin_amdgcn_alignbit(x4, x3, ssh) & (len > 7 ? 0xffffffffu : len > 6 ? 0xffffu : 0u);
                     const bool odd = dofs & 1;
-                    o[0] = odd ? w[0] << 16 : w[0];
-#pragma unroll
-                    for (int j = 1; j < 4; j++) o[j] = odd ? __builtin_amdgcn_alignbit(w[j], w[j - 1], 16) : w[j];
-                    o[4] = odd ? w[3] >> 16 : 0u;
-                    lz2_or_window(wa, o, wba, (u32)wbits, (u32)(wbits >> 32));
+                    lz2_or_window(wa, odd ? w0 << 16 : w0, odd ? __builtin_amdgcn_alignbit(w1, w0, 16) : w1,
+                                  odd ? __builtin_amdgcn_alignbit(w2, w1, 16) : w2, odd ? __builtin_amdgcn_alignbit(w3, w2, 16) : w3,
+                                  odd ? w3 >> 16 : 0u, wba, (u32)wbits, (u32)(wbits >> 32));
                     pend = false;
                 } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
             } else if (pend) {
