@@ -103,6 +103,24 @@ __device__ __forceinline__ int chain_decode(u32 v, const u32 (&lc)[MAXL + 1], u3
     return (int)(so + ((v - lo) >> (MAXL - l_)));
 }
 
+// the same with the chain in memory (LDS, wave-shared: every lane reads the same word)
+template <int MAXL>
+__device__ __forceinline__ int chain_decode_mem(u32 v, const u32 *lc, u32 &len)
+{
+    u32 l_ = 1, lo = 0, so = 0;
+#pragma unroll
+    for (int l = 1; l < MAXL; l++) {
+        const u32 w = lc[l], lim = w & 0xffff;
+        const bool ge = v >= lim;
+        l_ += ge;
+        lo = ge ? lim : lo;
+        so += ge ? (w >> 16) : 0;
+    }
+    len = l_;
+    if (v >= (lc[MAXL] & 0xffff)) return -1;
+    return (int)(so + ((v - lo) >> (MAXL - l_)));
+}
+
 // Huffman scratch in LDS.  Element k of a user sits at k*stride + lane: stride 64 = one private table set
 // per lane of a wave (64 independent streams), stride 1 / lane 0 = one table set shared by a wave.
 constexpr int INF_LENS = 320;        // u8 code lengths
@@ -130,8 +148,8 @@ struct LaneLds {
 
 // Build the compare chain + sorted symbol table for lens[first .. first+nsym).
 // returns 0 complete, 1 incomplete, -1 over-subscribed; maxlen = longest code
-template <int MAXL, bool DIST>
-__device__ int build_chain(LaneLds &L, int first, int nsym, u32 (&lc)[MAXL + 1], int &maxlen)
+template <int MAXL, bool DIST, class CHAIN>
+__device__ int build_chain(LaneLds &L, int first, int nsym, CHAIN &&lc, int &maxlen)
 {
     for (int l = 0; l < 16; l++) L.c(l) = 0;
     for (int s = 0; s < nsym; s++) L.c(L.len(first + s))++;
@@ -168,7 +186,8 @@ __device__ int build_chain(LaneLds &L, int first, int nsym, u32 (&lc)[MAXL + 1],
 #define INF_TOOLONG (-2)
 
 // Code tables of a fixed (type 1) or dynamic (type 2) block; br stands right after the 3 header bits.
-__device__ int parse_tables(BitIn &br, LaneLds &L, u32 type, u32 (&LC)[16], u32 (&DC)[16])
+template <class CHAIN>
+__device__ int parse_tables(BitIn &br, LaneLds &L, u32 type, CHAIN &&LC, CHAIN &&DC)
 {
     int nlen_codes, ndist_codes;
     if (type == 1) {
@@ -285,29 +304,31 @@ __device__ __forceinline__ int decode_token(BitIn &br, LaneLds &L, const u32 (&L
 // (LUT_DBITS) stream bits index a u16 = symbol << 4 | code length; 0 = the code is longer (or invalid): those
 // go through the compare chain.  The tables are filled by decoding every index with the compare chain once.
 constexpr int LUT_LBITS = 10, LUT_DBITS = 8;
-constexpr int LUT_BYTES = 2 * ((1 << LUT_LBITS) + (1 << LUT_DBITS));
-__device__ __forceinline__ void build_luts(LaneLds &L, const u32 (&LC)[16], const u32 (&DC)[16], u16 *lutl, u16 *lutd, int lane)
+constexpr int LUT_BYTES = 2 * ((1 << LUT_LBITS) + (1 << LUT_DBITS)) + 2 * 16 * 4;      // tables + the two compare chains
+// lutl: lit/len table, then the distance table, then the chains LC[16], DC[16] (already there: parse_tables wrote them)
+__device__ __forceinline__ void build_luts(LaneLds &L, u16 *lutl, u16 *lutd, int lane)
 {
+    const u32 *LC = (const u32 *)(lutd + (1 << LUT_DBITS)), *DC = LC + 16;
     for (u32 e = lane; e < (1u << LUT_LBITS); e += 64) {
         u32 cl;
-        const int si = chain_decode<15>(__brev(e) >> 17, LC, cl);
+        const int si = chain_decode_mem<15>(__brev(e) >> 17, LC, cl);
         lutl[e] = (si >= 0 && cl <= (u32)LUT_LBITS) ? (u16)(((u32)L.ls(si) << 4) | cl) : (u16)0;
     }
     for (u32 e = lane; e < (1u << LUT_DBITS); e += 64) {
         u32 cl;
-        const int si = chain_decode<15>(__brev(e) >> 17, DC, cl);
+        const int si = chain_decode_mem<15>(__brev(e) >> 17, DC, cl);
         lutd[e] = (si >= 0 && cl <= (u32)LUT_DBITS) ? (u16)(((u32)L.ds(si) << 4) | cl) : (u16)0;
     }
 }
-__device__ __forceinline__ int decode_token_lut(BitIn &br, LaneLds &L, const u32 (&LC)[16], const u32 (&DC)[16],
-                                                const u16 *lutl, const u16 *lutd, u32 &tok, u32 &olen)
+__device__ __forceinline__ int decode_token_lut(BitIn &br, LaneLds &L, const u16 *lutl, const u16 *lutd, u32 &tok, u32 &olen)
 {
+    const u32 *LC = (const u32 *)(lutd + (1 << LUT_DBITS)), *DC = LC + 16;
     br.refill();
     u32 cl, sym;
     const u32 e = lutl[br.peek() & ((1u << LUT_LBITS) - 1)];
     if (e) { cl = e & 15; sym = e >> 4; }
     else {
-        const int si = chain_decode<15>(__brev(br.peek()) >> 17, LC, cl);
+        const int si = chain_decode_mem<15>(__brev(br.peek()) >> 17, LC, cl);
         if (si < 0) return INF_CORRUPT;
         sym = L.ls(si);
     }
@@ -326,7 +347,7 @@ __device__ __forceinline__ int decode_token_lut(BitIn &br, LaneLds &L, const u32
     const u32 d = lutd[br.peek() & ((1u << LUT_DBITS) - 1)];
     if (d) { cl = d & 15; dsym = d >> 4; }
     else {
-        const int si = chain_decode<15>(__brev(br.peek()) >> 17, DC, cl);
+        const int si = chain_decode_mem<15>(__brev(br.peek()) >> 17, DC, cl);
         if (si < 0) return INF_CORRUPT;
         dsym = L.ds(si);
     }
@@ -660,8 +681,8 @@ __global__ __launch_bounds__(256) void k_inf_sortc(const InfFast *__restrict__ f
 enum { SPAN_CONT = 0, SPAN_EOB = 1, SPAN_ERR = 2 };
 
 template <int MODE>      // 0: find the exit only, 1: count, 2: emit `want` tokens to tk
-__device__ __forceinline__ void decode_span(BitIn &br, LaneLds &L, const u32 (&LC)[16], const u32 (&DC)[16], const u16 *lutl,
-                                            const u16 *lutd, u64 stop, u32 &ntok, u32 &nout, int &flag, u32 *tk, u32 want)
+__device__ __forceinline__ void decode_span(BitIn &br, LaneLds &L, const u16 *lutl, const u16 *lutd, u64 stop, u32 &ntok, u32 &nout,
+                                            int &flag, u32 *tk, u32 want)
 {
     flag = SPAN_CONT;
     ntok = 0; nout = 0;
@@ -669,7 +690,7 @@ __device__ __forceinline__ void decode_span(BitIn &br, LaneLds &L, const u32 (&L
         if (MODE == 2) { if (ntok >= want) break; }
         else if (br.pos >= stop) break;
         u32 tok, olen;
-        const int t = decode_token_lut(br, L, LC, DC, lutl, lutd, tok, olen);
+        const int t = decode_token_lut(br, L, lutl, lutd, tok, olen);
         if (t < 0 || br.pos > br.end) { flag = SPAN_ERR; break; }
         if (t == 1) { flag = SPAN_EOB; break; }
         // a copy longer than LZ_PIECE bytes is written as several copies with the same distance (byte k of
@@ -706,14 +727,14 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     r.end_bit = 0; r.ntok = 0; r.nout = 0; r.nsub = 0; r.ok = 0; r.bfinal = 0; r.pad = 0;
     const u32 hdr = br.get(3);
     r.bfinal = hdr & 1;
-    u32 LC[16], DC[16];
+    __shared__ u16 lut_s[LUT_BYTES / 2];
+    u16 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
+    u32 *LC = (u32 *)(lutd + (1 << LUT_DBITS)), *DC = LC + 16;      // the compare chains live in LDS (wave-shared)
     // every lane parses the header redundantly (identical control flow, identical LDS writes)
     const int rc = parse_tables(br, L, hdr >> 1, LC, DC);
     if (rc != INF_OK) { if (lane == 0) cres[slot] = r; return; }
     __builtin_amdgcn_wave_barrier();
-    __shared__ u16 lut_s[LUT_BYTES / 2];
-    u16 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
-    build_luts(L, LC, DC, lutl, lutd, lane);
+    build_luts(L, lutl, lutd, lane);
     __builtin_amdgcn_wave_barrier();
     uint2 *sub = subs + (u64)slot * SUBCAP;
     u64 base = br.pos;
@@ -725,7 +746,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
         u32 nt, no; int fl;
         // speculative pass: exits only
         br.seek(start);
-        decode_span<0>(br, L, LC, DC, lutl, lutd, stop, nt, no, fl, nullptr, 0);
+        decode_span<0>(br, L, lutl, lutd, stop, nt, no, fl, nullptr, 0);
         ex = br.pos;
         bool counted = false;
         for (int it = 0; it < 66; it++) {
@@ -744,7 +765,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
             if (redo) {
                 start = want_start;
                 br.seek(start);
-                decode_span<1>(br, L, LC, DC, lutl, lutd, stop, nt, no, fl, nullptr, 0);
+                decode_span<1>(br, L, lutl, lutd, stop, nt, no, fl, nullptr, 0);
                 ex = br.pos;
                 counted = true;
             }
@@ -913,12 +934,12 @@ __global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, 
         return;
     }
     const u32 hdr = br.get(3);
-    u32 LC[16], DC[16];
-    if (parse_tables(br, L, hdr >> 1, LC, DC) != INF_OK) { if (lane == 0) res[ci].status = MTS_CHUNK_CORRUPT; return; }
-    __builtin_amdgcn_wave_barrier();
     __shared__ u16 lut_s[LUT_BYTES / 2];
     u16 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
-    build_luts(L, LC, DC, lutl, lutd, lane);
+    u32 *LC = (u32 *)(lutd + (1 << LUT_DBITS)), *DC = LC + 16;      // the compare chains live in LDS (wave-shared)
+    if (parse_tables(br, L, hdr >> 1, LC, DC) != INF_OK) { if (lane == 0) res[ci].status = MTS_CHUNK_CORRUPT; return; }
+    __builtin_amdgcn_wave_barrier();
+    build_luts(L, lutl, lutd, lane);
     __builtin_amdgcn_wave_barrier();
     const u32 nsub = cres[tb.cand].nsub;
     const uint2 *sub = subs + (u64)tb.cand * SUBCAP;
@@ -942,7 +963,7 @@ __global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, 
             const uint2 a = sub[j], b = sub[j + 1];
             br.seek(tb.start_bit + a.x);
             u32 nt, no; int fl;
-            decode_span<2>(br, L, LC, DC, lutl, lutd, 0, nt, no, fl, tk + a.y, b.y - a.y);
+            decode_span<2>(br, L, lutl, lutd, 0, nt, no, fl, tk + a.y, b.y - a.y);
             if (nt != b.y - a.y) res[ci].status = MTS_CHUNK_CORRUPT;
         }
     }
