@@ -502,7 +502,7 @@ constexpr int M5_RING = 256;
 constexpr int M5_ROWS = 32;
 constexpr int M5_LEVELS = 4;                         // tables for prefix lengths 4, 5, 6, 7
 constexpr int M5_TABLE = M5_ROWS * (M5_RING / 8);    // bytes per table
-constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_LEVELS * M5_TABLE;     // 8192: entries, bytes 7..14, tables
+constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_LEVELS * M5_TABLE + M5_RING / 8;     // 8224: entries, bytes 7..14, tables, run-start bits
 // requested LDS is padded so that TWO workgroups share a CU, not three: every workgroup reads its own 128 KiB
 // window through L2, and three per CU (12 MiB per XCD against 4 MiB of L2) measured 10 % slower than two
 constexpr int MATCH5_LDS = M5_WAVES * M5_WAVE_LDS > 56 * 1024 ? M5_WAVES * M5_WAVE_LDS : 56 * 1024;
@@ -530,6 +530,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     u64 *SE = (u64 *)wbase;
     u64 *SX = SE + M5_RING;                                        // bytes 7..14 of every slot: matches up to 15 never leave the LDS
     u32 *TB = (u32 *)(wbase + 2 * M5_RING * 8);                    // [level][row][8 words]
+    u32 *BND = TB + M5_LEVELS * (M5_TABLE / 4);                    // bit r: the slot at ring position r starts a hash run
     uint2 *T = tables + td.stream_off;
     if (threadIdx.x < 2) {
         const u32 hashed_end = td.w + td.wlen;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     }
     if (td.wlen == 0) return;
     const u32 *sk = sorted + td.sorted_off;
-    const u16 *snb = sorted_nb + td.sorted_off;
+    (void)sorted_nb;                                               // (chain lengths are derived here, from the run-start bits)
     const u32 wlen = td.wlen, n = td.n;
     const u32 ngroups = (wlen + 63) / 64;
     const u32 halo = td.a - td.w;
@@ -552,10 +553,18 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     __builtin_amdgcn_wave_barrier();
     // slot idx -> position -> its 8 bytes -> entry; enters the ring at idx & 255, replacing slot idx - 256.
     // The window words of a slot are loaded one group ahead (the loads stay in flight during the walk).
-    auto commit = [&](int idx, u32 rc, u32 lo, u32 hi, u64 x, u32 (&key)[M5_LEVELS]) -> u64 {
+    u32 h_carry = 0xffffffffu;                                     // hash of the slot before the one lane 0 commits next
+    auto commit = [&](int idx, u32 rc, u32 lo, u32 hi, u64 x, u32 (&key)[M5_LEVELS], bool &starts_run) -> u64 {
         const u32 rp = (u32)idx & (M5_RING - 1), word = rp >> 5, bit = 1u << (rp & 31);
         const bool valid = idx >= 0 && (u32)idx < wlen;
         const u64 ce = valid ? make_entry(rc, lo, hi) : ~0ull;
+        // a slot starts a run when its hash differs from its predecessor's (slots are committed in order)
+        const u32 h = valid ? hash_of(lo) : 0xfffffffeu;
+        const u32 hp = __shfl_up(h, 1, 64);
+        starts_run = h != (lane == 0 ? h_carry : hp);
+        h_carry = (u32)__builtin_amdgcn_readlane((int)h, 63);
+        const u64 sr = __ballot(starts_run);
+        if (lane == 0) { BND[word] = (u32)sr; BND[word + 1] = (u32)(sr >> 32); }
         u32 old[M5_LEVELS];
         m5_keys((u32)(SE[rp] >> 32), old);                          // the keys of the slot being replaced
         m5_keys((u32)(ce >> 32), key);
@@ -575,29 +584,28 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     const int i_first = (int)g_begin * 64 + lane;
     {
         u32 kk[M5_LEVELS];
+        bool sr;
         const u32 ra = slot_rel(i_first - 128), rb = slot_rel(i_first - 64);
         const u32 la = wread(ra), ha = wread(ra + 4), lb = wread(rb), hb = wread(rb + 4);
-        commit(i_first - 128, ra, la, ha, ext_bytes(ra, ha), kk);
-        commit(i_first - 64, rb, lb, hb, ext_bytes(rb, hb), kk);
+        commit(i_first - 128, ra, la, ha, ext_bytes(ra, ha), kk, sr);
+        commit(i_first - 64, rb, lb, hb, ext_bytes(rb, hb), kk, sr);
     }
     // pipeline: (rc, lo, hi, nb) of the group about to be walked, rc of the one after
     u32 rc_c = slot_rel(i_first), rc_n = slot_rel(i_first + 64);
     u32 lo_c = wread(rc_c), hi_c = wread(rc_c + 4);
     u64 x_c = ext_bytes(rc_c, hi_c);
-    u32 nb_c = snb[(u32)i_first < wlen ? (u32)i_first : wlen - 1];
     for (u32 g = g_begin; g < g_end; g++) {
         const u32 i0 = g * 64, i = i0 + lane;
         u32 key[M5_LEVELS];
         __builtin_amdgcn_wave_barrier();
-        const u64 e = commit((int)i, rc_c, lo_c, hi_c, x_c, key);
+        bool starts_run;
+        const u64 e = commit((int)i, rc_c, lo_c, hi_c, x_c, key, starts_run);
         const u64 ex = x_c;
         __builtin_amdgcn_wave_barrier();
-        const u32 nb_raw = nb_c;
         // next group's words, and the position of the one after
         rc_c = rc_n;
         lo_c = wread(rc_c); hi_c = wread(rc_c + 4);
         x_c = ext_bytes(rc_c, hi_c);
-        nb_c = snb[i + 64 < wlen ? i + 64 : wlen - 1];
         rc_n = slot_rel((int)i + 128);
         const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
         const u32 rel_p = e0 & REL_MASK;
@@ -609,11 +617,19 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
         const int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
         const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
-        u32 nbv = own ? nb_raw : 0;
-        nbv = nbv < chain ? nbv : chain;
         // the 128 slots before this lane's own are ring positions lo .. lo + 127 (mod 256); candidate j
         // (1 = newest) is bit 128 - j of the masks.  V = the candidates inside this lane's chain budget.
         const u32 lo = (i + 128) & (M5_RING - 1), w0 = lo >> 5, sh = lo & 31;
+        // the chain behind this slot = the slots back to the start of its hash run (at most 128 matter)
+        u32 nbv = 0;
+        if (!starts_run) {
+            const u32 R0 = BND[w0 & 7], R1 = BND[(w0 + 1) & 7], R2 = BND[(w0 + 2) & 7], R3 = BND[(w0 + 3) & 7], R4 = BND[(w0 + 4) & 7];
+            const u32 S0 = __builtin_amdgcn_alignbit(R1, R0, sh), S1 = __builtin_amdgcn_alignbit(R2, R1, sh),
+                      S2 = __builtin_amdgcn_alignbit(R3, R2, sh), S3 = __builtin_amdgcn_alignbit(R4, R3, sh);
+            // newest run start among the 128 slots before: bit t -> the run has 128 - t slots before this one
+            nbv = S3 ? (u32)__builtin_clz(S3) + 1 : S2 ? (u32)__builtin_clz(S2) + 33 : S1 ? (u32)__builtin_clz(S1) + 65 : S0 ? (u32)__builtin_clz(S0) + 97 : 128u;
+        }
+        nbv = own ? (nbv < chain ? nbv : chain) : 0;
         u32 V[4], A4[4], A5[4], A6[4], A7[4];                     // V = inside the budget; A_d = V & "first d bytes may match"
 #pragma unroll
         for (int k = 0; k < 4; k++) {
