@@ -265,7 +265,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     E.t_mark(st, "delta_transpose");
     u32 *tmp_k = E.sort_a.as<u32>(), *srt_k = E.sort_b.as<u32>();
     u16 *srt_nb = (u16 *)(tmp_k + sort_n);
-    if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, srt_nb))) return rc;
+    if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, srt_nb, cfg.chain > 128))) return rc;
     E.t_mark(st, "hash_sort");
     uint2 *d_tables = E.tables.as<uint2>();
     if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, srt_nb, d_tables, cfg))) return rc;

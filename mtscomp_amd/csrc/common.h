@@ -31,10 +31,15 @@ constexpr int STREAM_PAD = 512;
 constexpr int STREAM_ALIGN = 256;
 
 // ---- match stage tiling ---------------------------------------------------------------------------
+// A tile's history (HALO) is sorted and staged again by the next tile, so bigger tiles mean less work -- but the
+// match kernel reads the tile's window (TILE + HALO bytes) at random, two workgroups per CU: measured on MI355X,
+// 64..96 Ki tiles cost the same (41-42 ms: less work balances worse locality), 160 Ki 53 ms, 224 Ki 60 ms.
+// The 32-bit sort keys hold the window-relative position (REL_BITS allow windows up to 2^18) and the 7 hash bits
+// the second radix pass still needs; the first pass takes its 8 bits straight from the bytes.
 constexpr int TILE = 98304;                // positions a match-stage workgroup owns
 constexpr int HALO = 32768;                // history it additionally needs (>= MAX_DIST)
-constexpr int WIN = TILE + HALO;           // 131072 = 2^17: window-relative positions fit 17 bits
-constexpr int REL_BITS = 17;
+constexpr int WIN = TILE + HALO;           // 131072
+constexpr int REL_BITS = 18;
 constexpr u32 REL_MASK = (1u << REL_BITS) - 1;
 
 constexpr int SEG = 4096;                  // parse segment (positions per speculative walker)
@@ -114,7 +119,7 @@ int launch_adler_stream(hipStream_t st, const u8 *d_stream, const u64 *d_stream_
 
 // deflate.hip
 int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp,
-                     u32 *d_sorted, u16 *d_sorted_nb);
+                     u32 *d_sorted, u16 *d_sorted_nb, int want_nb /* chain lengths too (the kernel for budgets > 128 reads them) */);
 int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles,
                  const u32 *d_sorted, const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg);
 struct ParseBufs {

@@ -75,8 +75,8 @@ __device__ __forceinline__ u32 __reduce_max_sync_u32(u32 v)
 // ================================================================================================
 // S: hash sort
 // ================================================================================================
-// The radix passes move 32-bit keys  (hash << 17) | window-relative position.  Everything else the match
-// stage wants about a position (its bytes 0..7) is read from the window, which that kernel keeps in LDS.
+// The radix passes move 32-bit keys  (high 7 hash bits << 18) | window-relative position.  Everything else the
+// match stage wants about a position (its bytes, its chain length) it derives from the window bytes.
 // per-(wave, digit) counts -> where each wave's keys of each digit start (digit-major, wave-minor: stable)
 template <int NB>
 __device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
@@ -116,11 +116,15 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
+    // first pass: the fetched word is the 15-bit hash (digit = its low 8 bits; what is stored and sorted on is
+    // the key = high 7 hash bits : position); second pass: the key (digit = its 7 hash bits)
     auto fetch = [&](u32 i) -> u32 {
         if (i >= end) return 0;
-        if (FIRST) return (hash_of(gld_u32_unaligned(s, i)) << REL_BITS) | i;
+        if (FIRST) return hash_of(gld_u32_unaligned(s, i));
         return src[i];
     };
+    auto digit_of = [&](u32 f) -> u32 { return FIRST ? f & 255 : f >> REL_BITS; };
+    auto key_of = [&](u32 f, u32 i) -> u32 { return FIRST ? ((f >> 8) << REL_BITS) | i : f; };
     if (lane_ordered) {
         // The LDS retires the same-address atomics of one wave instruction in lane order (probed at start-up, see
         // k_probe_lds_order): the value returned by the add IS the stable destination -- no ballots, no barriers.
@@ -132,10 +136,9 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (base + 64 * k + lane < end) {
-                    const u32 d = FIRST ? (key[k] >> REL_BITS) & 255 : key[k] >> 25;
-                    const u32 at = atomicAdd(&cnt[wave][d], 1u);
-                    dst[at] = key[k];
-                    if (FIRST) atomicAdd(&cnt2[__umulhi(at, per_magic)][key[k] >> 25], 1u);
+                    const u32 at = atomicAdd(&cnt[wave][digit_of(key[k])], 1u);
+                    dst[at] = key_of(key[k], base + 64 * k + lane);
+                    if (FIRST) atomicAdd(&cnt2[per_magic ? __umulhi(at >> 6, per_magic) : at >> 6][key[k] >> 8], 1u);
                 }
             }
         }
@@ -150,7 +153,7 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
         const u32 key = key_n;
         key_n = key_nn;
         key_nn = fetch(i + 128);
-        const u32 d = FIRST ? (key >> REL_BITS) & 255 : key >> 25;
+        const u32 d = digit_of(key);
         const u64 actm = __ballot(act);
         const u64 m = match_digit<NB>(d, actm);
         const u32 rank = __popcll(m & lanemask_lt()), count = __popcll(m);
@@ -158,9 +161,9 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
         if (act) off = cnt[wave][d];
         __builtin_amdgcn_wave_barrier();
         if (act) {
-            dst[off + rank] = key;
+            dst[off + rank] = key_of(key, i);
             if (rank == count - 1) cnt[wave][d] = off + count;
-            if (FIRST) atomicAdd(&cnt2[__umulhi(off + rank, per_magic)][key >> 25], 1u);
+            if (FIRST) atomicAdd(&cnt2[per_magic ? __umulhi((off + rank) >> 6, per_magic) : (off + rank) >> 6][key >> 8], 1u);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -188,7 +191,8 @@ __global__ __launch_bounds__(1024) void k_probe_lds_order(u32 *bad, int iters)
 }
 
 // third phase: sorted keys -> number of same-hash predecessors of each slot (the chain behind it), capped
-__device__ __forceinline__ void chain_lengths(const u32 *__restrict__ sk, u16 *__restrict__ nb, u32 wlen, u32 *wmax, u32 *carry_p)
+__device__ __forceinline__ void chain_lengths(const u8 *__restrict__ s, const u32 *__restrict__ sk, u16 *__restrict__ nb, u32 wlen, u32 *wmax,
+                                              u32 *carry_p)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) *carry_p = 0;
@@ -196,8 +200,9 @@ __device__ __forceinline__ void chain_lengths(const u32 *__restrict__ sk, u16 *_
     for (u32 base = 0; base < wlen; base += 1024) {
         const u32 i = base + threadIdx.x;
         const bool act = i < wlen;
-        const u32 h = act ? sk[i] >> REL_BITS : 0xffffu;
-        const u32 hprev = (act && i > 0) ? sk[i - 1] >> REL_BITS : 0xfffeu;
+        // (the keys only hold 7 hash bits: the hash is recomputed from the bytes; only budgets > 128 come here)
+        const u32 h = act ? hash_of(gld_u32_unaligned(s, sk[i] & REL_MASK)) : 0xffffu;
+        const u32 hprev = (act && i > 0) ? hash_of(gld_u32_unaligned(s, sk[i - 1] & REL_MASK)) : 0xfffeu;
         // bucket start index + 1 where a bucket starts here, else 0; running max = start of my bucket
         u32 v = (act && h != hprev) ? i + 1 : 0;
 #pragma unroll
@@ -215,7 +220,8 @@ __device__ __forceinline__ void chain_lengths(const u32 *__restrict__ sk, u16 *_
 }
 
 __global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
-                                                    u32 *__restrict__ tmp, u32 *__restrict__ sorted, u16 *__restrict__ sorted_nb, int lane_ordered)
+                                                    u32 *__restrict__ tmp, u32 *__restrict__ sorted, u16 *__restrict__ sorted_nb, int lane_ordered,
+                                                    int want_nb)
 {
     const TileDesc td = tiles[blockIdx.x];
     __shared__ u32 cnt[16][256];
@@ -226,7 +232,8 @@ __global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ strea
     const u32 wlen = td.wlen;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 per = (((wlen + 15) / 16) + 63) & ~63u;              // keys per wave (both passes)
-    const u32 per_magic = 0xffffffffu / per + 1;                    // __umulhi(x, magic) == x / per for x < 2^17 (per < 2^15)
+    // __umulhi(x >> 6, magic) == x / per (per is a multiple of 64; x >> 6 < 2^12); magic 0 stands for per == 64 (x / per = x >> 6)
+    const u32 per_magic = per > 64 ? 0xffffffffu / (per >> 6) + 1 : 0;
     for (int i = threadIdx.x; i < 16 * 256; i += 1024) (&cnt[0][0])[i] = 0;
     for (int i = threadIdx.x; i < 16 * 128; i += 1024) (&cnt2[0][0])[i] = 0;
     __syncthreads();
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ strea
     __syncthreads();
     bin_offsets<7>(cnt, tot);
     rank_pass<7, false>(s, tmp + td.sorted_off, sorted + td.sorted_off, wlen, per, cnt, cnt2, per_magic, lane_ordered);  // high 7 bits
-    chain_lengths(sorted + td.sorted_off, sorted_nb + td.sorted_off, wlen, tot, tot + 32);
+    if (want_nb) chain_lengths(s, sorted + td.sorted_off, sorted_nb + td.sorted_off, wlen, tot, tot + 32);      // (k_match5 derives them itself)
 }
 
 // 1 if this device's LDS retires same-address atomics of a wave instruction in lane order (probed once per device)
@@ -271,11 +278,11 @@ static int lds_lane_ordered()
 }
 
 int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp, u32 *d_sorted,
-                     u16 *d_sorted_nb)
+                     u16 *d_sorted_nb, int want_nb)
 {
     if (n_tiles == 0) return MTS_OK;
     const int ordered = getenv("MTS_SORT_BALLOT") ? 0 : lds_lane_ordered();      // MTS_SORT_BALLOT=1: force the ballot ranking (tests)
-    hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(1024), 0, st, d_stream, d_tiles, d_tmp, d_sorted, d_sorted_nb, ordered);
+    hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(1024), 0, st, d_stream, d_tiles, d_tmp, d_sorted, d_sorted_nb, ordered, want_nb);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
@@ -284,11 +291,11 @@ int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles
 // M: per-position best matches (t_full, t_quarter) -- orc_match_tables() is the oracle
 // ================================================================================================
 // The kernel scores a candidate from a 64-bit "entry" built (from the LDS window) for every staged slot:
-//   w0 [16:0]  rel   window-relative position
-//      [25:17] d     9 bits that, TOGETHER WITH AN EQUAL 15-BIT HASH, prove bytes 0..2 equal:
+//   w0 [17:0]  rel   window-relative position
+//      [26:18] d     9 bits that, TOGETHER WITH AN EQUAL 15-BIT HASH, prove bytes 0..2 equal:
 //                    h = (b0<<10 ^ b1<<5 ^ b2) & 0x7fff exposes b0[4:3], b1[4:3], b2[4:0] directly and
 //                    b0[2:0]^b1[7:5], b1[2:0]^b2[7:5]; b0[7:5] not at all.  d = b0[7:5] : b0[2:0] : b1[2:0].
-//      [31:26] low 6 bits of byte 7
+//      [31:27] low 5 bits of byte 7
 //   w1         bytes 3..6
 // so the common prefix of two same-hash positions is known exactly up to 7 bytes from the entries alone;
 // only longer matches go back to the window bytes.
@@ -296,7 +303,7 @@ __device__ __forceinline__ u64 make_entry(u32 rel, u32 lo, u32 hi)       // lo =
 {
     const u32 b0 = lo & 0xff, b1 = (lo >> 8) & 0xff;
     const u32 d = ((b0 >> 5) << 6) | ((b0 & 7) << 3) | (b1 & 7);
-    const u32 w0 = rel | (d << REL_BITS) | (((hi >> 24) & 0x3f) << 26);
+    const u32 w0 = rel | (d << REL_BITS) | (((hi >> 24) & 0x1f) << (REL_BITS + 9));
     const u32 w1 = (lo >> 24) | (hi << 8);
     return (u64)w0 | ((u64)w1 << 32);
 }
