@@ -1276,7 +1276,6 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
                 __builtin_amdgcn_s_sleep(2);
             }
             idle = 0;
-#pragma unroll
             for (u32 o = lo + lane * 16; o < lo + LZ_FLUSH; o += 1024) {
                 if (o < hi) {
                     u32x4 c;
@@ -1519,7 +1518,6 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                 __builtin_amdgcn_s_sleep(2);
             }
             idle = 0;
-#pragma unroll
             for (u32 o = lo + lane * 8; o < lo + LZ_FLUSH; o += 512) {
                 if (o < hi && o + 8 > B) {
                     u32x4 c;
