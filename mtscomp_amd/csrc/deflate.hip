@@ -341,10 +341,10 @@ __device__ __forceinline__ u32 bit_range(int lo, int hi)
     return (0xffffffffu >> (31 - h)) & (0xffffffffu << l);
 }
 
-// SLIDE (chain budget <= 128): a wave owns a contiguous range of 64-slot groups and keeps the last 192
-// slots it needs in a 256-slot ring, so every slot's entry is built exactly once per wave (the window
-// bytes come from L2).  Larger budgets restage 192 slots per 128 candidates.
-template <bool SLIDE>
+// k_match4: chain budgets > 128 (levels 7..9).  A wave takes every 16th group and restages 192 slots per 128
+// candidates; the filter masks come from SWAR compares of two byte keys per candidate.  (Budgets <= 128 go to
+// k_match5 below, which keeps a sliding ring per wave and looks the masks up.)
+constexpr bool SLIDE = false;
 __global__ __launch_bounds__(1024, 2) void k_match4(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
                                                     const u32 *__restrict__ sorted, const u16 *__restrict__ sorted_nb,
                                                     uint2 *__restrict__ tables, LevelCfg cfg)
@@ -725,15 +725,12 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
                  const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg)
 {
     if (n_tiles == 0) return MTS_OK;
-    static const bool use4 = getenv("MTS_MATCH_V4") != nullptr;       // A/B switch for measurements
-    if (cfg.chain <= 128 && !use4) {
+    if (cfg.chain <= 128) {
         static bool attr_done = false;
         if (!attr_done && MATCH5_LDS > 65536) { MTS_HIP(hipFuncSetAttribute((const void *)k_match5, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH5_LDS)); attr_done = true; }
         hipLaunchKernelGGL(k_match5, dim3(n_tiles), dim3(M5_WAVES * 64), MATCH5_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
-    } else if (cfg.chain <= 128)
-        hipLaunchKernelGGL(k_match4<true>, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
-    else
-        hipLaunchKernelGGL(k_match4<false>, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
+    } else
+        hipLaunchKernelGGL(k_match4, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }

@@ -193,6 +193,29 @@ def test_inflate_errors():
             assert st == 0 and out == want
 
 
+def test_inflate_errors_segmented_resolver(monkeypatch):
+    """Bit flips in a stream big enough to be cut into resolver segments: same verdicts as zlib."""
+    monkeypatch.setenv('MTS_LZ_SEGS', '4')
+    data = inputs.repeats(500000, 21) + inputs.ar1_stream(2000, 64)
+    z = zlib.compress(data)
+    st, out = hip.debug_inflate(z, len(data))
+    assert st == 0 and out == data
+    r = np.random.RandomState(6)
+    for _ in range(40):
+        b = bytearray(z)
+        i = int(r.randint(2, len(b) - 4))
+        b[i] ^= 1 << int(r.randint(0, 8))
+        try:
+            want = zlib.decompress(bytes(b))
+        except zlib.error:
+            want = None
+        st, out = hip.debug_inflate(bytes(b), len(data))
+        if want is None or len(want) != len(data):
+            assert st != 0
+        else:
+            assert st == 0 and out == want
+
+
 @pytest.mark.parametrize('flags', [5, 7, 4, 1, 0, 3])
 def test_compress_decompress_chunks(flags):
     from mtscomp_amd.synth import synth_int16
