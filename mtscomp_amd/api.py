@@ -146,6 +146,7 @@ class HipCodec:
     """Per-chunk codec on MI355X.  ``devices``: list of device indices (default: all visible)."""
 
     name = 'hip'
+    takes_ranges = True          # decompress() also accepts (buffer, offsets, lengths)
 
     def __init__(self, devices=None):
         n = hip.require_device()
@@ -182,6 +183,12 @@ class HipCodec:
 
     def decompress(self, cbufs, n_rows, n_channels, dtype, flags):
         """-> (status list, list of (n_rows[i], n_channels) arrays or None)."""
+        if isinstance(cbufs, tuple):                        # (buffer, offsets, lengths): chunks already in one buffer
+            buf, offs, lens = cbufs
+            if len(self.devices) == 1:
+                return hip.decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=self.devices[0])
+            mv = memoryview(buf)
+            cbufs = [mv[o:o + l] for o, l in zip(offs, lens)]
         n = len(cbufs)
         status, arrays = [0] * n, [None] * n
         shards = [s for s in self._shards(n) if s]
@@ -430,6 +437,20 @@ class Writer:
 # ------------------------------------------------------------------------------------------------
 # Reader (mtscomp.py:514-859)
 # ------------------------------------------------------------------------------------------------
+def _join_rows(chunks):
+    """np.concatenate(chunks, axis=0) -- without the copy when the chunks already lie back to back in memory
+    (the arrays of one codec call do)."""
+    if len(chunks) == 1:
+        return chunks[0]
+    addr = [c.__array_interface__['data'][0] for c in chunks]
+    if all(c.flags.c_contiguous and c.dtype == chunks[0].dtype and c.shape[1] == chunks[0].shape[1] for c in chunks) and \
+            all(addr[k] + chunks[k].nbytes == addr[k + 1] for k in range(len(chunks) - 1)) and \
+            all(c.base is not None and c.base is chunks[0].base for c in chunks):
+        total = sum(c.shape[0] for c in chunks)
+        return np.lib.stride_tricks.as_strided(chunks[0], shape=(total, chunks[0].shape[1]))
+    return np.concatenate(chunks, axis=0)
+
+
 class Reader:
     """NumPy-style read access to a compressed file; chunks are decoded on the device."""
 
@@ -509,8 +530,14 @@ class Reader:
         todo = [t for t in triples if t[0] not in self._cache]
         result = {}
         if todo:
-            cbufs = [self._pread(length, start) for (_, start, length) in todo]
             rows = [self.chunk_bounds[i + 1] - self.chunk_bounds[i] for (i, _, _) in todo]
+            consecutive = all(todo[k][1] + todo[k][2] == todo[k + 1][1] for k in range(len(todo) - 1))
+            if consecutive and len(todo) > 1 and getattr(self.codec, 'takes_ranges', False):
+                base = todo[0][1]                              # one read for the whole byte range
+                buf = self._pread(todo[-1][1] + todo[-1][2] - base, base)
+                cbufs = (buf, [t[1] - base for t in todo], [t[2] for t in todo])
+            else:
+                cbufs = [self._pread(length, start) for (_, start, length) in todo]
             status, arrays = self.codec.decompress(cbufs, rows, self.n_channels, self.dtype, self._flags())
             for (idx, _, _), st, arr in zip(todo, status, arrays):
                 if st == hip.CHUNK_BADSIZE:
@@ -522,11 +549,18 @@ class Reader:
             if idx in self._cache:
                 self._cache.move_to_end(idx)
                 result[idx] = self._cache[idx]
+        # the arrays of one call are views of one buffer: what stays cached after a big batch is copied, so that a
+        # few cached chunks do not keep the whole batch alive
+        big = len(todo) > self.cache_size
         for idx, arr in result.items():
             self._cache[idx] = arr
             self._cache.move_to_end(idx)
         while len(self._cache) > self.cache_size:
             self._cache.popitem(last=False)
+        if big:
+            for idx in list(self._cache):
+                if self._cache[idx].base is not None:
+                    self._cache[idx] = self._cache[idx].copy()
         return result
 
     def read_chunk(self, chunk_idx, chunk_start, chunk_length):
@@ -671,7 +705,7 @@ class Reader:
                 while len(self._cache) > self.cache_size:
                     self._cache.popitem(last=False)
             chunks = [decoded[i] for i in range(first, last + 1)]
-            arr = chunks[0] if len(chunks) == 1 else np.concatenate(chunks, axis=0)
+            arr = _join_rows(chunks)
             a = i0 - self.chunk_bounds[first]
             b = i1 - self.chunk_bounds[first]
             assert 0 <= a <= b <= arr.shape[0]

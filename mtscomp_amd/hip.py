@@ -171,17 +171,29 @@ def compress_chunks(data, chunk_bounds, flags, level=6, device=0):
 
 
 def decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=0):
-    """cbufs: list of bytes-like compressed chunks.  Returns (status list, list of arrays or None)."""
+    """cbufs: list of bytes-like compressed chunks, or (buffer, offsets, lengths) for chunks that already sit in
+    one buffer.  Returns (status list, list of arrays or None).  The arrays are views of ONE output buffer, back to
+    back in the order given, so consecutive chunks can be joined without copying."""
     dtype = check_dtype(dtype)
-    n = len(cbufs)
-    if n == 0:
-        return [], []
-    lens = _longs([len(c) for c in cbufs])
-    offs = _longs(np.concatenate(([0], np.cumsum(lens)))[:-1])
-    cdata = np.frombuffer(b''.join(bytes(c) for c in cbufs) + b'\0' * 16, dtype=np.uint8)
+    if isinstance(cbufs, tuple):
+        buf, offs, lens = cbufs
+        n = len(lens)
+        if n == 0:
+            return [], []
+        cdata = np.frombuffer(buf, dtype=np.uint8)
+        offs, lens = _longs(offs), _longs(lens)
+        if int(offs[-1] + lens[-1]) + 16 > cdata.size:          # the kernels may read a few bytes past a stream
+            cdata = np.concatenate((cdata, np.zeros(16, dtype=np.uint8)))
+    else:
+        n = len(cbufs)
+        if n == 0:
+            return [], []
+        lens = _longs([len(c) for c in cbufs])
+        offs = _longs(np.concatenate(([0], np.cumsum(lens)))[:-1])
+        cdata = np.frombuffer(b''.join(bytes(c) for c in cbufs) + b'\0' * 16, dtype=np.uint8)
     rows = _longs(n_rows)
     sizes = rows * (n_channels * dtype.itemsize)
-    ooffs = _longs(np.concatenate(([0], np.cumsum((sizes + 255) // 256 * 256)))[:-1])
+    ooffs = _longs(np.concatenate(([0], np.cumsum(sizes)))[:-1])
     out = np.empty(int(ooffs[-1] + sizes[-1]) + 256, dtype=np.uint8)
     status = np.zeros(n, dtype=np.int32)
     _check(lib().mts_decompress_chunks(device, _ptr(cdata), _lp(offs), _lp(lens), _lp(rows), n, n_channels,
@@ -190,8 +202,7 @@ def decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=0):
     arrays = []
     for i in range(n):
         if status[i] == CHUNK_OK:
-            a = out[int(ooffs[i]):int(ooffs[i] + sizes[i])].view(dtype).reshape(int(rows[i]), n_channels)
-            arrays.append(a.copy())
+            arrays.append(out[int(ooffs[i]):int(ooffs[i] + sizes[i])].view(dtype).reshape(int(rows[i]), n_channels))
         else:
             arrays.append(None)
     return [int(s) for s in status], arrays
