@@ -362,6 +362,87 @@ __device__ __forceinline__ int decode_token_lut(BitIn &br, LaneLds &L, const u16
     return 0;
 }
 
+// Lean bit reader for the wave-shared kernels: the words come from an LDS copy of the piece of stream the wave
+// works on (staged with coalesced loads, zero padded past the data), positions are 32-bit and relative to the first
+// staged word.  No range checks: the caller stages enough slack for the two words the reader runs ahead.
+struct BitL {
+    const u32 *w;
+    u32 widx;          // index of `nextw`
+    u64 buf;
+    u32 cnt;           // valid bits in buf
+    u32 nextw;
+    u32 pos;           // bits consumed (relative to word 0)
+    __device__ __forceinline__ void seek(u32 p)
+    {
+        pos = p;
+        const u32 i = p >> 5;
+        buf = (u64)w[i] >> (p & 31);
+        cnt = 32 - (p & 31);
+        widx = i + 1;
+        nextw = w[widx];
+        refill();
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if (cnt <= 32) {
+            buf |= (u64)nextw << cnt;
+            cnt += 32;
+            widx++;
+            nextw = w[widx];
+        }
+    }
+    __device__ __forceinline__ u32 peek() const { return (u32)buf; }
+    __device__ __forceinline__ void skip(u32 n) { buf >>= n; cnt -= n; pos += n; }
+    __device__ __forceinline__ u32 get(u32 n)      // n <= 13
+    {
+        refill();
+        const u32 v = (u32)buf & ((1u << n) - 1);
+        skip(n);
+        return v;
+    }
+};
+__device__ __forceinline__ int decode_token_fast(BitL &br, LaneLds &L, const u16 *lutl, const u16 *lutd, u32 &tok, u32 &olen)
+{
+    const u32 *LC = (const u32 *)(lutd + (1 << LUT_DBITS)), *DC = LC + 16;
+    br.refill();
+    u32 cl, sym;
+    const u32 e = lutl[br.peek() & ((1u << LUT_LBITS) - 1)];
+    if (e) { cl = e & 15; sym = e >> 4; }
+    else {
+        const int si = chain_decode_mem<15>(__brev(br.peek()) >> 17, LC, cl);
+        if (si < 0) return INF_CORRUPT;
+        sym = L.ls(si);
+    }
+    br.skip(cl);
+    if (sym < 256) { tok = sym; olen = 1; return 0; }
+    if (sym == 256) return 1;
+    sym -= 257;
+    if (sym >= 29) return INF_CORRUPT;
+    u32 eb, lbase;
+    if (sym < 8) { eb = 0; lbase = 3 + sym; }
+    else if (sym == 28) { eb = 0; lbase = 258; }
+    else { eb = (sym - 4) >> 2; lbase = 3 + ((4 + (sym & 3)) << eb); }
+    const u32 length = lbase + br.get(eb);
+    br.refill();
+    u32 dsym;
+    const u32 d = lutd[br.peek() & ((1u << LUT_DBITS) - 1)];
+    if (d) { cl = d & 15; dsym = d >> 4; }
+    else {
+        const int si = chain_decode_mem<15>(__brev(br.peek()) >> 17, DC, cl);
+        if (si < 0) return INF_CORRUPT;
+        dsym = L.ds(si);
+    }
+    br.skip(cl);
+    if (dsym >= 30) return INF_CORRUPT;
+    u32 dbase;
+    if (dsym < 4) { eb = 0; dbase = 1 + dsym; }
+    else { eb = (dsym - 2) >> 1; dbase = 1 + ((2 + (dsym & 1)) << eb); }
+    const u32 dist = dbase + br.get(eb);
+    tok = 0x80000000u | ((length - 3) << 16) | (dist - 1);
+    olen = length;
+    return 0;
+}
+
 // One whole deflate block, sequentially by one lane, starting at br.pos (reads BFINAL/BTYPE itself).
 // EMIT: write tokens to tk[ntok...].  nout = bytes produced so far in the stream (distance check).
 template <bool EMIT>
@@ -526,6 +607,7 @@ struct TrueBlk {
     u32 ntok;
     u32 chunk;
 };
+constexpr int PASSA_STAGE_WORDS = 64 * 1024 / 32 + 16;   // a round of pass A: 64 sub-sequences + the reader's look-ahead and a token's overshoot
 constexpr int PASSB_STAGE_WORDS = 3072;   // LDS copy of the 64 sub-sequences a wave decodes in one step (~2048 words + slack)
 constexpr int SUBCAP = 512;      // sub-sequences recorded per candidate block
 constexpr u32 SUB_BITS = 1024;   // bits per sub-sequence (measured 1024 .. 3072: shorter is faster, the lanes' serial chains dominate)
@@ -701,6 +783,26 @@ __device__ __forceinline__ void decode_span(BitIn &br, LaneLds &L, const u16 *lu
     }
 }
 
+// the same on the lean reader; `end` = first bit past the compressed data (relative, like the positions)
+template <int MODE>
+__device__ __forceinline__ void decode_span_fast(BitL &br, LaneLds &L, const u16 *lutl, const u16 *lutd, u32 stop, u32 end, u32 &ntok,
+                                                 u32 &nout, int &flag, u32 *tk, u32 want)
+{
+    flag = SPAN_CONT;
+    ntok = 0; nout = 0;
+    for (;;) {
+        if (MODE == 2) { if (ntok >= want) break; }
+        else if (br.pos >= stop) break;
+        u32 tok, olen;
+        const int t = decode_token_fast(br, L, lutl, lutd, tok, olen);
+        if (t < 0 || br.pos > end) { flag = SPAN_ERR; break; }
+        if (t == 1) { flag = SPAN_EOB; break; }
+        const u32 np = lz_pieces(tok, olen);
+        if (MODE == 2) lz_emit_pieces(tk + ntok, tok, olen);
+        ntok += np; nout += olen;
+    }
+}
+
 // position of the first lane (>= 1 bit set) in a ballot, or 64
 __device__ __forceinline__ int first_lane(u64 m) { return m ? __ffsll((long long)m) - 1 : 64; }
 
@@ -740,33 +842,43 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     u64 base = br.pos;
     u32 tot_tok = 0, tot_out = 0, nsub = 0;
     bool done = false, fail = false;
+    // a round = 64 sub-sequences: that piece of the stream (+ slack for the reader's look-ahead and the last token's
+    // overshoot) is staged in LDS; positions inside a round are relative to its first staged word
+    __shared__ u32 stage[PASSA_STAGE_WORDS];
+    BitL bl;
+    bl.w = stage;
     while (!done && !fail) {
-        const u64 stop = base + (u64)(lane + 1) * SUB_BITS;
-        u64 start = base + (u64)lane * SUB_BITS, ex;
+        const u64 wb0 = base >> 5;
+        const u32 bofs = (u32)(base & 31);
+        __builtin_amdgcn_wave_barrier();
+        for (u32 k2 = lane; k2 < (u32)PASSA_STAGE_WORDS; k2 += 64) stage[k2] = br.word(wb0 + k2);
+        __builtin_amdgcn_wave_barrier();
+        const u64 end_rel64 = br.end - (wb0 << 5);
+        const u32 end_rel = end_rel64 < 0x7fffffffull ? (u32)end_rel64 : 0x7fffffffu;
+        const u32 stop = bofs + (u32)(lane + 1) * SUB_BITS;
+        u32 start = bofs + (u32)lane * SUB_BITS, ex;
         u32 nt, no; int fl;
         // speculative pass: exits only
-        br.seek(start);
-        decode_span<0>(br, L, lutl, lutd, stop, nt, no, fl, nullptr, 0);
-        ex = br.pos;
+        bl.seek(start);
+        decode_span_fast<0>(bl, L, lutl, lutd, stop, end_rel, nt, no, fl, nullptr, 0);
+        ex = bl.pos;
         bool counted = false;
         for (int it = 0; it < 66; it++) {
             // true start of lane i = exit of lane i-1; lanes after the first EOB/ERR lane are void
-            const u64 pex = __shfl_up(ex, 1, 64);
-            const int pfl = __shfl_up(fl, 1, 64);
-            const u64 want_start = lane == 0 ? base : pex;
+            const u32 pex = __shfl_up(ex, 1, 64);
+            const u32 want_start = lane == 0 ? bofs : pex;
             const u64 stopm = __ballot(fl != SPAN_CONT);
             const int fstop = first_lane(stopm);              // lanes > fstop are void
             const bool valid = lane <= fstop;
-            (void)pfl;
             const bool redo = valid && (!counted || want_start != start);
             // (a lane that is void now may become valid later only if an earlier lane changes: handled
             //  because `counted` stays false for lanes that never ran the counting pass)
             if (!__any(redo)) break;
             if (redo) {
                 start = want_start;
-                br.seek(start);
-                decode_span<1>(br, L, lutl, lutd, stop, nt, no, fl, nullptr, 0);
-                ex = br.pos;
+                bl.seek(start);
+                decode_span_fast<1>(bl, L, lutl, lutd, stop, end_rel, nt, no, fl, nullptr, 0);
+                ex = bl.pos;
                 counted = true;
             }
         }
@@ -775,7 +887,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
         const int fstop = first_lane(stopm);
         const bool valid = lane <= fstop && counted;
         // verify (a lane could still be inconsistent if the iteration cap was hit)
-        const u64 pex = __shfl_up(ex, 1, 64);
+        const u32 pex = __shfl_up(ex, 1, 64);
         const bool bad = valid && lane > 0 && pex != start;
         if (__any(bad) || __any(lane <= fstop && !counted)) { fail = true; break; }
         // prefix sums of the token counts
@@ -787,16 +899,16 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
         }
         const int nvalid = fstop < 64 ? fstop + 1 : 64;
         if (nsub + nvalid > SUBCAP - 1) { fail = true; break; }
-        if (valid) sub[nsub + lane] = make_uint2((u32)(start - o), tot_tok + x - nt);
+        if (valid) sub[nsub + lane] = make_uint2((u32)((wb0 << 5) + start - o), tot_tok + x - nt);
         const u32 rt = __shfl(x, nvalid - 1, 64), ro = __shfl(y, nvalid - 1, 64);
         tot_tok += rt; tot_out += ro;
         nsub += nvalid;
         if (fstop < 64) {
             const int ffl = __shfl(fl, fstop, 64);
-            const u64 fex = __shfl(ex, fstop, 64);
-            if (ffl == SPAN_EOB) { done = true; r.end_bit = fex; }
+            const u32 fex = __shfl(ex, fstop, 64);
+            if (ffl == SPAN_EOB) { done = true; r.end_bit = (wb0 << 5) + fex; }
             else fail = true;
-        } else base = __shfl(ex, 63, 64);
+        } else base = (wb0 << 5) + (u32)__shfl(ex, 63, 64);
     }
     if (lane == 0) {
         if (done && !fail) {
@@ -952,18 +1064,25 @@ __global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, 
         const u32 jl = min(j0 + 64, nsub);
         const u64 wlo = (tb.start_bit + sub[j0].x) >> 5, whi = ((tb.start_bit + sub[jl].x) >> 5) + 3;
         __builtin_amdgcn_wave_barrier();
-        br.lwn = 0;
-        if (whi - wlo < (u64)PASSB_STAGE_WORDS) {
+        const bool staged = whi - wlo < (u64)PASSB_STAGE_WORDS;
+        if (staged) {
             const u32 nw = (u32)(whi - wlo) + 1;
             for (u32 k = lane; k < nw; k += 64) stage[k] = br.word(wlo + k);
-            br.lw = stage; br.lw0 = wlo; br.lwn = nw;
         }
         __builtin_amdgcn_wave_barrier();
         if (j < nsub) {
             const uint2 a = sub[j], b = sub[j + 1];
-            br.seek(tb.start_bit + a.x);
             u32 nt, no; int fl;
-            decode_span<2>(br, L, lutl, lutd, 0, nt, no, fl, tk + a.y, b.y - a.y);
+            if (staged) {
+                BitL bl;
+                bl.w = stage;
+                const u64 end_rel64 = br.end - (wlo << 5);
+                bl.seek((u32)(tb.start_bit + a.x - (wlo << 5)));
+                decode_span_fast<2>(bl, L, lutl, lutd, 0, end_rel64 < 0x7fffffffull ? (u32)end_rel64 : 0x7fffffffu, nt, no, fl, tk + a.y, b.y - a.y);
+            } else {
+                br.seek(tb.start_bit + a.x);
+                decode_span<2>(br, L, lutl, lutd, 0, nt, no, fl, tk + a.y, b.y - a.y);
+            }
             if (nt != b.y - a.y) res[ci].status = MTS_CHUNK_CORRUPT;
         }
     }
