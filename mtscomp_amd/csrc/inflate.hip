@@ -301,62 +301,82 @@ __device__ __forceinline__ int decode_token(BitIn &br, LaneLds &L, const u32 (&L
 }
 
 // Wave-shared lookup tables for the kernels in which all 64 lanes decode the SAME block: the next LUT_LBITS
-// (LUT_DBITS) stream bits index a u16 = symbol << 4 | code length; 0 = the code is longer (or invalid): those
-// go through the compare chain.  The tables are filled by decoding every index with the compare chain once.
+// (LUT_DBITS) stream bits index a 32-bit entry that already holds what the symbol means:
+//   [3:0] code length (0 = the code is longer than the index, or invalid: those go through the compare chain)
+//   [5:4] 0 literal, 1 length / distance, 2 end of block, 3 invalid symbol
+//   [23:8] literal byte, or base length / base distance      [27:24] number of extra bits
+// The tables are filled by decoding every index with the compare chain once.
 constexpr int LUT_LBITS = 10, LUT_DBITS = 8;
-constexpr int LUT_BYTES = 2 * ((1 << LUT_LBITS) + (1 << LUT_DBITS)) + 2 * 16 * 4;      // tables + the two compare chains
-// lutl: lit/len table, then the distance table, then the chains LC[16], DC[16] (already there: parse_tables wrote them)
-__device__ __forceinline__ void build_luts(LaneLds &L, u16 *lutl, u16 *lutd, int lane)
+constexpr int LUT_BYTES = 4 * ((1 << LUT_LBITS) + (1 << LUT_DBITS)) + 2 * 16 * 4;      // tables + the two compare chains
+__device__ __forceinline__ u32 lut_len_entry(u32 sym, u32 cl)
 {
-    const u32 *LC = (const u32 *)(lutd + (1 << LUT_DBITS)), *DC = LC + 16;
-    for (u32 e = lane; e < (1u << LUT_LBITS); e += 64) {
-        u32 cl;
-        const int si = chain_decode_mem<15>(__brev(e) >> 17, LC, cl);
-        lutl[e] = (si >= 0 && cl <= (u32)LUT_LBITS) ? (u16)(((u32)L.ls(si) << 4) | cl) : (u16)0;
-    }
-    for (u32 e = lane; e < (1u << LUT_DBITS); e += 64) {
-        u32 cl;
-        const int si = chain_decode_mem<15>(__brev(e) >> 17, DC, cl);
-        lutd[e] = (si >= 0 && cl <= (u32)LUT_DBITS) ? (u16)(((u32)L.ds(si) << 4) | cl) : (u16)0;
-    }
-}
-__device__ __forceinline__ int decode_token_lut(BitIn &br, LaneLds &L, const u16 *lutl, const u16 *lutd, u32 &tok, u32 &olen)
-{
-    const u32 *LC = (const u32 *)(lutd + (1 << LUT_DBITS)), *DC = LC + 16;
-    br.refill();
-    u32 cl, sym;
-    const u32 e = lutl[br.peek() & ((1u << LUT_LBITS) - 1)];
-    if (e) { cl = e & 15; sym = e >> 4; }
-    else {
-        const int si = chain_decode_mem<15>(__brev(br.peek()) >> 17, LC, cl);
-        if (si < 0) return INF_CORRUPT;
-        sym = L.ls(si);
-    }
-    br.skip(cl);
-    if (sym < 256) { tok = sym; olen = 1; return 0; }
-    if (sym == 256) return 1;
+    if (sym < 256) return (sym << 8) | cl;
+    if (sym == 256) return (2u << 4) | cl;
     sym -= 257;
-    if (sym >= 29) return INF_CORRUPT;
+    if (sym >= 29) return (3u << 4) | cl;
     u32 eb, lbase;
     if (sym < 8) { eb = 0; lbase = 3 + sym; }
     else if (sym == 28) { eb = 0; lbase = 258; }
     else { eb = (sym - 4) >> 2; lbase = 3 + ((4 + (sym & 3)) << eb); }
-    const u32 length = lbase + br.get(eb);
-    br.refill();
-    u32 dsym;
-    const u32 d = lutd[br.peek() & ((1u << LUT_DBITS) - 1)];
-    if (d) { cl = d & 15; dsym = d >> 4; }
-    else {
-        const int si = chain_decode_mem<15>(__brev(br.peek()) >> 17, DC, cl);
-        if (si < 0) return INF_CORRUPT;
-        dsym = L.ds(si);
-    }
-    br.skip(cl);
-    if (dsym >= 30) return INF_CORRUPT;
-    u32 dbase;
+    return (eb << 24) | (lbase << 8) | (1u << 4) | cl;
+}
+__device__ __forceinline__ u32 lut_dist_entry(u32 dsym, u32 cl)
+{
+    if (dsym >= 30) return (3u << 4) | cl;
+    u32 eb, dbase;
     if (dsym < 4) { eb = 0; dbase = 1 + dsym; }
     else { eb = (dsym - 2) >> 1; dbase = 1 + ((2 + (dsym & 1)) << eb); }
-    const u32 dist = dbase + br.get(eb);
+    return (eb << 24) | (dbase << 8) | (1u << 4) | cl;
+}
+// lutl: lit/len table, then the distance table, then the chains LC[16], DC[16] (already there: parse_tables wrote them)
+__device__ __forceinline__ void build_luts(LaneLds &L, u32 *lutl, u32 *lutd, int lane)
+{
+    const u32 *LC = lutd + (1 << LUT_DBITS), *DC = LC + 16;
+    for (u32 e = lane; e < (1u << LUT_LBITS); e += 64) {
+        u32 cl;
+        const int si = chain_decode_mem<15>(__brev(e) >> 17, LC, cl);
+        lutl[e] = (si >= 0 && cl <= (u32)LUT_LBITS) ? lut_len_entry(L.ls(si), cl) : 0u;
+    }
+    for (u32 e = lane; e < (1u << LUT_DBITS); e += 64) {
+        u32 cl;
+        const int si = chain_decode_mem<15>(__brev(e) >> 17, DC, cl);
+        lutd[e] = (si >= 0 && cl <= (u32)LUT_DBITS) ? lut_dist_entry(L.ds(si), cl) : 0u;
+    }
+}
+// One token through the tables; READER = BitIn or BitL.  Returns 0 literal/match decoded, 1 end of block, <0 error.
+template <class READER>
+__device__ __forceinline__ int decode_token_lut(READER &br, LaneLds &L, const u32 *lutl, const u32 *lutd, u32 &tok, u32 &olen)
+{
+    const u32 *LC = lutd + (1 << LUT_DBITS), *DC = LC + 16;
+    br.refill();
+    u32 p = br.peek();
+    u32 e = lutl[p & ((1u << LUT_LBITS) - 1)];
+    if (!(e & 15)) {
+        u32 cl;
+        const int si = chain_decode_mem<15>(__brev(p) >> 17, LC, cl);
+        if (si < 0) return INF_CORRUPT;
+        e = lut_len_entry(L.ls(si), cl);
+    }
+    const u32 type = (e >> 4) & 3, cl = e & 15;
+    if (type == 0) { br.skip(cl); tok = (e >> 8) & 0xff; olen = 1; return 0; }
+    if (type == 2) { br.skip(cl); return 1; }
+    if (type == 3) return INF_CORRUPT;
+    const u32 eb = e >> 24;
+    const u32 length = ((e >> 8) & 0xffff) + ((p >> cl) & ((1u << eb) - 1));      // code + extra bits: <= 15 + 5 of the >= 32 valid bits
+    br.skip(cl + eb);
+    br.refill();
+    p = br.peek();
+    u32 d = lutd[p & ((1u << LUT_DBITS) - 1)];
+    if (!(d & 15)) {
+        u32 dl;
+        const int si = chain_decode_mem<15>(__brev(p) >> 17, DC, dl);
+        if (si < 0) return INF_CORRUPT;
+        d = lut_dist_entry(L.ds(si), dl);
+    }
+    if (((d >> 4) & 3) == 3) return INF_CORRUPT;
+    const u32 dcl = d & 15, deb = d >> 24;
+    const u32 dist = ((d >> 8) & 0xffff) + ((p >> dcl) & ((1u << deb) - 1));      // <= 15 + 13 bits
+    br.skip(dcl + deb);
     tok = 0x80000000u | ((length - 3) << 16) | (dist - 1);
     olen = length;
     return 0;
@@ -401,48 +421,6 @@ struct BitL {
         return v;
     }
 };
-__device__ __forceinline__ int decode_token_fast(BitL &br, LaneLds &L, const u16 *lutl, const u16 *lutd, u32 &tok, u32 &olen)
-{
-    const u32 *LC = (const u32 *)(lutd + (1 << LUT_DBITS)), *DC = LC + 16;
-    br.refill();
-    u32 cl, sym;
-    const u32 e = lutl[br.peek() & ((1u << LUT_LBITS) - 1)];
-    if (e) { cl = e & 15; sym = e >> 4; }
-    else {
-        const int si = chain_decode_mem<15>(__brev(br.peek()) >> 17, LC, cl);
-        if (si < 0) return INF_CORRUPT;
-        sym = L.ls(si);
-    }
-    br.skip(cl);
-    if (sym < 256) { tok = sym; olen = 1; return 0; }
-    if (sym == 256) return 1;
-    sym -= 257;
-    if (sym >= 29) return INF_CORRUPT;
-    u32 eb, lbase;
-    if (sym < 8) { eb = 0; lbase = 3 + sym; }
-    else if (sym == 28) { eb = 0; lbase = 258; }
-    else { eb = (sym - 4) >> 2; lbase = 3 + ((4 + (sym & 3)) << eb); }
-    const u32 length = lbase + br.get(eb);
-    br.refill();
-    u32 dsym;
-    const u32 d = lutd[br.peek() & ((1u << LUT_DBITS) - 1)];
-    if (d) { cl = d & 15; dsym = d >> 4; }
-    else {
-        const int si = chain_decode_mem<15>(__brev(br.peek()) >> 17, DC, cl);
-        if (si < 0) return INF_CORRUPT;
-        dsym = L.ds(si);
-    }
-    br.skip(cl);
-    if (dsym >= 30) return INF_CORRUPT;
-    u32 dbase;
-    if (dsym < 4) { eb = 0; dbase = 1 + dsym; }
-    else { eb = (dsym - 2) >> 1; dbase = 1 + ((2 + (dsym & 1)) << eb); }
-    const u32 dist = dbase + br.get(eb);
-    tok = 0x80000000u | ((length - 3) << 16) | (dist - 1);
-    olen = length;
-    return 0;
-}
-
 // One whole deflate block, sequentially by one lane, starting at br.pos (reads BFINAL/BTYPE itself).
 // EMIT: write tokens to tk[ntok...].  nout = bytes produced so far in the stream (distance check).
 template <bool EMIT>
@@ -763,7 +741,7 @@ __global__ __launch_bounds__(256) void k_inf_sortc(const InfFast *__restrict__ f
 enum { SPAN_CONT = 0, SPAN_EOB = 1, SPAN_ERR = 2 };
 
 template <int MODE>      // 0: find the exit only, 1: count, 2: emit `want` tokens to tk
-__device__ __forceinline__ void decode_span(BitIn &br, LaneLds &L, const u16 *lutl, const u16 *lutd, u64 stop, u32 &ntok, u32 &nout,
+__device__ __forceinline__ void decode_span(BitIn &br, LaneLds &L, const u32 *lutl, const u32 *lutd, u64 stop, u32 &ntok, u32 &nout,
                                             int &flag, u32 *tk, u32 want)
 {
     flag = SPAN_CONT;
@@ -785,7 +763,7 @@ __device__ __forceinline__ void decode_span(BitIn &br, LaneLds &L, const u16 *lu
 
 // the same on the lean reader; `end` = first bit past the compressed data (relative, like the positions)
 template <int MODE>
-__device__ __forceinline__ void decode_span_fast(BitL &br, LaneLds &L, const u16 *lutl, const u16 *lutd, u32 stop, u32 end, u32 &ntok,
+__device__ __forceinline__ void decode_span_fast(BitL &br, LaneLds &L, const u32 *lutl, const u32 *lutd, u32 stop, u32 end, u32 &ntok,
                                                  u32 &nout, int &flag, u32 *tk, u32 want)
 {
     flag = SPAN_CONT;
@@ -794,7 +772,7 @@ __device__ __forceinline__ void decode_span_fast(BitL &br, LaneLds &L, const u16
         if (MODE == 2) { if (ntok >= want) break; }
         else if (br.pos >= stop) break;
         u32 tok, olen;
-        const int t = decode_token_fast(br, L, lutl, lutd, tok, olen);
+        const int t = decode_token_lut(br, L, lutl, lutd, tok, olen);
         if (t < 0 || br.pos > end) { flag = SPAN_ERR; break; }
         if (t == 1) { flag = SPAN_EOB; break; }
         const u32 np = lz_pieces(tok, olen);
@@ -829,9 +807,9 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     r.end_bit = 0; r.ntok = 0; r.nout = 0; r.nsub = 0; r.ok = 0; r.bfinal = 0; r.pad = 0;
     const u32 hdr = br.get(3);
     r.bfinal = hdr & 1;
-    __shared__ u16 lut_s[LUT_BYTES / 2];
-    u16 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
-    u32 *LC = (u32 *)(lutd + (1 << LUT_DBITS)), *DC = LC + 16;      // the compare chains live in LDS (wave-shared)
+    __shared__ u32 lut_s[LUT_BYTES / 4];
+    u32 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
+    u32 *LC = lutd + (1 << LUT_DBITS), *DC = LC + 16;               // the compare chains live in LDS (wave-shared)
     // every lane parses the header redundantly (identical control flow, identical LDS writes)
     const int rc = parse_tables(br, L, hdr >> 1, LC, DC);
     if (rc != INF_OK) { if (lane == 0) cres[slot] = r; return; }
@@ -1046,9 +1024,9 @@ __global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, 
         return;
     }
     const u32 hdr = br.get(3);
-    __shared__ u16 lut_s[LUT_BYTES / 2];
-    u16 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
-    u32 *LC = (u32 *)(lutd + (1 << LUT_DBITS)), *DC = LC + 16;      // the compare chains live in LDS (wave-shared)
+    __shared__ u32 lut_s[LUT_BYTES / 4];
+    u32 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
+    u32 *LC = lutd + (1 << LUT_DBITS), *DC = LC + 16;               // the compare chains live in LDS (wave-shared)
     if (parse_tables(br, L, hdr >> 1, LC, DC) != INF_OK) { if (lane == 0) res[ci].status = MTS_CHUNK_CORRUPT; return; }
     __builtin_amdgcn_wave_barrier();
     build_luts(L, lutl, lutd, lane);
