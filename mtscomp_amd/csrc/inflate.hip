@@ -554,6 +554,7 @@ __device__ bool validate_dyn_header(const u32 *w, u64 nwords, u64 end, u64 o)
             if (nl && val > maxl) maxl = val;
             if (nd && val > maxd) maxd = val;
             if (idx <= 256 && 256 < idx + rep) len256 = val;
+            if (kl > 32768u || kd > 32768u) return false;       // over-subscribed already: random bits get here after ~50 symbols
         }
         idx += rep;
         if (br.pos > end) return false;
