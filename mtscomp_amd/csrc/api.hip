@@ -320,12 +320,9 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
 // split a call into sub-batches that fit the workspace budget (stream bytes per sub-batch)
 static size_t batch_budget_bytes()
 {
-    static size_t v = 0;
-    if (!v) {
-        const char *e = getenv("MTS_BATCH_BYTES");
-        v = e ? (size_t)atoll(e) : ((size_t)3 << 30);      // 3 GiB of stream -> ~75 GiB of workspace
-        if (v < (1u << 20)) v = 1u << 20;
-    }
+    const char *e = getenv("MTS_BATCH_BYTES");               // read per call: tests force small sub-batches with it
+    size_t v = e ? (size_t)atoll(e) : ((size_t)3 << 30);     // 3 GiB of stream -> ~75 GiB of workspace
+    if (v < (1u << 20)) v = 1u << 20;
     return v;
 }
 

@@ -7,12 +7,17 @@ import numpy as np
 import pytest
 
 from mtscomp_amd import hip
+from mtscomp_amd.synth import synth_int16
 from oracle import oracle as O
 from tests import inputs
 from tests.inputs import cases_small, ar1_stream, repeats
 
 pytestmark = pytest.mark.gpu
 CASES = cases_small()
+
+
+def synth_rows(nt, nc, seed):
+    return synth_int16(seed * 100000, seed * 100000 + nt, nc, 0)
 
 
 def _first_diff(a, b):
@@ -191,6 +196,23 @@ def test_inflate_errors():
             assert st != 0
         else:
             assert st == 0 and out == want
+
+
+def test_sub_batches(monkeypatch):
+    """A call bigger than the workspace budget is split into sub-batches (MTS_BATCH_BYTES forces it: 1 MiB of stream
+    per compress sub-batch, 4 MiB per decompress sub-batch, against 9 chunks of 0.3 .. 1.2 MB)."""
+    monkeypatch.setenv('MTS_BATCH_BYTES', str(1 << 20))
+    r = np.random.RandomState(9)
+    chunks = [synth_rows(int(n), 64, k) for k, n in enumerate(r.randint(2400, 9600, size=9))]
+    flags = 5
+    bounds = np.concatenate(([0], np.cumsum([c.shape[0] for c in chunks])))
+    cbufs = hip.compress_chunks(np.concatenate(chunks, axis=0), bounds, flags, 6)
+    for c, z in zip(chunks, cbufs):
+        assert bytes(z) == O.ref_compress_chunk(c)
+    st, back = hip.decompress_chunks(cbufs, [c.shape[0] for c in chunks], 64, 'int16', flags)
+    assert st == [0] * len(chunks)
+    for c, b in zip(chunks, back):
+        assert np.array_equal(c, b)
 
 
 def test_inflate_errors_segmented_resolver(monkeypatch):
