@@ -7,17 +7,20 @@
 //   S  k_hash_sort     per tile (TILE owned positions + HALO history): stable 2-pass radix sort of the
 //                      positions by their 15-bit zlib hash -> every hash chain becomes a contiguous,
 //                      position-ordered run (parse independent because deflate_slow inserts every
-//                      position).
-//   M  k_match         per tile: window bytes in LDS; one lane per position walks its run newest first
-//                      (<= chain candidates, stop at nice / MAX_DIST) and records the best match within
-//                      the full budget and within budget>>2 (the prev_length >= good_match case).
+//                      position).  Ranking by lane-ordered LDS atomics (probed), ballots as fallback.
+//   M  k_match5        (budgets <= 128) per tile: a wave walks contiguous 64-slot groups of the sorted order
+//                      with a ring of per-slot entries in LDS; one lane per position scores, newest
+//                      first, only the candidates its looked-up filter masks let through, and records
+//                      the best match within the full budget and within budget>>2 (the
+//                      prev_length >= good_match case).  k_match4: budgets > 128, SWAR key compares.
 //   P  k_parse_*       lazy-evaluation state machine over the tables; one lane per SEG positions,
 //                      speculative entry, iterated to a fixed point (walks re-converge after a few
-//                      tokens); then count + emit tokens.
+//                      tokens); then count + emit tokens (LDS rows, written out coalesced).
 //   T  k_block_trees   per 16383-token block: symbol histogram (LDS atomics) and zlib's exact
 //                      build_tree / gen_bitlen / scan_tree by one lane; stored/fixed/dynamic choice.
 //   L  k_block_layout  per chunk: bit offsets of the blocks, stream size, adler32.
-//   B  k_block_pack    per block: canonical codes -> bitstream (each lane packs a run of tokens).
+//   B  k_block_pack    per block: codes OR-ed into an LDS image of the block at scanned bit positions,
+//                      image written out as whole words.
 #include <stdlib.h>
 
 #include "common.h"

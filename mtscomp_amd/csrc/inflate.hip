@@ -3,13 +3,14 @@
 // encoder), verifies the adler32 trailer, ignores trailing bytes, reports corruption per chunk
 // (mtscomp.py:620-621).  orc_inflate() in oracle/mtsc_oracle.c is the oracle.
 //
-// Two passes per chunk:
-//   H  k_inf_decode   bitstream -> token list (literal | (length, distance)); Huffman decoding by
-//                     canonical-code compare chains held in registers (no big lookup tables), symbol
-//                     tables lane-interleaved in LDS.
-//   Z  k_inf_lz       token list -> bytes: one wave per chunk, 64 tokens per step; the 32 KiB history
-//                     lives in an LDS ring; copies that only need older bytes run in parallel,
-//                     the few that depend on the current step are resolved in lane order.
+// Fast path (dynamic-Huffman streams, i.e. what zlib writes for this kind of data):
+//   k_inf_scan/validate  every bit offset is tested for a well-formed dynamic block header -> candidate block starts
+//   k_inf_passA          wave per candidate: 64 lanes decode 64 consecutive sub-sequences, re-synchronise, count tokens
+//   k_inf_chain          wave per chunk: accept candidates only where the previous block really ends
+//   k_inf_passB          wave per accepted block: decode again from the recorded starts, write tokens
+//   k_inf_decode         one lane per chunk, sequential: authoritative for whatever the fast path declined
+//   k_inf_lz(_seg) ...   tokens -> bytes through an LDS ring with per-byte dataflow (see "Z" below); a chunk is cut
+//                        into segments resolved on symbolic 16-bit cells when there are fewer chunks than CUs
 // followed by the adler32 reduction over the produced stream.
 #include <stdlib.h>
 
