@@ -744,18 +744,24 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
 // One step of the state machine from a base state (no pending match) at p0.  Emits the literals
 // b[p0 .. mpos-1] followed by match (mlen, mdist) at mpos, or the single literal b[p0] when mlen == 0.
 // Returns the next base position.
+// the entries of positions p and p + 1 with one 16-byte load (8-byte aligned; the tables have slack past n): nearly
+// every step looks at both, and for lanes that are each somewhere else in memory the number of load instructions
+// is what the address unit charges for
+typedef u32 u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 template <class RD>
-__device__ __forceinline__ u32 lazy_step(RD &&rd, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos, u32 &mlen, u32 &mdist)
+__device__ __forceinline__ u32 lazy_step(RD &&rd, const uint2 *T, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos, u32 &mlen, u32 &mdist)
 {
     u32 p = p0;
-    const u32 c = rd(p).x;
+    const u32x4_a8 pr = *(const u32x4_a8 *)&T[p];
+    const u32 c = pr.x;
     u32 len = c >> 16, dist = c & 0xffff;
     if (len == MIN_MATCH && dist > (u32)TOO_FAR) len = 0;
     if (len < MIN_MATCH) { mpos = p0; mlen = 0; mdist = 0; return p0 + 1; }
+    uint2 d2 = make_uint2(pr.z, pr.w);
     for (;;) {
         const u32 q = p + 1;
         if (q < n && len < (u32)cfg.lazy) {
-            const uint2 d2 = rd(q);
+            if (q != p0 + 1) d2 = rd(q);
             const u32 d = len >= (u32)cfg.good ? d2.y : d2.x;
             if ((d >> 16) > len) { p = q; len = d >> 16; dist = d & 0xffff; continue; }
         }
@@ -791,7 +797,7 @@ __global__ __launch_bounds__(64) void k_parse_spec(const uint2 *__restrict__ tab
     while (pos < segend) {
         while (k < 8 && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++; }
         const u32 p0 = pos;
-        pos = lazy_step(rd, pos, n, cfg, mp, ml, md);
+        pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md);
         cnt += mp - p0 + 1;
     }
     for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }      // checkpoints past the exit
@@ -836,7 +842,7 @@ __global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tabl
             return;
         }
         const u32 p0 = pos;
-        pos = lazy_step(rd, pos, n, cfg, mp, ml, md);
+        pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md);
         cnt += mp - p0 + 1;
     }
     for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }
@@ -913,7 +919,7 @@ __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream
         };
         while (act && pos < segend && k - k0 < (u32)PTCAP) {
             const u32 p0 = pos;
-            pos = lazy_step(rd, pos, n, cfg, mp, ml, md);
+            pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md);
             if (pos >= n) cout[ci].trailing = (ml == 0) ? 1u : 0u;       // last token of the chunk
             const u32 nlit = ml ? mp - p0 : 1;
             for (u32 q = 0; q < nlit; q++) put((u32)b[p0 + q] << 16, p0 + q);
