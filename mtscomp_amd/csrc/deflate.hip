@@ -588,22 +588,36 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         SX[rp] = x;
         return ce;
     };
-    // bytes 7..14 of the string at window offset r, given its bytes 4..7
-    auto ext_bytes = [&](u32 r, u32 hi) -> u64 { return (u64)(hi >> 24) | ((u64)wread(r + 8) << 8) | ((u64)(wread(r + 12) & 0xffffffu) << 40); };
+    // bytes 0..15 of the string at window offset r: TWO loads (the five dwords around it), not four unaligned ones -- the
+    // lanes are each somewhere else in the window, and the address unit charges by the instruction
+    typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    auto load16 = [&](u32 r, u32 &lo, u32 &hi, u64 &x) {
+        const u8 *q = gwin + (r & ~3u);
+        const u32x4_a4 w = *(const u32x4_a4 *)q;
+        const u32 w4 = *(const u32 *)(q + 16);
+        lo = alignbyte(w.y, w.x, r);
+        hi = alignbyte(w.z, w.y, r);
+        const u32 b8 = alignbyte(w.w, w.z, r), b12 = alignbyte(w4, w.w, r);
+        x = (u64)(hi >> 24) | ((u64)b8 << 8) | ((u64)(b12 & 0xffffffu) << 40);      // bytes 7..14
+    };
     auto slot_rel = [&](int idx) -> u32 { return sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1] & REL_MASK; };
     const int i_first = (int)g_begin * 64 + lane;
     {
         u32 kk[M5_LEVELS];
         bool sr;
         const u32 ra = slot_rel(i_first - 128), rb = slot_rel(i_first - 64);
-        const u32 la = wread(ra), ha = wread(ra + 4), lb = wread(rb), hb = wread(rb + 4);
-        commit(i_first - 128, ra, la, ha, ext_bytes(ra, ha), kk, sr);
-        commit(i_first - 64, rb, lb, hb, ext_bytes(rb, hb), kk, sr);
+        u32 la, ha, lb, hb;
+        u64 xa, xb;
+        load16(ra, la, ha, xa);
+        load16(rb, lb, hb, xb);
+        commit(i_first - 128, ra, la, ha, xa, kk, sr);
+        commit(i_first - 64, rb, lb, hb, xb, kk, sr);
     }
     // pipeline: (rc, lo, hi, nb) of the group about to be walked, rc of the one after
     u32 rc_c = slot_rel(i_first), rc_n = slot_rel(i_first + 64);
-    u32 lo_c = wread(rc_c), hi_c = wread(rc_c + 4);
-    u64 x_c = ext_bytes(rc_c, hi_c);
+    u32 lo_c, hi_c;
+    u64 x_c;
+    load16(rc_c, lo_c, hi_c, x_c);
     for (u32 g = g_begin; g < g_end; g++) {
         const u32 i0 = g * 64, i = i0 + lane;
         u32 key[M5_LEVELS];
@@ -614,8 +628,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         __builtin_amdgcn_wave_barrier();
         // next group's words, and the position of the one after
         rc_c = rc_n;
-        lo_c = wread(rc_c); hi_c = wread(rc_c + 4);
-        x_c = ext_bytes(rc_c, hi_c);
+        load16(rc_c, lo_c, hi_c, x_c);
         rc_n = slot_rel((int)i + 128);
         const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
         const u32 rel_p = e0 & REL_MASK;
