@@ -306,7 +306,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         if (tap->t_full && n) {
             std::vector<uint2> h(n);
             MTS_HIP(hipMemcpy(h.data(), d_tables + cd[0].stream_off, sizeof(uint2) * n, hipMemcpyDeviceToHost));
-            for (u32 i = 0; i < n; i++) { tap->t_full[i] = h[i].x; tap->t_quarter[i] = h[i].y; }
+            for (u32 i = 0; i < n; i++) { tap->t_full[i] = h[i].x & 0x01ffffffu; tap->t_quarter[i] = h[i].y & 0x01ffffffu; }      // (the spare bits carry the position's byte)
         }
         if (tap->tokens) {
             const u32 nt = h_cout[0].ntok;

@@ -302,6 +302,12 @@ int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles
 //   w1         bytes 3..6
 // so the common prefix of two same-hash positions is known exactly up to 7 bytes from the entries alone;
 // only longer matches go back to the window bytes.
+// A table entry is two words (full budget, quarter budget) of  len << 16 | dist  (len <= 258: 25 bits).  The spare bits
+// carry the position's own byte (low 7 bits in x[31:25], top bit in y[31]), so the emitting walk, which loads the
+// entries of the literals it emits anyway, never touches the stream.
+__device__ __forceinline__ uint2 table_entry(u32 full, u32 quarter, u32 byte) { return make_uint2(full | ((byte & 0x7f) << 25), quarter | ((byte >> 7) << 31)); }
+__device__ __forceinline__ u32 entry_byte(u32 x, u32 y) { return (x >> 25) | ((y >> 31) << 7); }
+constexpr u32 ENTRY_MASK = 0x01ffffffu;
 __device__ __forceinline__ u64 make_entry(u32 rel, u32 lo, u32 hi)       // lo = bytes 0..3, hi = bytes 4..7
 {
     const u32 b0 = lo & 0xff, b1 = (lo >> 8) & 0xff;
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(1024, 2) void k_match4(const u8 *__restrict__ strea
     if (threadIdx.x < 2) {
         const u32 hashed_end = td.w + td.wlen;
         const u32 p = hashed_end + threadIdx.x;
-        if (p >= td.a && p < td.own_end) T[p] = make_uint2(0, 0);
+        if (p >= td.a && p < td.own_end) T[p] = table_entry(0, 0, stream[td.stream_off + p]);
     }
     if (td.wlen == 0) return;
     const u32 *sk = sorted + td.sorted_off;
@@ -403,8 +409,9 @@ __global__ __launch_bounds__(1024, 2) void k_match4(const u8 *__restrict__ strea
     for (u32 g = g_begin; g < g_end; g += g_step) {
         const u32 i0 = g * 64, i = i0 + lane;
         u64 e;
+        u32 own_lo = 0;
         if (SLIDE) { __builtin_amdgcn_wave_barrier(); e = build((int)i, (int)(i & 255)); __builtin_amdgcn_wave_barrier(); }
-        else { const u32 rp = i < wlen ? sk[i] & REL_MASK : 0; e = make_entry(rp, wread(rp), wread(rp + 4)); }
+        else { const u32 rp = i < wlen ? sk[i] & REL_MASK : 0; own_lo = wread(rp); e = make_entry(rp, own_lo, wread(rp + 4)); }
         const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
         const u32 rel_p = e0 & REL_MASK;
         const bool own = i < wlen && rel_p >= halo;
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(1024, 2) void k_match4(const u8 *__restrict__ strea
             if (!__any(!stop && nbv > jbase + 128)) break;
         }
         if (!qtaken) { qbest = best; qdist = bdist; }
-        if (own) T[p_abs] = make_uint2(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0);
+        if (own) T[p_abs] = table_entry(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0, own_lo & 0xff);
     }
 }
 
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     if (threadIdx.x < 2) {
         const u32 hashed_end = td.w + td.wlen;
         const u32 p = hashed_end + threadIdx.x;
-        if (p >= td.a && p < td.own_end) T[p] = make_uint2(0, 0);
+        if (p >= td.a && p < td.own_end) T[p] = table_entry(0, 0, stream[td.stream_off + p]);
     }
     if (td.wlen == 0) return;
     const u32 *sk = sorted + td.sorted_off;
@@ -625,6 +632,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         bool starts_run;
         const u64 e = commit((int)i, rc_c, lo_c, hi_c, x_c, key, starts_run);
         const u64 ex = x_c;
+        const u32 own_lo = lo_c;                                   // (byte 0 of this lane's own position rides along in its table entry)
         __builtin_amdgcn_wave_barrier();
         // next group's words, and the position of the one after
         rc_c = rc_n;
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         MTS_WALK(1, 0xffffffffu);
         MTS_WALK(0, 0xffffffffu);
 #undef MTS_WALK
-        if (own) T[p_abs] = make_uint2(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0);
+        if (own) T[p_abs] = table_entry(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0, own_lo & 0xff);
     }
 }
 
@@ -762,11 +770,13 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
 // is what the address unit charges for
 typedef u32 u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 template <class RD>
-__device__ __forceinline__ u32 lazy_step(RD &&rd, const uint2 *T, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos, u32 &mlen, u32 &mdist)
+__device__ __forceinline__ u32 lazy_step(RD &&rd, const uint2 *T, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos, u32 &mlen, u32 &mdist,
+                                         u32 &byte0, u32 &byte1)
 {
     u32 p = p0;
     const u32x4_a8 pr = *(const u32x4_a8 *)&T[p];
-    const u32 c = pr.x;
+    byte0 = entry_byte(pr.x, pr.y); byte1 = entry_byte(pr.z, pr.w);      // the bytes at p0 and p0 + 1
+    const u32 c = pr.x & ENTRY_MASK;
     u32 len = c >> 16, dist = c & 0xffff;
     if (len == MIN_MATCH && dist > (u32)TOO_FAR) len = 0;
     if (len < MIN_MATCH) { mpos = p0; mlen = 0; mdist = 0; return p0 + 1; }
@@ -775,7 +785,7 @@ __device__ __forceinline__ u32 lazy_step(RD &&rd, const uint2 *T, u32 p0, u32 n,
         const u32 q = p + 1;
         if (q < n && len < (u32)cfg.lazy) {
             if (q != p0 + 1) d2 = rd(q);
-            const u32 d = len >= (u32)cfg.good ? d2.y : d2.x;
+            const u32 d = (len >= (u32)cfg.good ? d2.y : d2.x) & ENTRY_MASK;
             if ((d >> 16) > len) { p = q; len = d >> 16; dist = d & 0xffff; continue; }
         }
         break;
@@ -806,11 +816,11 @@ __global__ __launch_bounds__(64) void k_parse_spec(const uint2 *__restrict__ tab
     const uint2 *T = tables + ch.stream_off;
     auto rd = [&](u32 q) -> uint2 { return T[q]; };
     u32 *cp = pb.cp + (u64)g * 16;
-    u32 pos = s, mp, ml, md, cnt = 0, k = 1;
+    u32 pos = s, mp, ml, md, cnt = 0, k = 1, lb0, lb1;
     while (pos < segend) {
         while (k < 8 && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++; }
         const u32 p0 = pos;
-        pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md);
+        pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md, lb0, lb1);
         cnt += mp - p0 + 1;
     }
     for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }      // checkpoints past the exit
@@ -839,7 +849,7 @@ __global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tabl
     auto rd = [&](u32 q) -> uint2 { return T[q]; };
     u32 *cp = pb.cp + (u64)g * 16;
     const u32 old_cnt = pb.cnt[g];
-    u32 pos = ne, mp, ml, md, cnt = 0, k = 1;
+    u32 pos = ne, mp, ml, md, cnt = 0, k = 1, lb0, lb1;
     while (pos < segend) {
         bool merged = false;
         while (k < 8 && pos >= s + k * PARSE_CP) {
@@ -855,7 +865,7 @@ __global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tabl
             return;
         }
         const u32 p0 = pos;
-        pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md);
+        pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md, lb0, lb1);
         cnt += mp - p0 + 1;
     }
     for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }
@@ -932,10 +942,12 @@ __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream
         };
         while (act && pos < segend && k - k0 < (u32)PTCAP) {
             const u32 p0 = pos;
-            pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md);
+            u32 lb0, lb1;
+            pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md, lb0, lb1);
             if (pos >= n) cout[ci].trailing = (ml == 0) ? 1u : 0u;       // last token of the chunk
             const u32 nlit = ml ? mp - p0 : 1;
-            for (u32 q = 0; q < nlit; q++) put((u32)b[p0 + q] << 16, p0 + q);
+            // the literals' bytes ride in the table entries the step loaded (a third literal in one step is rare)
+            for (u32 q = 0; q < nlit; q++) put((q == 0 ? lb0 : q == 1 ? lb1 : (u32)b[p0 + q]) << 16, p0 + q);
             if (ml) put(((ml - MIN_MATCH) << 16) | md, mp);
         }
         __builtin_amdgcn_wave_barrier();
