@@ -115,7 +115,7 @@ __device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
 // so the second pass needs no counting loop of its own.
 template <int NB, bool FIRST>
 __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *__restrict__ src, u32 *__restrict__ dst, u32 wlen,
-                                          u32 per, u32 (*cnt)[256], u32 (*cnt2)[128], u32 per_magic, int lane_ordered)
+                                          u32 per, u32 (*cnt)[256], u32 (*cnt2)[128], u32 per_magic, int lane_ordered, u32 *stg, u32 *dlt)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
@@ -131,19 +131,40 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
     if (lane_ordered) {
         // The LDS retires the same-address atomics of one wave instruction in lane order (probed at start-up, see
         // k_probe_lds_order): the value returned by the add IS the stable destination -- no ballots, no barriers.
-        // Four steps are in flight: their instructions are issued in position order, and so are they executed.
+        // The kernel is bound by its scattered 4-byte stores (partial sectors), so the 256 keys of a step are first
+        // put in destination order in LDS (keys of one digit sit together there: slot = destination - first destination
+        // of the digit in this step + keys of smaller digits in this step) and then stored by consecutive lanes.
+        constexpr int NBIN = 1 << NB;
+        u32 *K = stg + wave * 512, *A = K + 256, *D = dlt + wave * 256;
         for (u32 base = beg; base < end; base += 256) {
-            u32 key[4];
+            u32 key[4], at[4], bf[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) key[k] = fetch(base + 64 * k + lane);
 #pragma unroll
+            for (int j = 0; j < 4; j++) bf[j] = 4 * lane + j < NBIN ? cnt[wave][4 * lane + j] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) at[k] = base + 64 * k + lane < end ? atomicAdd(&cnt[wave][digit_of(key[k])], 1u) : 0u;
+            u32 lc[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { lc[j] = 4 * lane + j < NBIN ? cnt[wave][4 * lane + j] - bf[j] : 0u; sum += lc[j]; }
+            u32 total;
+            u32 ex = wave_excl_scan_u32(sum, total);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { if (4 * lane + j < NBIN) D[4 * lane + j] = ex - bf[j]; ex += lc[j]; }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (base + 64 * k + lane < end) {
-                    const u32 at = atomicAdd(&cnt[wave][digit_of(key[k])], 1u);
-                    dst[at] = key_of(key[k], base + 64 * k + lane);
-                    if (FIRST) atomicAdd(&cnt2[per_magic ? __umulhi(at >> 6, per_magic) : at >> 6][key[k] >> 8], 1u);
+                    const u32 slot = at[k] + D[digit_of(key[k])];
+                    K[slot] = key_of(key[k], base + 64 * k + lane);
+                    A[slot] = at[k];
+                    if (FIRST) atomicAdd(&cnt2[per_magic ? __umulhi(at[k] >> 6, per_magic) : at[k] >> 6][key[k] >> 8], 1u);
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const u32 j = 64 * k + lane; if (j < total) dst[A[j]] = K[j]; }
+            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
         return;
@@ -230,6 +251,8 @@ __global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ strea
     __shared__ u32 cnt[16][256];
     __shared__ u32 cnt2[16][128];
     __shared__ u32 tot[256];
+    __shared__ u32 stg[16 * 512];            // per wave: 256 keys + their destinations, in destination order
+    __shared__ u32 dlt[16 * 256];            // per wave and digit: slot of the digit's first key of the step - its destination
     if (td.wlen == 0) return;
     const u8 *s = stream + td.stream_off + td.w;
     const u32 wlen = td.wlen;
@@ -252,11 +275,11 @@ __global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ strea
     }
     __syncthreads();
     bin_offsets<8>(cnt, tot);
-    rank_pass<8, true>(s, nullptr, tmp + td.sorted_off, wlen, per, cnt, cnt2, per_magic, lane_ordered);                  // low 8 hash bits
+    rank_pass<8, true>(s, nullptr, tmp + td.sorted_off, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);        // low 8 hash bits
     for (int i = threadIdx.x; i < 16 * 128; i += 1024) cnt[i >> 7][i & 127] = cnt2[i >> 7][i & 127];
     __syncthreads();
     bin_offsets<7>(cnt, tot);
-    rank_pass<7, false>(s, tmp + td.sorted_off, sorted + td.sorted_off, wlen, per, cnt, cnt2, per_magic, lane_ordered);  // high 7 bits
+    rank_pass<7, false>(s, tmp + td.sorted_off, sorted + td.sorted_off, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);  // high 7 bits
     if (want_nb) chain_lengths(s, sorted + td.sorted_off, sorted_nb + td.sorted_off, wlen, tot, tot + 32);      // (k_match5 derives them itself)
 }
 
