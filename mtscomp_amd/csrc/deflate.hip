@@ -80,6 +80,9 @@ __device__ __forceinline__ u32 __reduce_max_sync_u32(u32 v)
 // ================================================================================================
 // The radix passes move 32-bit keys  (high 7 hash bits << 18) | window-relative position.  Everything else the
 // match stage wants about a position (its bytes, its chain length) it derives from the window bytes.
+constexpr int SORT_WAVES = 16;           // waves per sort workgroup (one tile)
+constexpr int SORT_KPL = 4;              // keys per lane and step: SORT_KPL * 64 keys are staged in destination order per wave
+constexpr int SORT_NT = SORT_WAVES * 64;
 // per-(wave, digit) counts -> where each wave's keys of each digit start (digit-major, wave-minor: stable)
 template <int NB>
 __device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
@@ -88,7 +91,7 @@ __device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < NBIN) {
         u32 run = 0;
-        for (int w = 0; w < 16; w++) { const u32 c = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += c; }
+        for (int w = 0; w < SORT_WAVES; w++) { const u32 c = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += c; }
         tot[threadIdx.x] = run;
     }
     __syncthreads();
@@ -104,7 +107,7 @@ __device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
     __syncthreads();
     if (threadIdx.x < NBIN) {
         const u32 base = tot[threadIdx.x];
-        for (int w = 0; w < 16; w++) cnt[w][threadIdx.x] += base;
+        for (int w = 0; w < SORT_WAVES; w++) cnt[w][threadIdx.x] += base;
     }
     __syncthreads();
 }
@@ -135,15 +138,16 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
         // put in destination order in LDS (keys of one digit sit together there: slot = destination - first destination
         // of the digit in this step + keys of smaller digits in this step) and then stored by consecutive lanes.
         constexpr int NBIN = 1 << NB;
-        u32 *K = stg + wave * 512, *A = K + 256, *D = dlt + wave * 256;
-        for (u32 base = beg; base < end; base += 256) {
-            u32 key[4], at[4], bf[4];
+        constexpr int KPL = SORT_KPL, BK = 64 * KPL;
+        u32 *K = stg + wave * (2 * BK), *A = K + BK, *D = dlt + wave * 256;
+        for (u32 base = beg; base < end; base += BK) {
+            u32 key[KPL], at[KPL], bf[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) key[k] = fetch(base + 64 * k + lane);
+            for (int k = 0; k < KPL; k++) key[k] = fetch(base + 64 * k + lane);
 #pragma unroll
             for (int j = 0; j < 4; j++) bf[j] = 4 * lane + j < NBIN ? cnt[wave][4 * lane + j] : 0u;
 #pragma unroll
-            for (int k = 0; k < 4; k++) at[k] = base + 64 * k + lane < end ? atomicAdd(&cnt[wave][digit_of(key[k])], 1u) : 0u;
+            for (int k = 0; k < KPL; k++) at[k] = base + 64 * k + lane < end ? atomicAdd(&cnt[wave][digit_of(key[k])], 1u) : 0u;
             u32 lc[4], sum = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) { lc[j] = 4 * lane + j < NBIN ? cnt[wave][4 * lane + j] - bf[j] : 0u; sum += lc[j]; }
@@ -153,7 +157,7 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
             for (int j = 0; j < 4; j++) { if (4 * lane + j < NBIN) D[4 * lane + j] = ex - bf[j]; ex += lc[j]; }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < KPL; k++) {
                 if (base + 64 * k + lane < end) {
                     const u32 slot = at[k] + D[digit_of(key[k])];
                     K[slot] = key_of(key[k], base + 64 * k + lane);
@@ -163,7 +167,7 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const u32 j = 64 * k + lane; if (j < total) dst[A[j]] = K[j]; }
+            for (int k = 0; k < KPL; k++) { const u32 j = 64 * k + lane; if (j < total) dst[A[j]] = K[j]; }
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
@@ -221,7 +225,7 @@ __device__ __forceinline__ void chain_lengths(const u8 *__restrict__ s, const u3
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) *carry_p = 0;
     __syncthreads();
-    for (u32 base = 0; base < wlen; base += 1024) {
+    for (u32 base = 0; base < wlen; base += SORT_NT) {
         const u32 i = base + threadIdx.x;
         const bool act = i < wlen;
         // (the keys only hold 7 hash bits: the hash is recomputed from the bytes; only budgets > 128 come here)
@@ -237,31 +241,31 @@ __device__ __forceinline__ void chain_lengths(const u8 *__restrict__ s, const u3
         for (int w = 0; w < wave; w++) pre = max(pre, wmax[w]);
         v = max(v, pre);
         __syncthreads();
-        if (threadIdx.x == 1023) *carry_p = v;
+        if (threadIdx.x == SORT_NT - 1) *carry_p = v;
         if (act) { const u32 c = i + 1 - v; nb[i] = (u16)(c < 65535u ? c : 65535u); }
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
+__global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
                                                     u32 *__restrict__ tmp, u32 *__restrict__ sorted, u16 *__restrict__ sorted_nb, int lane_ordered,
                                                     int want_nb)
 {
     const TileDesc td = tiles[blockIdx.x];
-    __shared__ u32 cnt[16][256];
-    __shared__ u32 cnt2[16][128];
+    __shared__ u32 cnt[SORT_WAVES][256];
+    __shared__ u32 cnt2[SORT_WAVES][128];
     __shared__ u32 tot[256];
-    __shared__ u32 stg[16 * 512];            // per wave: 256 keys + their destinations, in destination order
-    __shared__ u32 dlt[16 * 256];            // per wave and digit: slot of the digit's first key of the step - its destination
+    __shared__ u32 stg[SORT_WAVES * 2 * 64 * SORT_KPL];      // per wave: the keys of a step + their destinations, in destination order
+    __shared__ u32 dlt[SORT_WAVES * 256];                     // per wave and digit: slot of the digit's first key of the step - its destination
     if (td.wlen == 0) return;
     const u8 *s = stream + td.stream_off + td.w;
     const u32 wlen = td.wlen;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 per = (((wlen + 15) / 16) + 63) & ~63u;              // keys per wave (both passes)
+    const u32 per = (((wlen + SORT_WAVES - 1) / SORT_WAVES) + 63) & ~63u;      // keys per wave (both passes)
     // __umulhi(x >> 6, magic) == x / per (per is a multiple of 64; x >> 6 < 2^12); magic 0 stands for per == 64 (x / per = x >> 6)
     const u32 per_magic = per > 64 ? 0xffffffffu / (per >> 6) + 1 : 0;
-    for (int i = threadIdx.x; i < 16 * 256; i += 1024) (&cnt[0][0])[i] = 0;
-    for (int i = threadIdx.x; i < 16 * 128; i += 1024) (&cnt2[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < SORT_WAVES * 256; i += SORT_NT) (&cnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < SORT_WAVES * 128; i += SORT_NT) (&cnt2[0][0])[i] = 0;
     __syncthreads();
     {   // digits of the first pass: 4 positions per lane and step, so four loads are in flight
         const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(1024) void k_hash_sort(const u8 *__restrict__ strea
     __syncthreads();
     bin_offsets<8>(cnt, tot);
     rank_pass<8, true>(s, nullptr, tmp + td.sorted_off, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);        // low 8 hash bits
-    for (int i = threadIdx.x; i < 16 * 128; i += 1024) cnt[i >> 7][i & 127] = cnt2[i >> 7][i & 127];
+    for (int i = threadIdx.x; i < SORT_WAVES * 128; i += SORT_NT) cnt[i >> 7][i & 127] = cnt2[i >> 7][i & 127];
     __syncthreads();
     bin_offsets<7>(cnt, tot);
     rank_pass<7, false>(s, tmp + td.sorted_off, sorted + td.sorted_off, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);  // high 7 bits
@@ -308,7 +312,7 @@ int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles
 {
     if (n_tiles == 0) return MTS_OK;
     const int ordered = getenv("MTS_SORT_BALLOT") ? 0 : lds_lane_ordered();      // MTS_SORT_BALLOT=1: force the ballot ranking (tests)
-    hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(1024), 0, st, d_stream, d_tiles, d_tmp, d_sorted, d_sorted_nb, ordered, want_nb);
+    hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(SORT_NT), 0, st, d_stream, d_tiles, d_tmp, d_sorted, d_sorted_nb, ordered, want_nb);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
