@@ -345,6 +345,8 @@ __device__ __forceinline__ void build_luts(LaneLds &L, u32 *lutl, u32 *lutd, int
     }
 }
 // One token through the tables; READER = BitIn or BitL.  Returns 0 literal/match decoded, 1 end of block, <0 error.
+// Written without a literal / match branch: in a wave both kinds are always present, and a divergent wave pays for
+// both sides one after the other.  A literal lane simply looks at a distance entry it does not use and skips 0 bits.
 template <class READER>
 __device__ __forceinline__ int decode_token_lut(READER &br, LaneLds &L, const u32 *lutl, const u32 *lutd, u32 &tok, u32 &olen)
 {
@@ -352,34 +354,32 @@ __device__ __forceinline__ int decode_token_lut(READER &br, LaneLds &L, const u3
     br.refill();
     u32 p = br.peek();
     u32 e = lutl[p & ((1u << LUT_LBITS) - 1)];
-    if (!(e & 15)) {
+    if (!(e & 15)) {                                             // (rare) longer than the table index
         u32 cl;
         const int si = chain_decode_mem<15>(__brev(p) >> 17, LC, cl);
         if (si < 0) return INF_CORRUPT;
         e = lut_len_entry(L.ls(si), cl);
     }
-    const u32 type = (e >> 4) & 3, cl = e & 15;
-    if (type == 0) { br.skip(cl); tok = (e >> 8) & 0xff; olen = 1; return 0; }
-    if (type == 2) { br.skip(cl); return 1; }
-    if (type == 3) return INF_CORRUPT;
-    const u32 eb = e >> 24;
-    const u32 length = ((e >> 8) & 0xffff) + ((p >> cl) & ((1u << eb) - 1));      // code + extra bits: <= 15 + 5 of the >= 32 valid bits
+    const u32 type = (e >> 4) & 3, cl = e & 15, eb = e >> 24, val = (e >> 8) & 0xffff;
+    const bool is_match = type == 1;
+    const u32 length = val + ((p >> cl) & ((1u << eb) - 1));      // code + extra bits: <= 15 + 5 of the >= 32 valid bits (eb = 0 unless a length)
     br.skip(cl + eb);
     br.refill();
     p = br.peek();
     u32 d = lutd[p & ((1u << LUT_DBITS) - 1)];
-    if (!(d & 15)) {
+    if (is_match && !(d & 15)) {
         u32 dl;
         const int si = chain_decode_mem<15>(__brev(p) >> 17, DC, dl);
         if (si < 0) return INF_CORRUPT;
         d = lut_dist_entry(L.ds(si), dl);
     }
-    if (((d >> 4) & 3) == 3) return INF_CORRUPT;
     const u32 dcl = d & 15, deb = d >> 24;
     const u32 dist = ((d >> 8) & 0xffff) + ((p >> dcl) & ((1u << deb) - 1));      // <= 15 + 13 bits
-    br.skip(dcl + deb);
-    tok = 0x80000000u | ((length - 3) << 16) | (dist - 1);
-    olen = length;
+    br.skip(is_match ? dcl + deb : 0u);
+    tok = is_match ? 0x80000000u | ((length - 3) << 16) | (dist - 1) : val & 0xff;
+    olen = is_match ? length : 1u;
+    if (type >= 2) return type == 2 ? 1 : INF_CORRUPT;
+    if (is_match && ((d >> 4) & 3) == 3) return INF_CORRUPT;
     return 0;
 }
 
