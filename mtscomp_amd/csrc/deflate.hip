@@ -957,12 +957,14 @@ __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream
     u32 *bis = blk_in_start + ch.blk0;
     auto rd = [&](u32 q) -> uint2 { return T[q]; };
     u32 pos = pb.entry[gc], mp, ml, md, k = pb.tokbase[gc];
+    u32 kmod = k % BLOCK_TOKENS;                 // k mod BLOCK_TOKENS, kept by counting
     for (;;) {
         const bool act = valid && pos < segend;
         if (!__any(act)) break;
         const u32 k0 = k;
         auto put = [&](u32 v, u32 at) {
-            if (k % BLOCK_TOKENS == 0) bis[k / BLOCK_TOKENS] = at;
+            if (kmod == 0) bis[k / BLOCK_TOKENS] = at;                           // first token of a block: where its input starts
+            kmod = kmod + 1 == (u32)BLOCK_TOKENS ? 0 : kmod + 1;
             const u32 j = k - k0;
             if (j < (u32)PTCAP) tokb[lane * PTROW + j] = v; else tk[k] = v;      // (a step longer than the row: straight to memory)
             k++;
