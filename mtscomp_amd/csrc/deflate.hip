@@ -1062,80 +1062,64 @@ __device__ __forceinline__ u32 bit_reverse(u32 code, int len) { return __brev(co
 
 constexpr int HEAP_SIZE = 2 * L_CODES + 1;       // 573
 
-struct TreeWS {                                  // scratch of one tree build (LDS)
-    u16 freq[HEAP_SIZE];
+// Scratch of one tree build (LDS).  The workgroup is one wave: the heap (zlib's exact order, ties and all) is one lane's
+// serial work, everything around it (heap fill, leaf depths, bl_count / opt_len sums, code assignment) uses all 64 lanes.
+struct TreeWS {
+    u16 freq[L_CODES + 2];                       // leaf frequencies; internal nodes carry theirs in the heap entries
     u16 len[HEAP_SIZE + 1];
     u16 dad[HEAP_SIZE];
-    u16 heap[HEAP_SIZE];
-    u8 depth[HEAP_SIZE];
-    u16 bl_count[16];
-    int heap_len, heap_max, max_code;
+    u32 bl_count[16];
+    u32 next_code[16];
+    int heap_len, heap_max, max_code, n_nodes, height, serial_lengths;
+    long long opt_acc, static_acc;               // lane 0's contributions (forced nodes, serial gen_bitlen)
+    // zlib's heap[] with the sort key carried in the entry:  freq << 15 | depth << 10 | node.  A block holds at most 16384
+    // symbols, so freq < 2^15 + 1 and (Fibonacci bound on Huffman heights) depth < 32; smaller() is "key <= key" on
+    // entry >> 10, and the two children of a slot are one aligned 8-byte LDS read.
+    __attribute__((aligned(8))) u32 hp[HEAP_SIZE + 1];
 };
 
-__device__ __forceinline__ bool tw_smaller(const TreeWS &t, int n, int m)
-{
-    return t.freq[n] < t.freq[m] || (t.freq[n] == t.freq[m] && t.depth[n] <= t.depth[m]);
-}
+typedef u32 tw_pair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 tw_entry(u32 freq, u32 depth, u32 node) { return freq << 15 | depth << 10 | node; }
 __device__ void tw_downheap(TreeWS &t, int k)
 {
-    const int v = t.heap[k];
+    const u32 v = t.hp[k];
     int j = k << 1;
     while (j <= t.heap_len) {
-        if (j < t.heap_len && tw_smaller(t, t.heap[j + 1], t.heap[j])) j++;
-        if (tw_smaller(t, v, t.heap[j])) break;
-        t.heap[k] = t.heap[j]; k = j; j <<= 1;
+        const tw_pair pr = *(const tw_pair *)&t.hp[j];                // children j, j + 1 (j is even)
+        u32 c = pr.x;
+        if (j < t.heap_len && (pr.y >> 10) <= (c >> 10)) { j++; c = pr.y; }
+        if ((v >> 10) <= (c >> 10)) break;
+        t.hp[k] = c; k = j; j <<= 1;
     }
-    t.heap[k] = (u16)v;
+    t.hp[k] = v;
 }
 
-// kind 0 literal/length, 1 distance, 2 bit-length.  freq[] is the input; len[] the output.
-__device__ void tw_build(TreeWS &t, int kind, long &opt_len, long &static_len)
+__device__ __forceinline__ int tw_xbits(int kind, int n, int base)
 {
-    const int elems = kind == 0 ? L_CODES : kind == 1 ? D_CODES : BL_CODES;
-    const int max_length = kind == 2 ? 7 : 15;
-    const int base = kind == 0 ? 257 : 0;
-    int n, m, max_code = -1, node;
-    t.heap_len = 0; t.heap_max = HEAP_SIZE;
-    for (n = 0; n < elems; n++) {
-        if (t.freq[n] != 0) { t.heap[++t.heap_len] = (u16)(max_code = n); t.depth[n] = 0; }
-        else t.len[n] = 0;
-    }
-    while (t.heap_len < 2) {
-        node = (max_code < 2 ? ++max_code : 0);
-        t.heap[++t.heap_len] = (u16)node;
-        t.freq[node] = 1; t.depth[node] = 0; opt_len--;
-        if (kind == 0) static_len -= static_llen(node); else if (kind == 1) static_len -= 5;
-    }
-    t.max_code = max_code;
-    for (n = t.heap_len / 2; n >= 1; n--) tw_downheap(t, n);
-    node = elems;
-    do {
-        n = t.heap[1]; t.heap[1] = t.heap[t.heap_len--]; tw_downheap(t, 1);
-        m = t.heap[1];
-        t.heap[--t.heap_max] = (u16)n; t.heap[--t.heap_max] = (u16)m;
-        t.freq[node] = (u16)(t.freq[n] + t.freq[m]);
-        t.depth[node] = (u8)((t.depth[n] >= t.depth[m] ? t.depth[n] : t.depth[m]) + 1);
-        t.dad[n] = t.dad[m] = (u16)node;
-        t.heap[1] = (u16)node++;
-        tw_downheap(t, 1);
-    } while (t.heap_len >= 2);
-    t.heap[--t.heap_max] = t.heap[1];
-    // gen_bitlen
-    int h, bits, overflow = 0;
+    if (n < base) return 0;
+    return kind == 0 ? c_extra_lbits[n - base] : kind == 1 ? c_extra_dbits[n - base] : c_extra_blbits[n - base];
+}
+
+// zlib's gen_bitlen as written (one lane): only needed when the tree is higher than max_length, where the length
+// repair walks the heap order.  Accumulates into t.opt_acc / t.static_acc.
+__device__ void tw_gen_bitlen_serial(TreeWS &t, int kind, int max_length, int base)
+{
+    const int max_code = t.max_code;
+    int h, n, m, bits, overflow = 0;
+    long long opt_len = 0, static_len = 0;
     for (bits = 0; bits <= 15; bits++) t.bl_count[bits] = 0;
-    t.len[t.heap[t.heap_max]] = 0;
+    t.len[t.hp[t.heap_max] & 1023] = 0;
     for (h = t.heap_max + 1; h < HEAP_SIZE; h++) {
-        n = t.heap[h];
+        n = (int)(t.hp[h] & 1023);
         bits = t.len[t.dad[n]] + 1;
         if (bits > max_length) { bits = max_length; overflow++; }
         t.len[n] = (u16)bits;
         if (n > max_code) continue;
         t.bl_count[bits]++;
-        int xbits = 0;
-        if (n >= base) xbits = kind == 0 ? c_extra_lbits[n - base] : kind == 1 ? c_extra_dbits[n - base] : c_extra_blbits[n - base];
-        const long f = t.freq[n];
+        const int xbits = tw_xbits(kind, n, base);
+        const long long f = t.freq[n];
         opt_len += f * (bits + xbits);
-        if (kind == 0) static_len += f * ((long)static_llen(n) + xbits);
+        if (kind == 0) static_len += f * ((long long)static_llen(n) + xbits);
         else if (kind == 1) static_len += f * (5 + xbits);
     }
     if (overflow > 0) {
@@ -1146,28 +1130,151 @@ __device__ void tw_build(TreeWS &t, int kind, long &opt_len, long &static_len)
             overflow -= 2;
         } while (overflow > 0);
         for (bits = max_length; bits != 0; bits--) {
-            n = t.bl_count[bits];
+            n = (int)t.bl_count[bits];
             while (n != 0) {
-                m = t.heap[--h];
+                m = (int)(t.hp[--h] & 1023);
                 if (m > max_code) continue;
                 if (t.len[m] != (u16)bits) {
-                    opt_len += ((long)bits - (long)t.len[m]) * (long)t.freq[m];
+                    opt_len += ((long long)bits - (long long)t.len[m]) * (long long)t.freq[m];
                     t.len[m] = (u16)bits;
                 }
                 n--;
             }
         }
     }
+    t.opt_acc += opt_len; t.static_acc += static_len;
 }
 
-// canonical codes (bit reversed) from t.len[0..max_code] and t.bl_count; out[n] = code | len << 16
-__device__ void tw_gen_codes(const TreeWS &t, u32 *out, int elems)
+__device__ __forceinline__ u32 wave_sum_u32(u32 v)
 {
-    u32 next_code[16], code = 0;
-    for (int bits = 1; bits <= 15; bits++) { code = (code + t.bl_count[bits - 1]) << 1; next_code[bits] = code; }
-    for (int n = 0; n < elems; n++) {
-        const int l = n <= t.max_code ? t.len[n] : 0;
-        out[n] = l ? (bit_reverse(next_code[l]++, l) | ((u32)l << 16)) : 0;
+    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// kind 0 literal/length, 1 distance, 2 bit-length.  t.freq[0 .. elems) is the input; t.len[], t.bl_count[], t.max_code the
+// output.  Called by all 64 lanes; opt_len / static_len stay uniform.
+__device__ void tw_build(TreeWS &t, int kind, int lane, long &opt_len, long &static_len)
+{
+    const int elems = kind == 0 ? L_CODES : kind == 1 ? D_CODES : BL_CODES;
+    const int max_length = kind == 2 ? 7 : 15;
+    const int base = kind == 0 ? 257 : 0;
+    const u64 lt = ((u64)1 << lane) - 1;
+    // heap fill in symbol order
+    int heap_len = 0, max_code = -1;
+    for (int n0 = 0; n0 < elems; n0 += 64) {
+        const int n = n0 + lane;
+        const u32 f = n < elems ? t.freq[n] : 0;
+        const u64 m = __ballot(f != 0);
+        if (f) t.hp[heap_len + 1 + __popcll(m & lt)] = tw_entry(f, 0, (u32)n);
+        else if (n < elems) t.len[n] = 0;
+        if (m) max_code = n0 + 63 - __clzll(m);
+        heap_len += __popcll(m);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int node;
+        long long oa = 0, sa = 0;
+        while (heap_len < 2) {
+            node = (max_code < 2 ? ++max_code : 0);
+            t.hp[++heap_len] = tw_entry(1, 0, (u32)node);
+            t.freq[node] = 1; oa--;
+            if (kind == 0) sa -= static_llen(node); else if (kind == 1) sa -= 5;
+        }
+        t.opt_acc = oa; t.static_acc = sa;
+        t.heap_len = heap_len; t.heap_max = HEAP_SIZE; t.max_code = max_code;
+        for (int n = heap_len / 2; n >= 1; n--) tw_downheap(t, n);
+        node = elems;
+        do {
+            const u32 en = t.hp[1];
+            t.hp[1] = t.hp[t.heap_len--]; tw_downheap(t, 1);
+            const u32 em = t.hp[1];
+            t.hp[--t.heap_max] = en; t.hp[--t.heap_max] = em;
+            const u32 dn = (en >> 10) & 31, dm = (em >> 10) & 31;
+            t.dad[en & 1023] = t.dad[em & 1023] = (u16)node;
+            t.hp[1] = tw_entry((en >> 15) + (em >> 15), (dn >= dm ? dn : dm) + 1, (u32)node);
+            node++;
+            tw_downheap(t, 1);
+        } while (t.heap_len >= 2);
+        t.heap_max--; t.hp[t.heap_max] = t.hp[1];
+        t.n_nodes = node;
+        t.height = (int)((t.hp[1] >> 10) & 31);
+        t.serial_lengths = t.height > max_length;
+        if (t.serial_lengths) tw_gen_bitlen_serial(t, kind, max_length, base);
+    }
+    __syncthreads();
+    max_code = t.max_code;
+    u32 o = 0, sl = 0;
+    if (!t.serial_lengths) {
+        // no length exceeds max_length: a leaf's length is its depth.  Pointer jumping over dad[] (in place, read phase
+        // then write phase), len[] holds the distance covered so far.
+        const int n_nodes = t.n_nodes, root = n_nodes - 1, height = t.height;
+        constexpr int PER = (HEAP_SIZE + 63) / 64;
+        for (int k = 0; k < PER; k++) {
+            const int i = lane + 64 * k;
+            if (i < n_nodes && (i >= elems || t.freq[i] != 0)) { t.len[i] = i == root ? 0 : 1; if (i == root) t.dad[i] = (u16)root; }
+        }
+        __syncthreads();
+        for (int span = 1; span < height; span <<= 1) {
+            u16 da[PER], aa[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int i = lane + 64 * k;
+                da[k] = 0; aa[k] = 0;
+                if (i < n_nodes && (i >= elems || t.freq[i] != 0)) { const int a = t.dad[i]; da[k] = t.len[a]; aa[k] = t.dad[a]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int i = lane + 64 * k;
+                if (i < n_nodes && (i >= elems || t.freq[i] != 0)) { t.len[i] += da[k]; t.dad[i] = aa[k]; }
+            }
+            __syncthreads();
+        }
+        if (lane < 16) t.bl_count[lane] = 0;
+        __syncthreads();
+        for (int n = lane; n <= max_code; n += 64) {
+            const u32 f = t.freq[n];
+            if (f) {
+                const u32 bits = t.len[n], xbits = (u32)tw_xbits(kind, n, base);
+                atomicAdd(&t.bl_count[bits], 1u);
+                o += f * (bits + xbits);
+                if (kind == 0) sl += f * (static_llen(n) + xbits); else if (kind == 1) sl += f * (5 + xbits);
+            }
+        }
+        o = wave_sum_u32(o); sl = wave_sum_u32(sl);
+        __syncthreads();
+    }
+    opt_len += (long)t.opt_acc + (long)o;
+    static_len += (long)t.static_acc + (long)sl;
+}
+
+// canonical codes (bit reversed) from t.len[0..max_code] and t.bl_count; out[n] = code | len << 16.  All 64 lanes: a symbol's
+// code is next_code[len] plus the number of earlier symbols of the same length (ballot ranks, 64 symbols a round).
+__device__ void tw_gen_codes(const TreeWS &t, int lane, u32 *out, int elems)
+{
+    u32 mine = 0, present = 0;                   // lane L (1..15) owns next_code[L]
+    {
+        u32 code = 0;
+        for (int bits = 1; bits <= 15; bits++) {
+            code = (code + t.bl_count[bits - 1]) << 1;
+            if (bits == lane) mine = code;
+            present |= (t.bl_count[bits] ? 1u : 0u) << bits;
+        }
+    }
+    const u64 lt = ((u64)1 << lane) - 1;
+    const int max_code = t.max_code;
+    for (int n0 = 0; n0 < elems; n0 += 64) {
+        const int n = n0 + lane;
+        const u32 l = (n < elems && n <= max_code) ? t.len[n] : 0;
+        u32 code = 0;
+        for (u32 pm = present; pm; pm &= pm - 1) {
+            const int bits = __ffs(pm) - 1;
+            const u64 m = __ballot(l == (u32)bits);
+            const u32 nc = __shfl(mine, bits);
+            if (l == (u32)bits) code = nc + (u32)__popcll(m & lt);
+            if (lane == bits) mine += (u32)__popcll(m);
+        }
+        if (n < elems) out[n] = l ? (bit_reverse(code, (int)l) | (l << 16)) : 0;
     }
 }
 
@@ -1254,42 +1361,58 @@ __global__ __launch_bounds__(64) void k_block_trees(const ChunkDesc *__restrict_
     const u32 last = bi == nblk - 1;
     const u32 in_start = nt ? blk_in_start[b] : ch.n;
     const u32 in_end = tok0 + nt < ntok_c ? blk_in_start[b + 1] : ch.n;
-    __shared__ u32 lfreq[L_CODES + 2], dfreq[D_CODES + 2];
+    __shared__ u32 dfreq[D_CODES + 2];
     __shared__ TreeWS tw;
     __shared__ u16 llen_s[L_CODES + 2], dlen_s[D_CODES + 2];
+    u32 *lfreq = tw.hp;                              // the literal/length histogram lives in the heap's storage until it is copied out
     const int lane = threadIdx.x;
     for (int i = lane; i < L_CODES + 2; i += 64) lfreq[i] = 0;
     if (lane < D_CODES + 2) dfreq[lane] = 0;
     __syncthreads();
     const u32 *tk = tokens + ch.tok_off + tok0;
-    for (u32 i = lane; i < nt; i += 64) {
-        const u32 t = tk[i], dist = t & 0xffff, lc = t >> 16;
-        u32 ex;
-        if (dist == 0) atomicAdd(&lfreq[lc], 1u);
-        else { atomicAdd(&lfreq[257 + len_code(lc, ex)], 1u); atomicAdd(&dfreq[dist_code(dist - 1, ex)], 1u); }
+    {
+        typedef u32 tok4 __attribute__((ext_vector_type(4), aligned(4)));
+        auto count = [&](u32 t) {
+            const u32 dist = t & 0xffff, lc = t >> 16;
+            u32 ex;
+            if (dist == 0) atomicAdd(&lfreq[lc], 1u);
+            else { atomicAdd(&lfreq[257 + len_code(lc, ex)], 1u); atomicAdd(&dfreq[dist_code(dist - 1, ex)], 1u); }
+        };
+        const u32 nt4 = nt & ~3u;
+        for (u32 i = (u32)lane * 4; i < nt4; i += 256) {
+            const tok4 q = *(const tok4 *)(tk + i);
+            count(q.x); count(q.y); count(q.z); count(q.w);
+        }
+        if ((u32)lane < nt - nt4) count(tk[nt4 + lane]);
     }
     __syncthreads();
-    if (lane != 0) return;
-    lfreq[256] = 1;
     long opt_len = 0, static_len = 0;
     // literal/length tree
-    for (int i = 0; i < HEAP_SIZE; i++) tw.freq[i] = i < L_CODES ? (u16)lfreq[i] : 0;
-    tw_build(tw, 0, opt_len, static_len);
+    for (int i = lane; i < L_CODES; i += 64) tw.freq[i] = i == 256 ? (u16)1 : (u16)lfreq[i];
+    __syncthreads();
+    tw_build(tw, 0, lane, opt_len, static_len);
     const int l_max = tw.max_code;
-    for (int i = 0; i <= l_max; i++) llen_s[i] = tw.len[i];
+    for (int i = lane; i <= l_max; i += 64) llen_s[i] = tw.len[i];
     u32 *codes = blk_codes + (u64)b * BLK_CODE_WORDS;
-    tw_gen_codes(tw, codes, L_CODES);
+    tw_gen_codes(tw, lane, codes, L_CODES);
+    __syncthreads();
     // distance tree
-    for (int i = 0; i < HEAP_SIZE; i++) tw.freq[i] = i < D_CODES ? (u16)dfreq[i] : 0;
-    tw_build(tw, 1, opt_len, static_len);
+    if (lane < D_CODES) tw.freq[lane] = (u16)dfreq[lane];
+    __syncthreads();
+    tw_build(tw, 1, lane, opt_len, static_len);
     const int d_max = tw.max_code;
-    for (int i = 0; i <= d_max; i++) dlen_s[i] = tw.len[i];
-    tw_gen_codes(tw, codes + L_CODES, D_CODES);
+    if (lane <= d_max) dlen_s[lane] = tw.len[lane];
+    tw_gen_codes(tw, lane, codes + L_CODES, D_CODES);
+    __syncthreads();
     // bit-length tree
-    for (int i = 0; i < HEAP_SIZE; i++) tw.freq[i] = 0;
-    tw_scan_tree(llen_s, l_max, tw.freq);
-    tw_scan_tree(dlen_s, d_max, tw.freq);
-    tw_build(tw, 2, opt_len, static_len);
+    if (lane < BL_CODES) tw.freq[lane] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        tw_scan_tree(llen_s, l_max, tw.freq);
+        tw_scan_tree(dlen_s, d_max, tw.freq);
+    }
+    __syncthreads();
+    tw_build(tw, 2, lane, opt_len, static_len);
     int max_blindex;
     for (max_blindex = BL_CODES - 1; max_blindex >= 3; max_blindex--)
         if (tw.len[c_bl_order[max_blindex]] != 0) break;
@@ -1315,38 +1438,43 @@ __global__ __launch_bounds__(64) void k_block_trees(const ChunkDesc *__restrict_
         r.btype = 0; r.nbits = 0;
     } else if (static_lenb == opt_lenb) {
         r.btype = 1; r.nbits = (u32)(3 + static_len);
-        // static codes
-        u32 next_code[16], code = 0;
-        const u32 cnt[10] = {0, 0, 0, 0, 0, 0, 0, 24, 152, 112};
-        for (int bits = 1; bits <= 9; bits++) { code = (code + cnt[bits - 1]) << 1; next_code[bits] = code; }
-        for (u32 n = 0; n < L_CODES; n++) { const u32 l = static_llen(n); codes[n] = bit_reverse(next_code[l]++, (int)l) | (l << 16); }
-        for (u32 n = 0; n < D_CODES; n++) codes[L_CODES + n] = bit_reverse(n, 5) | (5u << 16);
+        // static codes: 0..143 -> 8 bits from 0x30, 144..255 -> 9 bits from 0x190, 256..279 -> 7 bits from 0, 280..287 -> 8 bits from 0xc0
+        for (u32 n = lane; n < L_CODES; n += 64) {
+            const u32 l = static_llen(n);
+            const u32 code = n <= 143 ? 0x30 + n : n <= 255 ? 0x190 + (n - 144) : n <= 279 ? n - 256 : 0xc0 + (n - 280);
+            codes[n] = bit_reverse(code, (int)l) | (l << 16);
+        }
+        if (lane < D_CODES) codes[L_CODES + lane] = bit_reverse((u32)lane, 5) | (5u << 16);
     } else {
         r.btype = 2; r.nbits = (u32)(3 + opt_len);
-        u32 blc[BL_CODES];
-        {
-            u32 next_code[16], code = 0;
-            for (int bits = 1; bits <= 7; bits++) { code = (code + tw.bl_count[bits - 1]) << 1; next_code[bits] = code; }
-            for (int n = 0; n < BL_CODES; n++) {
-                const int l = n <= tw.max_code ? tw.len[n] : 0;
-                blc[n] = l ? (bit_reverse(next_code[l]++, l) | ((u32)l << 16)) : 0;
-            }
-        }
         u32 *hw = blk_hdr + (u64)b * BLK_HDR_WORDS;
-        for (int i = 0; i < BLK_HDR_WORDS; i++) hw[i] = 0;
-        BitW bw = {hw, 0, 0, 0};
-        bw_put(bw, (u32)(l_max + 1 - 257), 5);
-        bw_put(bw, (u32)(d_max + 1 - 1), 5);
-        bw_put(bw, (u32)(max_blindex + 1 - 4), 4);
-        for (int rank = 0; rank < max_blindex + 1; rank++) {
-            const int sym = c_bl_order[rank];
-            bw_put(bw, sym <= tw.max_code ? tw.len[sym] : 0, 3);
+        for (int i = lane; i < BLK_HDR_WORDS; i += 64) hw[i] = 0;
+        __syncthreads();
+        if (lane == 0) {
+            u32 blc[BL_CODES];
+            {
+                u32 next_code[16], code = 0;
+                for (int bits = 1; bits <= 7; bits++) { code = (code + tw.bl_count[bits - 1]) << 1; next_code[bits] = code; }
+                for (int n = 0; n < BL_CODES; n++) {
+                    const int l = n <= tw.max_code ? tw.len[n] : 0;
+                    blc[n] = l ? (bit_reverse(next_code[l]++, l) | ((u32)l << 16)) : 0;
+                }
+            }
+            BitW bw = {hw, 0, 0, 0};
+            bw_put(bw, (u32)(l_max + 1 - 257), 5);
+            bw_put(bw, (u32)(d_max + 1 - 1), 5);
+            bw_put(bw, (u32)(max_blindex + 1 - 4), 4);
+            for (int rank = 0; rank < max_blindex + 1; rank++) {
+                const int sym = c_bl_order[rank];
+                bw_put(bw, sym <= tw.max_code ? tw.len[sym] : 0, 3);
+            }
+            tw_send_tree(bw, llen_s, l_max, blc);
+            tw_send_tree(bw, dlen_s, d_max, blc);
+            r.hdr_bits = bw.pos * 32 + bw.nb;
+            if (bw.nb) hw[bw.pos] = (u32)bw.acc;
         }
-        tw_send_tree(bw, llen_s, l_max, blc);
-        tw_send_tree(bw, dlen_s, d_max, blc);
-        r.hdr_bits = bw.pos * 32 + bw.nb;
-        if (bw.nb) hw[bw.pos] = (u32)bw.acc;
     }
+    if (lane != 0) return;
     blocks[b] = r;
 }
 
