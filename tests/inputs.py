@@ -65,6 +65,24 @@ def farcopies(n, seed):
     return bytes(out[:n])
 
 
+def skewlen(n, seed, ratio=1.65, nsym=22, nlen=8):
+    """Tokens drawn i.i.d. from a geometric distribution (ratio just above the golden one): the rare ones are 14 literal
+    values, the frequent ones copies of length 4..11 from far back in random data.  The literal/length Huffman tree of
+    most blocks comes out 16-17 high, so zlib's gen_bitlen overflow repair (lengths clamped to 15) runs."""
+    r = _rng(seed)
+    p = np.array([ratio ** i for i in range(nsym)])
+    p /= p.sum()
+    out = bytearray(r.randint(0, 256, size=40000).astype(np.uint8).tobytes())
+    while len(out) < n:
+        for u in r.choice(nsym, size=4096, p=p):
+            if u < nsym - nlen:
+                out.append(int(u))
+            else:
+                s = len(out) - r.randint(5000, 30000)
+                out += out[s:s + 4 + (u - (nsym - nlen))]
+    return bytes(out[:n])
+
+
 def cases_small():
     r = _rng(1)
     c = {
@@ -81,6 +99,7 @@ def cases_small():
         'text_100k': textlike(100000, 2),
         'repeats_200k': repeats(200000, 3),
         'farcopies_900k': farcopies(900000, 5),
+        'skewlen_450k': skewlen(450000, 6),
         'first50': (lambda b: b + b)(r.randint(0, 256, size=50).astype(np.uint8).tobytes()),
         'ar1_8ch': ar1_stream(3000, 8),
         'ar1_64ch_4k': ar1_stream(4000, 64),
