@@ -31,6 +31,7 @@ extern "C" {
 #define MTS_E_NOMEM (-4)       /* device or host allocation failed */
 #define MTS_E_UNSUPPORTED (-5) /* valid request this build does not implement (e.g. level 1..3) */
 #define MTS_E_INTERNAL (-6)    /* internal consistency check failed */
+#define MTS_E_MISS (-7)        /* mts_cache_read_rows: a chunk given without bytes is not resident (any more) */
 
 /* per-chunk status written by mts_decompress_chunks */
 #define MTS_CHUNK_OK 0
@@ -94,6 +95,27 @@ int mts_decompress_chunks(int device, const unsigned char *cdata, const long *c_
                           const long *c_lengths, const long *n_rows, int n_chunks, int n_channels,
                           int itemsize, int flags, void *out, const long *out_offsets,
                           int *chunk_status);
+
+/*
+ * Reader random access (Reader.__getitem__, mtscomp.py:798-856, with read_chunk's lru_cache of decoded chunks,
+ * mtscomp.py:582-588, :602) -- the cache lives in HBM: decoded chunks stay on the device and a slice costs one
+ * device-to-host copy of exactly the requested rows.
+ *   mts_cache_create    capacity in bytes of decoded chunks (least recently used chunks are dropped beyond it)
+ *   mts_cache_query     present[i] = 1 if the decoded chunk with key chunk_keys[i] is resident
+ *   mts_cache_read_rows the chunks of one slice, in file order: resident ones may come with c_lengths[i] = 0, the others
+ *                       with their compressed bytes (cdata + c_offsets[i], c_lengths[i]) and are decoded in one batch and
+ *                       kept.  Rows [row_begin, row_end) of the concatenation of the n_chunks chunks are written to `out`
+ *                       (C order).  chunk_status as in mts_decompress_chunks (rows of a failed chunk are not written).
+ *                       MTS_E_MISS: a chunk given without bytes is not resident -- call again with its bytes.
+ * Keys are the caller's (the Reader uses the chunk index; one cache per open file).
+ */
+int mts_cache_create(int device, long capacity_bytes, long *cache_id);
+int mts_cache_destroy(long cache_id);
+int mts_cache_query(long cache_id, const long *chunk_keys, int n, int *present);
+int mts_cache_read_rows(long cache_id, int n_chunks, const long *chunk_keys, const unsigned char *cdata,
+                        const long *c_offsets, const long *c_lengths, const long *n_rows, int n_channels,
+                        int itemsize, int flags, long row_begin, long row_end, void *out,
+                        int *chunk_status);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-resident variants (inputs and outputs already in HBM; used by bench.py and by callers that

@@ -53,6 +53,8 @@ DEFAULT_CONFIG = tuple(dict(
 CHECK_ATOL = 1e-16              # mtscomp.py:59
 CRITICAL_ERROR_URL = "https://github.com/int-brain-lab/mtscomp/issues/new?title=Critical+error"
 DEFAULT_BATCH_CHUNKS = 64       # chunks handed to one device call
+DEFAULT_DEVICE_CACHE_GB = 32    # decoded chunks a Reader may keep in HBM for slicing (allocated as touched; env MTSCOMP_DEVICE_CACHE_GB, 0 = off)
+DEVICE_CACHE_MAX_CHUNKS = 8     # longer slices are streamed through the host path instead of the cache
 
 logger = logging.getLogger('mtscomp_amd')
 logger.setLevel(logging.INFO)
@@ -201,6 +203,16 @@ class HipCodec:
                 status[i], arrays[i] = s, a
         self._run_shards(run, len(shards))
         return status, arrays
+
+    # -- decoded-chunk cache in HBM (Reader random access); lives on the first device
+    device_cache = True
+
+    def cache_create(self, capacity_bytes):
+        return hip.cache_create(capacity_bytes, device=self.devices[0])
+
+    cache_destroy = staticmethod(hip.cache_destroy)
+    cache_query = staticmethod(hip.cache_query)
+    cache_read_rows = staticmethod(hip.cache_read_rows)
 
     @staticmethod
     def _run_shards(fn, n):
@@ -464,6 +476,8 @@ class Reader:
         self.batch_chunks = int(self.config.get('batch_chunks', None) or DEFAULT_BATCH_CHUNKS)
         self._codec = codec
         self._cache = OrderedDict()
+        self._dev_cache = None
+        self._dev_cache_bytes = int(float(os.environ.get('MTSCOMP_DEVICE_CACHE_GB', DEFAULT_DEVICE_CACHE_GB)) * 2 ** 30)
 
     @property
     def codec(self):
@@ -563,6 +577,49 @@ class Reader:
                     self._cache[idx] = self._cache[idx].copy()
         return result
 
+    def _slice_from_device_cache(self, first, last, i0, i1):
+        """Rows [i0, i1) -- inside chunks first..last -- through the codec's decoded-chunk cache in HBM: chunks that are
+        not resident are read from the file and decoded in one batch (and stay on the device), and only the requested
+        rows come back.  None when the slice should take the host path (no device cache, slice too large for it, or the
+        chunks are already in the host LRU of read_chunk)."""
+        n = last - first + 1
+        if not getattr(self.codec, 'device_cache', False) or self._dev_cache_bytes <= 0 or n > DEVICE_CACHE_MAX_CHUNKS:
+            return None
+        rows = [self.chunk_bounds[i + 1] - self.chunk_bounds[i] for i in range(first, last + 1)]
+        if 2 * sum(rows) * self.n_channels * self.dtype.itemsize > self._dev_cache_bytes:
+            return None
+        if all(i in self._cache for i in range(first, last + 1)):
+            return None
+        if self._dev_cache is None:
+            self._dev_cache = self.codec.cache_create(self._dev_cache_bytes)
+        keys = list(range(first, last + 1))
+        a, b = i0 - self.chunk_bounds[first], i1 - self.chunk_bounds[first]
+        present = self.codec.cache_query(self._dev_cache, keys)
+        for attempt in range(2):
+            need = [k for k, p in zip(keys, present) if not p]
+            offs, lens = [0] * n, [0] * n
+            buf = b''
+            if need:
+                base = self.chunk_offsets[need[0]]                 # one read from the first to the last missing chunk
+                buf = self._pread(self.chunk_offsets[need[-1] + 1] - base, base)
+                for k in need:
+                    offs[k - first] = self.chunk_offsets[k] - base
+                    lens[k - first] = self.chunk_offsets[k + 1] - self.chunk_offsets[k]
+            try:
+                status, out = self.codec.cache_read_rows(self._dev_cache, keys, buf, offs, lens, rows, self.n_channels,
+                                                         self.dtype, self._flags(), a, b)
+                break
+            except hip.HipError as e:
+                if e.code != hip.E_MISS or attempt:
+                    raise
+                present = [False] * n                          # dropped since the query: send everything
+        for k, st in zip(keys, status):
+            if st == hip.CHUNK_BADSIZE:
+                raise AssertionError("Chunk #%d does not have the expected size." % k)
+            if st != hip.CHUNK_OK:
+                raise IOError("Compressed chunk #%d is corrupted." % k)
+        return out
+
     def read_chunk(self, chunk_idx, chunk_start, chunk_length):
         """One decoded chunk, (n_samples_chunk, n_channels), C-contiguous (mtscomp.py:602-635)."""
         return self._decode([(chunk_idx, chunk_start, chunk_length)])[chunk_idx]
@@ -649,6 +706,12 @@ class Reader:
 
     def close(self):
         """mtscomp.py:745-748."""
+        if self._dev_cache is not None:
+            cache, self._dev_cache = self._dev_cache, None
+            try:
+                self.codec.cache_destroy(cache)
+            except Exception:  # pragma: no cover
+                pass
         if self.cdata:
             self.cdata.close()
 
@@ -694,6 +757,11 @@ class Reader:
             # are never part of the result, so it is not decoded here
             if last > first and self.chunk_bounds[last] >= i1:
                 last -= 1
+            rows = self._slice_from_device_cache(first, last, i0, i1)
+            if rows is not None:
+                out = rows[::item.step, :]
+                assert out.shape[0] == len(range(i0, i1, item.step or 1))
+                return out
             triples = list(self.iter_chunks(first, last))
             keep = self.cache_size
             if len(triples) > keep:

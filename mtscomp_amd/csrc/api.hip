@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -480,6 +481,7 @@ const char *mts_strerror(int code)
     case MTS_E_NOMEM: return "out of memory";
     case MTS_E_UNSUPPORTED: return "not implemented";
     case MTS_E_INTERNAL: return "internal error";
+    case MTS_E_MISS: return "chunk not resident in the device cache";
     default: return "unknown error";
     }
 }
@@ -488,11 +490,76 @@ const char *mts_last_error(void) { return g_err; }
 
 long mts_compress_bound(long raw_len) { return compress_bound(raw_len); }
 
+// ---- decoded-chunk cache on the device (Reader random access) ------------------------------------
+namespace {
+struct CacheEntry { u8 *d = nullptr; u64 cap = 0, size = 0, stamp = 0; long rows = 0; };
+struct DevCache {
+    int device = 0;
+    u64 capacity = 0, used = 0, clock = 0;
+    std::unordered_map<long, CacheEntry> map;
+    std::vector<std::pair<u8 *, u64>> spare;         // buffers of evicted entries, reused for new ones
+    void drop(long key)
+    {
+        auto it = map.find(key);
+        if (it == map.end()) return;
+        used -= it->second.cap;
+        if (spare.size() < 4) spare.push_back({it->second.d, it->second.cap}); else (void)hipFree(it->second.d);
+        map.erase(it);
+    }
+    // room for `need` more bytes: evict least recently used entries that this call does not use (stamp < keep_from)
+    void make_room(u64 need, u64 keep_from)
+    {
+        while (used + need > capacity) {
+            long victim = 0; u64 best = ~0ull; bool found = false;
+            for (auto &kv : map) if (kv.second.stamp < keep_from && kv.second.stamp < best) { best = kv.second.stamp; victim = kv.first; found = true; }
+            if (!found) break;                       // everything left belongs to this call: overshoot rather than fail
+            drop(victim);
+        }
+    }
+    int alloc(u64 size, u8 **out, u64 *cap)
+    {
+        for (size_t k = 0; k < spare.size(); k++)
+            if (spare[k].second >= size && spare[k].second <= size + size / 2 + 4096) {
+                *out = spare[k].first; *cap = spare[k].second; spare.erase(spare.begin() + k); return MTS_OK;
+            }
+        while (!spare.empty()) { (void)hipFree(spare.back().first); spare.pop_back(); }
+        const u64 want = align_up(size ? size : 1, 4096);
+        hipError_t e = hipMalloc((void **)out, want);
+        if (e != hipSuccess) { set_error("hipMalloc(%llu) for the chunk cache failed: %s", (unsigned long long)want, hipGetErrorString(e)); return MTS_E_NOMEM; }
+        *cap = want;
+        return MTS_OK;
+    }
+    void clear()
+    {
+        for (auto &kv : map) (void)hipFree(kv.second.d);
+        map.clear();
+        for (auto &b : spare) (void)hipFree(b.first);
+        spare.clear();
+        used = 0;
+    }
+};
+std::mutex g_cache_mu;
+std::unordered_map<long, DevCache *> g_caches;
+long g_cache_next = 1;
+DevCache *find_cache(long id)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    auto it = g_caches.find(id);
+    return it == g_caches.end() ? nullptr : it->second;
+}
+}  // namespace
+
 void mts_release(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     for (Engine *e : g_engines)
-        if (e) { std::lock_guard<std::mutex> l2(e->mu); (void)hipSetDevice(e->dev); e->release_all(); }
+        if (e) {
+            std::lock_guard<std::mutex> l2(e->mu);
+            (void)hipSetDevice(e->dev);
+            e->release_all();
+            std::lock_guard<std::mutex> l3(g_cache_mu);
+            for (auto &kv : g_caches) if (kv.second->device == e->dev) kv.second->clear();
+        }
 }
 
 int mts_dev_compress_chunks(int device, void *stream, const void *d_raw, int n_channels, int itemsize,
@@ -651,6 +718,131 @@ int mts_decompress_chunks(int device, const unsigned char *cdata, const long *c_
     for (int i = 0; i < n_chunks; i++)
         if (chunk_status[i] == MTS_CHUNK_OK && n_rows[i])
             MTS_HIP(hipMemcpy((u8 *)out + out_offsets[i], E->h_out.as<u8>() + ooff[i], (size_t)((u64)n_rows[i] * row_bytes), hipMemcpyDeviceToHost));
+    return MTS_OK;
+}
+
+// ---- decoded-chunk cache: entry points (state above mts_release) ----------------------------------
+
+int mts_cache_create(int device, long capacity_bytes, long *cache_id)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    if (!cache_id || capacity_bytes < 0) return MTS_E_ARG;
+    DevCache *c = new DevCache();
+    c->device = device; c->capacity = (u64)capacity_bytes;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    *cache_id = g_cache_next++;
+    g_caches[*cache_id] = c;
+    return MTS_OK;
+}
+
+int mts_cache_destroy(long cache_id)
+{
+    DevCache *c;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_caches.find(cache_id);
+        if (it == g_caches.end()) return MTS_E_ARG;
+        c = it->second;
+        g_caches.erase(it);
+    }
+    Engine *E;
+    if (get_engine(c->device, &E) == MTS_OK) {
+        std::lock_guard<std::mutex> lk(E->mu);
+        (void)hipSetDevice(E->dev);
+        c->clear();
+    }
+    delete c;
+    return MTS_OK;
+}
+
+int mts_cache_query(long cache_id, const long *chunk_keys, int n, int *present)
+{
+    DevCache *c = find_cache(cache_id);
+    if (!c || n < 0) return MTS_E_ARG;
+    Engine *E;
+    int rc = get_engine(c->device, &E);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(E->mu);
+    for (int i = 0; i < n; i++) present[i] = c->map.count(chunk_keys[i]) ? 1 : 0;
+    return MTS_OK;
+}
+
+int mts_cache_read_rows(long cache_id, int n_chunks, const long *chunk_keys, const unsigned char *cdata, const long *c_offsets,
+                        const long *c_lengths, const long *n_rows, int n_channels, int itemsize, int flags, long row_begin,
+                        long row_end, void *out, int *chunk_status)
+{
+    DevCache *c = find_cache(cache_id);
+    if (!c || n_chunks < 0 || n_channels <= 0 || row_begin < 0 || row_end < row_begin) return MTS_E_ARG;
+    Engine *E;
+    int rc = get_engine(c->device, &E);
+    if (rc) return rc;
+    if (n_chunks == 0) return row_end == 0 ? MTS_OK : MTS_E_ARG;
+    std::lock_guard<std::mutex> lk(E->mu);
+    MTS_HIP(hipSetDevice(E->dev));
+    const u64 row_bytes = (u64)n_channels * itemsize;
+    const u64 call_stamp = ++c->clock;
+    // resident chunks are pinned for this call by their stamp; the others must come with their bytes
+    std::vector<int> miss;
+    long total_rows = 0;
+    for (int i = 0; i < n_chunks; i++) {
+        if (n_rows[i] < 0) return MTS_E_ARG;
+        total_rows += n_rows[i];
+        chunk_status[i] = MTS_CHUNK_OK;
+        auto it = c->map.find(chunk_keys[i]);
+        if (it != c->map.end() && it->second.rows == n_rows[i] && it->second.size == (u64)n_rows[i] * row_bytes) { it->second.stamp = call_stamp; continue; }
+        if (it != c->map.end()) c->drop(chunk_keys[i]);        // same key, other shape: stale
+        if (c_lengths[i] <= 0) { set_error("chunk key %ld is not resident and no compressed bytes were given", chunk_keys[i]); return MTS_E_MISS; }
+        miss.push_back(i);
+    }
+    if (row_end > total_rows) return MTS_E_ARG;
+    if (!miss.empty()) {
+        const int m = (int)miss.size();
+        std::vector<long> coff(m), clen(m), rows(m), ooff(m);
+        std::vector<int> st(m);
+        u64 ctot = 0, otot = 0;
+        for (int k = 0; k < m; k++) {
+            const int i = miss[k];
+            clen[k] = c_lengths[i]; rows[k] = n_rows[i];
+            coff[k] = (long)ctot; ctot += align_up((u64)clen[k] + 8, 16);
+            ooff[k] = (long)otot; otot += align_up((u64)rows[k] * row_bytes, 256);
+        }
+        if ((rc = E->h_in.ensure(ctot + 256))) return rc;
+        if ((rc = E->h_out.ensure(otot + 256))) return rc;
+        for (int k = 0; k < m; k++)
+            MTS_HIP(hipMemcpyAsync(E->h_in.as<u8>() + coff[k], cdata + c_offsets[miss[k]], (size_t)clen[k], hipMemcpyHostToDevice, nullptr));
+        rc = dev_decompress(*E, nullptr, E->h_in.as<u8>(), coff.data(), clen.data(), rows.data(), m, n_channels, itemsize, flags,
+                            E->h_out.as<u8>(), ooff.data(), st.data());
+        if (rc) return rc;
+        for (int k = 0; k < m; k++) {
+            const int i = miss[k];
+            chunk_status[i] = st[k];
+            if (st[k] != MTS_CHUNK_OK) continue;
+            const u64 size = (u64)rows[k] * row_bytes;
+            CacheEntry e;
+            c->make_room(align_up(size ? size : 1, 4096), call_stamp);
+            if ((rc = c->alloc(size, &e.d, &e.cap))) return rc;
+            e.size = size; e.rows = rows[k]; e.stamp = call_stamp;
+            if (size) MTS_HIP(hipMemcpyAsync(e.d, E->h_out.as<u8>() + ooff[k], (size_t)size, hipMemcpyDeviceToDevice, nullptr));
+            c->used += e.cap;
+            c->map[chunk_keys[i]] = e;
+        }
+    }
+    // rows [row_begin, row_end) of the concatenation, straight from the resident chunks
+    long r0 = 0;
+    for (int i = 0; i < n_chunks; i++) {
+        const long r1 = r0 + n_rows[i];
+        const long lo = row_begin > r0 ? row_begin : r0, hi = row_end < r1 ? row_end : r1;
+        if (lo < hi && chunk_status[i] == MTS_CHUNK_OK) {
+            const CacheEntry &e = c->map[chunk_keys[i]];
+            MTS_HIP(hipMemcpyAsync((u8 *)out + (u64)(lo - row_begin) * row_bytes, e.d + (u64)(lo - r0) * row_bytes,
+                                   (size_t)((u64)(hi - lo) * row_bytes), hipMemcpyDeviceToHost, nullptr));
+        }
+        r0 = r1;
+    }
+    MTS_HIP(hipStreamSynchronize(nullptr));
+    c->make_room(0, ~0ull);                         // back under the capacity (this call's chunks may go too)
     return MTS_OK;
 }
 

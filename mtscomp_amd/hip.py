@@ -22,6 +22,7 @@ CHUNK_BADSIZE = -2
 
 E_NODEV = -2
 E_UNSUPPORTED = -5
+E_MISS = -7
 
 
 class HipError(RuntimeError):
@@ -71,6 +72,11 @@ def lib():
     L.mts_debug_tokens.argtypes = [C.c_int, vp, C.c_long, C.c_int, vp, lp]
     L.mts_debug_deflate.argtypes = [C.c_int, vp, C.c_long, C.c_int, vp, C.c_long, lp]
     L.mts_debug_inflate.argtypes = [C.c_int, vp, C.c_long, vp, C.c_long, lp, ip]
+    L.mts_cache_create.argtypes = [C.c_int, C.c_long, lp]
+    L.mts_cache_destroy.argtypes = [C.c_long]
+    L.mts_cache_query.argtypes = [C.c_long, lp, C.c_int, ip]
+    L.mts_cache_read_rows.argtypes = [C.c_long, C.c_int, lp, vp, lp, lp, lp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long,
+                                      vp, ip]
     L.mts_release.restype = None
     _lib = L
     return L
@@ -80,7 +86,8 @@ EXPORTS = ['mts_version', 'mts_device_count', 'mts_strerror', 'mts_last_error', 
            'mts_delta_transpose', 'mts_cumsum_transpose', 'mts_compress_chunks', 'mts_decompress_chunks',
            'mts_dev_compress_chunks', 'mts_dev_decompress_chunks', 'mts_dev_synth_int16',
            'mts_last_stage_times', 'mts_debug_match_tables', 'mts_debug_tokens', 'mts_debug_deflate',
-           'mts_debug_inflate', 'mts_release']
+           'mts_debug_inflate', 'mts_release', 'mts_cache_create', 'mts_cache_destroy', 'mts_cache_query',
+           'mts_cache_read_rows']
 
 
 def _check(rc, what):
@@ -206,6 +213,45 @@ def decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=0):
         else:
             arrays.append(None)
     return [int(s) for s in status], arrays
+
+
+# ------------------------------------------------------------------------------------------------
+# decoded-chunk cache on the device (Reader random access)
+# ------------------------------------------------------------------------------------------------
+def cache_create(capacity_bytes, device=0):
+    cid = C.c_long(0)
+    _check(lib().mts_cache_create(device, int(capacity_bytes), C.byref(cid)), 'mts_cache_create')
+    return int(cid.value)
+
+
+def cache_destroy(cache_id):
+    if _lib is not None:
+        _lib.mts_cache_destroy(int(cache_id))
+
+
+def cache_query(cache_id, keys):
+    keys = _longs(keys)
+    present = np.zeros(keys.size, dtype=np.int32)
+    _check(lib().mts_cache_query(int(cache_id), _lp(keys), int(keys.size), present.ctypes.data_as(C.POINTER(C.c_int))),
+           'mts_cache_query')
+    return present.astype(bool)
+
+
+def cache_read_rows(cache_id, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, row_begin, row_end):
+    """Rows [row_begin, row_end) of the concatenation of the chunks `keys` (file order).  Chunks with lens[i] == 0 must be
+    resident (HipError with code E_MISS otherwise).  Returns (status list, (row_end - row_begin, n_channels) array)."""
+    dtype = check_dtype(dtype)
+    keys, offs, lens, rows = _longs(keys), _longs(offs), _longs(lens), _longs(n_rows)
+    n = int(keys.size)
+    cdata = np.frombuffer(cdata, dtype=np.uint8) if len(cdata) else np.zeros(16, dtype=np.uint8)
+    if n and int((offs + lens).max()) + 16 > cdata.size:          # the kernels may read a few bytes past a stream
+        cdata = np.concatenate((cdata, np.zeros(16, dtype=np.uint8)))
+    out = np.empty((int(row_end - row_begin), n_channels), dtype=dtype)
+    status = np.zeros(n, dtype=np.int32)
+    _check(lib().mts_cache_read_rows(int(cache_id), n, _lp(keys), _ptr(cdata), _lp(offs), _lp(lens), _lp(rows), n_channels,
+                                     dtype.itemsize, flags, int(row_begin), int(row_end), _ptr(out),
+                                     status.ctypes.data_as(C.POINTER(C.c_int))), 'mts_cache_read_rows')
+    return [int(x) for x in status], out
 
 
 def last_stage_times(device=0):

@@ -139,3 +139,85 @@ def test_full_size_chunk_properties():
     assert st == [0, 0, 0] and all(np.array_equal(arrs[i], x[bounds[i]:bounds[i + 1]]) for i in range(3))
     ratio = sum(map(len, got)) / x.nbytes
     assert 0.35 < ratio < 0.37
+
+
+# ---- decoded-chunk cache in HBM (Reader slices) ----------------------------------------------------
+def _write_recording(tmp, nt=30000, nc=16, chunk=0.1, rate=10000., seed=7):
+    arr = synth_int16(0, nt, nc, seed)
+    raw = tmp / 'rec.bin'
+    arr.tofile(raw)
+    out, outmeta = tmp / 'rec.cbin', tmp / 'rec.ch'
+    mtscomp_amd.compress(raw, out, outmeta, sample_rate=rate, n_channels=nc, dtype=arr.dtype, chunk_duration=chunk)
+    return arr, out, outmeta
+
+
+@pytest.mark.parametrize('cache_gb', ['8', '0.0001', '0'])           # roomy, 105 KB (three decoded chunks: evicts all the time), off
+def test_slices_through_device_cache(cache_gb, tmp_cfg, monkeypatch):
+    monkeypatch.setenv('MTSCOMP_DEVICE_CACHE_GB', cache_gb)
+    arr, out, outmeta = _write_recording(tmp_cfg)                  # 30 chunks of 1000 rows (32 KB decoded each)
+    r = mtscomp_amd.decompress(out, outmeta)
+    rng = np.random.RandomState(0)
+    for _ in range(60):
+        a = int(rng.randint(0, arr.shape[0] - 1))
+        b = int(min(arr.shape[0], a + rng.randint(1, 3500)))
+        step = [None, 1, 2, 7][rng.randint(0, 4)]
+        got = r[a:b:step]
+        assert got.dtype == arr.dtype and np.array_equal(got, arr[a:b:step]), (a, b, step)
+    assert np.array_equal(r[-5:], arr[-5:]) and np.array_equal(r[12345], arr[12345])
+    assert np.array_equal(r[999:1001, 3:9], arr[999:1001, 3:9])
+    assert np.array_equal(r[:], arr)                               # long slices take the streaming path
+    if float(cache_gb) > 0:
+        assert r._dev_cache is not None
+        if cache_gb == '8':
+            assert hip.cache_query(r._dev_cache, list(range(30))).sum() >= 25     # what was touched stays resident
+        else:
+            assert 1 <= hip.cache_query(r._dev_cache, list(range(30))).sum() <= 3
+    else:
+        assert r._dev_cache is None
+    r.close()
+    assert r._dev_cache is None
+
+
+def test_device_cache_corrupt_chunk_and_short_last(tmp_cfg):
+    arr, out, outmeta = _write_recording(tmp_cfg, nt=10450)        # 10 chunks of 1000 rows + one of 450
+    meta = json.loads(outmeta.read_text())
+    b = bytearray(out.read_bytes())
+    b[meta['chunk_offsets'][4] + 30] ^= 0x55
+    out.write_bytes(bytes(b))
+    r = mtscomp_amd.decompress(out, outmeta)
+    assert np.array_equal(r[9500:10450], arr[9500:10450])
+    assert np.array_equal(r[3000:4000], arr[3000:4000])
+    with pytest.raises(IOError, match='#4'):
+        r[3990:4010]
+    assert np.array_equal(r[3990:4000], arr[3990:4000])            # its neighbour stayed resident and readable
+    assert np.array_equal(r[5000:5010], arr[5000:5010])
+    r.close()
+
+
+def test_cache_c_abi_miss_and_eviction():
+    x = synth_int16(0, 4000, 8, 3)
+    bounds = np.arange(5) * 1000
+    z = hip.compress_chunks(x, bounds, hip.make_flags(), 6)
+    flags = hip.make_flags()
+    cid = hip.cache_create(3 * 16384)                              # room for three decoded chunks (16 000 B each, 4 KiB granules)
+    try:
+        with pytest.raises(hip.HipError) as e:                     # not resident, no bytes
+            hip.cache_read_rows(cid, [0], b'', [0], [0], [1000], 8, np.int16, flags, 0, 10)
+        assert e.value.code == hip.E_MISS
+        buf = b''.join(z)
+        offs = np.concatenate(([0], np.cumsum([len(c) for c in z])))[:-1]
+        lens = [len(c) for c in z]
+        st, rows = hip.cache_read_rows(cid, [0, 1, 2], buf, offs[:3], lens[:3], [1000] * 3, 8, np.int16, flags, 500, 2500)
+        assert st == [0, 0, 0] and np.array_equal(rows, x[500:2500])
+        assert list(hip.cache_query(cid, [0, 1, 2, 3])) == [True, True, True, False]
+        st, rows = hip.cache_read_rows(cid, [1, 2], b'', [0, 0], [0, 0], [1000] * 2, 8, np.int16, flags, 0, 2000)   # from HBM only
+        assert np.array_equal(rows, x[1000:3000])
+        st, rows = hip.cache_read_rows(cid, [3], buf, [offs[3]], [lens[3]], [1000], 8, np.int16, flags, 0, 1000)
+        assert np.array_equal(rows, x[3000:4000])
+        assert list(hip.cache_query(cid, [0, 1, 2, 3])) == [False, True, True, True]                                # LRU: chunk 0 went
+        st, rows = hip.cache_read_rows(cid, [0], buf, [offs[0]], [lens[0]], [999], 8, np.int16, flags, 0, 999)     # wrong row count
+        assert st == [hip.CHUNK_BADSIZE]
+    finally:
+        hip.cache_destroy(cid)
+    with pytest.raises(hip.HipError):
+        hip.cache_query(cid, [0])
