@@ -397,20 +397,27 @@ class Writer:
         Path(out).parent.mkdir(exist_ok=True, parents=True)
         self.chunk_offsets = [0]
         logger.info("Starting compression on %s.", getattr(self.codec, 'name', 'codec'))
-        # The two SHA-1s and the file write are host work in file order (mtscomp.py:477-483); they run on one
-        # background thread while the devices compress the next batch (hashlib and ctypes both release the GIL).
+        # The two SHA-1s and the file write are host work in file order (mtscomp.py:477-483).  One SHA-1 over the whole raw
+        # file (~1.2 GB/s per core) is the slowest thing in a file-to-file run, so it gets its own thread from the start
+        # (it needs nothing from the devices: hashing chunk after chunk is hashing the file); a second thread writes and
+        # hashes the compressed chunks of the previous batch while the devices work on the next one (hashlib and ctypes
+        # release the GIL).
         state = {'offset': 0}
+
+        def hash_raw():
+            for idx in range(self.n_chunks):
+                self.sha1_uncompressed.update(np.ascontiguousarray(self.get_chunk(idx)))
 
         def consume(done):
             for idx in sorted(done.keys()):                     # strictly in file order
-                raw_chunk, cbuf = done[idx]
+                _, cbuf = done[idx]
                 fb.write(cbuf)
                 state['offset'] += len(cbuf)
                 self.chunk_offsets.append(state['offset'])
-                self.sha1_uncompressed.update(np.ascontiguousarray(raw_chunk))
                 self.sha1_compressed.update(cbuf)
 
-        with open(out, 'wb') as fb, ThreadPool(1) as sink:
+        with open(out, 'wb') as fb, ThreadPool(2) as sink:
+            raw_job = sink.apply_async(hash_raw)
             pending = None
             for batch in range(self.n_batches):
                 first = self.batch_size * batch
@@ -422,6 +429,7 @@ class Writer:
                 pending = sink.apply_async(consume, (done,))
             if pending is not None:
                 pending.get()
+            raw_job.get()
             csize = fb.tell()
         assert self.chunk_offsets[-1] == csize
         ratio = csize / self.file_size
