@@ -20,6 +20,7 @@ import json
 import logging
 import multiprocessing as mp
 import os
+import threading
 import os.path as op
 from collections import OrderedDict
 from multiprocessing.dummy import Pool as ThreadPool
@@ -485,6 +486,7 @@ class Reader:
         self._codec = codec
         self._cache = OrderedDict()
         self._dev_cache = None
+        self._dev_cache_lock = threading.Lock()
         self._dev_cache_bytes = int(float(os.environ.get('MTSCOMP_DEVICE_CACHE_GB', DEFAULT_DEVICE_CACHE_GB)) * 2 ** 30)
 
     @property
@@ -598,8 +600,9 @@ class Reader:
             return None
         if all(i in self._cache for i in range(first, last + 1)):
             return None
-        if self._dev_cache is None:
-            self._dev_cache = self.codec.cache_create(self._dev_cache_bytes)
+        with self._dev_cache_lock:                             # slices may come from several threads (mtscomp.py:422, :648)
+            if self._dev_cache is None:
+                self._dev_cache = self.codec.cache_create(self._dev_cache_bytes)
         keys = list(range(first, last + 1))
         a, b = i0 - self.chunk_bounds[first], i1 - self.chunk_bounds[first]
         present = self.codec.cache_query(self._dev_cache, keys)

@@ -221,3 +221,17 @@ def test_cache_c_abi_miss_and_eviction():
         hip.cache_destroy(cid)
     with pytest.raises(hip.HipError):
         hip.cache_query(cid, [0])
+
+
+def test_device_cache_concurrent_readers(tmp_cfg):
+    # the reference's Reader is used from ThreadPool workers (mtscomp.py:648): slices from several threads at once
+    from multiprocessing.pool import ThreadPool
+    arr, out, outmeta = _write_recording(tmp_cfg, nt=20000)
+    r = mtscomp_amd.decompress(out, outmeta)
+    rng = np.random.RandomState(5)
+    jobs = [(int(a), int(a + n)) for a, n in zip(rng.randint(0, 19000, size=64), rng.randint(1, 1000, size=64))]
+    with ThreadPool(8) as pool:
+        got = pool.map(lambda ab: r[ab[0]:ab[1]], jobs)
+    for (a, b), g in zip(jobs, got):
+        assert np.array_equal(g, arr[a:b]), (a, b)
+    r.close()
