@@ -545,8 +545,12 @@ constexpr int M5_WAVES = 8;
 constexpr int M5_RING = 256;
 constexpr int M5_ROWS = 32;
 constexpr int M5_LEVELS = 4;                         // tables for prefix lengths 4, 5, 6, 7
-constexpr int M5_TABLE = M5_ROWS * (M5_RING / 8);    // bytes per table
-constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_LEVELS * M5_TABLE + M5_RING / 8;     // 8224: entries, bytes 7..14, tables, run-start bits
+constexpr int M5_ROW_WORDS = M5_RING / 32 + 1;       // a row is 8 words of bits + 1 of padding, so that rows start in different LDS banks: with 8
+                                                     // the 64 lanes of a wave (32 keys, 2 word indices) hit 8 banks.  PMC: SQ_LDS_BANK_CONFLICT
+                                                     // 2.2e10 -> 0.69e10, SQ_LDS_IDX_ACTIVE 2.8e10 -> 1.3e10 (the run time does not move: the
+                                                     // waves wait for their window loads instead, SQ_INST_LEVEL_VMEM 0.95e10 -> 1.35e10)
+constexpr int M5_TABLE = M5_ROWS * M5_ROW_WORDS * 4; // bytes per table
+constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_LEVELS * M5_TABLE + M5_RING / 8 + 32;     // 8768: entries, bytes 7..14, tables, run-start bits     // 8224: entries, bytes 7..14, tables, run-start bits
 // requested LDS is padded so that TWO workgroups share a CU, not three: every workgroup reads its own 128 KiB
 // window through L2, and three per CU (12 MiB per XCD against 4 MiB of L2) measured 10 % slower than two
 constexpr int MATCH5_LDS = M5_WAVES * M5_WAVE_LDS > 56 * 1024 ? M5_WAVES * M5_WAVE_LDS : 56 * 1024;
@@ -615,8 +619,8 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
 #pragma unroll
         for (int d = 0; d < M5_LEVELS; d++) {
             u32 *tb = TB + d * (M5_TABLE / 4);
-            atomicAnd(&tb[old[d] * 8 + word], ~bit);
-            if (valid) atomicOr(&tb[key[d] * 8 + word], bit);
+            atomicAnd(&tb[old[d] * M5_ROW_WORDS + word], ~bit);
+            if (valid) atomicOr(&tb[key[d] * M5_ROW_WORDS + word], bit);
         }
         SE[rp] = ce;
         SX[rp] = x;
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
             V[k] = s <= 0 ? 0u : s >= 32 ? 0xffffffffu : 0xffffffffu << (32 - s);
         }
         auto rowmask = [&](const int d, const u32 (&in)[4], u32 (&out)[4]) __attribute__((always_inline)) {
-            const u32 *row = TB + d * (M5_TABLE / 4) + key[d] * 8;
+            const u32 *row = TB + d * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS;
             const u32 W0 = row[w0 & 7], W1 = row[(w0 + 1) & 7], W2 = row[(w0 + 2) & 7], W3 = row[(w0 + 3) & 7], W4 = row[(w0 + 4) & 7];
             out[0] = in[0] & __builtin_amdgcn_alignbit(W1, W0, sh);
             out[1] = in[1] & __builtin_amdgcn_alignbit(W2, W1, sh);
