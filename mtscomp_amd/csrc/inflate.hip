@@ -486,10 +486,21 @@ constexpr int SCAN_SPAN_BITS = SCAN_THREADS * 32;
 constexpr int SCAN_SURV_CAP = 512;
 constexpr int SCAN_TAIL = 88;            // words staged past the span: a dynamic header is < 2560 bits long
 
-// full validation of the header at absolute bit `o` (BFINAL bit); true if well formed
-__device__ bool validate_dyn_header(const u32 *w, u64 nwords, u64 end, u64 o)
-{
+// Full validation of the dynamic header at absolute bit `o` (BFINAL bit), as a state machine: vh_setup reads the counts
+// and the code-length code, vh_step decodes one code-length symbol (0 = go on, 1 = well formed, -1 = not a header).  A lane
+// whose candidate is decided takes the next one, so the few real headers (316 symbols) do not hold 63 lanes that were
+// done after ~50.
+struct VhState {
     BitIn br;
+    u32 CC[8];
+    u64 t0, t1;                           // sorted symbol k at bits 5*(k%12) of t[k/12]
+    int nlen, total, idx, prev, len256, maxl, maxd;
+    u32 kl, kd;                           // Kraft sums scaled by 2^15
+};
+
+__device__ bool vh_setup(VhState &s, const u32 *w, u64 nwords, u64 end, u64 o)
+{
+    BitIn &br = s.br;
     br.w = w; br.nwords = nwords; br.end = end;
     br.seek(o + 3);
     const int nlen = (int)br.get(5) + 257, ndist = (int)br.get(5) + 1, ncode = (int)br.get(4) + 4;
@@ -499,71 +510,76 @@ __device__ bool validate_dyn_header(const u32 *w, u64 nwords, u64 end, u64 o)
     u64 cl = 0;
     for (int i = 0; i < ncode; i++) cl |= (u64)br.get(3) << (3 * order[i]);
     // compare chain of the 7-bit code + its sorted symbols packed 5 bits each (two u64)
-    u32 CC[8];
     u32 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int s = 0; s < 19; s++) {
-        const u32 l = (u32)(cl >> (3 * s)) & 7;
+    for (int k = 0; k < 19; k++) {
+        const u32 l = (u32)(cl >> (3 * k)) & 7;
 #pragma unroll
-        for (int k = 1; k < 8; k++) cnt[k] += (l == (u32)k);
+        for (int j = 1; j < 8; j++) cnt[j] += (l == (u32)j);
     }
     u32 firstc = 0, offs[8], off = 0;
     int left = 1;
-    CC[0] = 0;
+    s.CC[0] = 0;
 #pragma unroll
     for (int l = 1; l <= 7; l++) {
         left = (left << 1) - (int)cnt[l];
         offs[l] = off; off += cnt[l];
-        CC[l] = (((firstc + cnt[l]) << (7 - l)) & 0xffff) | (cnt[l] << 16);
+        s.CC[l] = (((firstc + cnt[l]) << (7 - l)) & 0xffff) | (cnt[l] << 16);
         firstc = (firstc + cnt[l]) << 1;
     }
     if (left != 0) return false;
-    u64 t0 = 0, t1 = 0;                   // sorted symbol k at bits 5*(k%12) of t[k/12]
+    u64 t0 = 0, t1 = 0;
 #pragma unroll
     for (int l = 1; l <= 7; l++) {
         u32 o2 = offs[l];
-        for (int s = 0; s < 19; s++) {
-            if (((u32)(cl >> (3 * s)) & 7) == (u32)l) {
-                if (o2 < 12) t0 |= (u64)s << (5 * o2); else t1 |= (u64)s << (5 * (o2 - 12));
+        for (int k = 0; k < 19; k++) {
+            if (((u32)(cl >> (3 * k)) & 7) == (u32)l) {
+                if (o2 < 12) t0 |= (u64)k << (5 * o2); else t1 |= (u64)k << (5 * (o2 - 12));
                 o2++;
             }
         }
     }
-    const int total = nlen + ndist;
-    int idx = 0, prev = 0, len256 = 0, maxl = 0, maxd = 0;
-    u32 kl = 0, kd = 0;                   // Kraft sums scaled by 2^15
-    while (idx < total) {
-        br.refill();
-        u32 clen;
-        const int si = chain_decode<7>(__brev(br.peek()) >> 25, CC, clen);
-        if (si < 0) return false;
-        const int sym = (int)((si < 12 ? t0 >> (5 * si) : t1 >> (5 * (si - 12))) & 31);
-        br.skip(clen);
-        int rep = 1, val = sym;
-        if (sym >= 16) {
-            if (sym == 16) { if (idx == 0) return false; val = prev; rep = 3 + (int)br.get(2); }
-            else if (sym == 17) { val = 0; rep = 3 + (int)br.get(3); }
-            else { val = 0; rep = 11 + (int)br.get(7); }
-            if (idx + rep > total) return false;
-        }
-        prev = val;
-        if (val) {
-            const int nl = idx >= nlen ? 0 : (idx + rep <= nlen ? rep : nlen - idx);
-            const int nd = rep - nl;
-            kl += (u32)nl * (32768u >> val);
-            kd += (u32)nd * (32768u >> val);
-            if (nl && val > maxl) maxl = val;
-            if (nd && val > maxd) maxd = val;
-            if (idx <= 256 && 256 < idx + rep) len256 = val;
-            if (kl > 32768u || kd > 32768u) return false;       // over-subscribed already: random bits get here after ~50 symbols
-        }
-        idx += rep;
-        if (br.pos > end) return false;
-    }
-    if (len256 == 0) return false;
-    if (kl > 32768u || (kl < 32768u && maxl != 1)) return false;
-    if (kd > 32768u || (kd < 32768u && maxd > 1)) return false;
+    s.t0 = t0; s.t1 = t1;
+    s.nlen = nlen; s.total = nlen + ndist;
+    s.idx = 0; s.prev = 0; s.len256 = 0; s.maxl = 0; s.maxd = 0; s.kl = 0; s.kd = 0;
     return true;
+}
+
+__device__ __forceinline__ int vh_step(VhState &s)
+{
+    BitIn &br = s.br;
+    br.refill();
+    u32 clen;
+    const int si = chain_decode<7>(__brev(br.peek()) >> 25, s.CC, clen);
+    if (si < 0) return -1;
+    const int sym = (int)((si < 12 ? s.t0 >> (5 * si) : s.t1 >> (5 * (si - 12))) & 31);
+    br.skip(clen);
+    int rep = 1, val = sym;
+    const int idx = s.idx, nlen = s.nlen;
+    if (sym >= 16) {
+        if (sym == 16) { if (idx == 0) return -1; val = s.prev; rep = 3 + (int)br.get(2); }
+        else if (sym == 17) { val = 0; rep = 3 + (int)br.get(3); }
+        else { val = 0; rep = 11 + (int)br.get(7); }
+        if (idx + rep > s.total) return -1;
+    }
+    s.prev = val;
+    if (val) {
+        const int nl = idx >= nlen ? 0 : (idx + rep <= nlen ? rep : nlen - idx);
+        const int nd = rep - nl;
+        s.kl += (u32)nl * (32768u >> val);
+        s.kd += (u32)nd * (32768u >> val);
+        if (nl && val > s.maxl) s.maxl = val;
+        if (nd && val > s.maxd) s.maxd = val;
+        if (idx <= 256 && 256 < idx + rep) s.len256 = val;
+        if (s.kl > 32768u || s.kd > 32768u) return -1;          // over-subscribed already: random bits get here after ~50 symbols
+    }
+    s.idx = idx + rep;
+    if (br.pos > br.end) return -1;
+    if (s.idx < s.total) return 0;
+    if (s.len256 == 0) return -1;
+    if (s.kl > 32768u || (s.kl < 32768u && s.maxl != 1)) return -1;
+    if (s.kd > 32768u || (s.kd < 32768u && s.maxd > 1)) return -1;
+    return 1;
 }
 
 struct InfFast {                 // per-chunk bookkeeping of the fast path (device arrays, one entry per chunk)
@@ -612,7 +628,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
     __shared__ u32 surv[SCAN_SURV_CAP];
     __shared__ u32 wsum[16];
     __shared__ u32 nsurv;
+    __shared__ u16 ktab[4096];                                     // Kraft sum (in 1/128) of four 3-bit code lengths
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < 4096; i += SCAN_THREADS) {
+        u32 k = 0;
+        for (int f = 0; f < 4; f++) k += (0x80u >> ((i >> (3 * f)) & 7)) & 0x7f;
+        ktab[i] = (u16)k;
+    }
     const u64 word0 = span0 >> 5;
     for (int i = tid; i < SCAN_THREADS + SCAN_TAIL; i += SCAN_THREADS) sw[i] = word0 + i < nwords ? w[word0 + i] : 0;
     if (tid == 0) nsurv = 0;
@@ -665,16 +687,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
         const u32 ncode = ((f0 >> 13) & 15) + 4;
         // bits 17.. of the stream at this offset: g0 = fields 0..9 (+2 bits of field 10), g1 = rest
         const u32 g0 = __builtin_amdgcn_alignbit(f1, f0, 17), g1 = __builtin_amdgcn_alignbit(f2, f1, 17);
-        u32 kraft = 0;
-#pragma unroll
-        for (u32 i = 0; i < 19; i++) {
-            u32 l;
-            if (i < 10) l = (g0 >> (3 * i)) & 7;
-            else if (i == 10) l = ((g0 >> 30) | (g1 << 2)) & 7;
-            else l = (g1 >> (3 * i - 32)) & 7;
-            const u32 c = (0x80u >> l) & 0x7f;                    // 128 >> l, 0 for l == 0
-            kraft += i < ncode ? c : 0;
-        }
+        // fields at and after ncode do not count; the rest is summed four fields (12 bits) per table look-up
+        const u32 nb = 3 * ncode;                                 // 12 .. 57 bits
+        const u32 h0 = nb >= 32 ? g0 : g0 & ((1u << nb) - 1u);
+        const u32 h1 = nb > 32 ? g1 & ((1u << (nb - 32)) - 1u) : 0u;
+        const u32 kraft = ktab[h0 & 0xfff] + ktab[(h0 >> 12) & 0xfff] + ktab[((h0 >> 24) | (h1 << 8)) & 0xfff] +
+                          ktab[(h1 >> 4) & 0xfff] + ktab[(h1 >> 16) & 0xfff];
         if (kraft == 128) {
             const u32 slot = atomicAdd(&nsurv, 1u);
             if (slot < SCAN_SURV_CAP) surv[slot] = rel;
@@ -691,25 +709,62 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
     (void)fast; (void)cand_pos; (void)cand_cnt;
 }
 
+constexpr int VAL_STEPS = 8;             // code-length symbols between two looks at the idle lanes
+constexpr u32 VAL_REFILL = 32;           // idle lanes that make a refill worth its setup (global loads + the code-length code)
 __global__ __launch_bounds__(256) void k_inf_validate(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
                                                       const InfFast *__restrict__ fast, const u64 *__restrict__ surv_list,
                                                       const u32 *__restrict__ surv_cnt, u32 surv_cap,
                                                       u64 *__restrict__ cand_pos, u32 *__restrict__ cand_cnt)
 {
-    const u32 idx = blockIdx.x * 256 + threadIdx.x;
-    const u32 n = min(*surv_cnt, surv_cap);
-    if (idx >= n) return;
-    const u64 v = surv_list[idx];
-    const u32 ci = (u32)(v >> 40);
-    const u64 o = v & ((1ull << 40) - 1);
-    const InfChunk ch = chunks[ci];
-    const u64 a = (u64)(cdata + ch.c_off);
-    const u32 *w = (const u32 *)(a & ~(u64)3);
-    const u64 bit0 = (a & 3) * 8, end = bit0 + 8 * ch.c_len, nwords = (end + 31) >> 5;
-    if (validate_dyn_header(w, nwords, end, o)) {
-        const InfFast f = fast[ci];
-        const u32 slot = atomicAdd(&cand_cnt[ci], 1u);
-        if (slot < f.cand_cap) cand_pos[f.cand_off + slot] = o;
+    const u32 n = min(surv_cnt[0], surv_cap);
+    const int lane = threadIdx.x & 63;
+    const u64 lt = ((u64)1 << lane) - 1;
+    // every wave owns a contiguous slice of the survivor list (a shared counter would be one hot atomic)
+    const u32 n_waves = gridDim.x * 4, wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u32 per = (n + n_waves - 1) / n_waves;
+    u32 next = min(n, wave_id * per);
+    const u32 stop = min(n, next + per);
+    VhState s;
+    bool active = false;
+    u32 ci = 0;
+    u64 o = 0;
+    for (;;) {
+        const u64 idle = __ballot(!active);
+        if ((u32)__popcll(idle) >= VAL_REFILL) {
+            const u32 cnt = (u32)__popcll(idle);
+            const u32 base = next;
+            next = min(stop, next + cnt);
+            const u32 n = stop;
+            if (!active) {
+                const u32 my = base + (u32)__popcll(idle & lt);
+                if (my < n) {
+                    const u64 v = surv_list[my];
+                    ci = (u32)(v >> 40);
+                    o = v & ((1ull << 40) - 1);
+                    const InfChunk ch = chunks[ci];
+                    const u64 a = (u64)(cdata + ch.c_off);
+                    const u64 bit0 = (a & 3) * 8, end = bit0 + 8 * ch.c_len;
+                    active = vh_setup(s, (const u32 *)(a & ~(u64)3), (end + 31) >> 5, end, o);
+                }
+            }
+            if (!__any(active)) {
+                if (base + cnt >= n) break;
+                continue;
+            }
+        }
+        for (int k = 0; k < VAL_STEPS; k++) {
+            if (active) {
+                const int r = vh_step(s);
+                if (r) {
+                    active = false;
+                    if (r > 0) {
+                        const InfFast f = fast[ci];
+                        const u32 slot = atomicAdd(&cand_cnt[ci], 1u);
+                        if (slot < f.cand_cap) cand_pos[f.cand_off + slot] = o;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -1899,7 +1954,7 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
         MTS_HIP(hipMemsetAsync(d_surv_cnt, 0, 4, st));
         hipLaunchKernelGGL(k_inf_scan, gscan, dim3(SCAN_THREADS), 0, st, d_cdata, d_chunks, d_fast, d_cand_pos, d_cand_cnt, d_surv,
                            d_surv_cnt, l.surv_cap);
-        hipLaunchKernelGGL(k_inf_validate, dim3((l.surv_cap + 255) / 256), dim3(256), 0, st, d_cdata, d_chunks, d_fast, d_surv,
+        hipLaunchKernelGGL(k_inf_validate, dim3(std::min((l.surv_cap + 255) / 256, 2048u)), dim3(256), 0, st, d_cdata, d_chunks, d_fast, d_surv,
                            d_surv_cnt, l.surv_cap, d_cand_pos, d_cand_cnt);
         hipLaunchKernelGGL(k_inf_sortc, dim3(n_chunks), dim3(256), 0, st, d_fast, d_cand_pos, d_cand_tmp, d_cand_cnt);
         inflate_mark(engine, st, "inflate_scan");
