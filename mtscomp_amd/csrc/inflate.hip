@@ -498,10 +498,11 @@ struct VhState {
     u32 kl, kd;                           // Kraft sums scaled by 2^15
 };
 
-__device__ bool vh_setup(VhState &s, const u32 *w, u64 nwords, u64 end, u64 o)
+__device__ bool vh_setup(VhState &s, const u32 *w, u64 nwords, u64 end, u64 o, const u32 *lw, u32 lwn)
 {
     BitIn &br = s.br;
     br.w = w; br.nwords = nwords; br.end = end;
+    br.lw = lw; br.lw0 = o >> 5; br.lwn = lwn;            // the first words of the header, staged by the caller
     br.seek(o + 3);
     const int nlen = (int)br.get(5) + 257, ndist = (int)br.get(5) + 1, ncode = (int)br.get(4) + 4;
     if (nlen > 286 || ndist > 30) return false;
@@ -509,34 +510,32 @@ __device__ bool vh_setup(VhState &s, const u32 *w, u64 nwords, u64 end, u64 o)
     const u8 order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     u64 cl = 0;
     for (int i = 0; i < ncode; i++) cl |= (u64)br.get(3) << (3 * order[i]);
-    // compare chain of the 7-bit code + its sorted symbols packed 5 bits each (two u64)
-    u32 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // compare chain of the 7-bit code + its sorted symbols packed 5 bits each (two u64).  Counts per length live in one
+    // u64, 5 bits each (at most 19 codes), so nothing is indexed by a run-time value.
+    u64 cntp = 0;
 #pragma unroll
-    for (int k = 0; k < 19; k++) {
-        const u32 l = (u32)(cl >> (3 * k)) & 7;
-#pragma unroll
-        for (int j = 1; j < 8; j++) cnt[j] += (l == (u32)j);
-    }
-    u32 firstc = 0, offs[8], off = 0;
+    for (int k = 0; k < 19; k++) cntp += 1ull << (5 * ((u32)(cl >> (3 * k)) & 7));
+    u32 firstc = 0, off = 0;
+    u64 offp = 0;                         // first sorted slot of each length, 5 bits each
     int left = 1;
     s.CC[0] = 0;
 #pragma unroll
     for (int l = 1; l <= 7; l++) {
-        left = (left << 1) - (int)cnt[l];
-        offs[l] = off; off += cnt[l];
-        s.CC[l] = (((firstc + cnt[l]) << (7 - l)) & 0xffff) | (cnt[l] << 16);
-        firstc = (firstc + cnt[l]) << 1;
+        const u32 c = (u32)(cntp >> (5 * l)) & 31;
+        left = (left << 1) - (int)c;
+        offp |= (u64)off << (5 * l); off += c;
+        s.CC[l] = (((firstc + c) << (7 - l)) & 0xffff) | (c << 16);
+        firstc = (firstc + c) << 1;
     }
     if (left != 0) return false;
     u64 t0 = 0, t1 = 0;
 #pragma unroll
-    for (int l = 1; l <= 7; l++) {
-        u32 o2 = offs[l];
-        for (int k = 0; k < 19; k++) {
-            if (((u32)(cl >> (3 * k)) & 7) == (u32)l) {
-                if (o2 < 12) t0 |= (u64)k << (5 * o2); else t1 |= (u64)k << (5 * (o2 - 12));
-                o2++;
-            }
+    for (int k = 0; k < 19; k++) {
+        const u32 l = (u32)(cl >> (3 * k)) & 7;
+        if (l) {
+            const u32 o2 = (u32)(offp >> (5 * l)) & 31;
+            offp += 1ull << (5 * l);
+            if (o2 < 12) t0 |= (u64)k << (5 * o2); else t1 |= (u64)k << (5 * (o2 - 12));
         }
     }
     s.t0 = t0; s.t1 = t1;
@@ -709,8 +708,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
     (void)fast; (void)cand_pos; (void)cand_cnt;
 }
 
+constexpr int VAL_STAGE = 16;            // words of a candidate header staged in LDS
 constexpr int VAL_STEPS = 8;             // code-length symbols between two looks at the idle lanes
-constexpr u32 VAL_REFILL = 32;           // idle lanes that make a refill worth its setup (global loads + the code-length code)
+constexpr u32 VAL_REFILL = 16;           // idle lanes that make a refill worth its setup (global loads + the code-length code)
 __global__ __launch_bounds__(256) void k_inf_validate(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
                                                       const InfFast *__restrict__ fast, const u64 *__restrict__ surv_list,
                                                       const u32 *__restrict__ surv_cnt, u32 surv_cap,
@@ -724,6 +724,7 @@ __global__ __launch_bounds__(256) void k_inf_validate(const u8 *__restrict__ cda
     const u32 per = (n + n_waves - 1) / n_waves;
     u32 next = min(n, wave_id * per);
     const u32 stop = min(n, next + per);
+    __shared__ u32 stage[4][64][VAL_STAGE + 1];                    // (odd row pitch: lanes read their own rows)
     VhState s;
     bool active = false;
     u32 ci = 0;
@@ -744,7 +745,21 @@ __global__ __launch_bounds__(256) void k_inf_validate(const u8 *__restrict__ cda
                     const InfChunk ch = chunks[ci];
                     const u64 a = (u64)(cdata + ch.c_off);
                     const u64 bit0 = (a & 3) * 8, end = bit0 + 8 * ch.c_len;
-                    active = vh_setup(s, (const u32 *)(a & ~(u64)3), (end + 31) >> 5, end, o);
+                    // the first VAL_STAGE words from the header on go to this lane's LDS row with four loads in flight: a
+                    // candidate that is not a header is decided inside them (~44 symbols of ~7 bits), and the bit reader
+                    // would otherwise fetch them one dependent load after the other
+                    const u32 *w = (const u32 *)(a & ~(u64)3);
+                    const u64 nwords = (end + 31) >> 5, i0 = o >> 5;
+                    u32 *row = &stage[threadIdx.x >> 6][lane][0];
+                    if (i0 + VAL_STAGE <= nwords) {
+                        typedef u32 w4 __attribute__((ext_vector_type(4), aligned(4)));
+                        const w4 q0 = *(const w4 *)(w + i0), q1 = *(const w4 *)(w + i0 + 4), q2 = *(const w4 *)(w + i0 + 8), q3 = *(const w4 *)(w + i0 + 12);
+                        row[0] = q0.x; row[1] = q0.y; row[2] = q0.z; row[3] = q0.w; row[4] = q1.x; row[5] = q1.y; row[6] = q1.z; row[7] = q1.w;
+                        row[8] = q2.x; row[9] = q2.y; row[10] = q2.z; row[11] = q2.w; row[12] = q3.x; row[13] = q3.y; row[14] = q3.z; row[15] = q3.w;
+                    } else {
+                        for (int k = 0; k < VAL_STAGE; k++) row[k] = i0 + k < nwords ? w[i0 + k] : 0u;
+                    }
+                    active = vh_setup(s, w, nwords, end, o, row, VAL_STAGE);
                 }
             }
             if (!__any(active)) {
