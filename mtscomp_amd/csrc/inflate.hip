@@ -735,10 +735,9 @@ __global__ __launch_bounds__(256) void k_inf_validate(const u8 *__restrict__ cda
             const u32 cnt = (u32)__popcll(idle);
             const u32 base = next;
             next = min(stop, next + cnt);
-            const u32 n = stop;
             if (!active) {
                 const u32 my = base + (u32)__popcll(idle & lt);
-                if (my < n) {
+                if (my < stop) {
                     const u64 v = surv_list[my];
                     ci = (u32)(v >> 40);
                     o = v & ((1ull << 40) - 1);
@@ -763,7 +762,7 @@ __global__ __launch_bounds__(256) void k_inf_validate(const u8 *__restrict__ cda
                 }
             }
             if (!__any(active)) {
-                if (base + cnt >= n) break;
+                if (base + cnt >= stop) break;
                 continue;
             }
         }
