@@ -83,6 +83,8 @@ __device__ __forceinline__ u32 __reduce_max_sync_u32(u32 v)
 constexpr int SORT_WAVES = 16;           // waves per sort workgroup (one tile)
 constexpr int SORT_KPL = 4;              // keys per lane and step: SORT_KPL * 64 keys are staged in destination order per wave
 constexpr int SORT_NT = SORT_WAVES * 64;
+constexpr int SORT_PASSES = 2;           // 2: 8 + 7 hash bits (12.4 ms), 3: 5 + 5 + 5 (runs of ~8 keys per store, but 17.8 ms: a pass costs ~6 ms whatever its stores look like)
+constexpr int SORT_B1 = SORT_PASSES == 2 ? 8 : 5;
 // per-(wave, digit) counts -> where each wave's keys of each digit start (digit-major, wave-minor: stable)
 template <int NB>
 __device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
@@ -116,7 +118,10 @@ __device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
 // time with wave ballots.  The first pass makes the keys from the stream and, while it scatters them,
 // counts the SECOND pass's digits per second-pass wave (a key's destination says which wave will own it),
 // so the second pass needs no counting loop of its own.
-template <int NB, bool FIRST>
+// NB = bits of this pass's digit; FIRST: the digit is the low NB bits of the hash made from the stream bytes (and the key
+// that is stored keeps the other hash bits above the position); otherwise the digit is NB bits at SHIFT above the position.
+// NNB > 0: count the next pass's digit (the NNB bits above this pass's) for the wave that will own the key there.
+template <int NB, bool FIRST, int SHIFT, int NNB>
 __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *__restrict__ src, u32 *__restrict__ dst, u32 wlen,
                                           u32 per, u32 (*cnt)[256], u32 (*cnt2)[128], u32 per_magic, int lane_ordered, u32 *stg, u32 *dlt)
 {
@@ -129,8 +134,9 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
         if (FIRST) return hash_of(gld_u32_unaligned(s, i));
         return src[i];
     };
-    auto digit_of = [&](u32 f) -> u32 { return FIRST ? f & 255 : f >> REL_BITS; };
-    auto key_of = [&](u32 f, u32 i) -> u32 { return FIRST ? ((f >> 8) << REL_BITS) | i : f; };
+    auto digit_of = [&](u32 f) -> u32 { return FIRST ? f & ((1u << NB) - 1) : (f >> (REL_BITS + SHIFT)) & ((1u << NB) - 1); };
+    auto key_of = [&](u32 f, u32 i) -> u32 { return FIRST ? ((f >> NB) << REL_BITS) | i : f; };
+    auto next_digit_of = [&](u32 f) -> u32 { return (FIRST ? f >> NB : f >> (REL_BITS + SHIFT + NB)) & ((1u << (NNB > 0 ? NNB : 1)) - 1); };
     if (lane_ordered) {
         // The LDS retires the same-address atomics of one wave instruction in lane order (probed at start-up, see
         // k_probe_lds_order): the value returned by the add IS the stable destination -- no ballots, no barriers.
@@ -162,7 +168,7 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
                     const u32 slot = at[k] + D[digit_of(key[k])];
                     K[slot] = key_of(key[k], base + 64 * k + lane);
                     A[slot] = at[k];
-                    if (FIRST) atomicAdd(&cnt2[per_magic ? __umulhi(at[k] >> 6, per_magic) : at[k] >> 6][key[k] >> 8], 1u);
+                    if (NNB > 0) atomicAdd(&cnt2[per_magic ? __umulhi(at[k] >> 6, per_magic) : at[k] >> 6][next_digit_of(key[k])], 1u);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -191,7 +197,7 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
         if (act) {
             dst[off + rank] = key_of(key, i);
             if (rank == count - 1) cnt[wave][d] = off + count;
-            if (FIRST) atomicAdd(&cnt2[per_magic ? __umulhi((off + rank) >> 6, per_magic) : (off + rank) >> 6][key >> 8], 1u);
+            if (NNB > 0) atomicAdd(&cnt2[per_magic ? __umulhi((off + rank) >> 6, per_magic) : (off + rank) >> 6][next_digit_of(key)], 1u);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -274,16 +280,33 @@ __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ st
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = gld_u32_unaligned(s, min(i0 + 64 * k, end - 1));
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (i0 + 64 * k < end) atomicAdd(&cnt[wave][hash_of(v[k]) & 255], 1u);
+            for (int k = 0; k < 4; k++) if (i0 + 64 * k < end) atomicAdd(&cnt[wave][hash_of(v[k]) & ((1u << SORT_B1) - 1)], 1u);
         }
     }
     __syncthreads();
-    bin_offsets<8>(cnt, tot);
-    rank_pass<8, true>(s, nullptr, tmp + td.sorted_off, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);        // low 8 hash bits
-    for (int i = threadIdx.x; i < SORT_WAVES * 128; i += SORT_NT) cnt[i >> 7][i & 127] = cnt2[i >> 7][i & 127];
-    __syncthreads();
-    bin_offsets<7>(cnt, tot);
-    rank_pass<7, false>(s, tmp + td.sorted_off, sorted + td.sorted_off, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);  // high 7 bits
+    u32 *tmp_t = tmp + td.sorted_off, *out_t = sorted + td.sorted_off;
+    auto next_counts = [&]() {                       // the fused counts become the next pass's
+        for (int i = threadIdx.x; i < SORT_WAVES * 128; i += SORT_NT) { cnt[i >> 7][i & 127] = cnt2[i >> 7][i & 127]; cnt2[i >> 7][i & 127] = 0; }
+        __syncthreads();
+    };
+    if (SORT_PASSES == 2) {
+        bin_offsets<8>(cnt, tot);
+        rank_pass<8, true, 0, 7>(s, nullptr, tmp_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);        // low 8 hash bits
+        next_counts();
+        bin_offsets<7>(cnt, tot);
+        rank_pass<7, false, 0, 0>(s, tmp_t, out_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);          // high 7 bits
+    } else {
+        // three passes of 5 bits: a wave step's 256 keys fall into 32 bins, so the stores of a step are runs of ~8 keys
+        // (whole sectors) instead of single keys; the sorted array goes tmp <- out <- tmp <- ... so that it ends in `sorted`
+        bin_offsets<5>(cnt, tot);
+        rank_pass<5, true, 0, 5>(s, nullptr, out_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);
+        next_counts();
+        bin_offsets<5>(cnt, tot);
+        rank_pass<5, false, 0, 5>(s, out_t, tmp_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);
+        next_counts();
+        bin_offsets<5>(cnt, tot);
+        rank_pass<5, false, 5, 0>(s, tmp_t, out_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);
+    }
     if (want_nb) chain_lengths(s, sorted + td.sorted_off, sorted_nb + td.sorted_off, wlen, tot, tot + 32);      // (k_match5 derives them itself)
 }
 
