@@ -209,7 +209,7 @@ def main():
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': measured_traffic(n_chunks, nc),
                          'algorithmic_bytes_per_launch': algo, 'launch_ms': match_ms},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:             # (the CPU comparison is taken once, at N = 1)
             m = max(1, min(args.cpu_chunks, n_chunks))
             res['cpu_baseline'] = cpu_baseline(raw[:m * rate].cpu().numpy(), nc, rate, m)
         print(json.dumps(res))
