@@ -1234,7 +1234,7 @@ constexpr u32 LZ_SPIN_MAX = 1u << 20;                     // bound on every wait
 // so it works on 16-bit cells: 0..255 = a byte, 256 + i = "byte i of my unknown window".  The cells leave
 // as they are; k_inf_windows then makes the real windows one after the other (window k = the last 32 KiB
 // of segment k-1, translated with window k-1) and k_inf_translate turns every cell into a byte.
-constexpr int LZ_MAXSEG = 8;
+constexpr int LZ_MAXSEG = 32;
 constexpr u32 LZ_WIN = 32768;
 struct LzPlan {
     u32 nseg;                          // 1: the whole chunk by k_inf_lz (bytes)
@@ -1585,29 +1585,33 @@ __global__ __launch_bounds__(64) void k_inf_plan(const InfResult *__restrict__ r
     const int ci = blockIdx.x * 64 + threadIdx.x;
     if (ci >= n_chunks) return;
     const InfResult r = res[ci];
-    LzPlan p;
-    p.nseg = 1;
-    for (int k = 0; k <= LZ_MAXSEG; k++) { p.g0[k] = 0; p.b0[k] = 0; }
+    LzPlan *p = plan + ci;
+    p->nseg = 1;
+    for (int k = 0; k <= LZ_MAXSEG; k++) { p->g0[k] = 0; p->b0[k] = 0; }
     if (r.status == MTS_CHUNK_OK && r.ntok) {
         const u32 ngroups = (r.ntok + 63) / 64;
         const u32 *gbl = gbase + gb_off[ci];
         const u32 *tbs = tile_base + tb_off[ci];
         auto gb = [&](u32 g) -> u32 { return g >= ngroups ? r.n_out : tbs[g / GS_TILE] + gbl[g]; };
-        p.g0[1] = ngroups; p.b0[1] = r.n_out;
-        if (nseg_req > 1) {
-            const u32 per = (ngroups + nseg_req - 1) / nseg_req;
+        p->g0[1] = ngroups; p->b0[1] = r.n_out;
+        // the largest number of segments (the requested one, halved until it fits) such that every segment but the last
+        // produces a whole window and every segment has work
+        for (int ns = nseg_req; ns > 1; ns >>= 1) {
+            const u32 per = (ngroups + ns - 1) / ns;
             bool ok = per > 0;
-            u32 g0[LZ_MAXSEG + 1], b0[LZ_MAXSEG + 1];
-            for (int k = 0; k <= nseg_req; k++) { g0[k] = min((u32)k * per, ngroups); b0[k] = gb(g0[k]); }
-            // every segment but the last must produce a whole window; every segment must have work
-            for (int k = 0; k < nseg_req; k++) {
-                if (g0[k + 1] <= g0[k]) ok = false;
-                if (k + 1 < nseg_req && b0[k + 1] - b0[k] < LZ_WIN + 512) ok = false;
+            u32 prev_g = 0, prev_b = 0;
+            for (int k = 1; k <= ns && ok; k++) {
+                const u32 g = min((u32)k * per, ngroups), b = gb(g);
+                if (g <= prev_g) ok = false;
+                if (k < ns && b - prev_b < LZ_WIN + 512) ok = false;
+                prev_g = g; prev_b = b;
             }
-            if (ok) { p.nseg = (u32)nseg_req; for (int k = 0; k <= nseg_req; k++) { p.g0[k] = g0[k]; p.b0[k] = b0[k]; } }
+            if (!ok) continue;
+            p->nseg = (u32)ns;
+            for (int k = 0; k <= ns; k++) { const u32 g = min((u32)k * per, ngroups); p->g0[k] = g; p->b0[k] = gb(g); }
+            break;
         }
     }
-    plan[ci] = p;
 }
 
 __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict__ tokens, const InfChunk *__restrict__ chunks,
@@ -1781,12 +1785,13 @@ __global__ __launch_bounds__(1024) void k_inf_windows(const InfChunk *__restrict
 {
     const int ci = blockIdx.x;
     if (res[ci].status != MTS_CHUNK_OK) return;
-    const LzPlan pl = plan[ci];
-    if (pl.nseg < 2) return;
+    const LzPlan *pl = plan + ci;
+    const u32 nseg = pl->nseg;
+    if (nseg < 2) return;
     const u16 *cells = sym + chunks[ci].stream_off;
     u8 *W = win + (size_t)ci * LZ_MAXSEG * LZ_WIN;                  // W[k] = window of segment k
-    for (u32 k = 1; k < pl.nseg; k++) {
-        const u32 p0 = pl.b0[k] - LZ_WIN;                           // >= b0[k - 1]: segments are at least a window long
+    for (u32 k = 1; k < nseg; k++) {
+        const u32 p0 = pl->b0[k] - LZ_WIN;                           // >= b0[k - 1]: segments are at least a window long
         const u8 *prev = W + (size_t)(k - 1) * LZ_WIN;
         for (u32 i = threadIdx.x; i < LZ_WIN; i += 1024) {
             const u32 c = cells[p0 + i];
@@ -1805,14 +1810,19 @@ __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restric
     const int ci = blockIdx.y;
     const InfResult r = res[ci];
     if (r.status != MTS_CHUNK_OK) return;
-    const LzPlan pl = plan[ci];
-    if (pl.nseg < 2) return;
+    const LzPlan *pl = plan + ci;
+    const u32 nseg = pl->nseg;
+    if (nseg < 2) return;
     const u32 p = (blockIdx.x * 256 + threadIdx.x) * 16;
     if (p >= r.n_out) return;
     const u16 *cells = sym + chunks[ci].stream_off;
     u8 *out = stream + chunks[ci].stream_off;
     const u8 *W = win + (size_t)ci * LZ_MAXSEG * LZ_WIN;
-    auto seg_of = [&](u32 q) -> u32 { u32 k = 0; while (k + 1 < pl.nseg && q >= pl.b0[k + 1]) k++; return k; };
+    auto seg_of = [&](u32 q) -> u32 {                               // last k with b0[k] <= q
+        u32 lo = 0, hi = nseg - 1;
+        while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (q >= pl->b0[mid]) lo = mid; else hi = mid - 1; }
+        return lo;
+    };
     if (p + 16 <= r.n_out) {
         const uint4 a = *(const uint4 *)(cells + p), b = *(const uint4 *)(cells + p + 8);
         const u32 cw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};

@@ -141,7 +141,7 @@ def test_inflate(name):
     assert st == 0 and out == data
 
 
-@pytest.mark.parametrize('nseg', [2, 3, 4, 8])
+@pytest.mark.parametrize('nseg', [2, 3, 4, 8, 16, 32])
 def test_inflate_segmented_resolver(monkeypatch, nseg):
     """With few chunks in a batch the LZ resolver cuts a chunk into segments resolved by different workgroups on
     symbolic 16-bit cells (unknown 32 KiB window), then translates.  MTS_LZ_SEGS forces the cut."""
