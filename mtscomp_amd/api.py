@@ -538,6 +538,16 @@ class Reader:
     def _pread(self, length, start):
         if hasattr(os, 'pread'):
             buf = os.pread(self.cdata.fileno(), length, start)       # thread safe (mtscomp.py:609)
+            if len(buf) < length:                                    # one pread returns at most 2 GiB - 4 KiB on Linux
+                parts = [buf]
+                got = len(buf)
+                while got < length:
+                    more = os.pread(self.cdata.fileno(), length - got, start + got)
+                    if not more:
+                        break
+                    parts.append(more)
+                    got += len(more)
+                buf = b''.join(parts)
         else:  # pragma: no cover
             with _seek_lock:
                 self.cdata.seek(start)
@@ -771,6 +781,21 @@ class Reader:
             rows = self._slice_from_device_cache(first, last, i0, i1)
             if rows is not None:
                 out = rows[::item.step, :]
+                assert out.shape[0] == len(range(i0, i1, item.step or 1))
+                return out
+            if last - first + 1 > self.batch_size:
+                # a long slice: batch after batch straight into the result (one codec call for everything would need the
+                # whole slice in device memory, and the chunk cache could not hold it anyway)
+                out = np.empty((i1 - i0, self.n_channels), dtype=self.dtype)
+                for b0 in range(first, last + 1, self.batch_size):
+                    b1 = min(b0 + self.batch_size, last + 1)
+                    chunks = self.decompress_chunks(range(b0, b1))
+                    for idx in range(b0, b1):
+                        lo, hi = max(i0, self.chunk_bounds[idx]), min(i1, self.chunk_bounds[idx + 1])
+                        if lo < hi:
+                            out[lo - i0:hi - i0] = chunks[idx][lo - self.chunk_bounds[idx]:hi - self.chunk_bounds[idx]]
+                    del chunks
+                out = out[::item.step, :]
                 assert out.shape[0] == len(range(i0, i1, item.step or 1))
                 return out
             triples = list(self.iter_chunks(first, last))

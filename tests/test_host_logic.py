@@ -1,5 +1,6 @@
 """Host-side logic without a GPU: C-ABI surface, error behaviour, scheduler/sharding, config, Reader
 semantics (driven through the test-only OracleCodec)."""
+import os
 import ctypes
 import json
 import re
@@ -212,5 +213,23 @@ def test_3d_npy_and_options(tmp_cfg):
 def test_chunk_durations(tmp_cfg, chunk_duration):
     arr = (np.random.RandomState(7).randn(6997, 3) * 300).astype(np.int16)
     r, _ = _write(tmp_cfg, arr, chunk_duration=chunk_duration)
+    assert np.array_equal(r[:], arr)
+    r.close()
+
+
+def test_long_slices_go_batch_by_batch_and_short_preads_are_completed(tmp_cfg, monkeypatch):
+    arr = (np.random.RandomState(8).randn(6997, 7) * 900).astype(np.int16)
+    r, codec = _write(tmp_cfg, arr, check_after_compress=False)          # 6 chunks
+    r.batch_size = 2                                                     # slices over more than 2 chunks are batched
+    codec.calls.clear()
+    assert np.array_equal(r[:], arr)
+    assert [c for c in codec.calls if c[0] == 'decompress'] == [('decompress', 2)] * 3
+    for s in (slice(3, -5, 3), slice(1234, 6000), slice(100, 6997, 1000)):
+        assert np.array_equal(r[s], arr[s]), s
+    # os.pread may return fewer bytes than asked for (it does above 2 GiB): the reader asks again
+    real = os.pread
+    monkeypatch.setattr(os, 'pread', lambda fd, n, off: real(fd, min(n, 1000), off))
+    r._cache.clear()
+    assert np.array_equal(r[500:3000], arr[500:3000])
     assert np.array_equal(r[:], arr)
     r.close()
