@@ -41,6 +41,7 @@ extern "C" {
 #define MTS_FLAG_TIME_DIFF 1
 #define MTS_FLAG_SPATIAL_DIFF 2
 #define MTS_FLAG_ORDER_F 4
+#define MTS_FLAG_FLOAT 8          /* items are IEEE floats (itemsize 4 or 8): np.diff / np.cumsum in that type, bit for bit */
 
 int mts_version(void);
 int mts_device_count(void);                 /* number of gfx950 devices visible; 0 if none */

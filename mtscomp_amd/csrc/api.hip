@@ -334,6 +334,7 @@ static int dev_compress(Engine &E, hipStream_t st, const void *d_raw, int nc, in
     if (level < 1 || level > 9) { set_error("level %d out of range", level); return MTS_E_ARG; }
     if (level < 4) { set_error("levels 1-3 (deflate_fast) are not implemented on device yet"); return MTS_E_UNSUPPORTED; }
     if (sz != 1 && sz != 2 && sz != 4 && sz != 8) { set_error("itemsize %d unsupported", sz); return MTS_E_ARG; }
+    if ((flags & MTS_FLAG_FLOAT) && sz != 4 && sz != 8) { set_error("float items of %d bytes unsupported", sz); return MTS_E_ARG; }
     if (nc <= 0 || n_chunks < 0) return MTS_E_ARG;
     MTS_HIP(hipSetDevice(E.dev));
     const size_t budget = batch_budget_bytes();
@@ -434,6 +435,7 @@ static int dev_decompress(Engine &E, hipStream_t st, const u8 *d_cdata, const lo
                           int n_chunks, int nc, int sz, int flags, u8 *d_out, const long *out_off, int *status)
 {
     if (sz != 1 && sz != 2 && sz != 4 && sz != 8) { set_error("itemsize %d unsupported", sz); return MTS_E_ARG; }
+    if ((flags & MTS_FLAG_FLOAT) && sz != 4 && sz != 8) { set_error("float items of %d bytes unsupported", sz); return MTS_E_ARG; }
     if (nc <= 0 || n_chunks < 0) return MTS_E_ARG;
     MTS_HIP(hipSetDevice(E.dev));
     const size_t budget = batch_budget_bytes() * 4;          // inflate needs ~5 bytes of workspace per byte

@@ -41,6 +41,16 @@ __device__ __forceinline__ void block_sum2(u64 &a, u64 &b, u64 *sh /* 8 entries 
 //   adler: A = 1 + sum b_i, B = n + sum (n - i) b_i  (mod 65521); partial sums are atomically
 //   accumulated per chunk (already reduced mod 65521 per workgroup, so the u64 cannot overflow).
 // ------------------------------------------------------------------------------------------------
+// bit pattern of an item (the adler32 sums run over the bytes of the stream)
+__device__ __forceinline__ u64 item_bits(u8 v) { return v; }
+__device__ __forceinline__ u64 item_bits(u16 v) { return v; }
+__device__ __forceinline__ u64 item_bits(u32 v) { return v; }
+__device__ __forceinline__ u64 item_bits(u64 v) { return v; }
+__device__ __forceinline__ u64 item_bits(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ u64 item_bits(double v) { return (u64)__double_as_longlong(v); }
+
+// T = unsigned integer of the item size (wrap-around arithmetic, like numpy's), or float / double (MTS_FLAG_FLOAT: every
+// difference rounded in T, the time difference first, like np.diff applied twice)
 template <typename T>
 __global__ __launch_bounds__(256) void k_delta_transpose(const u8 *__restrict__ raw, u8 *__restrict__ stream,
                                                          const ChunkDesc *__restrict__ chunks, int nc,
@@ -82,7 +92,7 @@ __global__ __launch_bounds__(256) void k_delta_transpose(const u8 *__restrict__ 
         }
         const u64 I = of ? (u64)c * nt + t : (u64)t * nc + c;
         out[I] = d;
-        u64 v = (u64)d;
+        const u64 v = item_bits(d);
 #pragma unroll
         for (int k = 0; k < (int)sizeof(T); k++) {
             const u64 b = (v >> (8 * k)) & 0xff;
@@ -262,6 +272,13 @@ int launch_delta_transpose(hipStream_t st, const void *d_raw, void *d_stream, co
         MTS_HIP(hipGetLastError());
         return MTS_OK;
     }
+    if (flags & MTS_FLAG_FLOAT) {
+        if (itemsize == 4) hipLaunchKernelGGL(k_delta_transpose<float>, grid, block, 0, st, raw, stream, d_chunks, n_channels, flags, d_adler_acc);
+        else if (itemsize == 8) hipLaunchKernelGGL(k_delta_transpose<double>, grid, block, 0, st, raw, stream, d_chunks, n_channels, flags, d_adler_acc);
+        else return MTS_E_ARG;
+        MTS_HIP(hipGetLastError());
+        return MTS_OK;
+    }
     switch (itemsize) {
     case 1: hipLaunchKernelGGL(k_delta_transpose<u8>, grid, block, 0, st, raw, stream, d_chunks, n_channels, flags, d_adler_acc); break;
     case 2: hipLaunchKernelGGL(k_delta_transpose<u16>, grid, block, 0, st, raw, stream, d_chunks, n_channels, flags, d_adler_acc); break;
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(256) void k_spatial_cumsum(u8 *stream, const u64 *_
     T acc = 0;
     for (int c = 0; c < nc; c++) {
         const u64 I = order_f ? (u64)c * nt + t : (u64)t * nc + c;
-        acc += d[I];
+        acc = c ? acc + d[I] : d[I];             // (not 0 + d: -0.0 stays -0.0 for float items)
         d[I] = acc;
     }
 }
@@ -444,6 +461,58 @@ __global__ __launch_bounds__(256) void k_cumsum_transpose(const u8 *__restrict__
         const int c = c0 + cc;
         if (t < nt && c < nc) out[(u64)t * nc + c] = tile[cc][tt];
     }
+}
+
+// Float items: np.cumsum adds one after the other (r[t] = r[t-1] + d[t], rounded in T each time), and so does this -- one
+// lane per channel, 30000 dependent adds -- because any tree-shaped scan rounds differently.  (Loads are issued eight
+// ahead; the C-order stores of a wave are consecutive channels.)
+template <typename T>
+__global__ __launch_bounds__(256) void k_cumsum_seq(const u8 *__restrict__ stream, u8 *__restrict__ outb,
+                                                    const u64 *__restrict__ stream_off, const u64 *__restrict__ out_off,
+                                                    const u32 *__restrict__ rows, const int *__restrict__ status, int nc, int flags)
+{
+    const int chunk = blockIdx.y;
+    if (status && status[chunk] != 0) return;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nc) return;
+    const long nt = rows[chunk];
+    const T *d = (const T *)(stream + stream_off[chunk]);
+    T *o = (T *)(outb + out_off[chunk]);
+    const bool td = flags & MTS_FLAG_TIME_DIFF, of = flags & MTS_FLAG_ORDER_F;
+    const long step = of ? 1 : nc;
+    const T *p = d + (of ? (long)c * nt : (long)c);
+    T acc = 0;
+    long t = 0;
+    for (; t + 8 <= nt; t += 8) {
+        T v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = p[(t + k) * step];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            acc = (td && t + k > 0) ? acc + v[k] : v[k];
+            o[(t + k) * nc + c] = acc;
+        }
+    }
+    for (; t < nt; t++) {
+        const T v = p[t * step];
+        acc = (td && t > 0) ? acc + v : v;
+        o[t * nc + c] = acc;
+    }
+}
+
+template <typename T>
+static int run_cumsum_float(hipStream_t st, const u8 *stream, u8 *out, const u64 *d_stream_off, const u64 *d_out_off,
+                            const u32 *d_rows, const int *d_status, int n_chunks, u32 max_rows, int nc, int flags)
+{
+    const int of = (flags & MTS_FLAG_ORDER_F) ? 1 : 0;
+    if (flags & MTS_FLAG_SPATIAL_DIFF) {
+        dim3 g((max_rows + 255) / 256, n_chunks);
+        hipLaunchKernelGGL(k_spatial_cumsum<T>, g, dim3(256), 0, st, (u8 *)stream, d_stream_off, d_rows, d_status, nc, of);
+    }
+    hipLaunchKernelGGL(k_cumsum_seq<T>, dim3((nc + 255) / 256, n_chunks), dim3(256), 0, st, stream, out, d_stream_off, d_out_off, d_rows,
+                       d_status, nc, flags);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
 }
 
 template <typename T, int SEGR>
@@ -637,6 +706,11 @@ int launch_cumsum_transpose(hipStream_t st, const void *d_stream, void *d_out, c
     u8 *o = (u8 *)d_out;
     u64 *ss = (u64 *)d_segsums;
     (void)segr_for;
+    if (flags & MTS_FLAG_FLOAT) {
+        if (itemsize == 4) return run_cumsum_float<float>(st, s, o, d_stream_off, d_out_off, d_rows, d_status, n_chunks, max_rows, n_channels, flags);
+        if (itemsize == 8) return run_cumsum_float<double>(st, s, o, d_stream_off, d_out_off, d_rows, d_status, n_chunks, max_rows, n_channels, flags);
+        return MTS_E_ARG;
+    }
     if (flags == (MTS_FLAG_TIME_DIFF | MTS_FLAG_ORDER_F) && itemsize <= 4 && n_channels >= 2 && rows_tile(n_channels, itemsize) && !getenv("MTS_K12_GENERIC")) {
         switch (itemsize) {
         case 1: run_cumsum_rows<u8>(st, s, o, d_stream_off, d_out_off, d_rows, d_status, n_chunks, max_rows, n_channels, (u32 *)ss); break;

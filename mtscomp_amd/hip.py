@@ -15,6 +15,7 @@ LIB_PATH = _HERE / 'libmtscomp_hip.so'
 FLAG_TIME_DIFF = 1
 FLAG_SPATIAL_DIFF = 2
 FLAG_ORDER_F = 4
+FLAG_FLOAT = 8
 
 CHUNK_OK = 0
 CHUNK_CORRUPT = -1
@@ -129,10 +130,15 @@ def make_flags(do_time_diff=True, do_spatial_diff=False, chunk_order='F'):
 
 def check_dtype(dtype):
     dtype = np.dtype(dtype)
-    if dtype.kind not in 'iu' or dtype.itemsize not in (1, 2, 4, 8):
+    if not ((dtype.kind in 'iu' and dtype.itemsize in (1, 2, 4, 8)) or (dtype.kind == 'f' and dtype.itemsize in (4, 8))):
         raise NotImplementedError(
-            'the MI355X codec handles integer dtypes of 1/2/4/8 bytes; got %s' % dtype)
+            'the MI355X codec handles integer dtypes of 1/2/4/8 bytes and float32/float64; got %s' % dtype)
     return dtype
+
+
+def _dflags(flags, dtype):
+    """flags as the C ABI wants them: the float bit comes from the dtype."""
+    return (int(flags) & ~FLAG_FLOAT) | (FLAG_FLOAT if np.dtype(dtype).kind == 'f' else 0)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -143,7 +149,7 @@ def delta_transpose(chunk, flags, device=0):
     check_dtype(chunk.dtype)
     nt, nc = chunk.shape
     out = np.empty(chunk.nbytes, dtype=np.uint8)
-    _check(lib().mts_delta_transpose(device, _ptr(chunk), nt, nc, chunk.itemsize, flags, _ptr(out)),
+    _check(lib().mts_delta_transpose(device, _ptr(chunk), nt, nc, chunk.itemsize, _dflags(flags, chunk.dtype), _ptr(out)),
            'mts_delta_transpose')
     return out
 
@@ -154,7 +160,7 @@ def cumsum_transpose(stream, nt, nc, dtype, flags, device=0):
                                   else stream.view(np.uint8).ravel())
     assert stream.size == nt * nc * dtype.itemsize
     out = np.empty((nt, nc), dtype=dtype)
-    _check(lib().mts_cumsum_transpose(device, _ptr(stream), nt, nc, dtype.itemsize, flags, _ptr(out)),
+    _check(lib().mts_cumsum_transpose(device, _ptr(stream), nt, nc, dtype.itemsize, _dflags(flags, dtype), _ptr(out)),
            'mts_cumsum_transpose')
     return out
 
@@ -172,8 +178,8 @@ def compress_chunks(data, chunk_bounds, flags, level=6, device=0):
     slots = _longs(np.concatenate(([0], np.cumsum(bounds)))[:-1]) if n_chunks else _longs([])
     out = np.empty(int(sum(bounds)) + 16, dtype=np.uint8)
     sizes = np.zeros(max(n_chunks, 1), dtype=np.int64)
-    _check(lib().mts_compress_chunks(device, _ptr(data), data.shape[1], data.itemsize, _lp(b), n_chunks, flags,
-                                     level, _ptr(out), _lp(slots), _lp(sizes)), 'mts_compress_chunks')
+    _check(lib().mts_compress_chunks(device, _ptr(data), data.shape[1], data.itemsize, _lp(b), n_chunks,
+                                     _dflags(flags, data.dtype), level, _ptr(out), _lp(slots), _lp(sizes)), 'mts_compress_chunks')
     return [out[int(slots[i]):int(slots[i]) + int(sizes[i])].tobytes() for i in range(n_chunks)]
 
 
@@ -204,7 +210,7 @@ def decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=0):
     out = np.empty(int(ooffs[-1] + sizes[-1]) + 256, dtype=np.uint8)
     status = np.zeros(n, dtype=np.int32)
     _check(lib().mts_decompress_chunks(device, _ptr(cdata), _lp(offs), _lp(lens), _lp(rows), n, n_channels,
-                                       dtype.itemsize, flags, _ptr(out), _lp(ooffs),
+                                       dtype.itemsize, _dflags(flags, dtype), _ptr(out), _lp(ooffs),
                                        status.ctypes.data_as(C.POINTER(C.c_int))), 'mts_decompress_chunks')
     arrays = []
     for i in range(n):
@@ -249,7 +255,7 @@ def cache_read_rows(cache_id, keys, cdata, offs, lens, n_rows, n_channels, dtype
     out = np.empty((int(row_end - row_begin), n_channels), dtype=dtype)
     status = np.zeros(n, dtype=np.int32)
     _check(lib().mts_cache_read_rows(int(cache_id), n, _lp(keys), _ptr(cdata), _lp(offs), _lp(lens), _lp(rows), n_channels,
-                                     dtype.itemsize, flags, int(row_begin), int(row_end), _ptr(out),
+                                     dtype.itemsize, _dflags(flags, dtype), int(row_begin), int(row_end), _ptr(out),
                                      status.ctypes.data_as(C.POINTER(C.c_int))), 'mts_cache_read_rows')
     return [int(x) for x in status], out
 

@@ -68,8 +68,49 @@ static uint64_t ld(const uint8_t *p, int sz)
 static void st(uint8_t *p, int sz, uint64_t v) { memcpy(p, &v, (size_t)sz); }
 
 /* raw: C-order (nt, nc) items of `sz` bytes.  out: the byte stream handed to zlib.compress. */
+/* float items (flags & 8): np.diff / np.cumsum in the item type, every operation rounded in that type, in numpy's order:
+   r[t] = r[t-1] + d[t] one after the other (mtscomp.py:150-155, :162-169 on float arrays, tests.py:212-237) */
+#define ORC_FLOAT_TRANSFORMS(T, NAME)                                                                               \
+    static void NAME##_delta(const T *x, long nt, long nc, int flags, T *out)                                       \
+    {                                                                                                               \
+        long n = nt * nc;                                                                                           \
+        T *d = (T *)malloc(sizeof(T) * (size_t)(n ? n : 1));                                                        \
+        for (long t = 0; t < nt; t++)                                                                               \
+            for (long c = 0; c < nc; c++) {                                                                         \
+                volatile T v = x[t * nc + c];                                                                       \
+                if ((flags & 1) && t > 0) v = x[t * nc + c] - x[(t - 1) * nc + c];                                  \
+                d[t * nc + c] = v;                                                                                  \
+            }                                                                                                       \
+        if (flags & 2)                                                                                              \
+            for (long t = 0; t < nt; t++)                                                                           \
+                for (long c = nc - 1; c > 0; c--) { volatile T v = d[t * nc + c] - d[t * nc + c - 1]; d[t * nc + c] = v; } \
+        if (flags & 4) { for (long c = 0; c < nc; c++) for (long t = 0; t < nt; t++) out[c * nt + t] = d[t * nc + c]; } \
+        else memcpy(out, d, sizeof(T) * (size_t)n);                                                                 \
+        free(d);                                                                                                    \
+    }                                                                                                               \
+    static void NAME##_cumsum(const T *s, long nt, long nc, int flags, T *out)                                      \
+    {                                                                                                               \
+        long n = nt * nc;                                                                                           \
+        if (flags & 4) { for (long c = 0; c < nc; c++) for (long t = 0; t < nt; t++) out[t * nc + c] = s[c * nt + t]; } \
+        else memcpy(out, s, sizeof(T) * (size_t)n);                                                                 \
+        if (flags & 2)                                                                                              \
+            for (long t = 0; t < nt; t++)                                                                           \
+                for (long c = 1; c < nc; c++) { volatile T v = out[t * nc + c] + out[t * nc + c - 1]; out[t * nc + c] = v; } \
+        if (flags & 1)                                                                                              \
+            for (long t = 1; t < nt; t++)                                                                           \
+                for (long c = 0; c < nc; c++) { volatile T v = out[t * nc + c] + out[(t - 1) * nc + c]; out[t * nc + c] = v; } \
+    }
+ORC_FLOAT_TRANSFORMS(float, orc_f32)
+ORC_FLOAT_TRANSFORMS(double, orc_f64)
+
 int orc_delta_transpose(const uint8_t *raw, long nt, long nc, int sz, int flags, uint8_t *out)
 {
+    if (flags & 8) {
+        if (sz == 4) orc_f32_delta((const float *)raw, nt, nc, flags, (float *)out);
+        else if (sz == 8) orc_f64_delta((const double *)raw, nt, nc, flags, (double *)out);
+        else return ORC_E_ARG;
+        return ORC_OK;
+    }
     if (sz != 1 && sz != 2 && sz != 4 && sz != 8) return ORC_E_ARG;
     long n = nt * nc;
     uint64_t *d = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n ? n : 1));
@@ -99,6 +140,12 @@ int orc_delta_transpose(const uint8_t *raw, long nt, long nc, int sz, int flags,
 /* stream: inflated bytes.  out: C-order (nt, nc) array, the value read_chunk returns. */
 int orc_cumsum_transpose(const uint8_t *stream, long nt, long nc, int sz, int flags, uint8_t *out)
 {
+    if (flags & 8) {
+        if (sz == 4) orc_f32_cumsum((const float *)stream, nt, nc, flags, (float *)out);
+        else if (sz == 8) orc_f64_cumsum((const double *)stream, nt, nc, flags, (double *)out);
+        else return ORC_E_ARG;
+        return ORC_OK;
+    }
     if (sz != 1 && sz != 2 && sz != 4 && sz != 8) return ORC_E_ARG;
     long n = nt * nc;
     uint64_t *d = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n ? n : 1));

@@ -96,6 +96,11 @@ def make_flags(do_time_diff=True, do_spatial_diff=False, chunk_order='F'):
 # ------------------------------------------------------------------------------------------------
 # C oracle
 # ------------------------------------------------------------------------------------------------
+def _dflags(flags, dtype):
+    """the float bit (8) of the C functions' flags comes from the dtype"""
+    return (int(flags) & ~8) | (8 if np.dtype(dtype).kind == 'f' else 0)
+
+
 def adler32(data):
     a = _bytes_arr(data)
     return int(lib().orc_adler32(_ptr(a), a.size))
@@ -106,7 +111,7 @@ def delta_transpose(chunk, flags):
     chunk = np.ascontiguousarray(chunk)
     nt, nc = chunk.shape
     out = np.empty(chunk.nbytes, dtype=np.uint8)
-    rc = lib().orc_delta_transpose(_ptr(chunk), nt, nc, chunk.itemsize, flags, _ptr(out))
+    rc = lib().orc_delta_transpose(_ptr(chunk), nt, nc, chunk.itemsize, _dflags(flags, chunk.dtype), _ptr(out))
     assert rc == 0, rc
     return out
 
@@ -115,7 +120,7 @@ def cumsum_transpose(stream, nt, nc, dtype, flags):
     stream = _bytes_arr(stream)
     dtype = np.dtype(dtype)
     out = np.empty((nt, nc), dtype=dtype)
-    rc = lib().orc_cumsum_transpose(_ptr(stream), nt, nc, dtype.itemsize, flags, _ptr(out))
+    rc = lib().orc_cumsum_transpose(_ptr(stream), nt, nc, dtype.itemsize, _dflags(flags, dtype), _ptr(out))
     assert rc == 0, rc
     return out
 
@@ -178,7 +183,7 @@ def compress_chunk(chunk, flags, level=6):
     nt, nc = chunk.shape
     cap = int(lib().orc_compress_bound(chunk.nbytes)) + 64
     out = np.empty(cap, dtype=np.uint8)
-    r = lib().orc_compress_chunk(_ptr(chunk), nt, nc, chunk.itemsize, flags, level, _ptr(out), cap)
+    r = lib().orc_compress_chunk(_ptr(chunk), nt, nc, chunk.itemsize, _dflags(flags, chunk.dtype), level, _ptr(out), cap)
     assert r >= 0, r
     return out[:r].tobytes()
 
@@ -188,7 +193,7 @@ def decompress_chunk(cbuf, nt, nc, dtype, flags):
     a = _bytes_arr(cbuf)
     dtype = np.dtype(dtype)
     out = np.empty((nt, nc), dtype=dtype)
-    rc = lib().orc_decompress_chunk(_ptr(a), a.size, nt, nc, dtype.itemsize, flags, _ptr(out))
+    rc = lib().orc_decompress_chunk(_ptr(a), a.size, nt, nc, dtype.itemsize, _dflags(flags, dtype), _ptr(out))
     return int(rc), out
 
 

@@ -24,7 +24,7 @@ class OracleCodec:
         out = []
         for c in chunks:
             c = np.ascontiguousarray(c)
-            if self.use_c and c.dtype.kind in 'iu':
+            if self.use_c and c.dtype.kind in 'iuf':
                 out.append(O.compress_chunk(c, flags, level))
             else:
                 out.append(O.ref_compress_chunk(c, *self._unflags(flags)))
@@ -35,7 +35,7 @@ class OracleCodec:
         status, arrays = [], []
         dtype = np.dtype(dtype)
         for cb, nr in zip(cbufs, n_rows):
-            if self.use_c and dtype.kind in 'iu':
+            if self.use_c and dtype.kind in 'iuf':
                 rc, arr = O.decompress_chunk(cb, nr, n_channels, dtype, flags)
                 rc = 0 if rc == 0 else (-2 if rc == 1 else -1)
             else:

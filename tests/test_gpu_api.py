@@ -11,7 +11,7 @@ import mtscomp_amd
 from mtscomp_amd import api, hip
 from mtscomp_amd.synth import synth_int16
 from oracle import oracle as O
-from tests.test_golden import CASES, golden_cbin, make_input, parse_slice, sha1
+from tests.test_golden import CASES, golden_cbin, make_input, parse_slice, same_as_reference_decode, sha1
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,7 @@ def test_golden_files_byte_identical(name, tmp_cfg):
     assert sha1(out.read_bytes()) == case['cbin_sha1']
     assert outmeta.read_text() == case['ch_text']
     r = mtscomp_amd.decompress(out, outmeta)
-    assert np.array_equal(r[:], arr)
+    assert same_as_reference_decode(r[:], case, arr)
     for s in case['slices']:
         v = r[parse_slice(s['s'])]
         assert list(v.shape) == s['shape'] and sha1(np.ascontiguousarray(v).tobytes()) == s['sha1'], s['s']
@@ -44,13 +44,13 @@ def test_golden_files_byte_identical(name, tmp_cfg):
 
 
 def test_reads_reference_written_files(tmp_cfg):
-    for name in ('ar1_8ch_3chunks', 'uniform_random_stored', 'tiny_chunks', 'both_diffs_order_c', 'int32'):
+    for name in ('ar1_8ch_3chunks', 'uniform_random_stored', 'tiny_chunks', 'both_diffs_order_c', 'int32', 'float32', 'float64_spatial'):
         case = CASES[name]
         out = tmp_cfg / (name + '.cbin')
         out.write_bytes(golden_cbin(case))
         out.with_suffix('.ch').write_text(case['ch_text'])
         r = mtscomp_amd.decompress(out)
-        assert np.array_equal(r[:], make_input(case)), name
+        assert same_as_reference_decode(r[:], case, make_input(case)), name
         r.close()
 
 
@@ -112,8 +112,45 @@ def test_diff_cumsum_roundtrip():
             assert back.dtype == x.dtype and np.array_equal(back, x)
 
 
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_float_transforms_bit_identical_to_numpy(dtype):
+    """np.diff / np.cumsum on float items (tests.py:190-205, :212-237 run the reference on float arrays): every flag
+    combination, with -0.0, inf, denormals and a wide range of magnitudes, compared bit for bit with numpy."""
+    import zlib
+    r = np.random.RandomState(4)
+    for fl in range(8):
+        x = (r.randn(3001, 37) * 10 ** r.uniform(-3, 6, size=(3001, 37))).astype(dtype)
+        x[0, 0] = -0.0; x[5, 3] = np.inf; x[7, 7] = 1e-42 if dtype == 'float32' else 1e-310; x[100:110, 5] = 0
+        td, sd, order = bool(fl & 1), bool(fl & 2), 'F' if fl & 4 else 'C'
+        want = O.ref_diff_along_axis(O.ref_diff_along_axis(x, 0 if td else None), 1 if sd else None).tobytes(order=order)
+        assert hip.delta_transpose(x, fl).tobytes() == want, (dtype, fl)
+        with np.errstate(all='ignore'):
+            back = O.ref_decompress_chunk(zlib.compress(want, 1), 3001, 37, dtype, td, sd, order)
+        assert hip.cumsum_transpose(want, 3001, 37, dtype, fl).tobytes() == back.tobytes(), (dtype, fl)
+        z = hip.compress_chunks(x, [0, 1000, 3001], fl, 6)
+        assert z[1] == O.ref_compress_chunk(x[1000:], td, sd, order, 6)
+        st, arrs = hip.decompress_chunks(z, [1000, 2001], 37, dtype, fl)
+        with np.errstate(all='ignore'):
+            assert st == [0, 0] and arrs[1].tobytes() == O.ref_decompress_chunk(z[1], 2001, 37, dtype, td, sd, order).tobytes()
+
+
+def test_float_files_like_the_reference_tests(tmp_cfg):
+    # tests.py:212-237 (test_low / test_high on float arrays): np.allclose after the round trip
+    t = np.linspace(0., 10., 20000)[:, np.newaxis]
+    for arr in (np.zeros((20000, 19), dtype=np.float32), np.sin(10 * t) + np.random.RandomState(0).normal(0, .02, size=(20000, 19))):
+        raw = tmp_cfg / 'f.bin'
+        arr.tofile(raw)
+        mtscomp_amd.compress(raw, tmp_cfg / 'f.cbin', tmp_cfg / 'f.ch', sample_rate=20000., n_channels=19, dtype=arr.dtype)
+        r = mtscomp_amd.decompress(tmp_cfg / 'f.cbin', tmp_cfg / 'f.ch')
+        assert r[:].dtype == arr.dtype and np.allclose(arr, r[:])
+        assert np.allclose(arr[5000:5100], r[5000:5100])
+        r.close()
+        for f in ('f.cbin', 'f.ch'):
+            (tmp_cfg / f).unlink()
+
+
 def test_float_dtype_fails_loudly(tmp_cfg):
-    arr = np.zeros((100, 4), dtype=np.float32)
+    arr = np.zeros((100, 4), dtype=np.float16)
     raw = tmp_cfg / 'f.bin'
     arr.tofile(raw)
     with pytest.raises(NotImplementedError):
