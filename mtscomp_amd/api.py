@@ -378,6 +378,10 @@ class Writer:
         assert 0 <= chunk_idx <= self.n_chunks - 1
         return self.data[self.chunk_bounds[chunk_idx]:self.chunk_bounds[chunk_idx + 1], :]
 
+    def _compress_chunk(self, chunk_idx):
+        """(chunk_idx, (raw chunk, compressed bytes)) -- mtscomp.py:375-397; a device batch of one."""
+        return chunk_idx, self.compress_batch(chunk_idx, chunk_idx + 1)[chunk_idx]
+
     def compress_batch(self, first_chunk, last_chunk):
         """Chunks [first_chunk, last_chunk) -> {idx: (raw chunk, compressed bytes)}
         (mtscomp.py:399-423; the per-chunk work of :375-397 happens on the device)."""
