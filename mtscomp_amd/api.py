@@ -491,6 +491,7 @@ class Reader:
         self._cache = OrderedDict()
         self._dev_cache = None
         self._dev_cache_lock = threading.Lock()
+        self._cache_lock = threading.RLock()                      # the host LRU is shared by the threads that slice (mtscomp.py:648)
         self._dev_cache_bytes = int(float(os.environ.get('MTSCOMP_DEVICE_CACHE_GB', DEFAULT_DEVICE_CACHE_GB)) * 2 ** 30)
 
     @property
@@ -529,9 +530,10 @@ class Reader:
         """LRU size for decoded chunks (mtscomp.py:582-588)."""
         cache_size = cache_size or self.cache_size
         assert cache_size > 0
-        self.cache_size = cache_size
-        while len(self._cache) > self.cache_size:
-            self._cache.popitem(last=False)
+        with self._cache_lock:
+            self.cache_size = cache_size
+            while len(self._cache) > self.cache_size:
+                self._cache.popitem(last=False)
 
     def iter_chunks(self, first_chunk=0, last_chunk=None):
         """Yield (chunk_idx, chunk_start, chunk_length) (mtscomp.py:590-600)."""
@@ -565,6 +567,10 @@ class Reader:
     def _decode(self, triples):
         """Decode chunks [(idx, start, length)] not in the cache with ONE codec call; returns
         {idx: array}.  Error mapping as mtscomp.py:618-628."""
+        with self._cache_lock:
+            return self._decode_locked(triples)
+
+    def _decode_locked(self, triples):
         todo = [t for t in triples if t[0] not in self._cache]
         result = {}
         if todo:
@@ -660,15 +666,16 @@ class Reader:
         (mtscomp.py:645-650; `pool` is accepted for compatibility and not needed)."""
         ids = list(chunk_ids)
         triples = [(i, self.chunk_offsets[i], self.chunk_offsets[i + 1] - self.chunk_offsets[i]) for i in ids]
-        keep = self.cache_size
-        if len(ids) > keep:
-            self.cache_size = len(ids)          # a batch must not evict itself
-        try:
-            out = self._decode(triples)
-        finally:
-            self.cache_size = keep
-            while len(self._cache) > self.cache_size:
-                self._cache.popitem(last=False)
+        with self._cache_lock:
+            keep = self.cache_size
+            if len(ids) > keep:
+                self.cache_size = len(ids)          # a batch must not evict itself
+            try:
+                out = self._decode(triples)
+            finally:
+                self.cache_size = keep
+                while len(self._cache) > self.cache_size:
+                    self._cache.popitem(last=False)
         assert set(out.keys()) == set(ids)
         return out
 
@@ -803,15 +810,16 @@ class Reader:
                 assert out.shape[0] == len(range(i0, i1, item.step or 1))
                 return out
             triples = list(self.iter_chunks(first, last))
-            keep = self.cache_size
-            if len(triples) > keep:
-                self.cache_size = len(triples)
-            try:
-                decoded = self._decode(triples)
-            finally:
-                self.cache_size = keep
-                while len(self._cache) > self.cache_size:
-                    self._cache.popitem(last=False)
+            with self._cache_lock:
+                keep = self.cache_size
+                if len(triples) > keep:
+                    self.cache_size = len(triples)
+                try:
+                    decoded = self._decode(triples)
+                finally:
+                    self.cache_size = keep
+                    while len(self._cache) > self.cache_size:
+                        self._cache.popitem(last=False)
             chunks = [decoded[i] for i in range(first, last + 1)]
             arr = _join_rows(chunks)
             a = i0 - self.chunk_bounds[first]

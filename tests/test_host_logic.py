@@ -233,3 +233,18 @@ def test_long_slices_go_batch_by_batch_and_short_preads_are_completed(tmp_cfg, m
     assert np.array_equal(r[500:3000], arr[500:3000])
     assert np.array_equal(r[:], arr)
     r.close()
+
+
+def test_host_cache_is_safe_under_concurrent_slicing(tmp_cfg):
+    # the reference's Reader is sliced from ThreadPool workers (mtscomp.py:648); the LRU of decoded chunks is shared
+    from multiprocessing.pool import ThreadPool
+    arr = (np.random.RandomState(9).randn(6997, 5) * 500).astype(np.int16)
+    r, _ = _write(tmp_cfg, arr, check_after_compress=False)
+    r.set_cache_size(2)
+    rs = np.random.RandomState(1)
+    jobs = [(int(a), int(a + n)) for a, n in zip(rs.randint(0, 6000, size=200), rs.randint(1, 900, size=200))]
+    with ThreadPool(8) as pool:
+        got = pool.map(lambda ab: r[ab[0]:ab[1]], jobs)
+    assert all(np.array_equal(g, arr[a:b]) for (a, b), g in zip(jobs, got))
+    assert len(r._cache) <= 2
+    r.close()
