@@ -184,12 +184,15 @@ class HipCodec:
         self._run_shards(run, len(shards))
         return out
 
-    def decompress(self, cbufs, n_rows, n_channels, dtype, flags):
-        """-> (status list, list of (n_rows[i], n_channels) arrays or None)."""
+    takes_out = True
+
+    def decompress(self, cbufs, n_rows, n_channels, dtype, flags, out=None):
+        """-> (status list, list of (n_rows[i], n_channels) arrays or None).  `out`: optional array of exactly the decoded
+        size; with one device the chunks are decoded straight into it."""
         if isinstance(cbufs, tuple):                        # (buffer, offsets, lengths): chunks already in one buffer
             buf, offs, lens = cbufs
             if len(self.devices) == 1:
-                return hip.decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=self.devices[0])
+                return hip.decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=self.devices[0], out=out)
             mv = memoryview(buf)
             cbufs = [mv[o:o + l] for o, l in zip(offs, lens)]
         n = len(cbufs)
@@ -651,6 +654,21 @@ class Reader:
                 raise IOError("Compressed chunk #%d is corrupted." % k)
         return out
 
+    def _decode_into(self, b0, b1, dst):
+        """Chunks b0 .. b1-1 (consecutive in the file) decoded straight into `dst` (their rows, C-contiguous): one read, one
+        codec call, no copy on the host and nothing left in the chunk cache."""
+        base = self.chunk_offsets[b0]
+        buf = self._pread(self.chunk_offsets[b1] - base, base)
+        offs = [self.chunk_offsets[i] - base for i in range(b0, b1)]
+        lens = [self.chunk_offsets[i + 1] - self.chunk_offsets[i] for i in range(b0, b1)]
+        rows = [self.chunk_bounds[i + 1] - self.chunk_bounds[i] for i in range(b0, b1)]
+        status, _ = self.codec.decompress((buf, offs, lens), rows, self.n_channels, self.dtype, self._flags(), out=dst)
+        for idx, st in zip(range(b0, b1), status):
+            if st == hip.CHUNK_BADSIZE:
+                raise AssertionError("Chunk #%d does not have the expected size." % idx)
+            if st != hip.CHUNK_OK:
+                raise IOError("Compressed chunk #%d is corrupted." % idx)
+
     def read_chunk(self, chunk_idx, chunk_start, chunk_length):
         """One decoded chunk, (n_samples_chunk, n_channels), C-contiguous (mtscomp.py:602-635)."""
         return self._decode([(chunk_idx, chunk_start, chunk_length)])[chunk_idx]
@@ -797,16 +815,19 @@ class Reader:
             if last - first + 1 > self.batch_size:
                 # a long slice: batch after batch straight into the result (one codec call for everything would need the
                 # whole slice in device memory, and the chunk cache could not hold it anyway)
-                out = np.empty((i1 - i0, self.n_channels), dtype=self.dtype)
+                r0 = self.chunk_bounds[first]
+                whole = np.empty((self.chunk_bounds[last + 1] - r0, self.n_channels), dtype=self.dtype)   # whole chunks first..last
                 for b0 in range(first, last + 1, self.batch_size):
                     b1 = min(b0 + self.batch_size, last + 1)
-                    chunks = self.decompress_chunks(range(b0, b1))
-                    for idx in range(b0, b1):
-                        lo, hi = max(i0, self.chunk_bounds[idx]), min(i1, self.chunk_bounds[idx + 1])
-                        if lo < hi:
-                            out[lo - i0:hi - i0] = chunks[idx][lo - self.chunk_bounds[idx]:hi - self.chunk_bounds[idx]]
-                    del chunks
-                out = out[::item.step, :]
+                    dst = whole[self.chunk_bounds[b0] - r0:self.chunk_bounds[b1] - r0]
+                    if getattr(self.codec, 'takes_out', False) and len(getattr(self.codec, 'devices', [0])) == 1:
+                        self._decode_into(b0, b1, dst)
+                    else:
+                        chunks = self.decompress_chunks(range(b0, b1))
+                        for idx in range(b0, b1):
+                            dst[self.chunk_bounds[idx] - self.chunk_bounds[b0]:self.chunk_bounds[idx + 1] - self.chunk_bounds[b0]] = chunks[idx]
+                        del chunks
+                out = whole[i0 - r0:i1 - r0:item.step, :]
                 assert out.shape[0] == len(range(i0, i1, item.step or 1))
                 return out
             triples = list(self.iter_chunks(first, last))

@@ -183,10 +183,11 @@ def compress_chunks(data, chunk_bounds, flags, level=6, device=0):
     return [out[int(slots[i]):int(slots[i]) + int(sizes[i])].tobytes() for i in range(n_chunks)]
 
 
-def decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=0):
+def decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=0, out=None):
     """cbufs: list of bytes-like compressed chunks, or (buffer, offsets, lengths) for chunks that already sit in
     one buffer.  Returns (status list, list of arrays or None).  The arrays are views of ONE output buffer, back to
-    back in the order given, so consecutive chunks can be joined without copying."""
+    back in the order given, so consecutive chunks can be joined without copying.  `out`: a C-contiguous array of
+    exactly the decoded size to decode into (the views are then views of it)."""
     dtype = check_dtype(dtype)
     if isinstance(cbufs, tuple):
         buf, offs, lens = cbufs
@@ -207,7 +208,11 @@ def decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=0):
     rows = _longs(n_rows)
     sizes = rows * (n_channels * dtype.itemsize)
     ooffs = _longs(np.concatenate(([0], np.cumsum(sizes)))[:-1])
-    out = np.empty(int(ooffs[-1] + sizes[-1]) + 256, dtype=np.uint8)
+    if out is None:
+        out = np.empty(int(ooffs[-1] + sizes[-1]) + 256, dtype=np.uint8)
+    else:
+        assert out.flags.c_contiguous and out.nbytes == int(ooffs[-1] + sizes[-1])
+        out = out.reshape(-1).view(np.uint8)
     status = np.zeros(n, dtype=np.int32)
     _check(lib().mts_decompress_chunks(device, _ptr(cdata), _lp(offs), _lp(lens), _lp(rows), n, n_channels,
                                        dtype.itemsize, _dflags(flags, dtype), _ptr(out), _lp(ooffs),

@@ -290,3 +290,23 @@ def test_device_cache_concurrent_readers(tmp_cfg):
     for (a, b), g in zip(jobs, got):
         assert np.array_equal(g, arr[a:b]), (a, b)
     r.close()
+
+
+def test_long_slices_decode_into_the_result(tmp_cfg):
+    arr, out, outmeta = _write_recording(tmp_cfg, nt=30450)          # 30 chunks of 1000 rows + one of 450
+    r = mtscomp_amd.decompress(out, outmeta)
+    r.batch_size = 4                                                 # slices over more than 4 chunks: batch by batch, in place
+    assert np.array_equal(r[:], arr)
+    for s in (slice(5, -7, 3), slice(999, 30001), slice(12345, 30450), slice(0, 30450, 1000)):
+        assert np.array_equal(r[s], arr[s]), s
+    assert len(r._cache) == 0                                        # nothing of it went through the chunk cache
+    meta = json.loads(outmeta.read_text())
+    b = bytearray(out.read_bytes())
+    b[meta['chunk_offsets'][17] + 25] ^= 0x10
+    out.write_bytes(bytes(b))
+    r2 = mtscomp_amd.decompress(out, outmeta)
+    r2.batch_size = 4
+    with pytest.raises(IOError, match='#17'):
+        r2[:]
+    assert np.array_equal(r2[0:16000], arr[0:16000])
+    r.close(); r2.close()
