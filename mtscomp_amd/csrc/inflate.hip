@@ -254,16 +254,21 @@ __device__ __forceinline__ u32 lz_pieces(u32 tok, u32 olen) { return (tok >> 31)
 __device__ __forceinline__ void lz_emit_pieces(u32 *tk, u32 tok, u32 olen)
 {
     if (!(tok >> 31) || olen <= LZ_PIECE) { tk[0] = tok; return; }
-    const u32 dist1 = tok & 0x7fff;
+    const u32 dist = (tok & 0x7fff) + 1;
     u32 k = 0;
     // pieces of LZ_PIECE bytes; a short remainder (< 3 bytes is not encodable as len-3 >= 0) is merged
-    // into the last piece by making the last two pieces share the remainder
-    u32 left = olen;
+    // into the last piece by making the last two pieces share the remainder.
+    // A copy that overlaps itself (dist < length) repeats a pattern of `dist` bytes, so byte o of it equals the byte any
+    // multiple of dist further back, as long as that is not before the pattern: the piece at offset o reads at distance
+    // dist * (o / dist + 1), i.e. from [start - dist, start + 8) -- the bytes before the copy and its first piece -- instead
+    // of from the piece before it.  A run (dist 1, 33 pieces per 258 bytes) is then 2 dependent steps deep, not 33.
+    u32 left = olen, o = 0, next_mult = dist;                            // next_mult = dist * (o / dist + 1)
     while (left > 0) {
         u32 l = left > LZ_PIECE ? LZ_PIECE : left;
         if (left > LZ_PIECE && left - LZ_PIECE < 3) l = left - 3;          // leave >= 3 for the last piece
-        tk[k++] = 0x80000000u | ((l - 3) << 16) | dist1;
-        left -= l;
+        if (next_mult <= o) next_mult = dist * (o / dist + 1);
+        tk[k++] = 0x80000000u | ((l - 3) << 16) | (next_mult - 1);
+        left -= l; o += l;
     }
 }
 
@@ -1111,7 +1116,9 @@ __global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, 
     for (u32 j0 = 0; j0 < nsub; j0 += 64) {
         const u32 j = j0 + lane;
         const u32 jl = min(j0 + 64, nsub);
-        const u64 wlo = (tb.start_bit + sub[j0].x) >> 5, whi = ((tb.start_bit + sub[jl].x) >> 5) + 3;
+        // (the entry after the last sub-sequence is a terminator without a position: the round then ends where the block does)
+        const u64 round_end = jl < nsub ? tb.start_bit + sub[jl].x : cres[tb.cand].end_bit;
+        const u64 wlo = (tb.start_bit + sub[j0].x) >> 5, whi = (round_end >> 5) + 3;
         __builtin_amdgcn_wave_barrier();
         const bool staged = whi - wlo < (u64)PASSB_STAGE_WORDS;
         if (staged) {

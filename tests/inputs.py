@@ -93,6 +93,8 @@ def cases_small():
         'aaa': b'a' * 10,
         'zeros_1k': bytes(1000),
         'zeros_70k': bytes(70000),
+        'zeros_64k': bytes(65536),             # one block whose last pass-B round ends with the block (stale LDS staging once)
+        'zeros_999468': bytes(999468),
         'rand_300': r.randint(0, 256, size=300).astype(np.uint8).tobytes(),
         'rand_70k': r.randint(0, 256, size=70000).astype(np.uint8).tobytes(),
         'rand4_50k': r.randint(0, 4, size=50000).astype(np.uint8).tobytes(),
