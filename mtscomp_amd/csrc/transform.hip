@@ -693,8 +693,11 @@ static int segr_for(int itemsize) { return itemsize <= 2 ? 256 : itemsize == 4 ?
 
 size_t cumsum_scratch_bytes(int n_chunks, u32 max_rows, int n_channels)
 {
-    // worst case SEGR = 64 (u64 sums), or row tiles of 16 (u32 sums)
-    return (size_t)n_chunks * ((max_rows + 63) / 64 + 1) * n_channels * sizeof(u64) + 256;
+    // generic kernels: u64 sums per (segment of >= 64 rows, channel); row-tile kernels: u32 sums per (tile of >= 16 rows,
+    // channel) -- the wide-channel case (tiles of 16 rows from 1024 int16 channels on) needs twice the first bound
+    const size_t seg = (size_t)n_chunks * ((max_rows + 63) / 64 + 1) * n_channels * sizeof(u64);
+    const size_t til = (size_t)n_chunks * ((max_rows + 15) / 16 + 1) * n_channels * sizeof(u32);
+    return (seg > til ? seg : til) + 256;
 }
 
 int launch_cumsum_transpose(hipStream_t st, const void *d_stream, void *d_out, const u64 *d_stream_off,

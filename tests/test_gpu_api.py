@@ -196,6 +196,19 @@ def test_stress_shape_1024_channels_levels():
     assert e.value.code == hip.E_UNSUPPORTED
 
 
+def test_wide_batch_with_tiny_chunks():
+    """1024 int16 channels (row tiles of 16) and chunks of 1, 2 and 63 rows next to one of 7500: the inverse transform's
+    per-tile sums once overran their scratch buffer here (found by tools/fuzz_gpu.py)."""
+    rows = [2, 1, 63, 1, 7500]
+    b = np.concatenate(([0], np.cumsum(rows)))
+    x = synth_int16(0, int(b[-1]), 1024, 9)
+    flags = hip.make_flags(True, False, 'F')
+    z = hip.compress_chunks(x, b, flags, 6)
+    assert all(z[i] == O.ref_compress_chunk(x[b[i]:b[i + 1]]) for i in range(4))
+    st, arrs = hip.decompress_chunks(z, rows, 1024, 'int16', flags)
+    assert st == [0] * 5 and all(np.array_equal(arrs[i], x[b[i]:b[i + 1]]) for i in range(5))
+
+
 # ---- decoded-chunk cache in HBM (Reader slices) ----------------------------------------------------
 def _write_recording(tmp, nt=30000, nc=16, chunk=0.1, rate=10000., seed=7):
     arr = synth_int16(0, nt, nc, seed)
