@@ -2,7 +2,7 @@
 points, every chunk compared byte for byte with the reference's statement sequence on numpy + stdlib zlib (oracle.ref_*:
 compressed bytes, status, decoded bytes).  Found the pass-B staging bug on run-length streams.
 
-    python tools/fuzz_gpu.py [seed] [seconds]
+    python tools/fuzz_gpu.py [seed] [seconds]          (FUZZ_LEVELS=1: zlib levels 4..9 instead of 6 only)
 """
 import os
 import sys
@@ -71,18 +71,19 @@ def main():
         b = np.concatenate(([0], np.cumsum(rows)))
         if os.environ.get('FUZZ_TRACE'):
             print('case dtype %s nc %d rows %s kind %d flags %d' % (dt, nc, rows, kind, fl), flush=True)
-        z = hip.compress_chunks(x, b, fl, 6)
+        level = int(r.choice([6, 6, 6, 4, 5, 7, 8, 9])) if os.environ.get('FUZZ_LEVELS') else 6
+        z = hip.compress_chunks(x, b, fl, level)
         st, arrs = hip.decompress_chunks(z, rows, nc, dt, fl)
         for i in range(len(rows)):
             c = x[b[i]:b[i + 1]]
             with np.errstate(all='ignore'):
-                want = O.ref_compress_chunk(c, td, sd, of, 6)
+                want = O.ref_compress_chunk(c, td, sd, of, level)
                 ok = z[i] == want and st[i] == 0 and \
                     arrs[i].tobytes() == O.ref_decompress_chunk(want, rows[i], nc, dt, td, sd, of).tobytes()
             if not ok:
                 bad += 1
-                print('MISMATCH dtype %s nc %d rows %s kind %d flags %d chunk %d: %d vs %d bytes, status %d'
-                      % (dt, nc, rows, kind, fl, i, len(z[i]), len(want), st[i]))
+                print('MISMATCH dtype %s nc %d rows %s kind %d flags %d level %d chunk %d: %d vs %d bytes, status %d'
+                      % (dt, nc, rows, kind, fl, level, i, len(z[i]), len(want), st[i]))
         n += len(rows)
     print('fuzz seed %d: %d chunks, %d mismatches' % (seed, n, bad))
     return 1 if bad else 0
