@@ -134,6 +134,9 @@ static int get_engine(int device, Engine **out)
     return MTS_OK;
 }
 
+constexpr int PARSE_PARALLEL_ROUNDS = 96;     // parallel correction rounds of the speculative parse (~40 us each) before the in-order pass:
+                                              // chains of a few dozen segments (a dead channel) are cheaper in parallel, whole-chunk chains are not
+
 static long compress_bound(long n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 13; }
 
 // ------------------------------------------------------------------------------------------------
@@ -281,7 +284,10 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         MTS_HIP(hipStreamSynchronize(st));
         if (!changed) break;
         MTS_HIP(hipMemsetAsync(pb.changed, 0, 4, st));
-        if (round > (int)nseg + 2) { set_error("parse fixed point did not converge"); return MTS_E_INTERNAL; }
+        if (round >= PARSE_PARALLEL_ROUNDS) {            // (runs, periodic data: the parse does not re-synchronise) the rest in order
+            if ((rc = launch_parse_fix_serial(st, d_tables, d_chunks, pb, n_chunks, cfg, round))) return rc;
+            break;
+        }
     }
     // after an odd number of fix rounds the current exits live in exit_b; nothing downstream needs them
     E.t_mark(st, "parse_fixpoint");

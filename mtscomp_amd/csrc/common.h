@@ -132,6 +132,8 @@ int launch_parse_spec(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_
                       int n_segs, LevelCfg cfg);
 int launch_parse_fix(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb,
                      int n_segs, LevelCfg cfg, int round);
+int launch_parse_fix_serial(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_chunks,
+                            LevelCfg cfg, int rounds_done);
 int launch_parse_count(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb,
                        int n_segs, int n_chunks, LevelCfg cfg, ChunkOut *d_cout);
 int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables,

@@ -883,23 +883,14 @@ __global__ __launch_bounds__(64) void k_parse_spec(const uint2 *__restrict__ tab
     pb.cnt[g] = cnt;
 }
 
-__global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
-                                                  ParseBufs pb, int n_segs, LevelCfg cfg, int round)
+// One segment walked again from the entry `ne` (the exit of the segment before it); returns its exit.  The walk stops early
+// when it lands on a checkpoint of the previous walk (from there on the two are the same walk).
+__device__ __forceinline__ u32 parse_rewalk(const uint2 *__restrict__ T, const ChunkDesc &ch, ParseBufs &pb, u32 g, u32 ne, u32 old_exit,
+                                            LevelCfg cfg)
 {
-    const int g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= n_segs) return;
-    const u32 *exit_in = (round & 1) ? pb.exit_b : pb.exit_a;
-    u32 *exit_out = (round & 1) ? pb.exit_a : pb.exit_b;
-    const u32 ci = pb.seg_chunk[g];
-    const ChunkDesc ch = chunks[ci];
-    const u32 old_exit = exit_in[g];
-    const bool first = (u32)g == ch.seg0;
-    const u32 ne = first ? 0 : exit_in[g - 1];
-    if (ne == pb.entry[g]) { exit_out[g] = old_exit; return; }
     pb.entry[g] = ne;
     const u32 s = pb.seg_start[g], n = ch.n;
     const u32 segend = min(s + (u32)SEG, n);
-    const uint2 *T = tables + ch.stream_off;
     auto rd = [&](u32 q) -> uint2 { return T[q]; };
     u32 *cp = pb.cp + (u64)g * 16;
     const u32 old_cnt = pb.cnt[g];
@@ -915,17 +906,68 @@ __global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tabl
             const u32 at_old = cp[8 + k - 1];
             for (u32 q = k; q < 8; q++) cp[8 + q - 1] = cp[8 + q - 1] - at_old + cnt;
             pb.cnt[g] = cnt + (old_cnt - at_old);
-            exit_out[g] = old_exit;
-            return;
+            return old_exit;
         }
         const u32 p0 = pos;
         pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md, lb0, lb1);
         cnt += mp - p0 + 1;
     }
     for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }
-    exit_out[g] = pos;
     pb.cnt[g] = cnt;
-    if (pos != old_exit) *pb.changed = 1;
+    return pos;
+}
+
+__global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
+                                                  ParseBufs pb, int n_segs, LevelCfg cfg, int round)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_segs) return;
+    const u32 *exit_in = (round & 1) ? pb.exit_b : pb.exit_a;
+    u32 *exit_out = (round & 1) ? pb.exit_a : pb.exit_b;
+    const u32 ci = pb.seg_chunk[g];
+    const ChunkDesc ch = chunks[ci];
+    const u32 old_exit = exit_in[g];
+    const bool first = (u32)g == ch.seg0;
+    const u32 ne = first ? 0 : exit_in[g - 1];
+    if (ne == pb.entry[g]) { exit_out[g] = old_exit; return; }
+    const u32 e = parse_rewalk(tables + ch.stream_off, ch, pb, (u32)g, ne, old_exit, cfg);
+    exit_out[g] = e;
+    if (e != old_exit) *pb.changed = 1;
+}
+
+// Data whose parse never re-synchronises (a run of zeros is one 258-byte match after the other, in whatever phase the walk
+// starts) would need one parallel round per segment.  After PARSE_PARALLEL_ROUNDS rounds the rest is done in order
+// instead, each segment from the exit of the one before; a single pass is exact.
+__global__ __launch_bounds__(64) void k_parse_fix_serial(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
+                                                         ParseBufs pb, int n_chunks, LevelCfg cfg, u32 *__restrict__ exits)
+{
+    // one wave per chunk: 64 segments at a time are checked for an entry that is not the exit before it; the first such
+    // segment is walked again, and so is what follows it for as long as the exits keep changing
+    const int ci = blockIdx.x, lane = threadIdx.x;
+    if (ci >= n_chunks) return;
+    const ChunkDesc ch = chunks[ci];
+    const uint2 *T = tables + ch.stream_off;
+    const u32 g_end = ch.seg0 + ch.nseg;
+    u32 g0 = ch.seg0;
+    while (g0 < g_end) {
+        const u32 g = g0 + lane;
+        bool wrong = false;
+        if (g < g_end) wrong = ((g == ch.seg0) ? 0u : exits[g - 1]) != pb.entry[g];
+        const u64 m = __ballot(wrong);
+        if (m == 0) { g0 += 64; continue; }
+        u32 gg = g0 + (u32)__ffsll((unsigned long long)m) - 1;
+        if (lane == 0) {
+            for (; gg < g_end; gg++) {
+                const u32 ne = gg == ch.seg0 ? 0u : exits[gg - 1];
+                if (ne == pb.entry[gg]) break;                   // consistent again: back to scanning
+                const u32 old_exit = exits[gg];
+                exits[gg] = parse_rewalk(T, ch, pb, gg, ne, old_exit, cfg);
+            }
+        }
+        gg = (u32)__shfl((int)gg, 0);
+        __threadfence_block();
+        g0 = gg;                                               // (gg is consistent, or the end)
+    }
 }
 
 // exclusive scan of the per-segment token counts of each chunk (one workgroup per chunk)
@@ -1039,6 +1081,15 @@ int launch_parse_fix(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_c
 {
     if (n_segs == 0) return MTS_OK;
     hipLaunchKernelGGL(k_parse_fix, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_tables, d_chunks, pb, n_segs, cfg, round);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+int launch_parse_fix_serial(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_chunks, LevelCfg cfg,
+                            int rounds_done)
+{
+    if (n_chunks == 0) return MTS_OK;
+    u32 *exits = ((rounds_done - 1) & 1) ? pb.exit_a : pb.exit_b;        // where the last parallel round left the exits
+    hipLaunchKernelGGL(k_parse_fix_serial, dim3(n_chunks), dim3(64), 0, st, d_tables, d_chunks, pb, n_chunks, cfg, exits);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
