@@ -250,6 +250,7 @@ __device__ int parse_tables(BitIn &br, LaneLds &L, u32 type, CHAIN &&LC, CHAIN &
 }
 
 constexpr u32 LZ_PIECE = 8;          // longest copy handed to one lane of the LZ resolver
+constexpr u32 LZ_WINDOW_BYTES = 32768; // the deflate window (= LZ_WIN of the segmented resolver)
 __device__ __forceinline__ u32 lz_pieces(u32 tok, u32 olen) { return (tok >> 31) ? (olen + LZ_PIECE - 1) / LZ_PIECE : 1; }
 __device__ __forceinline__ void lz_emit_pieces(u32 *tk, u32 tok, u32 olen)
 {
@@ -266,7 +267,12 @@ __device__ __forceinline__ void lz_emit_pieces(u32 *tk, u32 tok, u32 olen)
     while (left > 0) {
         u32 l = left > LZ_PIECE ? LZ_PIECE : left;
         if (left > LZ_PIECE && left - LZ_PIECE < 3) l = left - 3;          // leave >= 3 for the last piece
-        if (next_mult <= o) next_mult = dist * (o / dist + 1);
+        if (next_mult <= o) {
+            // (never further back than the 32 KiB a resolver segment knows of what precedes it: its pieces of a copy that
+            //  began in the segment before must find their source inside that window)
+            const u32 m = o / dist + 1, mmax = LZ_WINDOW_BYTES / dist;
+            next_mult = dist * (m < mmax ? m : mmax);
+        }
         tk[k++] = 0x80000000u | ((l - 3) << 16) | (next_mult - 1);
         left -= l; o += l;
     }
@@ -1519,6 +1525,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
         u64 c2_ = prof ? __builtin_readcyclecounter() : 0;
         while (__any(pend)) {
             if (prof) pc_iter++;
+            bool moved = false;
             if (pend && !slow) {
                 u32 b0, b1, x0, x1, x2;
                 lz_load_window(ba, da, b0, b1, x0, x1, x2);
@@ -1534,7 +1541,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
                     const u64 w01 = v << wsh;
                     const u32 w2 = (u32)(((v >> 32) << wsh) >> 32);
                     lz_or_window(wa, (u32)w01, (u32)(w01 >> 32), w2, wba, (u32)wbits, (u32)(wbits >> 32));
-                    pend = false;
+                    pend = false; moved = true;
                 } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }       // bounded spin: never hang the GPU
             } else if (pend) {
                 // byte-wise path (window across the ring end): one byte per round
@@ -1544,9 +1551,13 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
                 if ((bw >> (so & 31)) & 1) {
                     lz_or_byte(lds_data + (dd & ~3u), dv << (8 * (dd & 3)), lds_bits + ((dd >> 5) << 2), 1u << (dd & 31));
                     if (++k == len) pend = false;
-                    spins = 0;
+                    spins = 0; moved = true;
                 } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
             }
+            // nothing of this wave's could commit: its sources are another wave's work.  Step back for a moment -- sixteen
+            // waves polling the LDS at full rate leave the one wave that can make progress a sixteenth of it (a chain of
+            // dependent copies, e.g. 7-byte matches at distance 8 through int64 data, then runs 100x slower than on one wave)
+            if (!__any(moved)) __builtin_amdgcn_s_sleep(4);
         }
         if (prof) { const u64 c3_ = __builtin_readcyclecounter(); pc_wait += c1_ - c0_; pc_pre += c2_ - c1_; pc_loop += c3_ - c2_; pc_groups++; }
     }
@@ -1751,6 +1762,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
         const u64 wbits = (u64)nbits << (dofs & 31);
         u32 spins = 0, k = 0;
         while (__any(pend)) {
+            bool moved = false;
             if (pend && !slow) {
                 u32 b0, b1, x0, x1, x2, x3, x4;
                 lz2_load_window(ba, da, b0, b1, x0, x1, x2, x3, x4);
@@ -1765,7 +1777,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                     lz2_or_window(wa, odd ? w0 << 16 : w0, odd ? __builtin_amdgcn_alignbit(w1, w0, 16) : w1,
                                   odd ? __builtin_amdgcn_alignbit(w2, w1, 16) : w2, odd ? __builtin_amdgcn_alignbit(w3, w2, 16) : w3,
                                   odd ? w3 >> 16 : 0u, wba, (u32)wbits, (u32)(wbits >> 32));
-                    pend = false;
+                    pend = false; moved = true;
                 } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
             } else if (pend) {
                 const u32 so = (src + k) & (LZ_RING - 1), dd = (dst + k) & (LZ_RING - 1);
@@ -1774,9 +1786,10 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                 if ((bw >> (so & 31)) & 1) {
                     lz_or_byte(lds_data + ((2 * dd) & ~3u), dv << (16 * (dd & 1)), lds_bits + ((dd >> 5) << 2), 1u << (dd & 31));
                     if (++k == len) pend = false;
-                    spins = 0;
+                    spins = 0; moved = true;
                 } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
             }
+            if (!__any(moved)) __builtin_amdgcn_s_sleep(4);          // (see k_inf_lz: do not starve the wave that can progress)
         }
     }
     if (lane == 0) lds_st(lds_prog + 4 * wave, 0xffffffffu);

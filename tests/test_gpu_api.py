@@ -209,6 +209,21 @@ def test_wide_batch_with_tiny_chunks():
     assert st == [0] * 5 and all(np.array_equal(arrs[i], x[b[i]:b[i + 1]]) for i in range(5))
 
 
+def test_dependent_copy_chains_do_not_starve_the_resolver():
+    """int64 items of small magnitude, no differencing: the stream is literal + 7-byte match at distance 8, each match
+    reading what the one before it wrote.  Fourteen resolver waves polling the LDS for their sources used to leave the
+    one wave that could progress so little of it that the bounded waits expired (a false 'corrupt', after seconds)."""
+    import time
+    r = np.random.RandomState(5)
+    x = (np.sin(np.arange(7500)[:, None] / 9.) * 1000 + r.randn(7500, 1024)).astype(np.int64)
+    z = hip.compress_chunks(x, [0, 7500], 0, 6)
+    assert z[0] == O.ref_compress_chunk(x, False, False, 'C')
+    t = time.perf_counter()
+    st, arrs = hip.decompress_chunks(z, [7500], 1024, 'int64', 0)
+    assert st == [0] and np.array_equal(arrs[0], x)
+    assert time.perf_counter() - t < 2.0
+
+
 # ---- decoded-chunk cache in HBM (Reader slices) ----------------------------------------------------
 def _write_recording(tmp, nt=30000, nc=16, chunk=0.1, rate=10000., seed=7):
     arr = synth_int16(0, nt, nc, seed)
