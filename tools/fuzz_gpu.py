@@ -46,7 +46,18 @@ def content(r, kind, nt, nc):
     if kind == 6:                                                                     # short periods along time
         per = int(r.randint(1, 40))
         return np.tile(r.randint(-5, 5, size=(per, nc)), (nt // per + 1, 1))[:nt].cumsum(axis=0) % 7
-    return r.randint(0, 4, size=(nt, nc))                                             # four symbols
+    if kind == 7:
+        return r.randint(0, 4, size=(nt, nc))                                         # four symbols
+    if kind == 8:                                                                     # repeats around the 32 KiB window edge
+        per = max(1, int((32768 + r.randint(-400, 400)) // r.choice([1, 2, 4, 8])))
+        x = np.tile(r.randint(-30000, 30000, size=(per, nc)), (nt // per + 1, 1))[:nt]
+        idx = r.randint(0, nt, size=max(1, nt // 500))
+        x[idx] += r.randint(-2, 3, size=(len(idx), nc))
+        return x
+    x = np.zeros((nt, nc))                                                            # sparse spikes
+    idx = r.randint(0, nt, size=max(1, nt // 50))
+    x[idx, r.randint(0, nc, size=len(idx))] = r.randint(-3000, 3000, size=len(idx))
+    return x
 
 
 def main():
@@ -64,7 +75,7 @@ def main():
             rows = [int(r.randint(20000, 120000))]
             nc = int(r.choice([1, 4, 16]))
         nt = sum(rows)
-        kind = int(r.randint(0, 8))
+        kind = int(r.randint(0, 10))
         x = content(r, kind, nt, nc).astype(dt)
         fl = int(r.randint(0, 8))
         td, sd, of = bool(fl & 1), bool(fl & 2), 'F' if fl & 4 else 'C'
