@@ -1248,6 +1248,7 @@ constexpr u32 LZ_SPIN_MAX = 1u << 20;                     // bound on every wait
 // as they are; k_inf_windows then makes the real windows one after the other (window k = the last 32 KiB
 // of segment k-1, translated with window k-1) and k_inf_translate turns every cell into a byte.
 constexpr int LZ_MAXSEG = 32;
+constexpr int LZ_STATUS_RETRY = 1000;                    // internal chunk status: a resolver wait expired, run the chunk again with one worker wave
 constexpr u32 LZ_WIN = 32768;
 struct LzPlan {
     u32 nseg;                          // 1: the whole chunk by k_inf_lz (bytes)
@@ -1392,11 +1393,12 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
                                                        InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
                                                        const u64 *__restrict__ tb_off, const u32 *__restrict__ gbase,
                                                        const u32 *__restrict__ tile_base, u8 *__restrict__ stream, int n_workers,
-                                                       u64 *__restrict__ prof, const LzPlan *__restrict__ plan)
+                                                       u64 *__restrict__ prof, const LzPlan *__restrict__ plan, int pass)
 {
     const int ci = blockIdx.x;
     const InfResult r = res[ci];
-    if (r.status != MTS_CHUNK_OK) return;
+    if (pass == 2) { if (threadIdx.x == 0 && r.status == MTS_CHUNK_OK && plan[ci].nseg == 1) res[ci].status = LZ_STATUS_RETRY; return; }   // (test hook)
+    if (r.status != (pass ? LZ_STATUS_RETRY : MTS_CHUNK_OK)) return;    // pass 1: only the chunks whose first run gave up waiting
     if (plan[ci].nseg != 1) return;                                  // cut into segments: k_inf_lz_seg
     const InfChunk ch = chunks[ci];
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -1570,7 +1572,9 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
     if (wave == 0) {
         // wait for the flushers before reporting (same workgroup: they are resident)
         for (u32 waits = 0; flushed() < nout && waits < 4 * LZ_SPIN_MAX; waits++) __builtin_amdgcn_s_sleep(8);
-        if (lane == 0 && (lds_ld(lds_bad) || flushed() < nout)) res[ci].status = MTS_CHUNK_CORRUPT;
+        // a copy that reaches before the data is corruption; an expired wait is not a verdict: the chunk is run once more,
+        // with a single worker wave (nothing to wait for but the flushers), and only then given up
+        if (lane == 0 && (lds_ld(lds_bad) || flushed() < nout)) res[ci].status = (pass || lds_ld(lds_bad) == 1) ? MTS_CHUNK_CORRUPT : LZ_STATUS_RETRY;
     }
 }
 
@@ -1636,11 +1640,12 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                                                            InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
                                                            const u64 *__restrict__ tb_off, const u32 *__restrict__ gbase,
                                                            const u32 *__restrict__ tile_base, const LzPlan *__restrict__ plan,
-                                                           u16 *__restrict__ sym, int n_workers)
+                                                           u16 *__restrict__ sym, int n_workers, int pass)
 {
     const int ci = blockIdx.y, seg = blockIdx.x;
     const InfResult r = res[ci];
-    if (r.status != MTS_CHUNK_OK) return;
+    if (pass == 2) { if (threadIdx.x == 0 && seg == 0 && r.status == MTS_CHUNK_OK && plan[ci].nseg >= 2) res[ci].status = LZ_STATUS_RETRY; return; }   // (test hook)
+    if (r.status != (pass ? LZ_STATUS_RETRY : MTS_CHUNK_OK)) return;
     const LzPlan *pl = plan + ci;
     if (pl->nseg < 2 || (u32)seg >= pl->nseg) return;
     const InfChunk ch = chunks[ci];
@@ -1795,11 +1800,18 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
     if (lane == 0) lds_st(lds_prog + 4 * wave, 0xffffffffu);
     if (wave == 0) {
         for (u32 waits = 0; flushed() < Bend && waits < 4 * LZ_SPIN_MAX; waits++) __builtin_amdgcn_s_sleep(8);
-        if (lane == 0 && (lds_ld(lds_bad) || flushed() < Bend)) res[ci].status = MTS_CHUNK_CORRUPT;
+        if (lane == 0 && (lds_ld(lds_bad) || flushed() < Bend)) res[ci].status = (pass || lds_ld(lds_bad) == 1) ? MTS_CHUNK_CORRUPT : LZ_STATUS_RETRY;
     }
 }
 
 // the real window of every segment, one after the other (one workgroup per chunk)
+// after the retry pass: chunks still marked for a retry were resolved by it
+__global__ __launch_bounds__(64) void k_inf_lz_settle(InfResult *__restrict__ res, int n_chunks)
+{
+    const int ci = blockIdx.x * 64 + threadIdx.x;
+    if (ci < n_chunks && res[ci].status == LZ_STATUS_RETRY) res[ci].status = MTS_CHUNK_OK;
+}
+
 __global__ __launch_bounds__(1024) void k_inf_windows(const InfChunk *__restrict__ chunks, const InfResult *__restrict__ res,
                                                       const LzPlan *__restrict__ plan, const u16 *__restrict__ sym, u8 *__restrict__ win)
 {
@@ -2028,13 +2040,21 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
     inflate_mark(engine, st, "inflate_offsets");
     u64 *d_prof = nullptr;                   // MTS_LZ_PROF=1: per-wave cycle counters of the resolver, printed to stderr
     if (getenv("MTS_LZ_PROF")) { MTS_HIP(hipMalloc(&d_prof, (size_t)n_chunks * 16 * 8 * 8)); MTS_HIP(hipMemsetAsync(d_prof, 0, (size_t)n_chunks * 16 * 8 * 8, st)); }
+    const int first_pass = getenv("MTS_LZ_FORCE_RETRY") ? 2 : 0;    // (tests: pretend every chunk's first run gave up, so that the retry pass does the work)
     hipLaunchKernelGGL(k_inf_lz, dim3(n_chunks), dim3(LZ_THREADS), LZ_LDS, st, d_tokens, d_chunks, d_res, (const u64 *)(S + l.gb_off),
                        (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base), d_stream, lz_workers,
-                       d_prof, (const LzPlan *)(S + l.plan));
+                       d_prof, (const LzPlan *)(S + l.plan), first_pass);
+    hipLaunchKernelGGL(k_inf_lz, dim3(n_chunks), dim3(LZ_THREADS), LZ_LDS, st, d_tokens, d_chunks, d_res, (const u64 *)(S + l.gb_off),
+                       (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base), d_stream, 1,
+                       nullptr, (const LzPlan *)(S + l.plan), 1);                                  // (retry pass: returns at once unless a wait expired)
     if (l.nseg > 1 && max_n > 0) {
-        hipLaunchKernelGGL(k_inf_lz_seg, dim3(l.nseg, n_chunks), dim3(LZ_THREADS), LZ2_LDS, st, d_tokens, d_chunks, d_res,
-                           (const u64 *)(S + l.gb_off), (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base),
-                           (const LzPlan *)(S + l.plan), (u16 *)(S + l.sym), lz_workers);
+        for (int pass = 0; pass < 2; pass++)
+            hipLaunchKernelGGL(k_inf_lz_seg, dim3(l.nseg, n_chunks), dim3(LZ_THREADS), LZ2_LDS, st, d_tokens, d_chunks, d_res,
+                               (const u64 *)(S + l.gb_off), (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base),
+                               (const LzPlan *)(S + l.plan), (u16 *)(S + l.sym), pass ? 1 : lz_workers, pass ? 1 : first_pass);
+    }
+    hipLaunchKernelGGL(k_inf_lz_settle, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_res, n_chunks);
+    if (l.nseg > 1 && max_n > 0) {
         hipLaunchKernelGGL(k_inf_windows, dim3(n_chunks), dim3(1024), 0, st, d_chunks, d_res, (const LzPlan *)(S + l.plan),
                            (const u16 *)(S + l.sym), (u8 *)(S + l.win));
         hipLaunchKernelGGL(k_inf_translate, dim3((max_n + 4095) / 4096, n_chunks), dim3(256), 0, st, d_chunks, d_res,
