@@ -1455,7 +1455,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
             if (lo >= nout) break;
             const u32 hi = lo + LZ_FLUSH < nout ? lo + LZ_FLUSH : nout;
             while (safe_bytes() < hi) {
-                if (++idle > LZ_SPIN_MAX) { if (lane == 0) { lds_st(lds_bad, 3); for (int k = 0; k < LZ_FLUSHERS; k++) lds_st(lds_flnext + 4 * k, 0xffffffffu); } return; }
+                if (++idle > LZ_SPIN_MAX || lds_ld(lds_bad)) { if (lane == 0) { if (!lds_ld(lds_bad)) lds_st(lds_bad, 3); for (int k = 0; k < LZ_FLUSHERS; k++) lds_st(lds_flnext + 4 * k, 0xffffffffu); } return; }
                 __builtin_amdgcn_s_sleep(2);
             }
             idle = 0;
@@ -1485,6 +1485,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
     u64 pc_vm = 0, pc_sleeps = 0, pc_wait = 0, pc_pre = 0, pc_loop = 0, pc_iter = 0, pc_groups = 0, pc_t0 = prof ? __builtin_readcyclecounter() : 0;
     u32 fl_seen = 0;                     // last value read of flushed(): it only grows
     for (u32 g = wave; g < ngroups; g += LZW) {
+        if (lds_ld(lds_bad)) break;                                 // the chunk is lost already (a copy from before the data, an expired wait)
         u64 c0_ = prof ? __builtin_readcyclecounter() : 0;
         const u32 t = t_n, base = tb0_n + gl0_n, next = g + 1 < ngroups ? tb1_n + gl1_n : nout;
         const u32 i = g * 64 + lane;
@@ -1500,7 +1501,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
                 if (prof && waits) pc_sleeps++;
                 fl_seen = flushed();
                 if (fl_seen >= lim) break;
-                if (waits > LZ_SPIN_MAX) { lds_st(lds_bad, 4); break; }                       // never hang
+                if (waits > LZ_SPIN_MAX) { if (!lds_ld(lds_bad)) lds_st(lds_bad, 4); break; }                       // never hang
                 __builtin_amdgcn_s_sleep(1);
             }
         }
@@ -1544,7 +1545,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
                     const u32 w2 = (u32)(((v >> 32) << wsh) >> 32);
                     lz_or_window(wa, (u32)w01, (u32)(w01 >> 32), w2, wba, (u32)wbits, (u32)(wbits >> 32));
                     pend = false; moved = true;
-                } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }       // bounded spin: never hang the GPU
+                } else if (++spins > (1u << 22)) { pend = false; if (!lds_ld(lds_bad)) lds_st(lds_bad, 2); }       // bounded spin: never hang the GPU
             } else if (pend) {
                 // byte-wise path (window across the ring end): one byte per round
                 const u32 so = (src + k) & (LZ_RING - 1), dd = (dst + k) & (LZ_RING - 1);
@@ -1554,12 +1555,12 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
                     lz_or_byte(lds_data + (dd & ~3u), dv << (8 * (dd & 3)), lds_bits + ((dd >> 5) << 2), 1u << (dd & 31));
                     if (++k == len) pend = false;
                     spins = 0; moved = true;
-                } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
+                } else if (++spins > (1u << 22)) { pend = false; if (!lds_ld(lds_bad)) lds_st(lds_bad, 2); }
             }
             // nothing of this wave's could commit: its sources are another wave's work.  Step back for a moment -- sixteen
             // waves polling the LDS at full rate leave the one wave that can make progress a sixteenth of it (a chain of
             // dependent copies, e.g. 7-byte matches at distance 8 through int64 data, then runs 100x slower than on one wave)
-            if (!__any(moved)) __builtin_amdgcn_s_sleep(4);
+            if (!__any(moved)) { if (lds_ld(lds_bad)) pend = false; else __builtin_amdgcn_s_sleep(4); }     // (what it waits for may never come)
         }
         if (prof) { const u64 c3_ = __builtin_readcyclecounter(); pc_wait += c1_ - c0_; pc_pre += c2_ - c1_; pc_loop += c3_ - c2_; pc_groups++; }
     }
@@ -1709,7 +1710,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
             if (lo >= Bend) break;
             const u32 hi = lo + LZ_FLUSH < Bend ? lo + LZ_FLUSH : Bend;
             while (safe_bytes() < hi) {
-                if (++idle > LZ_SPIN_MAX) { if (lane == 0) { lds_st(lds_bad, 3); for (int k = 0; k < LZ_FLUSHERS; k++) lds_st(lds_flnext + 4 * k, 0xffffffffu); } return; }
+                if (++idle > LZ_SPIN_MAX || lds_ld(lds_bad)) { if (lane == 0) { if (!lds_ld(lds_bad)) lds_st(lds_bad, 3); for (int k = 0; k < LZ_FLUSHERS; k++) lds_st(lds_flnext + 4 * k, 0xffffffffu); } return; }
                 __builtin_amdgcn_s_sleep(2);
             }
             idle = 0;
@@ -1736,6 +1737,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
     if (wave >= LZW) return;
     u32 fl_seen = 0;
     for (u32 g = g_lo + wave; g < g_hi; g += LZW) {
+        if (lds_ld(lds_bad)) break;
         const u32 t = t_n, base = tb0_n + gl0_n, next = g + 1 < ngroups ? tb1_n + gl1_n : r.n_out;
         const u32 i = g * 64 + lane;
         const bool act = i < ntok;
@@ -1746,7 +1748,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
             for (u32 waits = 0; fl_seen < lim; waits++) {
                 fl_seen = flushed();
                 if (fl_seen >= lim) break;
-                if (waits > LZ_SPIN_MAX) { lds_st(lds_bad, 4); break; }                       // never hang
+                if (waits > LZ_SPIN_MAX) { if (!lds_ld(lds_bad)) lds_st(lds_bad, 4); break; }                       // never hang
                 __builtin_amdgcn_s_sleep(1);
             }
         }
@@ -1783,7 +1785,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                                   odd ? __builtin_amdgcn_alignbit(w2, w1, 16) : w2, odd ? __builtin_amdgcn_alignbit(w3, w2, 16) : w3,
                                   odd ? w3 >> 16 : 0u, wba, (u32)wbits, (u32)(wbits >> 32));
                     pend = false; moved = true;
-                } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
+                } else if (++spins > (1u << 22)) { pend = false; if (!lds_ld(lds_bad)) lds_st(lds_bad, 2); }
             } else if (pend) {
                 const u32 so = (src + k) & (LZ_RING - 1), dd = (dst + k) & (LZ_RING - 1);
                 u32 bw, dv;
@@ -1792,9 +1794,9 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                     lz_or_byte(lds_data + ((2 * dd) & ~3u), dv << (16 * (dd & 1)), lds_bits + ((dd >> 5) << 2), 1u << (dd & 31));
                     if (++k == len) pend = false;
                     spins = 0; moved = true;
-                } else if (++spins > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
+                } else if (++spins > (1u << 22)) { pend = false; if (!lds_ld(lds_bad)) lds_st(lds_bad, 2); }
             }
-            if (!__any(moved)) __builtin_amdgcn_s_sleep(4);          // (see k_inf_lz: do not starve the wave that can progress)
+            if (!__any(moved)) { if (lds_ld(lds_bad)) pend = false; else __builtin_amdgcn_s_sleep(4); }     // (see k_inf_lz)
         }
     }
     if (lane == 0) lds_st(lds_prog + 4 * wave, 0xffffffffu);
