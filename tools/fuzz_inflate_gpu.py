@@ -83,7 +83,11 @@ def main():
             i = int(r.randint(0, len(b)))
             b[i] ^= 1 << int(r.randint(0, 8))
             want, wout = verdict(bytes(b), len(data))
+            t1 = time.time()
             st, out = hip.debug_inflate(bytes(b), len(data))
+            if time.time() - t1 > 2.0:
+                bad += 1
+                print('SLOW damaged stream (%.1f s): byte %d of %d, zlib says %d' % (time.time() - t1, i, len(z), want))
             n_flip += 1
             same = (st == want) or (want == -1 and st == -2) or (want == -2 and st == -1 and False)
             if not same or (want == 0 and out != wout):
