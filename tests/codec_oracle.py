@@ -55,3 +55,56 @@ class OracleCodec:
 
     def cumsum(self, stream, nt, nc, dtype, flags):
         return O.cumsum_transpose(stream, nt, nc, dtype, flags)
+
+
+class CachingOracleCodec(OracleCodec):
+    """OracleCodec + the decoded-chunk cache interface of HipCodec (mts_cache_* in the C ABI), kept in a dict: lets the CPU
+    suite drive Reader._slice_from_device_cache (reads of the missing byte ranges, the retry after a miss, error mapping)."""
+    device_cache = True
+
+    def __init__(self, capacity_chunks=3, **kw):
+        super().__init__(**kw)
+        self.capacity_chunks = capacity_chunks
+        self.caches = {}
+        self.drop_before_next_read = False          # simulate an eviction between query and read
+
+    def cache_create(self, capacity_bytes):
+        cid = len(self.caches) + 1
+        self.caches[cid] = {}
+        return cid
+
+    def cache_destroy(self, cid):
+        self.caches.pop(cid, None)
+
+    def cache_query(self, cid, keys):
+        return np.array([k in self.caches[cid] for k in keys], dtype=bool)
+
+    def cache_read_rows(self, cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, row_begin, row_end):
+        from mtscomp_amd import hip
+        cache = self.caches[cid]
+        if self.drop_before_next_read:
+            self.drop_before_next_read = False
+            cache.clear()
+        self.calls.append(('cache_read', sum(1 for n in lens if n)))
+        status = []
+        for k, o, n, nr in zip(keys, offs, lens, n_rows):
+            if k in cache:
+                status.append(0)
+                continue
+            if not n:
+                raise hip.HipError(hip.E_MISS, 'mts_cache_read_rows', 'chunk key %d is not resident' % k)
+            st, arrs = self.decompress([bytes(cdata[o:o + n])], [nr], n_channels, dtype, flags)
+            self.calls.pop()                         # (the inner decompress call is not a codec call of its own)
+            status.append(st[0])
+            if st[0] == 0:
+                cache[k] = arrs[0]
+        out = np.empty((row_end - row_begin, n_channels), dtype=dtype)
+        r0 = 0
+        for k, nr, st in zip(keys, n_rows, status):
+            lo, hi = max(row_begin, r0), min(row_end, r0 + nr)
+            if lo < hi and st == 0:
+                out[lo - row_begin:hi - row_begin] = cache[k][lo - r0:hi - r0]
+            r0 += nr
+        while len(cache) > self.capacity_chunks:     # least recently inserted goes first
+            cache.pop(next(iter(cache)))
+        return status, out

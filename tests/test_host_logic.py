@@ -248,3 +248,30 @@ def test_host_cache_is_safe_under_concurrent_slicing(tmp_cfg):
     assert all(np.array_equal(g, arr[a:b]) for (a, b), g in zip(jobs, got))
     assert len(r._cache) <= 2
     r.close()
+
+
+def test_slices_through_the_decoded_chunk_cache_interface(tmp_cfg):
+    """Reader slices against a codec that offers the cache interface (CPU stand-in for mts_cache_*): only missing chunks are
+    read and sent, a miss after the query is retried with all bytes, corrupt chunks map to IOError with their index."""
+    from tests.codec_oracle import CachingOracleCodec
+    arr = (np.random.RandomState(10).randn(6997, 6) * 700).astype(np.int16)
+    codec = CachingOracleCodec(capacity_chunks=3)
+    r, _ = _write(tmp_cfg, arr, check_after_compress=False, codec=codec)             # 6 chunks of 1234 rows
+    codec.calls.clear()
+    assert np.array_equal(r[100:1300], arr[100:1300])                                # chunks 0 and 1: both sent
+    assert np.array_equal(r[1300:2500:3], arr[1300:2500:3])                          # chunks 1 and 2: only 2 is sent
+    assert codec.calls == [('cache_read', 2), ('cache_read', 1)]
+    assert np.array_equal(r[-10:], arr[-10:]) and np.array_equal(r[3000], arr[3000])
+    codec.drop_before_next_read = True                                               # evicted between query and read
+    assert np.array_equal(r[2600:2700, 1:4], arr[2600:2700, 1:4])
+    assert codec.calls[-2:] == [('cache_read', 0), ('cache_read', 1)]                # first try without bytes, then with
+    assert np.array_equal(r[:], arr)                                                 # all six chunks: within DEVICE_CACHE_MAX_CHUNKS
+    b = bytearray((tmp_cfg / 'data.cbin').read_bytes())
+    b[r.chunk_offsets[4] + 20] ^= 0xff
+    (tmp_cfg / 'data.cbin').write_bytes(bytes(b))
+    r2 = mtscomp_amd.decompress(tmp_cfg / 'data.cbin', tmp_cfg / 'data.ch', codec=CachingOracleCodec())
+    with pytest.raises(IOError, match='#4'):
+        r2[4936:4950]
+    assert np.array_equal(r2[0:100], arr[0:100])
+    r.close(); r2.close()
+    assert codec.caches == {}
