@@ -39,6 +39,9 @@ def test_no_cpu_fallback_without_device(tmp_cfg):
     assert hip.device_count() == 0
     with pytest.raises(hip.HipError):
         hip.delta_transpose(np.zeros((4, 4), dtype=np.int16), 5)
+    with pytest.raises(hip.HipError) as e:                       # the decoded-chunk cache lives in HBM or nowhere
+        hip.cache_create(1 << 20)
+    assert e.value.code == hip.E_NODEV
     api.set_codec(None)
     arr = np.zeros((100, 4), dtype=np.int16)
     arr.tofile(tmp_cfg / 'd.bin')
