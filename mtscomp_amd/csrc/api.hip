@@ -23,6 +23,20 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+// (device, kernel) pairs whose dynamic-LDS limit has been raised
+int ensure_dynamic_lds(const void *kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void *>> done;
+    int dev = -1;
+    MTS_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &d : done) if (d.first == dev && d.second == kernel) return MTS_OK;
+    MTS_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.push_back({dev, kernel});
+    return MTS_OK;
+}
+
 static const LevelCfg LEVELS[10] = {{0, 0, 0, 0},     {4, 4, 8, 4},       {4, 5, 16, 8},       {4, 6, 32, 32},
                                     {4, 4, 16, 16},   {8, 16, 32, 32},    {8, 16, 128, 128},   {8, 32, 128, 256},
                                     {32, 128, 258, 1024}, {32, 258, 258, 4096}};
@@ -234,7 +248,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     }
     MTS_HIP(hipMemcpyAsync(d_blk_chunk, h_blk_chunk.data(), 4 * (size_t)nblk, hipMemcpyHostToDevice, st));
     MTS_HIP(hipMemsetAsync(d_cout, 0, sizeof(ChunkOut) * n_chunks, st));
-    MTS_HIP(hipMemsetAsync(pb.changed, 0, 4, st));
+    MTS_HIP(hipMemsetAsync(pb.changed, 0, 8, st));           // + the match stage's flag word behind it
     // zero the output slots (the packer ORs bits into them)
     {
         u64 lo = ~0ull, hi = 0;
@@ -269,25 +283,37 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     E.t_mark(st, "delta_transpose");
     u32 *tmp_k = E.sort_a.as<u32>(), *srt_k = E.sort_b.as<u32>();
     u16 *srt_nb = (u16 *)(tmp_k + sort_n);
-    if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, srt_nb, cfg.chain > 128))) return rc;
-    E.t_mark(st, "hash_sort");
     uint2 *d_tables = E.tables.as<uint2>();
-    if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, srt_nb, d_tables, cfg))) return rc;
-    E.t_mark(st, "match");
-    if ((rc = launch_parse_spec(st, d_tables, d_chunks, pb, (int)nseg, cfg))) return rc;
-    int round = 0;
+    u32 *d_flags = (u32 *)(pb.changed + 1);                   // [0] bit 0: the match stage found a hash run out of position order
+    int force_ballot = getenv("MTS_SORT_INJECT_DISORDER") ? 2 : 0;      // (test hook: the first sort of the call is deliberately mis-ranked)
     for (;;) {
-        if ((rc = launch_parse_fix(st, d_tables, d_chunks, pb, (int)nseg, cfg, round))) return rc;
-        round++;
-        int changed = 0;
-        MTS_HIP(hipMemcpyAsync(&changed, pb.changed, 4, hipMemcpyDeviceToHost, st));
-        MTS_HIP(hipStreamSynchronize(st));
-        if (!changed) break;
-        MTS_HIP(hipMemsetAsync(pb.changed, 0, 4, st));
-        if (round >= PARSE_PARALLEL_ROUNDS) {            // (runs, periodic data: the parse does not re-synchronise) the rest in order
-            if ((rc = launch_parse_fix_serial(st, d_tables, d_chunks, pb, n_chunks, cfg, round))) return rc;
-            break;
+        if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, srt_nb, cfg.chain > 128, force_ballot, d_flags))) return rc;
+        E.t_mark(st, "hash_sort");
+        if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, srt_nb, d_tables, cfg, d_flags))) return rc;
+        E.t_mark(st, "match");
+        if ((rc = launch_parse_spec(st, d_tables, d_chunks, pb, (int)nseg, cfg))) return rc;
+        int round = 0;
+        bool resort = false;
+        for (;;) {
+            if ((rc = launch_parse_fix(st, d_tables, d_chunks, pb, (int)nseg, cfg, round))) return rc;
+            round++;
+            int hflags[2] = {0, 0};                              // {changed, match-stage flags}
+            MTS_HIP(hipMemcpyAsync(hflags, pb.changed, 8, hipMemcpyDeviceToHost, st));
+            MTS_HIP(hipStreamSynchronize(st));
+            if (hflags[1] & 1) { resort = true; break; }
+            if (!hflags[0]) break;
+            MTS_HIP(hipMemsetAsync(pb.changed, 0, 4, st));
+            if (round >= PARSE_PARALLEL_ROUNDS) {            // (runs, periodic data: the parse does not re-synchronise) the rest in order
+                if ((rc = launch_parse_fix_serial(st, d_tables, d_chunks, pb, n_chunks, cfg, round))) return rc;
+                break;
+            }
         }
+        if (!resort) break;
+        // The lane-ordered LDS ranking of the sort (deflate.hip: rank_pass) did not hold: byte identity with zlib needs
+        // position-ordered chains, so the stage is repeated with the ballot ranking, which relies on nothing.
+        if (force_ballot == 1) { set_error("hash sort: runs out of position order even with the ballot ranking"); return MTS_E_INTERNAL; }
+        force_ballot = 1;
+        MTS_HIP(hipMemsetAsync(pb.changed, 0, 8, st));
     }
     // after an odd number of fix rounds the current exits live in exit_b; nothing downstream needs them
     E.t_mark(st, "parse_fixpoint");

@@ -36,7 +36,7 @@ constexpr int STREAM_ALIGN = 256;
 // 64..96 Ki tiles cost the same (41-42 ms: less work balances worse locality), 160 Ki 53 ms, 224 Ki 60 ms.
 // The 32-bit sort keys hold the window-relative position (REL_BITS allow windows up to 2^18) and the 7 hash bits
 // the second radix pass still needs; the first pass takes its 8 bits straight from the bytes.
-constexpr int TILE = 98304;                // positions a match-stage workgroup owns
+constexpr int TILE = 229376;               // positions a match-stage workgroup owns
 constexpr int HALO = 32768;                // history it additionally needs (>= MAX_DIST)
 constexpr int WIN = TILE + HALO;           // 131072
 constexpr int REL_BITS = 18;
@@ -104,6 +104,15 @@ void set_error(const char *fmt, ...);
         }                                                                                   \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the CURRENT DEVICE's function object: it is applied once per
+// (device, kernel), under a lock (several host threads drive several devices of one process; api.hip)
+int ensure_dynamic_lds(const void *kernel, int bytes);
+#define MTS_LDS_ATTR(kernel, bytes)                                                 \
+    do {                                                                            \
+        int rc_ = mts::ensure_dynamic_lds((const void *)(kernel), (int)(bytes));    \
+        if (rc_) return rc_;                                                        \
+    } while (0)
+
 // ---- kernel launchers (one per stage; all asynchronous on `st`) -----------------------------------
 // transform.hip
 int launch_delta_transpose(hipStream_t st, const void *d_raw, void *d_stream, const ChunkDesc *d_chunks,
@@ -119,9 +128,12 @@ int launch_adler_stream(hipStream_t st, const u8 *d_stream, const u64 *d_stream_
 
 // deflate.hip
 int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp,
-                     u32 *d_sorted, u16 *d_sorted_nb, int want_nb /* chain lengths too (the kernel for budgets > 128 reads them) */);
+                     u32 *d_sorted, u16 *d_sorted_nb, int want_nb /* chain lengths too (the kernel for budgets > 128 reads them) */,
+                     int force_ballot /* 1: rank with wave ballots whatever the probe said; 2: test hook, damages the order */,
+                     u32 *d_flags /* [0] |= 1: a hash run out of position order (budgets > 128: checked with the chain lengths) */);
 int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles,
-                 const u32 *d_sorted, const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg);
+                 const u32 *d_sorted, const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg,
+                 u32 *d_flags /* [0] |= 1: the sorted order was not position-ordered inside a hash run */);
 struct ParseBufs {
     u32 *entry, *exit_a, *exit_b, *cnt, *tokbase;   // per segment
     u32 *cp;                                        // per segment 16 words: 7 checkpoint positions, 7 token counts

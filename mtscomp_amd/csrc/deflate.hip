@@ -23,6 +23,8 @@
 //                      image written out as whole words.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace mts {
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(1024) void k_probe_lds_order(u32 *bad, int iters)
 
 // third phase: sorted keys -> number of same-hash predecessors of each slot (the chain behind it), capped
 __device__ __forceinline__ void chain_lengths(const u8 *__restrict__ s, const u32 *__restrict__ sk, u16 *__restrict__ nb, u32 wlen, u32 *wmax,
-                                              u32 *carry_p)
+                                              u32 *carry_p, u32 *__restrict__ flags)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) *carry_p = 0;
@@ -235,8 +237,10 @@ __device__ __forceinline__ void chain_lengths(const u8 *__restrict__ s, const u3
         const u32 i = base + threadIdx.x;
         const bool act = i < wlen;
         // (the keys only hold 7 hash bits: the hash is recomputed from the bytes; only budgets > 128 come here)
-        const u32 h = act ? hash_of(gld_u32_unaligned(s, sk[i] & REL_MASK)) : 0xffffu;
-        const u32 hprev = (act && i > 0) ? hash_of(gld_u32_unaligned(s, sk[i - 1] & REL_MASK)) : 0xfffeu;
+        const u32 pos = act ? sk[i] & REL_MASK : 0, pos_prev = (act && i > 0) ? sk[i - 1] & REL_MASK : 0;
+        const u32 h = act ? hash_of(gld_u32_unaligned(s, pos)) : 0xffffu;
+        const u32 hprev = (act && i > 0) ? hash_of(gld_u32_unaligned(s, pos_prev)) : 0xfffeu;
+        if (act && h == hprev && pos <= pos_prev) atomicOr(flags, 1u);      // a run out of position order (see k_match5)
         // bucket start index + 1 where a bucket starts here, else 0; running max = start of my bucket
         u32 v = (act && h != hprev) ? i + 1 : 0;
 #pragma unroll
@@ -255,7 +259,7 @@ __device__ __forceinline__ void chain_lengths(const u8 *__restrict__ s, const u3
 
 __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
                                                     u32 *__restrict__ tmp, u32 *__restrict__ sorted, u16 *__restrict__ sorted_nb, int lane_ordered,
-                                                    int want_nb)
+                                                    int want_nb, u32 *__restrict__ flags)
 {
     const TileDesc td = tiles[blockIdx.x];
     __shared__ u32 cnt[SORT_WAVES][256];
@@ -307,14 +311,25 @@ __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ st
         bin_offsets<5>(cnt, tot);
         rank_pass<5, false, 5, 0>(s, tmp_t, out_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);
     }
-    if (want_nb) chain_lengths(s, sorted + td.sorted_off, sorted_nb + td.sorted_off, wlen, tot, tot + 32);      // (k_match5 derives them itself)
+    if (want_nb) chain_lengths(s, sorted + td.sorted_off, sorted_nb + td.sorted_off, wlen, tot, tot + 32, flags);      // (k_match5 derives them itself)
+}
+
+__global__ __launch_bounds__(SORT_NT) void k_chain_lengths(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, const u32 *__restrict__ sorted,
+                                                        u16 *__restrict__ sorted_nb, u32 *__restrict__ flags)
+{
+    const TileDesc td = tiles[blockIdx.x];
+    __shared__ u32 tot[64];
+    if (td.wlen == 0) return;
+    chain_lengths(stream + td.stream_off + td.w, sorted + td.sorted_off, sorted_nb + td.sorted_off, td.wlen, tot, tot + 32, flags);
 }
 
 // 1 if this device's LDS retires same-address atomics of a wave instruction in lane order (probed once per device)
 static int lds_lane_ordered()
 {
+    static std::mutex mu;
     static int cached[64];
     static bool init = false;
+    std::lock_guard<std::mutex> lk(mu);
     if (!init) { for (int i = 0; i < 64; i++) cached[i] = -1; init = true; }
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
@@ -330,12 +345,30 @@ static int lds_lane_ordered()
     return cached[dev];
 }
 
+// test hook: swaps the first two neighbours of the first tile's sorted order that belong to one hash run (before the chain
+// lengths are taken), i.e. what a failure of the lane-ordered ranking would look like to the stages downstream
+__global__ void k_inject_disorder(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, u32 *__restrict__ sorted)
+{
+    const TileDesc td = tiles[0];
+    const u8 *s = stream + td.stream_off + td.w;
+    u32 *sk = sorted + td.sorted_off;
+    for (u32 i = 0; i + 1 < td.wlen; i++) {
+        const u32 a = sk[i], b = sk[i + 1];
+        if (hash_of(gld_u32_unaligned(s, a & REL_MASK)) == hash_of(gld_u32_unaligned(s, b & REL_MASK)) && (b & REL_MASK) >= td.a - td.w) { sk[i] = b; sk[i + 1] = a; return; }
+    }
+}
+
 int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp, u32 *d_sorted,
-                     u16 *d_sorted_nb, int want_nb)
+                     u16 *d_sorted_nb, int want_nb, int force_ballot, u32 *d_flags)
 {
     if (n_tiles == 0) return MTS_OK;
-    const int ordered = getenv("MTS_SORT_BALLOT") ? 0 : lds_lane_ordered();      // MTS_SORT_BALLOT=1: force the ballot ranking (tests)
-    hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(SORT_NT), 0, st, d_stream, d_tiles, d_tmp, d_sorted, d_sorted_nb, ordered, want_nb);
+    const int ordered = (force_ballot == 1 || getenv("MTS_SORT_BALLOT")) ? 0 : lds_lane_ordered();      // MTS_SORT_BALLOT=1: force the ballot ranking (tests)
+    if (force_ballot == 2) {       // (test hook) sort, damage the order, then take the chain lengths in a second launch that only does that
+        hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(SORT_NT), 0, st, d_stream, d_tiles, d_tmp, d_sorted, d_sorted_nb, ordered, 0, d_flags);
+        hipLaunchKernelGGL(k_inject_disorder, dim3(1), dim3(1), 0, st, d_stream, d_tiles, d_sorted);
+        if (want_nb) hipLaunchKernelGGL(k_chain_lengths, dim3(n_tiles), dim3(SORT_NT), 0, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_flags);
+    } else
+        hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(SORT_NT), 0, st, d_stream, d_tiles, d_tmp, d_sorted, d_sorted_nb, ordered, want_nb, d_flags);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
@@ -565,17 +598,14 @@ __global__ __launch_bounds__(1024, 2) void k_match4(const u8 *__restrict__ strea
 // scored candidates is about the number of times the best length improves.
 // ------------------------------------------------------------------------------------------------
 constexpr int M5_WAVES = 8;
+constexpr int M5_SLICES = 32;                        // workgroups per tile (MTS_MATCH_SLICES overrides: experiments)
 constexpr int M5_RING = 256;
 constexpr int M5_ROWS = 32;
 constexpr int M5_LEVELS = 4;                         // tables for prefix lengths 4, 5, 6, 7
-constexpr int M5_ROW_WORDS = M5_RING / 32 + 1;       // a row is 8 words of bits + 1 of padding, so that rows start in different LDS banks: with 8
-                                                     // the 64 lanes of a wave (32 keys, 2 word indices) hit 8 banks.  PMC: SQ_LDS_BANK_CONFLICT
-                                                     // 2.2e10 -> 0.69e10, SQ_LDS_IDX_ACTIVE 2.8e10 -> 1.3e10 (the run time does not move: the
-                                                     // waves wait for their window loads instead, SQ_INST_LEVEL_VMEM 0.95e10 -> 1.35e10)
+constexpr int M5_ROW_WORDS = M5_RING / 32 + 1;       // a row is 8 words of bits + 1 of padding, so that rows start in different LDS banks
 constexpr int M5_TABLE = M5_ROWS * M5_ROW_WORDS * 4; // bytes per table
-constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_LEVELS * M5_TABLE + M5_RING / 8 + 32;     // 8768: entries, bytes 7..14, tables, run-start bits     // 8224: entries, bytes 7..14, tables, run-start bits
-// requested LDS is padded so that TWO workgroups share a CU, not three: every workgroup reads its own 128 KiB
-// window through L2, and three per CU (12 MiB per XCD against 4 MiB of L2) measured 10 % slower than two
+constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_LEVELS * M5_TABLE;     // 8704: entries, bytes 7..12, tables
+// requested LDS is padded so that TWO workgroups share a CU, not three (16 waves per CU keep the vector units busy)
 constexpr int MATCH5_LDS = M5_WAVES * M5_WAVE_LDS > 56 * 1024 ? M5_WAVES * M5_WAVE_LDS : 56 * 1024;
 
 // 5-bit keys of the prefixes (b3), (b3,b4), (b3..b5), (b3..b6) of e1 = bytes 3..6
@@ -588,103 +618,133 @@ __device__ __forceinline__ void m5_keys(u32 e1, u32 (&k)[M5_LEVELS])
     k[3] = m5_hash24((e1 ^ (e1 >> 11)) & 0xffffff);
 }
 
-__global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
-                                                          const u32 *__restrict__ sorted, const u16 *__restrict__ sorted_nb,
-                                                          uint2 *__restrict__ tables, LevelCfg cfg)
+// Workgroups share tiles: `nsl` consecutive workgroups OF ONE XCD (block b runs on XCD b % 8) take the `nsl` slices of one
+// tile's sorted order, so an XCD has 64 / nsl tiles in flight and their windows (read at random) and table regions (written
+// at random) stay in its L2 until they are complete (L2 hit rate 12 % -> 92 %, 10x fewer misses: tools/pmc_cache.sh).
+// flags[0] |= 1 when the sorted order is found NOT to be position-ordered inside a hash run (the sort's ranking relies on
+// a hardware property, see rank_pass): the caller then sorts again with the ballot ranking and repeats the stage.
+__global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, int nsl,
+                                                          const u32 *__restrict__ sorted, uint2 *__restrict__ tables, LevelCfg cfg,
+                                                          u32 *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const TileDesc td = tiles[blockIdx.x];
+    const u32 xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const u32 tile_id = (jb / (u32)nsl) * 8 + xcd, slice = jb % (u32)nsl;
+    if (tile_id >= (u32)n_tiles) return;
+    const TileDesc td = tiles[tile_id];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u8 *wbase = smem + wave * M5_WAVE_LDS;
     const u8 *gwin = stream + td.stream_off + td.w;
     auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
     u64 *SE = (u64 *)wbase;
-    u64 *SX = SE + M5_RING;                                        // bytes 7..14 of every slot: matches up to 15 never leave the LDS
-    u32 *TB = (u32 *)(wbase + 2 * M5_RING * 8);                    // [level][row][8 words]
-    u32 *BND = TB + M5_LEVELS * (M5_TABLE / 4);                    // bit r: the slot at ring position r starts a hash run
+    u64 *SX = SE + M5_RING;                                        // bytes 7..12 of every slot: matches up to 13 never leave the LDS
+    u32 *TB = (u32 *)(wbase + 2 * M5_RING * 8);                    // [level][row][8 words + 1]
     uint2 *T = tables + td.stream_off;
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 2 && slice == 0) {
         const u32 hashed_end = td.w + td.wlen;
         const u32 p = hashed_end + threadIdx.x;
         if (p >= td.a && p < td.own_end) T[p] = table_entry(0, 0, stream[td.stream_off + p]);
     }
     if (td.wlen == 0) return;
     const u32 *sk = sorted + td.sorted_off;
-    (void)sorted_nb;                                               // (chain lengths are derived here, from the run-start bits)
     const u32 wlen = td.wlen, n = td.n;
     const u32 ngroups = (wlen + 63) / 64;
     const u32 halo = td.a - td.w;
     const u32 chain = (u32)cfg.chain, qchain = (u32)cfg.chain >> 2;
-    const u32 gpw = (ngroups + M5_WAVES - 1) / M5_WAVES;
-    const u32 g_begin = wave * gpw, g_end = min(ngroups, g_begin + gpw);
+    const u32 nwv = (u32)nsl * M5_WAVES;
+    const u32 gpw = (ngroups + nwv - 1) / nwv;
+    const u32 g_begin = (slice * M5_WAVES + wave) * gpw, g_end = min(ngroups, g_begin + gpw);
     if (g_begin >= g_end) return;
-    // the tables start empty (the entry ring may hold anything: the bits of a ring position are only ever
-    // set by the slot that is there, so clearing the bits of a stale or invalid entry clears nothing)
-    for (int k = lane; k < (M5_WAVE_LDS - 2 * M5_RING * 8) / 16; k += 64) ((uint4 *)(wbase + 2 * M5_RING * 8))[k] = make_uint4(0, 0, 0, 0);
+    // the tables start empty (the entry ring may hold anything: it is only read where table bits point)
+    for (int k = lane; k < M5_LEVELS * M5_TABLE / 16; k += 64) ((uint4 *)TB)[k] = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_wave_barrier();
-    // slot idx -> position -> its 8 bytes -> entry; enters the ring at idx & 255, replacing slot idx - 256.
-    // The window words of a slot are loaded one group ahead (the loads stay in flight during the walk).
     u32 h_carry = 0xffffffffu;                                     // hash of the slot before the one lane 0 commits next
-    auto commit = [&](int idx, u32 rc, u32 lo, u32 hi, u64 x, u32 (&key)[M5_LEVELS], bool &starts_run) -> u64 {
+    u32 rc_carry = 0;                                              // its position
+    u32 run_carry = 0;                                             // slots between the newest run start and lane 0 of the group being committed (capped)
+    const u32 le_lo = lane >= 31 ? 0xffffffffu : (2u << lane) - 1, le_hi = lane < 32 ? 0u : lane == 63 ? 0xffffffffu : (2u << (lane - 32)) - 1;      // lanes <= this one
+    u32 inv[5];                                                    // lane r (< 32) builds row r of the first table: bit j of r clear -> all ones
+#pragma unroll
+    for (int j = 0; j < 5; j++) inv[j] = ((lane >> j) & 1) ? 0u : 0xffffffffu;
+    // slot idx -> position -> its 13 bytes -> entry; enters the ring at idx & 255, replacing slot idx - 256.  The ring
+    // positions of a 64-slot group are two whole words of every table row: they are cleared and set again (the first table,
+    // whose keys repeat most -- 32 lanes adding the same bit to the same word would be serialised by the LDS -- is rebuilt
+    // from five ballots by the lane that owns the row; the others take one atomic OR per slot).  `nbv` = the chain behind
+    // the slot = the slots back to the start of its hash run (at most 128 matter), from the ballot of the run starts.
+    auto commit = [&](int idx, u32 rc, u32 lo, u32 hi, u64 x, u32 (&key)[M5_LEVELS], u32 &nbv) -> u64 {
         const u32 rp = (u32)idx & (M5_RING - 1), word = rp >> 5, bit = 1u << (rp & 31);
         const bool valid = idx >= 0 && (u32)idx < wlen;
         const u64 ce = valid ? make_entry(rc, lo, hi) : ~0ull;
         // a slot starts a run when its hash differs from its predecessor's (slots are committed in order)
         const u32 h = valid ? hash_of(lo) : 0xfffffffeu;
-        const u32 hp = __shfl_up(h, 1, 64);
-        starts_run = h != (lane == 0 ? h_carry : hp);
+        const u32 hp = __shfl_up(h, 1, 64), rcp = __shfl_up(rc, 1, 64);
+        const bool starts_run = h != (lane == 0 ? h_carry : hp);
+        const bool disorder = valid && !starts_run && rc <= (lane == 0 ? rc_carry : rcp);      // positions must increase inside a run
+        if (__any(disorder)) { if (lane == 0) atomicOr(flags, 1u); }
         h_carry = (u32)__builtin_amdgcn_readlane((int)h, 63);
+        rc_carry = (u32)__builtin_amdgcn_readlane((int)rc, 63);
         const u64 sr = __ballot(starts_run);
-        if (lane == 0) { BND[word] = (u32)sr; BND[word + 1] = (u32)(sr >> 32); }
-        u32 old[M5_LEVELS];
-        m5_keys((u32)(SE[rp] >> 32), old);                          // the keys of the slot being replaced
+        const u32 mlo = (u32)sr & le_lo, mhi = (u32)(sr >> 32) & le_hi;
+        const u32 top = mhi ? 63u - (u32)__builtin_clz(mhi) : 31u - (u32)__builtin_clz(mlo | 1u);
+        nbv = (mlo | mhi) ? (u32)lane - top : (u32)lane + run_carry;
+        nbv = nbv < 128u ? nbv : 128u;
+        run_carry = sr ? (u32)__builtin_clzll(sr) + 1u : (run_carry + 64u < 128u ? run_carry + 64u : 128u);
         m5_keys((u32)(ce >> 32), key);
+        const u32 wp = word & ~1u;                                 // the group's word pair
+        {
+            u32 *t1 = TB + (M5_TABLE / 4) + lane * M5_ROW_WORDS + wp;       // rows of tables 1..3 are contiguous: 96 rows
+            t1[0] = 0; t1[1] = 0;
+            if (lane < 32) { t1[64 * M5_ROW_WORDS] = 0; t1[64 * M5_ROW_WORDS + 1] = 0; }
+            const u64 vm = __ballot(valid);
+            u32 m0 = (u32)vm, m1 = (u32)(vm >> 32);
 #pragma unroll
-        for (int d = 0; d < M5_LEVELS; d++) {
-            u32 *tb = TB + d * (M5_TABLE / 4);
-            atomicAnd(&tb[old[d] * M5_ROW_WORDS + word], ~bit);
-            if (valid) atomicOr(&tb[key[d] * M5_ROW_WORDS + word], bit);
+            for (int j = 0; j < 5; j++) {
+                const u64 B = __ballot((key[0] >> j) & 1);
+                m0 &= (u32)B ^ inv[j]; m1 &= (u32)(B >> 32) ^ inv[j];
+            }
+            if (lane < 32) { u32 *t0 = TB + lane * M5_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
         }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int d = 1; d < M5_LEVELS; d++)
+            if (valid) atomicOr(&TB[d * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS + word], bit);
         SE[rp] = ce;
         SX[rp] = x;
         return ce;
     };
-    // bytes 0..15 of the string at window offset r: TWO loads (the five dwords around it), not four unaligned ones -- the
-    // lanes are each somewhere else in the window, and the address unit charges by the instruction
+    // bytes 0..12 of the string at window offset r with ONE 16-byte load (the four dwords around it): the lanes are each
+    // somewhere else in the window, and the address unit charges by the instruction
     typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     auto load16 = [&](u32 r, u32 &lo, u32 &hi, u64 &x) {
         const u8 *q = gwin + (r & ~3u);
         const u32x4_a4 w = *(const u32x4_a4 *)q;
-        const u32 w4 = *(const u32 *)(q + 16);
         lo = alignbyte(w.y, w.x, r);
         hi = alignbyte(w.z, w.y, r);
-        const u32 b8 = alignbyte(w.w, w.z, r), b12 = alignbyte(w4, w.w, r);
-        x = (u64)(hi >> 24) | ((u64)b8 << 8) | ((u64)(b12 & 0xffffffu) << 40);      // bytes 7..14
+        const u32 b8 = alignbyte(w.w, w.z, r), b12 = alignbyte(0u, w.w, r) & 0xffu;
+        x = (u64)(hi >> 24) | ((u64)b8 << 8) | ((u64)b12 << 40);                    // bytes 7..12
     };
     auto slot_rel = [&](int idx) -> u32 { return sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1] & REL_MASK; };
     const int i_first = (int)g_begin * 64 + lane;
     {
-        u32 kk[M5_LEVELS];
-        bool sr;
+        u32 kk[M5_LEVELS], nb;
         const u32 ra = slot_rel(i_first - 128), rb = slot_rel(i_first - 64);
         u32 la, ha, lb, hb;
         u64 xa, xb;
         load16(ra, la, ha, xa);
         load16(rb, lb, hb, xb);
-        commit(i_first - 128, ra, la, ha, xa, kk, sr);
-        commit(i_first - 64, rb, lb, hb, xb, kk, sr);
+        commit(i_first - 128, ra, la, ha, xa, kk, nb);
+        __builtin_amdgcn_wave_barrier();
+        commit(i_first - 64, rb, lb, hb, xb, kk, nb);
     }
-    // pipeline: (rc, lo, hi, nb) of the group about to be walked, rc of the one after
+    // pipeline: (rc, lo, hi) of the group about to be walked, rc of the one after
     u32 rc_c = slot_rel(i_first), rc_n = slot_rel(i_first + 64);
     u32 lo_c, hi_c;
     u64 x_c;
     load16(rc_c, lo_c, hi_c, x_c);
     for (u32 g = g_begin; g < g_end; g++) {
         const u32 i0 = g * 64, i = i0 + lane;
-        u32 key[M5_LEVELS];
+        u32 key[M5_LEVELS], nbv;
         __builtin_amdgcn_wave_barrier();
-        bool starts_run;
-        const u64 e = commit((int)i, rc_c, lo_c, hi_c, x_c, key, starts_run);
+        const u64 e = commit((int)i, rc_c, lo_c, hi_c, x_c, key, nbv);
         const u64 ex = x_c;
         const u32 own_lo = lo_c;                                   // (byte 0 of this lane's own position rides along in its table entry)
         __builtin_amdgcn_wave_barrier();
@@ -705,15 +765,6 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         // the 128 slots before this lane's own are ring positions lo .. lo + 127 (mod 256); candidate j
         // (1 = newest) is bit 128 - j of the masks.  V = the candidates inside this lane's chain budget.
         const u32 lo = (i + 128) & (M5_RING - 1), w0 = lo >> 5, sh = lo & 31;
-        // the chain behind this slot = the slots back to the start of its hash run (at most 128 matter)
-        u32 nbv = 0;
-        if (!starts_run) {
-            const u32 R0 = BND[w0 & 7], R1 = BND[(w0 + 1) & 7], R2 = BND[(w0 + 2) & 7], R3 = BND[(w0 + 3) & 7], R4 = BND[(w0 + 4) & 7];
-            const u32 S0 = __builtin_amdgcn_alignbit(R1, R0, sh), S1 = __builtin_amdgcn_alignbit(R2, R1, sh),
-                      S2 = __builtin_amdgcn_alignbit(R3, R2, sh), S3 = __builtin_amdgcn_alignbit(R4, R3, sh);
-            // newest run start among the 128 slots before: bit t -> the run has 128 - t slots before this one
-            nbv = S3 ? (u32)__builtin_clz(S3) + 1 : S2 ? (u32)__builtin_clz(S2) + 33 : S1 ? (u32)__builtin_clz(S1) + 65 : S0 ? (u32)__builtin_clz(S0) + 97 : 128u;
-        }
         nbv = own ? (nbv < chain ? nbv : chain) : 0;
         u32 V[4], A4[4], A5[4], A6[4], A7[4];                     // V = inside the budget; A_d = V & "first d bytes may match"
 #pragma unroll
@@ -765,7 +816,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                                 const u64 y = SX[slot] ^ ex;
                                 if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
                                 else {
-                                    len = 15;
+                                    len = 13;
                                     while (len < maxlen) {
                                         const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
                                         if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
@@ -800,13 +851,15 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
 }
 
 int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted,
-                 const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg)
+                 const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg, u32 *d_flags)
 {
     if (n_tiles == 0) return MTS_OK;
     if (cfg.chain <= 128) {
-        static bool attr_done = false;
-        if (!attr_done && MATCH5_LDS > 65536) { MTS_HIP(hipFuncSetAttribute((const void *)k_match5, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH5_LDS)); attr_done = true; }
-        hipLaunchKernelGGL(k_match5, dim3(n_tiles), dim3(M5_WAVES * 64), MATCH5_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
+        if (MATCH5_LDS > 65536) MTS_LDS_ATTR(k_match5, MATCH5_LDS);
+        int nsl = M5_SLICES;
+        if (const char *e = getenv("MTS_MATCH_SLICES")) nsl = atoi(e) > 0 ? atoi(e) : nsl;
+        const int grid = (n_tiles + 7) / 8 * 8 * nsl;
+        hipLaunchKernelGGL(k_match5, dim3(grid), dim3(M5_WAVES * 64), MATCH5_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, cfg, d_flags);
     } else
         hipLaunchKernelGGL(k_match4, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
     MTS_HIP(hipGetLastError());

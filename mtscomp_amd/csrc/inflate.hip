@@ -1950,13 +1950,9 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
                    void *d_scratch, void *engine)
 {
     if (n_chunks == 0) return MTS_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MTS_HIP(hipFuncSetAttribute((const void *)k_inf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, INF_LDS_PER_WAVE));
-        MTS_HIP(hipFuncSetAttribute((const void *)k_inf_lz, hipFuncAttributeMaxDynamicSharedMemorySize, LZ_LDS));
-        MTS_HIP(hipFuncSetAttribute((const void *)k_inf_lz_seg, hipFuncAttributeMaxDynamicSharedMemorySize, LZ2_LDS));
-        attr_set = true;
-    }
+    MTS_LDS_ATTR(k_inf_decode, INF_LDS_PER_WAVE);
+    MTS_LDS_ATTR(k_inf_lz, LZ_LDS);
+    MTS_LDS_ATTR(k_inf_lz_seg, LZ2_LDS);
     std::vector<u64> lens(n_chunks), so(n_chunks);
     std::vector<u32> nn(n_chunks);
     u64 max_clen = 0;

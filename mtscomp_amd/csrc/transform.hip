@@ -248,8 +248,7 @@ static void run_delta_rows(hipStream_t st, const u8 *raw, u8 *stream, const Chun
 {
     const int tt = rows_tile(nc, (int)sizeof(T)), pitch = rows_pitch(nc, (int)sizeof(T));
     const size_t lds = (size_t)(tt + 1) * pitch * sizeof(T);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_delta_rows<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }
+    (void)ensure_dynamic_lds((const void *)k_delta_rows<T>, 64 * 1024);
     dim3 grid((max_rows + tt - 1) / tt, n_chunks);
     hipLaunchKernelGGL(k_delta_rows<T>, grid, dim3(256), lds, st, raw, stream, d_chunks, nc, tt, pitch, 0xffffffffu / (u32)nc + 1, d_adler_acc);
 }
@@ -679,8 +678,7 @@ static void run_cumsum_rows(hipStream_t st, const u8 *stream, u8 *out, const u64
 {
     const int tt = rows_tile(nc, (int)sizeof(T)), pitch = rows_pitch(nc, (int)sizeof(T));
     const size_t lds = (size_t)tt * pitch * sizeof(T);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_cumsum_rows<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }
+    (void)ensure_dynamic_lds((const void *)k_cumsum_rows<T>, 64 * 1024);
     const int ntile = (max_rows + tt - 1) / tt;
     dim3 grid(ntile, n_chunks);
     hipLaunchKernelGGL(k_rows_sums<T>, grid, dim3(256), 0, st, stream, d_stream_off, d_rows, d_status, nc, tt, ntile, sums);
