@@ -145,6 +145,26 @@ def load_raw_data(path=None, n_channels=None, dtype=None, offset=None, mmap=True
 # ------------------------------------------------------------------------------------------------
 # the codec (device side)
 # ------------------------------------------------------------------------------------------------
+def _one_block(chunks):
+    """The chunks as one (rows, n_channels) array: a view when they already lie back to back in memory (consecutive
+    slices of one memmap, the Writer's case), a concatenation otherwise."""
+    if len(chunks) == 1:
+        return chunks[0]
+    first = chunks[0]
+    if first.ndim == 2 and first.size and all(c.flags['C_CONTIGUOUS'] and c.dtype == first.dtype and c.shape[1:] == first.shape[1:]
+                                              for c in chunks):
+        addr = first.__array_interface__['data'][0]
+        for c in chunks:
+            if c.__array_interface__['data'][0] != addr:
+                break
+            addr += c.nbytes
+        else:
+            rows = sum(c.shape[0] for c in chunks)
+            # (as_strided keeps `first`, hence the buffer under all the chunks, alive)
+            return np.lib.stride_tricks.as_strided(first, shape=(rows,) + first.shape[1:], writeable=False)
+    return np.concatenate(chunks, axis=0)
+
+
 class HipCodec:
     """Per-chunk codec on MI355X.  ``devices``: list of device indices (default: all visible)."""
 
@@ -176,7 +196,7 @@ class HipCodec:
         def run(k):
             ids = shards[k]
             rows = [chunks[i].shape[0] for i in ids]
-            data = chunks[ids[0]] if len(ids) == 1 else np.concatenate([chunks[i] for i in ids], axis=0)
+            data = _one_block([chunks[i] for i in ids])
             bounds = np.concatenate(([0], np.cumsum(rows)))
             res = hip.compress_chunks(data, bounds, flags, level, device=self.devices[k % len(self.devices)])
             for i, b in zip(ids, res):

@@ -288,7 +288,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     int force_ballot = getenv("MTS_SORT_INJECT_DISORDER") ? 2 : 0;      // (test hook: the first sort of the call is deliberately mis-ranked)
     for (;;) {
         if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, srt_nb, cfg.chain > 128, force_ballot, d_flags))) return rc;
-        E.t_mark(st, "hash_sort");
+        E.t_mark(st, force_ballot == 1 ? "hash_sort_retry" : "hash_sort");
         if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, srt_nb, d_tables, cfg, d_flags))) return rc;
         E.t_mark(st, "match");
         if ((rc = launch_parse_spec(st, d_tables, d_chunks, pb, (int)nseg, cfg))) return rc;

@@ -338,3 +338,60 @@ def test_long_slices_decode_into_the_result(tmp_cfg):
         r2[:]
     assert np.array_equal(r2[0:16000], arr[0:16000])
     r.close(); r2.close()
+
+
+def test_two_shards_on_one_device_match_the_goldens(tmp_cfg):
+    # HipCodec drives its devices from one host thread each (api.py: _run_shards); with devices=[0, 0] the two shard
+    # threads meet on one engine: round-robin sharding, the engine lock and the gather of the streams in chunk order
+    api.set_codec(api.HipCodec(devices=[0, 0]))
+    try:
+        for name in ('ar1_8ch_3chunks', 'tiny_chunks', 'ar1_8ch_short_last'):
+            case = CASES[name]
+            arr = make_input(case)
+            raw = tmp_cfg / (name + '.bin')
+            arr.tofile(raw)
+            out = tmp_cfg / (name + '.cbin')
+            mtscomp_amd.compress(raw, out, out.with_suffix('.ch'), sample_rate=case['sample_rate'], n_channels=arr.shape[1],
+                                 dtype=arr.dtype, **case['kwargs'])
+            assert sha1(out.read_bytes()) == case['cbin_sha1'], name
+            assert out.with_suffix('.ch').read_text() == case['ch_text'], name
+            r = mtscomp_amd.decompress(out)
+            assert same_as_reference_decode(r[:], case, arr), name
+            r.close()
+    finally:
+        api.set_codec(None)
+
+
+def test_concurrent_calls_into_one_engine():
+    # four host threads inside mts_compress_chunks / mts_decompress_chunks of the same device at once
+    from multiprocessing.dummy import Pool
+    flags = hip.make_flags(True, False, 'F')
+    xs = [synth_int16(1000 * k, 1000 * k + 2400, 48, k) for k in range(4)]
+    bounds = [0, 1000, 2000, 2400]
+    want = [[O.ref_compress_chunk(x[bounds[i]:bounds[i + 1]]) for i in range(3)] for x in xs]
+
+    def work(k):
+        for _ in range(3):
+            got = hip.compress_chunks(xs[k], bounds, flags, 6, device=0)
+            assert got == want[k], k
+            st, arrs = hip.decompress_chunks(got, [1000, 1000, 400], 48, 'int16', flags, device=0)
+            assert st == [0, 0, 0] and all(np.array_equal(arrs[i], xs[k][bounds[i]:bounds[i + 1]]) for i in range(3))
+        return True
+    with Pool(4) as pool:
+        assert all(pool.map(work, range(4)))
+
+
+def test_sort_order_guard_repeats_the_stage(monkeypatch):
+    # the hash sort's fast ranking relies on a hardware property; the match stage checks what it relies on (positions
+    # ascending inside a hash run) and the stage is repeated with the ballot ranking when that fails.  The hook damages
+    # the first sort of every call: the streams must still be zlib's, for both match kernels (levels 6 and 9)
+    x = synth_int16(0, 3000, 16, 3)
+    flags = hip.make_flags(True, False, 'F')
+    want6, want9 = O.compress_chunk(x, flags, 6), O.compress_chunk(x, flags, 9)
+    monkeypatch.setenv('MTS_SORT_INJECT_DISORDER', '1')
+    assert hip.compress_chunks(x, [0, 3000], flags, 6, device=0)[0] == want6
+    assert hip.compress_chunks(x, [0, 3000], flags, 9, device=0)[0] == want9
+    assert 'hash_sort_retry' in [n for n, _ in hip.last_stage_times(0)]
+    monkeypatch.delenv('MTS_SORT_INJECT_DISORDER')
+    assert hip.compress_chunks(x, [0, 3000], flags, 6, device=0)[0] == want6
+    assert 'hash_sort_retry' not in [n for n, _ in hip.last_stage_times(0)]
