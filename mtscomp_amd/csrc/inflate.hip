@@ -8,7 +8,7 @@
 //   k_inf_passA          wave per candidate: 64 lanes decode 64 consecutive sub-sequences, re-synchronise, count tokens
 //   k_inf_chain          wave per chunk: accept candidates only where the previous block really ends
 //   k_inf_passB          wave per accepted block: decode again from the recorded starts, write tokens
-//   k_inf_decode         one lane per chunk, sequential: authoritative for whatever the fast path declined
+//   k_inf_wave           one workgroup per chunk: finishes whatever the fast path declined (same sub-sequence decode, block after block)
 //   k_inf_lz(_seg) ...   tokens -> bytes through an LDS ring with per-byte dataflow (see "Z" below); a chunk is cut
 //                        into segments resolved on symbolic 16-bit cells when there are fewer chunks than CUs
 // followed by the adler32 reduction over the produced stream.
@@ -129,7 +129,6 @@ constexpr int INF_CNT = 32;          // u16: [0..15] counts, [16..31] offsets
 constexpr int INF_LSYM = 288;        // u16
 constexpr int INF_DSYM = 32;         // u16
 constexpr int INF_SET_BYTES = INF_LENS + 2 * (INF_CNT + INF_LSYM + INF_DSYM);      // 1024
-constexpr int INF_LDS_PER_WAVE = 64 * INF_SET_BYTES;
 
 struct LaneLds {
     u8 *lens; u16 *cnt; u16 *lsym; u16 *dsym; int lane; int stride;
@@ -982,7 +981,8 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
 // ================================================================================================
 // Fast path, step 3: chain the blocks of each chunk (one wave per chunk)
 // ================================================================================================
-constexpr int CHAIN_NEED_SEQ = 1;     // value of seq_flag: let the sequential decoder handle the chunk
+constexpr int CHAIN_NEED_SEQ = 1;     // value of seq_flag: the wave decoder finishes the chunk
+constexpr u64 CHAIN_INLINE_BYTES = 4096;   // longest unannounced Huffman block (bytes of output) the chain walk counts itself
 
 __global__ __launch_bounds__(64) void k_inf_chain(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
                                                   const InfFast *__restrict__ fast, const u64 *__restrict__ cand_pos,
@@ -1039,12 +1039,24 @@ __global__ __launch_bounds__(64) void k_inf_chain(const u8 *__restrict__ cdata, 
             if (c.ok) { b_ok = true; b_ntok = c.ntok; b_nout = c.nout; b_end = c.end_bit; b_cand = (u32)(f.cand_off + found); last = c.bfinal; }
         }
         if (!b_ok) {
-            // stored / fixed / unseen block: count it sequentially (every lane runs the same decode)
+            // A block the scan did not announce.  A stored block is its length field; anything else (fixed Huffman, a
+            // dynamic header the scan missed or pass A could not finish) is counted here, every lane running the same
+            // decode, only while it is SHORT (zlib closes a stream with a small fixed block now and then): a long one, or
+            // an error, hands the rest of the chunk to the wave decoder, which takes over at this block.
             br.seek(pos);
-            u32 nt = 0; u64 no = nout; bool lst = false;
-            const int st = decode_block<false>(br, L, nullptr, nt, no, ~0ull, lst);
-            if (st != INF_OK) { need_seq = true; break; }
-            b_ntok = nt; b_nout = (u32)(no - nout); b_end = br.pos; last = lst;
+            const u32 hdr = br.get(3);
+            if ((hdr >> 1) == 0 && br.pos <= br.end) {
+                br.seek((br.pos + 7) & ~7ull);
+                const u32 len = br.get(16), nlen = br.get(16);
+                if (br.pos > br.end || (len ^ 0xffff) != nlen || br.pos + 8ull * len > br.end) { need_seq = true; break; }
+                b_ntok = len; b_nout = len; b_end = br.pos + 8ull * len; last = hdr & 1;
+            } else {
+                br.seek(pos);
+                u32 nt = 0; u64 no = nout; bool lst = false;
+                const int st = decode_block<false>(br, L, nullptr, nt, no, nout + CHAIN_INLINE_BYTES, lst);
+                if (st != INF_OK) { need_seq = true; break; }
+                b_ntok = nt; b_nout = (u32)(no - nout); b_end = br.pos; last = lst;
+            }
         }
         if (ntrue >= f.true_cap || (u64)ntok + b_ntok > (u64)ch.n_expect + 1 || nout + b_nout > ch.n_expect) { need_seq = true; break; }
         if (lane == 0) {
@@ -1058,18 +1070,22 @@ __global__ __launch_bounds__(64) void k_inf_chain(const u8 *__restrict__ cdata, 
     }
     if (!need_seq) {
         const u64 tb = (pos + 7) & ~7ull;
-        if (tb + 32 > br.end || nout != ch.n_expect) need_seq = true;        // let the reference path classify
+        if (tb + 32 > br.end) r.status = MTS_CHUNK_CORRUPT;                   // no room for the check value
         else {
             const u8 *t = (const u8 *)br.w + (tb >> 3);
             r.adler_stored = ((u32)t[0] << 24) | ((u32)t[1] << 16) | ((u32)t[2] << 8) | t[3];
             r.end_bit = tb + 32;
-            r.n_out = (u32)nout; r.ntok = ntok;
+            if (nout != ch.n_expect) r.status = MTS_CHUNK_BADSIZE;            // a valid stream of another length
         }
+        r.n_out = (u32)nout; r.ntok = ntok;
+    } else {
+        // the wave decoder resumes where the walk stopped; the blocks accepted so far keep their tokens (pass B)
+        r.end_bit = pos; r.n_out = (u32)nout; r.ntok = ntok;
     }
     if (lane == 0) {
         res[ci] = r;
         seq_flag[ci] = need_seq ? CHAIN_NEED_SEQ : 0;
-        true_cnt[ci] = need_seq ? 0 : ntrue;
+        true_cnt[ci] = ntrue;
     }
 }
 
@@ -1097,7 +1113,18 @@ __global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, 
     br.seek(tb.start_bit);
     u32 *tk = tokens + ch.tok_off + tb.tok_off;
     if (tb.cand == 0xffffffffu) {
-        // sequential block (rare): every lane decodes it, lane 0 writes
+        // a block the chain walk counted itself: stored bytes become literal tokens 64 at a time; a short Huffman block is
+        // decoded by lane 0
+        const u32 hdr0 = br.get(3);
+        if ((hdr0 >> 1) == 0) {
+            br.seek((br.pos + 7) & ~7ull);
+            const u32 len = br.get(16);
+            const u8 *src = (const u8 *)br.w + ((br.pos + 16) >> 3);
+            if (len != tb.ntok) { if (lane == 0) res[ci].status = MTS_CHUNK_CORRUPT; return; }
+            for (u32 i = lane; i < len; i += 64) tk[i] = src[i];
+            return;
+        }
+        br.seek(tb.start_bit);
         u32 nt = 0; u64 no = 1ull << 40; bool lst;
         if (lane == 0) {
             const int st = decode_block<true>(br, L, tk, nt, no, ~0ull, lst);
@@ -1151,61 +1178,215 @@ __global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, 
 }
 
 // ================================================================================================
-// Reference path: one lane per chunk, sequential (authoritative for anything the fast path declines)
+// Block-after-block decoder: one workgroup per chunk, authoritative for whatever the fast path declined
 // ================================================================================================
-__global__ __launch_bounds__(64) void k_inf_decode(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
-                                                   int n_chunks, u32 *__restrict__ tokens, InfResult *__restrict__ res,
-                                                   const int *__restrict__ seq_flag)
+// Streams the block-start scan cannot open up (fixed-Huffman or stored blocks from end to end, more candidates than the
+// tables hold) and chunks whose block chain broke (damage) come here.  The blocks are taken in order, but each one is
+// decoded by all 1024 threads the way pass A does it with 64: consecutive sub-sequences of the block, every thread
+// restarting from its left neighbour's exit until the decodes chain like a sequential one -- and, once the chain stands,
+// decoded once more from the true starts to write the tokens (or, past the promised size, only to check them).  Wave 0
+// reads the block headers and builds the code tables.  A 23 MB chunk of fixed-Huffman blocks takes ~0.1 s instead of the
+// minutes of a single lane; a damaged chunk is refused within the block that is damaged (milliseconds).
+// With seq_flag the kernel resumes after the blocks the chain walk accepted (res[ci]: bit position, tokens, bytes so far).
+constexpr int WV_NT = 1024;
+constexpr u32 WV_SUB = 512;                                     // bits per sub-sequence
+constexpr int WV_STAGE_WORDS = WV_NT * WV_SUB / 32 + 16;        // a round of the stream + the readers' look-ahead
+struct WvCtl { u64 pos; u32 type, last, len; int st; };
+
+__global__ __launch_bounds__(WV_NT) void k_inf_wave(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
+                                                    int n_chunks, u32 *__restrict__ tokens, InfResult *__restrict__ res,
+                                                    const int *__restrict__ seq_flag)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const int ci = blockIdx.x * 64 + threadIdx.x;
-    LaneLds L;
-    L.bind(smem, 64, threadIdx.x);
+    const int ci = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (ci >= n_chunks) return;
     if (seq_flag && seq_flag[ci] == 0) return;
     const InfChunk ch = chunks[ci];
+    __shared__ __attribute__((aligned(16))) u8 tabs[INF_SET_BYTES];
+    __shared__ u32 lut_s[LUT_BYTES / 4];
+    __shared__ u32 stage[WV_STAGE_WORDS];
+    __shared__ u32 s_ex[WV_NT];
+    __shared__ u32 s_wt[WV_NT / 64], s_wo[WV_NT / 64], s_wstop[WV_NT / 64];
+    __shared__ int s_any;
+    __shared__ WvCtl ctl;
+    LaneLds L;
+    L.bind(tabs, 1, 0);
+    u32 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
+    u32 *LC = lutd + (1 << LUT_DBITS), *DC = LC + 16;
     InfResult r;
     r.status = MTS_CHUNK_OK; r.n_out = 0; r.ntok = 0; r.adler_stored = 0; r.end_bit = 0;
-    const u8 *cb = cdata + ch.c_off;
-    bool ok = ch.c_len >= 2;
-    if (ok) {
-        const u32 cmf = cb[0], flg = cb[1];
-        ok = ((cmf << 8) | flg) % 31 == 0 && (cmf & 15) == 8 && (cmf >> 4) <= 7 && !(flg & 0x20);
-    }
-    if (!ok) { r.status = MTS_CHUNK_CORRUPT; res[ci] = r; return; }
     BitIn br;
-    br.init(cdata, ch.c_off, ch.c_len, 16);
-    u32 *tk = tokens + ch.tok_off;
     u32 ntok = 0;
     u64 nout = 0;
-    bool last = false;
-    int st = INF_OK;
-    while (!last && st == INF_OK) st = decode_block<true>(br, L, tk, ntok, nout, (u64)ch.n_expect, last);
-    if (st == INF_TOOLONG) {
-        // More output than the header promises.  zlib.decompress would carry on: a stream that is valid
-        // to its end is a size mismatch (AssertionError, mtscomp.py:628), anything else is corruption
-        // (IOError, :621).  Re-walk the stream without emitting to tell the two apart (rare path).
+    if (seq_flag) {
+        const InfResult pr = res[ci];
+        if (pr.status != MTS_CHUNK_OK) return;                    // (pass B found an accepted block inconsistent: the verdict stands)
+        br.init(cdata, ch.c_off, ch.c_len, 0);
+        br.seek(pr.end_bit);
+        ntok = pr.ntok; nout = pr.n_out;
+    } else {
+        const u8 *cb = cdata + ch.c_off;
+        bool ok = ch.c_len >= 2;
+        if (ok) {
+            const u32 cmf = cb[0], flg = cb[1];
+            ok = ((cmf << 8) | flg) % 31 == 0 && (cmf & 15) == 8 && (cmf >> 4) <= 7 && !(flg & 0x20);
+        }
+        if (!ok) { r.status = MTS_CHUNK_CORRUPT; if (tid == 0) res[ci] = r; return; }
         br.init(cdata, ch.c_off, ch.c_len, 16);
-        u32 nt2 = 0; u64 no2 = 0;
-        last = false; st = INF_OK;
-        while (!last && st == INF_OK) st = decode_block<false>(br, L, tk, nt2, no2, ~0ull, last);
-        const u64 tb = (br.pos + 7) & ~7ull;
-        r.status = (st == INF_OK && tb + 32 <= br.end) ? MTS_CHUNK_BADSIZE : MTS_CHUNK_CORRUPT;
     }
-    else if (st != INF_OK) r.status = MTS_CHUNK_CORRUPT;
+    u32 *tk = tokens + ch.tok_off;
+    const u64 limit = ch.n_expect;
+    bool last = false, emit = true, fixed_ready = false;
+    int st = INF_OK;
+    u64 pos = br.pos;                                              // (uniform) where the next block starts
+    BitL bl;
+    bl.w = stage;
+    while (!last && st == INF_OK) {
+        // ---- wave 0: block header, stored-block fields, code tables ----
+        __syncthreads();
+        if (wave == 0) {
+            WvCtl c;
+            c.st = INF_OK; c.len = 0;
+            br.seek(pos);
+            const u32 hdr = br.get(3);
+            c.last = hdr & 1; c.type = hdr >> 1;
+            if (br.pos > br.end || c.type == 3) c.st = INF_CORRUPT;
+            else if (c.type == 0) {
+                br.seek((br.pos + 7) & ~7ull);
+                const u32 len = br.get(16), nlen = br.get(16);
+                if (br.pos > br.end || (len ^ 0xffff) != nlen || br.pos + 8ull * len > br.end) c.st = INF_CORRUPT;
+                c.len = len;
+            } else if (!(c.type == 1 && fixed_ready)) {
+                if (parse_tables(br, L, c.type, LC, DC) != INF_OK) c.st = INF_CORRUPT;
+            }
+            c.pos = br.pos;
+            if (lane == 0) ctl = c;
+        }
+        __syncthreads();
+        const WvCtl c = ctl;
+        st = c.st; last = c.last;
+        if (st != INF_OK) break;
+        if (c.type == 0) {
+            if (nout + c.len > limit) emit = false;               // more than the header promises: from here on the stream is only checked
+            const u8 *src = (const u8 *)br.w + (c.pos >> 3);
+            if (emit) for (u32 i = tid; i < c.len; i += WV_NT) tk[ntok + i] = src[i];
+            ntok += emit ? c.len : 0; nout += c.len;
+            pos = c.pos + 8ull * c.len;
+            continue;
+        }
+        if (!(c.type == 1 && fixed_ready)) {
+            for (u32 e = tid; e < (1u << LUT_LBITS); e += WV_NT) {
+                u32 cl;
+                const int si = chain_decode_mem<15>(__brev(e) >> 17, LC, cl);
+                lutl[e] = (si >= 0 && cl <= (u32)LUT_LBITS) ? lut_len_entry(L.ls(si), cl) : 0u;
+            }
+            for (u32 e = tid; e < (1u << LUT_DBITS); e += WV_NT) {
+                u32 cl;
+                const int si = chain_decode_mem<15>(__brev(e) >> 17, DC, cl);
+                lutd[e] = (si >= 0 && cl <= (u32)LUT_DBITS) ? lut_dist_entry(L.ds(si), cl) : 0u;
+            }
+            fixed_ready = c.type == 1;
+        }
+        u64 base = c.pos;
+        bool done = false;
+        while (!done && st == INF_OK) {
+            const u64 wb0 = base >> 5;
+            const u32 bofs = (u32)(base & 31);
+            __syncthreads();
+            for (u32 k2 = tid; k2 < (u32)WV_STAGE_WORDS; k2 += WV_NT) stage[k2] = br.word(wb0 + k2);
+            __syncthreads();
+            const u64 end_rel64 = br.end - (wb0 << 5);
+            const u32 end_rel = end_rel64 < 0x7fffffffull ? (u32)end_rel64 : 0x7fffffffu;
+            const u32 stop = bofs + (u32)(tid + 1) * WV_SUB;
+            u32 start = bofs + (u32)tid * WV_SUB, ex;
+            u32 nt, no; int fl;
+            bl.seek(start);
+            decode_span_fast<0>(bl, L, lutl, lutd, stop, end_rel, nt, no, fl, nullptr, 0);
+            ex = bl.pos;
+            bool counted = false;
+            int fstop = WV_NT;                                       // first thread whose span ends the block (or fails): threads behind it are void
+            for (int it = 0; it < WV_NT + 2; it++) {
+                s_ex[tid] = ex;
+                const u64 stopm = __ballot(fl != SPAN_CONT);
+                if (lane == 0) s_wstop[wave] = stopm ? (u32)(wave * 64 + first_lane(stopm)) : (u32)WV_NT;
+                if (tid == 0) s_any = 0;
+                __syncthreads();
+                fstop = WV_NT;
+#pragma unroll
+                for (int w = 0; w < WV_NT / 64; w++) fstop = min(fstop, (int)s_wstop[w]);
+                const u32 want_start = tid == 0 ? bofs : s_ex[tid - 1];
+                const bool redo = tid <= fstop && (!counted || want_start != start);
+                if (__any(redo) && lane == 0) s_any = 1;
+                __syncthreads();
+                if (!s_any) break;
+                if (redo) {
+                    start = want_start;
+                    bl.seek(start);
+                    decode_span_fast<1>(bl, L, lutl, lutd, stop, end_rel, nt, no, fl, nullptr, 0);
+                    ex = bl.pos;
+                    counted = true;
+                }
+                __syncthreads();                                     // (s_ex / s_any are rewritten at the top)
+            }
+            const bool valid = tid <= fstop && counted;
+            // token / byte offsets of every thread: wave scans + the wave totals
+            u32 x = valid ? nt : 0, y = valid ? no : 0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 xx = __shfl_up(x, off, 64), yy = __shfl_up(y, off, 64);
+                if (lane >= off) { x += xx; y += yy; }
+            }
+            __syncthreads();
+            if (lane == 63) { s_wt[wave] = x; s_wo[wave] = y; }
+            __syncthreads();
+            u32 pre_t = 0, pre_o = 0, rt = 0, ro = 0;
+#pragma unroll
+            for (int w = 0; w < WV_NT / 64; w++) { const u32 a = s_wt[w], bb = s_wo[w]; if (w < wave) { pre_t += a; pre_o += bb; } rt += a; ro += bb; }
+            if (nout + ro > limit) emit = false;
+            // the true sub-sequences once more: tokens out (or only checked), every copy against the bytes before it
+            bool bad = false;
+            if (valid) {
+                u32 *out = tk + ntok + pre_t + (x - nt);
+                u64 have = nout + pre_o + (y - no);
+                bl.seek(start);
+                u32 k = 0;
+                while (k < nt) {
+                    u32 tok, olen;
+                    if (decode_token_lut(bl, L, lutl, lutd, tok, olen) != 0) { bad = true; break; }
+                    if ((tok >> 31) && (u64)((tok & 0x7fff) + 1) > have) { bad = true; break; }       // too far back
+                    if (emit) lz_emit_pieces(out + k, tok, olen);
+                    k += lz_pieces(tok, olen); have += olen;
+                }
+            }
+            if (tid == 0) s_any = 0;
+            __syncthreads();
+            if (__any(bad) && lane == 0) s_any = 1;
+            // the thread that ended the round says how
+            if (fstop < WV_NT && tid == fstop) { s_wstop[0] = (u32)fl; s_wstop[1] = ex; }
+            if (fstop == WV_NT && tid == WV_NT - 1) s_wstop[1] = ex;
+            __syncthreads();
+            if (s_any) { st = INF_CORRUPT; break; }
+            ntok += emit ? rt : 0; nout += ro;
+            if (fstop < WV_NT) {
+                if ((int)s_wstop[0] == SPAN_EOB) { done = true; pos = (wb0 << 5) + s_wstop[1]; }
+                else st = INF_CORRUPT;
+            } else base = (wb0 << 5) + s_wstop[1];
+        }
+    }
+    if (st != INF_OK) r.status = MTS_CHUNK_CORRUPT;
     else {
-        // trailer: adler32, big endian, at the next byte boundary
-        const u64 tb = (br.pos + 7) & ~7ull;
+        // trailer: adler32, big endian, at the next byte boundary.  A stream that is valid to its end but of another size
+        // is a size mismatch (AssertionError, mtscomp.py:628); anything else is corruption (IOError, :621)
+        const u64 tb = (pos + 7) & ~7ull;
         if (tb + 32 > br.end) r.status = MTS_CHUNK_CORRUPT;
         else {
             const u8 *t = (const u8 *)br.w + (tb >> 3);
             r.adler_stored = ((u32)t[0] << 24) | ((u32)t[1] << 16) | ((u32)t[2] << 8) | t[3];
             r.end_bit = tb + 32;
-            if (nout != ch.n_expect) r.status = MTS_CHUNK_BADSIZE;
+            if (!emit || nout != limit) r.status = MTS_CHUNK_BADSIZE;
         }
     }
-    r.n_out = (u32)nout; r.ntok = ntok;
-    res[ci] = r;
+    r.n_out = (u32)(nout < 0xffffffffull ? nout : 0xffffffffull); r.ntok = ntok;
+    if (tid == 0) res[ci] = r;
 }
 
 // ================================================================================================
@@ -1950,7 +2131,6 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
                    void *d_scratch, void *engine)
 {
     if (n_chunks == 0) return MTS_OK;
-    MTS_LDS_ATTR(k_inf_decode, INF_LDS_PER_WAVE);
     MTS_LDS_ATTR(k_inf_lz, LZ_LDS);
     MTS_LDS_ATTR(k_inf_lz_seg, LZ2_LDS);
     std::vector<u64> lens(n_chunks), so(n_chunks);
@@ -2022,9 +2202,8 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
                            d_tblk, d_true_cnt, d_cres, d_subs, d_tokens, d_res);
         inflate_mark(engine, st, "inflate_passB");
     }
-    hipLaunchKernelGGL(k_inf_decode, dim3((n_chunks + 63) / 64), dim3(64), INF_LDS_PER_WAVE, st, d_cdata, d_chunks, n_chunks,
-                       d_tokens, d_res, fast_path ? d_seq : nullptr);
-    inflate_mark(engine, st, "inflate_seq_fallback");
+    hipLaunchKernelGGL(k_inf_wave, dim3(n_chunks), dim3(WV_NT), 0, st, d_cdata, d_chunks, n_chunks, d_tokens, d_res, fast_path ? d_seq : nullptr);
+    inflate_mark(engine, st, "inflate_wave_decoder");
     {
         u32 max_groups = 1;
         for (int i = 0; i < n_chunks; i++) { const u32 gmax = (u32)(((u64)nn[i] + 2 + 63) / 64); if (gmax > max_groups) max_groups = gmax; }

@@ -277,3 +277,50 @@ def test_lz_resolver_retry_pass(monkeypatch, segs):
     bad[len(bad) // 2] ^= 0x40
     st, _ = hip.debug_inflate(bytes(bad), len(CASES['text_100k']))
     assert st != 0
+
+
+def _timed_inflate(z, n):
+    hip.debug_inflate(z[:64] if len(z) > 64 else z, 1)          # (workspaces and code objects warm)
+    t0 = time.perf_counter()
+    st, out = hip.debug_inflate(z, n)
+    return st, out, time.perf_counter() - t0
+
+
+def test_inflate_full_size_streams_without_dynamic_blocks():
+    """Chunks of the headline size (385 x 30000 int16 = 23.1 MB) whose streams give the block-start scan nothing to find:
+    stored blocks (incompressible data, level 0) and fixed-Huffman blocks (Z_FIXED) go through the wave decoder, not one lane."""
+    n = 385 * 30000 * 2
+    rnd = np.random.RandomState(7).randint(0, 256, n, dtype=np.uint8).tobytes()
+    ar = inputs.ar1_stream(30000, 385)
+    assert len(ar) == n
+    for name, z, budget in (('uniform random, level 6 (stored blocks)', zlib.compress(rnd, 6), 0.25),
+                            ('level 0', zlib.compress(ar, 0), 0.25),
+                            ('Z_FIXED', (lambda co: co.compress(ar) + co.flush())(zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)), 2.6),
+                            ('Z_HUFFMAN_ONLY', (lambda co: co.compress(ar) + co.flush())(zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_HUFFMAN_ONLY)), 2.6)):
+        want = rnd if name.startswith('uniform') else ar
+        st, out, dt = _timed_inflate(z, n)
+        assert st == 0 and out == want, name
+        print('inflate %s: %.1f ms' % (name, dt * 1e3))
+        assert dt < budget, (name, dt)          # (host copies of 23 MB each way included; the one-lane decoder took seconds to minutes)
+
+
+def test_inflate_full_size_damage_is_refused_quickly():
+    n = 385 * 30000 * 2
+    ar = inputs.ar1_stream(30000, 385)
+    z = zlib.compress(ar, 6)
+    r = np.random.RandomState(11)
+    for k in range(6):
+        b = bytearray(z)
+        i = int(r.randint(2, len(b) - 4)) if k else 1000          # (an early flip: nearly the whole chunk lies behind the damage)
+        b[i] ^= 1 << int(r.randint(0, 8))
+        try:
+            want = zlib.decompress(bytes(b))
+        except zlib.error:
+            want = None
+        st, out, dt = _timed_inflate(bytes(b), n)
+        if want is None or len(want) != n:
+            assert st != 0, i
+        else:
+            assert st == 0 and out == want, i
+        print('inflate damaged at byte %d of %d: %.1f ms' % (i, len(z), dt * 1e3))
+        assert dt < 0.4, (i, dt)
