@@ -148,6 +148,7 @@ static int get_engine(int device, Engine **out)
     return MTS_OK;
 }
 
+constexpr int FAST_PARALLEL_ROUNDS = 1 << 20;     // levels 1..3: rounds of the speculative greedy walk before the in-order pass (one lane per chunk: slow, but exact whatever the data)
 constexpr int PARSE_PARALLEL_ROUNDS = 96;     // parallel correction rounds of the speculative parse (~40 us each) before the in-order pass:
                                               // chains of a few dozen segments (a dead channel) are cheaper in parallel, whole-chunk chains are not
 
@@ -185,6 +186,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         if (c.out_off & 15) { set_error("output slot %d is not 16-byte aligned", i); return MTS_E_ARG; }
         nseg += c.nseg; nblk += c.blk_cap;
         if (rows > max_rows) max_rows = (u32)rows;
+        c.tile0 = (u32)tiles.size(); c.pad = 0;
         for (u64 a = 0; a < n; a += TILE) {
             TileDesc t;
             t.stream_off = soff; t.sorted_off = sorted_off; t.n = (u32)n; t.a = (u32)a;
@@ -285,15 +287,46 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     u16 *srt_nb = (u16 *)(tmp_k + sort_n);
     uint2 *d_tables = E.tables.as<uint2>();
     u32 *d_flags = (u32 *)(pb.changed + 1);                   // [0] bit 0: the match stage found a hash run out of position order
+    u32 *d_tokens = E.tokens.as<u32>();
     int force_ballot = getenv("MTS_SORT_INJECT_DISORDER") ? 2 : 0;      // (test hook: the first sort of the call is deliberately mis-ranked)
+    const bool fast = level < 4;                              // deflate_fast: no candidate tables, the walk itself searches (deflate.hip, section F)
+    // levels 1..3 keep their per-position data where the other levels keep the candidate tables (8 bytes per stream byte):
+    // inverse map (4 bytes per byte), insertion bitmap (1 bit), per segment spill words and change stamps
+    u32 *d_inv = (u32 *)d_tables;
+    u32 *d_bm = d_inv + align_up(stream_bytes, 64);
+    u32 *d_spill = d_bm + align_up(stream_bytes / 32 + 2, 64);
+    u32 *d_stamp = d_spill + (size_t)(nseg + 1) * FAST_SPILL_WORDS_H;
+    u32 *d_front = d_stamp + 2 * ((size_t)nseg + 1);           // (the rounds of the segments' last walks sit behind the stamps)
+    if (fast && (size_t)((u8 *)(d_front + n_chunks + 1) - (u8 *)d_tables) > (stream_bytes + 64) * sizeof(uint2)) { set_error("internal: fast-level workspace"); return MTS_E_INTERNAL; }
     for (;;) {
-        if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, srt_nb, cfg.chain > 128, force_ballot, d_flags))) return rc;
+        if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, srt_nb, cfg.chain > 128 && !fast, force_ballot, d_flags))) return rc;
         E.t_mark(st, force_ballot == 1 ? "hash_sort_retry" : "hash_sort");
+        int round = 0;
+        bool resort = false;
+        if (fast) {
+            if ((rc = launch_inverse_map(st, d_stream, d_tiles, (int)tiles.size(), srt_k, d_inv, d_flags))) return rc;
+            MTS_HIP(hipMemsetAsync(d_bm, 0xff, (size_t)((u8 *)d_stamp - (u8 *)d_bm), st));      // everything counts as inserted until a walk says otherwise
+            MTS_HIP(hipMemsetAsync(d_stamp, 0, 4 * (2 * ((size_t)nseg + 1) + n_chunks + 1), st));      // + walk rounds + the fronts
+            if ((rc = launch_fast_init(st, d_chunks, pb, (int)nseg))) return rc;
+            E.t_mark(st, "inverse_map");
+            for (;;) {
+                if ((rc = launch_fast_round(st, d_stream, d_chunks, d_tiles, srt_k, pb, d_inv, d_bm, d_spill, d_stamp, d_front, (int)nseg, n_chunks, cfg, round))) return rc;
+                round++;
+                int hflags[2] = {0, 0};                          // {changed, sort-order flag}
+                MTS_HIP(hipMemcpyAsync(hflags, pb.changed, 8, hipMemcpyDeviceToHost, st));
+                MTS_HIP(hipStreamSynchronize(st));
+                if (hflags[1] & 1) { resort = true; break; }
+                if (!hflags[0]) break;
+                MTS_HIP(hipMemsetAsync(pb.changed, 0, 4, st));
+                if (round >= FAST_PARALLEL_ROUNDS) {
+                    if ((rc = launch_fast_serial(st, d_stream, d_chunks, d_tiles, srt_k, pb, d_inv, d_bm, d_spill, d_stamp, n_chunks, cfg, round))) return rc;
+                    break;
+                }
+            }
+        } else {
         if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, srt_nb, d_tables, cfg, d_flags))) return rc;
         E.t_mark(st, "match");
         if ((rc = launch_parse_spec(st, d_tables, d_chunks, pb, (int)nseg, cfg))) return rc;
-        int round = 0;
-        bool resort = false;
         for (;;) {
             if ((rc = launch_parse_fix(st, d_tables, d_chunks, pb, (int)nseg, cfg, round))) return rc;
             round++;
@@ -308,6 +341,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
                 break;
             }
         }
+        }
         if (!resort) break;
         // The lane-ordered LDS ranking of the sort (deflate.hip: rank_pass) did not hold: byte identity with zlib needs
         // position-ordered chains, so the stage is repeated with the ballot ranking, which relies on nothing.
@@ -318,11 +352,11 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     // after an odd number of fix rounds the current exits live in exit_b; nothing downstream needs them
     E.t_mark(st, "parse_fixpoint");
     if ((rc = launch_parse_count(st, d_tables, d_chunks, pb, (int)nseg, n_chunks, cfg, d_cout))) return rc;
-    u32 *d_tokens = E.tokens.as<u32>();
-    if ((rc = launch_parse_emit(st, d_stream, d_tables, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start, d_cout))) return rc;
+    if (fast) { if ((rc = launch_fast_emit(st, d_stream, d_chunks, d_tiles, srt_k, pb, d_inv, d_bm, d_spill, (int)nseg, cfg, d_tokens, d_blk_in_start))) return rc; }
+    else if ((rc = launch_parse_emit(st, d_stream, d_tables, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start, d_cout))) return rc;
     E.t_mark(st, "parse_emit");
     if ((rc = launch_block_trees(st, d_chunks, d_blk_chunk, (int)nblk, d_tokens, d_blk_in_start, d_cout, d_blocks,
-                                 E.blkcodes.as<u32>(), E.blkhdr.as<u32>()))) return rc;
+                                 E.blkcodes.as<u32>(), E.blkhdr.as<u32>(), fast ? 1 : 0))) return rc;
     if ((rc = launch_block_layout(st, d_chunks, n_chunks, d_blocks, d_cout, d_adler))) return rc;
     E.t_mark(st, "block_trees");
     if ((rc = launch_block_pack(st, d_stream, d_chunks, d_blk_chunk, (int)nblk, d_tokens, d_blocks, E.blkcodes.as<u32>(),
@@ -364,7 +398,6 @@ static int dev_compress(Engine &E, hipStream_t st, const void *d_raw, int nc, in
 {
     if (level == -1) level = 6;
     if (level < 1 || level > 9) { set_error("level %d out of range", level); return MTS_E_ARG; }
-    if (level < 4) { set_error("levels 1-3 (deflate_fast) are not implemented on device yet"); return MTS_E_UNSUPPORTED; }
     if (sz != 1 && sz != 2 && sz != 4 && sz != 8) { set_error("itemsize %d unsupported", sz); return MTS_E_ARG; }
     if ((flags & MTS_FLAG_FLOAT) && sz != 4 && sz != 8) { set_error("float items of %d bytes unsupported", sz); return MTS_E_ARG; }
     if (nc <= 0 || n_chunks < 0) return MTS_E_ARG;
@@ -906,7 +939,8 @@ static int debug_compress_stream(int device, const void *stream_bytes, long n, i
     int rc = get_engine(device, &E);
     if (rc) return rc;
     if (level == -1) level = 6;
-    if (level < 4 || level > 9) return MTS_E_UNSUPPORTED;
+    if (level < 1 || level > 9) return MTS_E_ARG;
+    if (level < 4 && tap && tap->t_full) return MTS_E_UNSUPPORTED;      // (deflate_fast has no candidate tables)
     if (n < 0 || n >= (1l << 31)) return MTS_E_ARG;
     std::lock_guard<std::mutex> lk(E->mu);
     MTS_HIP(hipSetDevice(E->dev));

@@ -70,6 +70,8 @@ struct ChunkDesc {
     u32 nseg;
     u32 blk0;            // first block slot (global index); capacity n / 16383 + 2
     u32 blk_cap;
+    u32 tile0;           // first match-stage tile of the chunk (global index)
+    u32 pad;
 };
 
 // per-block record produced by the tree stage
@@ -153,7 +155,18 @@ int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables,
                       u32 *d_blk_in_start, ChunkOut *d_cout);
 int launch_block_trees(hipStream_t st, const ChunkDesc *d_chunks, const u32 *d_blk_chunk, int total_blk_cap,
                        const u32 *d_tokens, const u32 *d_blk_in_start, const ChunkOut *d_cout,
-                       BlockRec *d_blocks, u32 *d_blk_codes, u32 *d_blk_hdr);
+                       BlockRec *d_blocks, u32 *d_blk_codes, u32 *d_blk_hdr, int fast /* levels 1..3: deflate_fast's flush points */);
+// levels 1..3 (deflate_fast): inverse map of the sorted order, the rounds of the speculative greedy walk, its in-order completion, the token pass
+int launch_inverse_map(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, u32 *d_inv, u32 *d_flags);
+int launch_fast_init(hipStream_t st, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs);
+int launch_fast_round(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, ParseBufs pb,
+                      const u32 *d_inv, u32 *d_bm, u32 *d_spill, u32 *d_stamp, u32 *d_front /* per chunk: segments already final */, int n_segs,
+                      int n_chunks, LevelCfg cfg, int round);
+int launch_fast_serial(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, ParseBufs pb,
+                       const u32 *d_inv, u32 *d_bm, u32 *d_spill, u32 *d_stamp, int n_chunks, LevelCfg cfg, int rounds_done);
+int launch_fast_emit(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, ParseBufs pb,
+                     const u32 *d_inv, u32 *d_bm, u32 *d_spill, int n_segs, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start);
+constexpr int FAST_SPILL_WORDS_H = 9;   // (= FAST_SPILL_WORDS of deflate.hip: spill words per parse segment)
 int launch_block_layout(hipStream_t st, const ChunkDesc *d_chunks, int n_chunks, BlockRec *d_blocks,
                         ChunkOut *d_cout, const u64 *d_adler_acc);
 int launch_block_pack(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const u32 *d_blk_chunk,

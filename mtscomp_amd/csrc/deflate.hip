@@ -1165,6 +1165,302 @@ int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables,
 }
 
 // ================================================================================================
+// F: levels 1..3 (zlib's deflate_fast) -- orc_deflate()'s fast branch is the oracle
+// ================================================================================================
+// deflate_fast is greedy (no lazy evaluation) and it does NOT enter the inside of a match longer than max_insert_length
+// (= the level's `lazy` field) into the hash chains, so the chains -- unlike deflate_slow's -- depend on the parse and
+// there are no parse-independent candidate tables.  What stays parse independent is the ORDER: the same hash sort as for
+// the other levels lists every position of a hash run newest-last; a decision point p finds its own slot through an
+// inverse map (k_inverse_map) and walks the run backwards, skipping the positions the parse did not insert.  Which
+// positions were inserted is one bit per position, written by the walk itself:
+//   * one lane per SEG positions walks its segment from an assumed entry (first: the segment start), greedily, and
+//     records its exit, its token count and the insertion bits of the positions it covered (its own segment's 32 words
+//     in the chunk's bitmap; the tail of a last match that reaches into the next segment in 9 spill words);
+//   * a position q is looked up in the bitmap word of its segment when q >= that segment's entry, in the spill words of
+//     the segment before otherwise (every word has one writer);
+//   * rounds repeat -- a segment walks again when its entry (= exit of its left neighbour) or anything within the
+//     32 KiB it can see changed in the round before -- until nothing changes.  The system is causal (what a segment does
+//     depends only on what lies to its left), so the fixed point is unique and is zlib's parse: segment 0 is right after
+//     round 0, every later one as soon as everything to its left is.  Local damage heals locally (walks re-synchronise,
+//     only the newest `chain` inserted members of a run matter), so a few rounds do; after FAST_PARALLEL_ROUNDS the rest
+//     is walked in order.
+constexpr int FAST_SPILL_WORDS = 9;            // insertion bits of [segment end, segment end + 288): a match is at most 258 long
+constexpr int FAST_DEP_SEGS = 34;              // segments to the left a walk can read (32 KiB of window + the spill of one more)
+
+struct FastBufs {
+    const u32 *inv;      // per stream byte: slot of the position in its tile's sorted order
+    u32 *bm;             // per stream byte one bit: position inserted into its hash chain
+    u32 *spill;          // per segment FAST_SPILL_WORDS
+    u32 *stamp;          // per segment: round (+2) in which its outputs last changed; [n_segs + 1 ...): round (+2) of its last walk, 0 = never
+    u32 *walked;
+};
+
+// (also checks what the walks rely on -- positions ascending inside a hash run -- like k_match5 does for the other levels)
+__global__ __launch_bounds__(256) void k_inverse_map(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, const u32 *__restrict__ sorted,
+                                                     u32 *__restrict__ inv, u32 *__restrict__ flags)
+{
+    const TileDesc td = tiles[blockIdx.y];
+    const u32 halo = td.a - td.w;
+    const u8 *s = stream + td.stream_off + td.w;
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < td.wlen; i += gridDim.x * 256) {
+        const u32 rel = sorted[td.sorted_off + i] & REL_MASK;
+        if (rel >= halo) inv[td.stream_off + td.w + rel] = i;
+        if (i > 0) {
+            const u32 prev = sorted[td.sorted_off + i - 1] & REL_MASK;
+            if (prev >= rel && hash_of(gld_u32_unaligned(s, prev)) == hash_of(gld_u32_unaligned(s, rel))) atomicOr(flags, 1u);
+        }
+    }
+}
+
+// common prefix of the strings at a and b (a > b), at most maxlen; the streams are padded, so 4-byte reads past n are fine
+__device__ __forceinline__ u32 common_len(const u8 *__restrict__ s, u32 a, u32 b, u32 maxlen)
+{
+    u32 len = 0;
+    while (len < maxlen) {
+        const u32 x = gld_u32_unaligned(s, (u64)a + len) ^ gld_u32_unaligned(s, (u64)b + len);
+        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+        len += 4;
+    }
+    return len < maxlen ? len : maxlen;
+}
+
+// One segment, walked from `entry`.  EMIT: tokens are written (k = first token index); otherwise the insertion bits are.
+// lb: this lane's LDS words (32 own-segment words + FAST_SPILL_WORDS), element e at lb[e * 64].
+template <bool EMIT>
+__device__ __forceinline__ u32 fast_walk(const u8 *__restrict__ s, const ChunkDesc &ch, const TileDesc *__restrict__ tiles, const u32 *__restrict__ sorted,
+                                         const FastBufs &fb, const u32 *__restrict__ seg_entry, u32 g, u32 seg_s, u32 entry, LevelCfg cfg,
+                                         u32 *lb, u32 &cnt_out, u32 *__restrict__ tk, u32 *__restrict__ bis, u32 k)
+{
+    const u32 n = ch.n, segend = min(seg_s + (u32)SEG, n);
+    const u32 *bmc = fb.bm + (ch.stream_off >> 5);
+    for (int e = 0; e < 32 + FAST_SPILL_WORDS; e++) lb[e * 64] = 0;
+    auto set_bit = [&](u32 q) { const u32 r = q - seg_s; lb[(r >> 5) * 64] |= 1u << (r & 31); };      // (r < 1024 + 288)
+    auto inserted = [&](u32 q) -> bool {
+        if (q >= seg_s) {
+            if (q >= entry) return (lb[((q - seg_s) >> 5) * 64] >> ((q - seg_s) & 31)) & 1;
+            const u32 r = q - seg_s;                                  // decided by the walk of the segment before
+            return (fb.spill[(u64)(g - 1) * FAST_SPILL_WORDS + (r >> 5)] >> (r & 31)) & 1;
+        }
+        const u32 kq = q / SEG, gq = ch.seg0 + kq;
+        if (q >= seg_entry[gq]) return (bmc[q >> 5] >> (q & 31)) & 1;
+        const u32 r = q - kq * SEG;
+        return (fb.spill[(u64)(gq - 1) * FAST_SPILL_WORDS + (r >> 5)] >> (r & 31)) & 1;
+    };
+    u32 kmod = EMIT ? k % BLOCK_TOKENS : 0;
+    auto put = [&](u32 v, u32 at) {
+        if (EMIT) {
+            if (kmod == 0) bis[k / BLOCK_TOKENS] = at;                // first token of a block: where its input starts
+            kmod = kmod + 1 == (u32)BLOCK_TOKENS ? 0 : kmod + 1;
+            tk[k] = v;
+            k++;
+        }
+    };
+    u32 pos = entry, cnt = 0;
+    while (pos < segend) {
+        const u32 look = n - pos;
+        if (look < (u32)MIN_MATCH) { put((u32)s[pos] << 16, pos); cnt++; pos++; continue; }      // (no hash: nothing inserted, no match)
+        set_bit(pos);
+        const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
+        const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
+        const u32 limit = pos > (u32)MAX_DIST ? pos - MAX_DIST : 0;
+        const TileDesc &td = tiles[ch.tile0 + pos / TILE];
+        const u32 *sk = sorted + td.sorted_off;
+        const u32 myhash = hash_of(gld_u32_unaligned(s, pos));
+        u32 j = fb.inv[ch.stream_off + pos];
+        u32 best = MIN_MATCH - 1, bstart = 0, examined = 0;
+        while (j > 0) {
+            j--;
+            const u32 q = td.w + (sk[j] & REL_MASK);
+            if (hash_of(gld_u32_unaligned(s, q)) != myhash) break;    // the run ends
+            if (!inserted(q)) continue;                               // not in the chain
+            if (examined == 0) { if (q == 0 || pos - q > (u32)MAX_DIST) break; }       // hash_head != NIL && strstart - hash_head <= MAX_DIST
+            else if (q <= limit) break;                               // cur_match > limit
+            examined++;
+            const u32 len = common_len(s, pos, q, maxlen);
+            if (len > best) { best = len; bstart = q; if (len >= nice) break; }
+            if (examined == (u32)cfg.chain) break;
+        }
+        if (best >= (u32)MIN_MATCH) {
+            put(((best - MIN_MATCH) << 16) | (pos - bstart), pos);
+            cnt++;
+            if (best <= (u32)cfg.lazy && look - best >= (u32)MIN_MATCH)      // short match: its inside is inserted too
+                for (u32 q = pos + 1; q < pos + best; q++) set_bit(q);
+            pos += best;
+        } else { put((u32)s[pos] << 16, pos); cnt++; pos++; }
+    }
+    cnt_out = cnt;
+    return pos;
+}
+
+// What a walk does depends on the exact insertion pattern of the 32 KiB before it.  On some parameter sets a wrong guess
+// there heals (the walks of segments far apart settle side by side: levels 1 and 3 on the 385-channel workload need ~450
+// rounds for chunks of 22 500 segments), on others it does not (level 2 there: every error breeds new ones, and only what
+// lies right behind the part that is already final comes out right).  So per chunk a FRONT is kept -- segments
+// [0, front) are final: the first segment behind the front walks on final inputs and becomes final, and so does every
+// further one for as long as the segments before it came out of the round unchanged (k_fast_front) -- and after
+// FAST_OPEN_ROUNDS rounds in which every segment may walk, only the `window` segments behind the front still do: the
+// work per round is then bounded and the front moves at least one segment per round whatever the data.
+constexpr u32 FAST_WINDOW = 128;
+
+__global__ __launch_bounds__(64) void k_fast_round(const u8 *__restrict__ stream, const ChunkDesc *__restrict__ chunks, const TileDesc *__restrict__ tiles,
+                                                   const u32 *__restrict__ sorted, ParseBufs pb, FastBufs fb, const u32 *__restrict__ front, int n_segs,
+                                                   LevelCfg cfg, int round, u32 window)
+{
+    __shared__ u32 lds[64 * (32 + FAST_SPILL_WORDS)];
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_segs) return;
+    const u32 *exit_in = (round & 1) ? pb.exit_b : pb.exit_a;
+    u32 *exit_out = (round & 1) ? pb.exit_a : pb.exit_b;
+    const u32 ci = pb.seg_chunk[g];
+    const ChunkDesc ch = chunks[ci];
+    const u32 seg_s = pb.seg_start[g];
+    const u32 kseg = (u32)g - ch.seg0, fr = front[ci];
+    if (kseg < fr || kseg - fr >= window) { exit_out[g] = exit_in[g]; return; }
+    const u32 entry = kseg == 0 ? 0u : exit_in[g - 1];
+    const u32 my_walk = fb.walked[g];                              // round (+2) of this segment's last walk, 0 = never
+    const bool walked = my_walk != 0;
+    if (walked) {
+        // walk again when the entry moved or something in sight changed in or after the round of the last walk
+        bool dirty = entry != pb.entry[g];
+        const u32 lo = kseg >= (u32)FAST_DEP_SEGS ? (u32)g - FAST_DEP_SEGS : ch.seg0;
+        for (u32 q = lo; q < (u32)g && !dirty; q++) dirty = fb.stamp[q] >= my_walk;
+        if (!dirty) { exit_out[g] = exit_in[g]; return; }
+    }
+    fb.walked[g] = (u32)round + 2;
+    u32 *lb = lds + threadIdx.x;
+    u32 cnt;
+    bool changed = !walked || entry != pb.entry[g];
+    pb.entry[g] = entry;
+    const u32 e = fast_walk<false>(stream + ch.stream_off, ch, tiles, sorted, fb, pb.entry, (u32)g, seg_s, entry, cfg, lb, cnt, nullptr, nullptr, 0);
+    // outputs: exit, count, the segment's bitmap words, its spill words; `changed` when any of them is new
+    changed = changed || e != exit_in[g];
+    exit_out[g] = e;
+    pb.cnt[g] = cnt;
+    u32 *bmw = fb.bm + ((ch.stream_off + seg_s) >> 5);
+    const u32 nw = (min(seg_s + (u32)SEG, ch.n) - seg_s + 31) / 32;
+    for (u32 w = 0; w < nw; w++) { const u32 v = lb[w * 64]; if (bmw[w] != v) { bmw[w] = v; changed = true; } }
+    u32 *sp = fb.spill + (u64)g * FAST_SPILL_WORDS;
+    for (u32 w = 0; w < (u32)FAST_SPILL_WORDS; w++) { const u32 v = lb[(32 + w) * 64]; if (sp[w] != v) { sp[w] = v; changed = true; } }
+    if (changed) fb.stamp[g] = (u32)round + 2;
+}
+
+// after a round: the front of every chunk moves past the first window segment whose outputs changed in this round (that
+// one walked on final inputs: it is final now; what follows it saw its old outputs); *pb.changed = some chunk is not done
+__global__ __launch_bounds__(64) void k_fast_front(const ChunkDesc *__restrict__ chunks, ParseBufs pb, FastBufs fb, u32 *__restrict__ front, int n_chunks, int round,
+                                                   u32 window)
+{
+    const int ci = blockIdx.x, lane = threadIdx.x;
+    if (ci >= n_chunks) return;
+    const ChunkDesc ch = chunks[ci];
+    u32 fr = front[ci];
+    if (fr >= ch.nseg) return;
+    const u32 hi = ch.nseg - fr > window ? fr + window : ch.nseg;
+    u32 nf = hi;
+    for (u32 k0 = fr; k0 < hi; k0 += 64) {
+        const u32 k = k0 + lane;
+        const bool ch_now = k < hi && fb.stamp[ch.seg0 + k] == (u32)round + 2;
+        const u64 m = __ballot(ch_now);
+        if (m) { nf = k0 + (u32)__ffsll((long long)m); break; }      // the changed one is final too: + 1
+    }
+    if (lane == 0) { front[ci] = nf; if (nf < ch.nseg) *pb.changed = 1; }
+}
+
+__global__ __launch_bounds__(256) void k_fast_init(const ChunkDesc *__restrict__ chunks, ParseBufs pb, int n_segs)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_segs) return;
+    const ChunkDesc ch = chunks[pb.seg_chunk[g]];
+    const u32 e = min(pb.seg_start[g] + (u32)SEG, ch.n);          // a segment that has not walked yet hands over at its end
+    pb.exit_a[g] = e; pb.exit_b[g] = e; pb.entry[g] = pb.seg_start[g]; pb.cnt[g] = 0;
+}
+
+// in-order completion (one lane per chunk) for data whose walks do not settle in parallel rounds
+__global__ __launch_bounds__(64) void k_fast_serial(const u8 *__restrict__ stream, const ChunkDesc *__restrict__ chunks, const TileDesc *__restrict__ tiles,
+                                                    const u32 *__restrict__ sorted, ParseBufs pb, FastBufs fb, int n_chunks, LevelCfg cfg, u32 *__restrict__ exits)
+{
+    __shared__ u32 lds[64 * (32 + FAST_SPILL_WORDS)];
+    const int ci = blockIdx.x * 64 + threadIdx.x;
+    if (ci >= n_chunks) return;
+    const ChunkDesc ch = chunks[ci];
+    u32 *lb = lds + threadIdx.x;
+    u32 entry = 0;
+    for (u32 g = ch.seg0; g < ch.seg0 + ch.nseg; g++) {
+        const u32 seg_s = pb.seg_start[g];
+        u32 cnt;
+        pb.entry[g] = entry;
+        const u32 e = fast_walk<false>(stream + ch.stream_off, ch, tiles, sorted, fb, pb.entry, g, seg_s, entry, cfg, lb, cnt, nullptr, nullptr, 0);
+        exits[g] = e; pb.cnt[g] = cnt;
+        u32 *bmw = fb.bm + ((ch.stream_off + seg_s) >> 5);
+        const u32 nw = (min(seg_s + (u32)SEG, ch.n) - seg_s + 31) / 32;
+        for (u32 w = 0; w < nw; w++) bmw[w] = lb[w * 64];
+        u32 *sp = fb.spill + (u64)g * FAST_SPILL_WORDS;
+        for (u32 w = 0; w < (u32)FAST_SPILL_WORDS; w++) sp[w] = lb[(32 + w) * 64];
+        __threadfence();
+        entry = e;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_fast_emit(const u8 *__restrict__ stream, const ChunkDesc *__restrict__ chunks, const TileDesc *__restrict__ tiles,
+                                                  const u32 *__restrict__ sorted, ParseBufs pb, FastBufs fb, int n_segs, LevelCfg cfg,
+                                                  u32 *__restrict__ tokens, u32 *__restrict__ blk_in_start)
+{
+    __shared__ u32 lds[64 * (32 + FAST_SPILL_WORDS)];
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_segs) return;
+    const ChunkDesc ch = chunks[pb.seg_chunk[g]];
+    u32 cnt;
+    fast_walk<true>(stream + ch.stream_off, ch, tiles, sorted, fb, pb.entry, (u32)g, pb.seg_start[g], pb.entry[g], cfg, lds + threadIdx.x, cnt,
+                    tokens + ch.tok_off, blk_in_start + ch.blk0, pb.tokbase[g]);
+}
+
+int launch_inverse_map(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, u32 *d_inv, u32 *d_flags)
+{
+    if (n_tiles == 0) return MTS_OK;
+    hipLaunchKernelGGL(k_inverse_map, dim3(64, n_tiles), dim3(256), 0, st, d_stream, d_tiles, d_sorted, d_inv, d_flags);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+int launch_fast_init(hipStream_t st, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs)
+{
+    if (n_segs == 0) return MTS_OK;
+    hipLaunchKernelGGL(k_fast_init, dim3((n_segs + 255) / 256), dim3(256), 0, st, d_chunks, pb, n_segs);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+int launch_fast_round(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, ParseBufs pb,
+                      const u32 *d_inv, u32 *d_bm, u32 *d_spill, u32 *d_stamp, u32 *d_front, int n_segs, int n_chunks, LevelCfg cfg, int round)
+{
+    if (n_segs == 0) return MTS_OK;
+    static const int open_rounds = getenv("MTS_FAST_OPEN_ROUNDS") ? atoi(getenv("MTS_FAST_OPEN_ROUNDS")) : 640;      // (tests force the windowed rounds with 0)
+    const u32 window = round < open_rounds ? 0x7fffffffu : FAST_WINDOW;
+    FastBufs fb; fb.inv = d_inv; fb.bm = d_bm; fb.spill = d_spill; fb.stamp = d_stamp; fb.walked = d_stamp + n_segs + 1;
+    hipLaunchKernelGGL(k_fast_round, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_stream, d_chunks, d_tiles, d_sorted, pb, fb, d_front, n_segs, cfg, round, window);
+    hipLaunchKernelGGL(k_fast_front, dim3(n_chunks), dim3(64), 0, st, d_chunks, pb, fb, d_front, n_chunks, round, window);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+int launch_fast_serial(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, ParseBufs pb,
+                       const u32 *d_inv, u32 *d_bm, u32 *d_spill, u32 *d_stamp, int n_chunks, LevelCfg cfg, int rounds_done)
+{
+    if (n_chunks == 0) return MTS_OK;
+    FastBufs fb; fb.inv = d_inv; fb.bm = d_bm; fb.spill = d_spill; fb.stamp = d_stamp; fb.walked = nullptr;
+    u32 *exits = ((rounds_done - 1) & 1) ? pb.exit_a : pb.exit_b;
+    hipLaunchKernelGGL(k_fast_serial, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_stream, d_chunks, d_tiles, d_sorted, pb, fb, n_chunks, cfg, exits);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+int launch_fast_emit(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, ParseBufs pb,
+                     const u32 *d_inv, u32 *d_bm, u32 *d_spill, int n_segs, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start)
+{
+    if (n_segs == 0) return MTS_OK;
+    FastBufs fb; fb.inv = d_inv; fb.bm = d_bm; fb.spill = d_spill; fb.stamp = nullptr; fb.walked = nullptr;
+    hipLaunchKernelGGL(k_fast_emit, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_stream, d_chunks, d_tiles, d_sorted, pb, fb, n_segs, cfg, d_tokens,
+                       d_blk_in_start);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
+// ================================================================================================
 // T: per-block Huffman trees (zlib trees.c, exact) -- flush_block() in the oracle
 // ================================================================================================
 __constant__ u8 c_extra_lbits[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
@@ -1477,7 +1773,7 @@ __global__ __launch_bounds__(64) void k_block_trees(const ChunkDesc *__restrict_
                                                     int total_blk_cap, const u32 *__restrict__ tokens,
                                                     const u32 *__restrict__ blk_in_start, const ChunkOut *__restrict__ cout,
                                                     BlockRec *__restrict__ blocks, u32 *__restrict__ blk_codes,
-                                                    u32 *__restrict__ blk_hdr)
+                                                    u32 *__restrict__ blk_hdr, int fast)
 {
     const int b = blockIdx.x;
     if (b >= total_blk_cap) return;
@@ -1560,7 +1856,9 @@ __global__ __launch_bounds__(64) void k_block_trees(const ChunkDesc *__restrict_
     if (last) q_top = ch.n;
     else {
         const u32 t_last = tk[nt - 1];
-        q_top = (t_last & 0xffff) ? in_end - ((t_last >> 16) + MIN_MATCH) + 1 : in_end;
+        // (deflate_fast tallies a token in the iteration whose top is at the token's own start, and flushes there)
+        if (fast) q_top = (t_last & 0xffff) ? in_end - ((t_last >> 16) + MIN_MATCH) : in_end - 1;
+        else q_top = (t_last & 0xffff) ? in_end - ((t_last >> 16) + MIN_MATCH) + 1 : in_end;
     }
     const bool buf_ok = (u64)in_start >= (u64)slides_at(q_top, ch.n) * WSIZE;
     BlockRec r;
@@ -1819,11 +2117,11 @@ __global__ __launch_bounds__(PACK_THREADS) void k_block_pack(const u8 *__restric
 
 int launch_block_trees(hipStream_t st, const ChunkDesc *d_chunks, const u32 *d_blk_chunk, int total_blk_cap,
                        const u32 *d_tokens, const u32 *d_blk_in_start, const ChunkOut *d_cout, BlockRec *d_blocks,
-                       u32 *d_blk_codes, u32 *d_blk_hdr)
+                       u32 *d_blk_codes, u32 *d_blk_hdr, int fast)
 {
     if (total_blk_cap == 0) return MTS_OK;
     hipLaunchKernelGGL(k_block_trees, dim3(total_blk_cap), dim3(64), 0, st, d_chunks, d_blk_chunk, total_blk_cap, d_tokens,
-                       d_blk_in_start, d_cout, d_blocks, d_blk_codes, d_blk_hdr);
+                       d_blk_in_start, d_cout, d_blocks, d_blk_codes, d_blk_hdr, fast);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }

@@ -179,21 +179,24 @@ def test_full_size_chunk_properties():
 
 
 def test_stress_shape_1024_channels_levels():
-    """BASELINE configs[4] chunk shape (1024 ch x 7500 rows, chunk = 0.25 s): byte identity vs zlib at levels 6 and 9 through
-    the C ABI's level parameter (the Python API, like the reference, always uses 6), round trip, and level 1 refused loudly."""
+    """BASELINE configs[4] chunk shape (1024 ch x 7500 rows, chunk = 0.25 s): byte identity vs zlib at levels 1, 2, 3
+    (deflate_fast), 6 and 9 through the C ABI's level parameter (the Python API, like the reference, always uses 6), round trip."""
     import zlib
     x = synth_int16(0, 2 * 7500, 1024, 5)
     bounds = [0, 7500, 15000]
     flags = hip.make_flags(True, False, 'F')
     stream0 = O.delta_transpose(x[:7500], flags).tobytes()
-    for level in (6, 9):
+    stream1 = O.delta_transpose(x[7500:], flags).tobytes()
+    for level in (1, 2, 3, 6, 9):
         got = hip.compress_chunks(x, bounds, flags, level)
         assert got[0] == zlib.compress(stream0, level), level
+        assert got[1] == zlib.compress(stream1, level), level
         st, arrs = hip.decompress_chunks(got, [7500, 7500], 1024, 'int16', flags)
         assert st == [0, 0] and np.array_equal(arrs[0], x[:7500]) and np.array_equal(arrs[1], x[7500:])
-    with pytest.raises(hip.HipError) as e:
-        hip.compress_chunks(x, bounds, flags, 1)
-    assert e.value.code == hip.E_UNSUPPORTED
+    with pytest.raises(hip.HipError):
+        hip.compress_chunks(x, bounds, flags, 0)
+    with pytest.raises(hip.HipError):
+        hip.compress_chunks(x, bounds, flags, 10)
 
 
 def test_wide_batch_with_tiny_chunks():
