@@ -103,6 +103,7 @@ int mts_decompress_chunks(int device, const unsigned char *cdata, const long *c_
  * device-to-host copy of exactly the requested rows.
  *   mts_cache_create    capacity in bytes of decoded chunks (least recently used chunks are dropped beyond it)
  *   mts_cache_query     present[i] = 1 if the decoded chunk with key chunk_keys[i] is resident
+ *   mts_cache_read_slices  (below) any number of row/column rectangles per call, gathered on the device
  *   mts_cache_read_rows the chunks of one slice, in file order: resident ones may come with c_lengths[i] = 0, the others
  *                       with their compressed bytes (cdata + c_offsets[i], c_lengths[i]) and are decoded in one batch and
  *                       kept.  Rows [row_begin, row_end) of the concatenation of the n_chunks chunks are written to `out`
@@ -117,6 +118,17 @@ int mts_cache_read_rows(long cache_id, int n_chunks, const long *chunk_keys, con
                         const long *c_offsets, const long *c_lengths, const long *n_rows, int n_channels,
                         int itemsize, int flags, long row_begin, long row_end, void *out,
                         int *chunk_status);
+/* Several rectangular pieces in one call -- Reader[rows, columns] (mtscomp.py:835-842, where the reference decodes whole
+ * chunks and drops rows and columns on the host) and many slices per launch.  The chunks are the union of what the requests
+ * touch (file order, every key once; residency and bytes as in mts_cache_read_rows).  Request k is six longs,
+ *   row_begin, row_end, row_step (>= 1), col_begin, col_end, col_step (>= 1),
+ * rows counted in the concatenation of the listed chunks; its ceil((row_end - row_begin) / row_step) x
+ * ceil((col_end - col_begin) / col_step) items are gathered ON THE DEVICE and written C-contiguous at out + out_offsets[k]
+ * (bytes); the out_bytes of `out` cross the bus in one copy and nothing else does.  Rows of a failed chunk are not written. */
+int mts_cache_read_slices(long cache_id, int n_chunks, const long *chunk_keys, const unsigned char *cdata,
+                          const long *c_offsets, const long *c_lengths, const long *n_rows, int n_channels,
+                          int itemsize, int flags, int n_requests, const long *requests, void *out,
+                          const long *out_offsets, long out_bytes, int *chunk_status);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-resident variants (inputs and outputs already in HBM; used by bench.py and by callers that

@@ -237,6 +237,7 @@ class HipCodec:
     cache_destroy = staticmethod(hip.cache_destroy)
     cache_query = staticmethod(hip.cache_query)
     cache_read_rows = staticmethod(hip.cache_read_rows)
+    cache_read_slices = staticmethod(hip.cache_read_slices)
 
     @staticmethod
     def _run_shards(fn, n):
@@ -674,6 +675,96 @@ class Reader:
                 raise IOError("Compressed chunk #%d is corrupted." % k)
         return out
 
+    def _gather_request(self, item):
+        """(i0, i1, row_step, c0, c1, col_step, squeeze) when the index is a rectangle the device gather serves, else None."""
+        if isinstance(item, slice):
+            item = (item, slice(None))
+        if not (isinstance(item, tuple) and len(item) == 2 and isinstance(item[0], slice)):
+            return None
+        rs = 1 if item[0].step is None else item[0].step
+        if not isinstance(rs, (int, np.integer)) or rs < 1:
+            return None
+        cols, squeeze = item[1], False
+        if isinstance(cols, (int, np.integer)):
+            c = int(cols) + (self.n_channels if cols < 0 else 0)
+            if not 0 <= c < self.n_channels:
+                return None                                    # (numpy raises IndexError: let it)
+            c0, c1, cs, squeeze = c, c + 1, 1, True
+        elif isinstance(cols, slice):
+            c0, c1, cs = cols.indices(self.n_channels)
+            if cs < 1:
+                return None
+            c1 = max(c0, c1)
+        else:
+            return None
+        i0 = self._validate_index(item[0].start, 0)
+        i1 = self._validate_index(item[0].stop, self.n_samples)
+        return i0, max(i0, i1), int(rs), c0, c1, cs, squeeze
+
+    def read_slices(self, items, _fallback=True):
+        """Several index expressions ``r[rows, columns]`` / ``r[rows]`` in ONE device call: the chunks they touch are decoded
+        (or found in the decoded-chunk cache in HBM), the requested rows and columns are gathered on the device and only
+        they cross the bus (the reference decodes whole chunks and slices on the host, mtscomp.py:835-842).  Returns the list
+        of arrays; items the device gather does not serve go through ``__getitem__`` one by one."""
+        reqs = [self._gather_request(it) for it in items]
+        usable = getattr(self.codec, 'device_cache', False) and hasattr(self.codec, 'cache_read_slices') and \
+            self._dev_cache_bytes > 0 and all(r is not None for r in reqs)
+        spans = []
+        if usable:
+            for i0, i1, _, _, _, _, _ in reqs:
+                if i1 <= i0:
+                    spans.append(None)
+                    continue
+                first, last = self._chunks_for_interval(i0, i1)
+                if last > first and self.chunk_bounds[last] >= i1:
+                    last -= 1
+                spans.append((first, last))
+            keys = sorted({k for sp in spans if sp for k in range(sp[0], sp[1] + 1)})
+            rows = [self.chunk_bounds[k + 1] - self.chunk_bounds[k] for k in keys]
+            usable = 0 < len(keys) <= DEVICE_CACHE_MAX_CHUNKS and \
+                2 * sum(rows) * self.n_channels * self.dtype.itemsize <= self._dev_cache_bytes
+        if not usable:
+            return [self[it] for it in items] if _fallback else None
+        with self._dev_cache_lock:
+            if self._dev_cache is None:
+                self._dev_cache = self.codec.cache_create(self._dev_cache_bytes)
+        where = {k: j for j, k in enumerate(keys)}
+        cum = np.concatenate(([0], np.cumsum(rows)))
+        requests = []
+        for (i0, i1, rs, c0, c1, cs, _), sp in zip(reqs, spans):
+            a = int(cum[where[sp[0]]]) + i0 - self.chunk_bounds[sp[0]] if sp else 0
+            requests.append((a, a + (i1 - i0), rs, c0, c1, cs))
+        present = self.codec.cache_query(self._dev_cache, keys)
+        for attempt in range(2):
+            offs, lens, parts, at = [0] * len(keys), [0] * len(keys), [], 0
+            need = [k for k, p in zip(keys, present) if not p]
+            j = 0
+            while j < len(need):                                # one read per run of neighbouring missing chunks
+                e = j
+                while e + 1 < len(need) and need[e + 1] == need[e] + 1:
+                    e += 1
+                base = self.chunk_offsets[need[j]]
+                parts.append(self._pread(self.chunk_offsets[need[e] + 1] - base, base))
+                for k in need[j:e + 1]:
+                    offs[where[k]] = at + self.chunk_offsets[k] - base
+                    lens[where[k]] = self.chunk_offsets[k + 1] - self.chunk_offsets[k]
+                at += len(parts[-1])
+                j = e + 1
+            try:
+                status, arrays = self.codec.cache_read_slices(self._dev_cache, keys, b''.join(parts), offs, lens, rows,
+                                                              self.n_channels, self.dtype, self._flags(), requests)
+                break
+            except hip.HipError as e:
+                if e.code != hip.E_MISS or attempt:
+                    raise
+                present = [False] * len(keys)                  # dropped since the query: send everything
+        for k, st in zip(keys, status):
+            if st == hip.CHUNK_BADSIZE:
+                raise AssertionError("Chunk #%d does not have the expected size." % k)
+            if st != hip.CHUNK_OK:
+                raise IOError("Compressed chunk #%d is corrupted." % k)
+        return [a[:, 0] if r[6] else a for a, r in zip(arrays, reqs)]
+
     def _decode_into(self, b0, b1, dst):
         """Chunks b0 .. b1-1 (consecutive in the file) decoded straight into `dst` (their rows, C-contiguous): one read, one
         codec call, no copy on the host and nothing left in the chunk cache."""
@@ -829,7 +920,7 @@ class Reader:
                 last -= 1
             rows = self._slice_from_device_cache(first, last, i0, i1)
             if rows is not None:
-                out = rows[::item.step, :]
+                out = rows[0:i1 - i0:item.step, :]             # (like arr[a:b:step] in the reference: a negative step gives nothing)
                 assert out.shape[0] == len(range(i0, i1, item.step or 1))
                 return out
             if last - first + 1 > self.batch_size:
@@ -875,6 +966,9 @@ class Reader:
             elif len(item) == 2 and np.isscalar(item[0]):
                 return self[item[0]][item[1]]
             elif len(item) == 2:
+                got = self.read_slices([item], _fallback=False)
+                if got is not None:
+                    return got[0]
                 return self[item[0]][:, item[1]]
         elif isinstance(item, (int, np.integer)):
             item = int(item)

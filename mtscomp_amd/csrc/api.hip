@@ -41,6 +41,8 @@ static const LevelCfg LEVELS[10] = {{0, 0, 0, 0},     {4, 4, 8, 4},       {4, 5,
                                     {4, 4, 16, 16},   {8, 16, 32, 32},    {8, 16, 128, 128},   {8, 32, 128, 256},
                                     {32, 128, 258, 1024}, {32, 258, 258, 4096}};
 
+void drop_device_caches();      // frees the decoded-chunk caches of the current device (called when a workspace allocation fails)
+
 // grow-only device buffer
 struct DBuf {
     void *p = nullptr;
@@ -53,6 +55,7 @@ struct DBuf {
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) { (void)hipGetLastError(); drop_device_caches(); e = hipMalloc(&p, bytes); }      // decoded chunks are only a cache
             if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return MTS_E_NOMEM; }
             cap = bytes;
         } else cap = want;
@@ -608,13 +611,30 @@ struct DevCache {
 std::mutex g_cache_mu;
 std::unordered_map<long, DevCache *> g_caches;
 long g_cache_next = 1;
-DevCache *find_cache(long id)
+DevCache *find_cache(long id, int *device = nullptr)
 {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     auto it = g_caches.find(id);
-    return it == g_caches.end() ? nullptr : it->second;
+    if (it == g_caches.end()) return nullptr;
+    if (device) *device = it->second->device;                  // (read under the lock: the cache may be freed once it is released)
+    return it->second;
 }
+// mts_cache_destroy unregisters a cache first and frees it under its engine's lock; an entry point that looked the cache
+// up before it took that lock asks again once it holds it, and never touches a cache that has gone in between
+bool cache_alive(long id, const DevCache *c) { return find_cache(id) == c; }
 }  // namespace
+
+}  // extern "C"
+namespace mts {
+void drop_device_caches()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (auto &kv : g_caches) if (kv.second->device == dev) kv.second->clear();      // (the caller holds this device's engine lock)
+}
+}  // namespace mts
+extern "C" {
 
 void mts_release(void)
 {
@@ -812,7 +832,7 @@ int mts_cache_destroy(long cache_id)
         auto it = g_caches.find(cache_id);
         if (it == g_caches.end()) return MTS_E_ARG;
         c = it->second;
-        g_caches.erase(it);
+        g_caches.erase(it);                                    // from here on no entry point starts on this cache; those inside finish first (engine lock)
     }
     Engine *E;
     if (get_engine(c->device, &E) == MTS_OK) {
@@ -826,31 +846,25 @@ int mts_cache_destroy(long cache_id)
 
 int mts_cache_query(long cache_id, const long *chunk_keys, int n, int *present)
 {
-    DevCache *c = find_cache(cache_id);
+    int dev = 0;
+    DevCache *c = find_cache(cache_id, &dev);
     if (!c || n < 0) return MTS_E_ARG;
     Engine *E;
-    int rc = get_engine(c->device, &E);
+    int rc = get_engine(dev, &E);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(E->mu);
+    if (!cache_alive(cache_id, c)) return MTS_E_ARG;
     for (int i = 0; i < n; i++) present[i] = c->map.count(chunk_keys[i]) ? 1 : 0;
     return MTS_OK;
 }
 
-int mts_cache_read_rows(long cache_id, int n_chunks, const long *chunk_keys, const unsigned char *cdata, const long *c_offsets,
-                        const long *c_lengths, const long *n_rows, int n_channels, int itemsize, int flags, long row_begin,
-                        long row_end, void *out, int *chunk_status)
+// make every listed chunk resident (decode the missing ones in one batch) and pin them for this call by their stamp
+static int cache_ensure(DevCache *c, Engine *E, int n_chunks, const long *chunk_keys, const unsigned char *cdata, const long *c_offsets,
+                        const long *c_lengths, const long *n_rows, int n_channels, int itemsize, int flags, int *chunk_status, u64 call_stamp,
+                        long *total_rows_out)
 {
-    DevCache *c = find_cache(cache_id);
-    if (!c || n_chunks < 0 || n_channels <= 0 || row_begin < 0 || row_end < row_begin) return MTS_E_ARG;
-    Engine *E;
-    int rc = get_engine(c->device, &E);
-    if (rc) return rc;
-    if (n_chunks == 0) return row_end == 0 ? MTS_OK : MTS_E_ARG;
-    std::lock_guard<std::mutex> lk(E->mu);
-    MTS_HIP(hipSetDevice(E->dev));
+    int rc;
     const u64 row_bytes = (u64)n_channels * itemsize;
-    const u64 call_stamp = ++c->clock;
-    // resident chunks are pinned for this call by their stamp; the others must come with their bytes
     std::vector<int> miss;
     long total_rows = 0;
     for (int i = 0; i < n_chunks; i++) {
@@ -863,39 +877,65 @@ int mts_cache_read_rows(long cache_id, int n_chunks, const long *chunk_keys, con
         if (c_lengths[i] <= 0) { set_error("chunk key %ld is not resident and no compressed bytes were given", chunk_keys[i]); return MTS_E_MISS; }
         miss.push_back(i);
     }
-    if (row_end > total_rows) return MTS_E_ARG;
-    if (!miss.empty()) {
-        const int m = (int)miss.size();
-        std::vector<long> coff(m), clen(m), rows(m), ooff(m);
-        std::vector<int> st(m);
-        u64 ctot = 0, otot = 0;
-        for (int k = 0; k < m; k++) {
-            const int i = miss[k];
-            clen[k] = c_lengths[i]; rows[k] = n_rows[i];
-            coff[k] = (long)ctot; ctot += align_up((u64)clen[k] + 8, 16);
-            ooff[k] = (long)otot; otot += align_up((u64)rows[k] * row_bytes, 256);
-        }
-        if ((rc = E->h_in.ensure(ctot + 256))) return rc;
-        if ((rc = E->h_out.ensure(otot + 256))) return rc;
-        for (int k = 0; k < m; k++)
-            MTS_HIP(hipMemcpyAsync(E->h_in.as<u8>() + coff[k], cdata + c_offsets[miss[k]], (size_t)clen[k], hipMemcpyHostToDevice, nullptr));
-        rc = dev_decompress(*E, nullptr, E->h_in.as<u8>(), coff.data(), clen.data(), rows.data(), m, n_channels, itemsize, flags,
-                            E->h_out.as<u8>(), ooff.data(), st.data());
-        if (rc) return rc;
-        for (int k = 0; k < m; k++) {
-            const int i = miss[k];
-            chunk_status[i] = st[k];
-            if (st[k] != MTS_CHUNK_OK) continue;
-            const u64 size = (u64)rows[k] * row_bytes;
-            CacheEntry e;
-            c->make_room(align_up(size ? size : 1, 4096), call_stamp);
-            if ((rc = c->alloc(size, &e.d, &e.cap))) return rc;
-            e.size = size; e.rows = rows[k]; e.stamp = call_stamp;
-            if (size) MTS_HIP(hipMemcpyAsync(e.d, E->h_out.as<u8>() + ooff[k], (size_t)size, hipMemcpyDeviceToDevice, nullptr));
-            c->used += e.cap;
-            c->map[chunk_keys[i]] = e;
-        }
+    *total_rows_out = total_rows;
+    auto all_resident = [&]() -> int {            // (a workspace allocation that failed may have emptied the caches of this device)
+        for (int i = 0; i < n_chunks; i++)
+            if (chunk_status[i] == MTS_CHUNK_OK && !c->map.count(chunk_keys[i])) { set_error("chunk key %ld was dropped from the cache during the call", chunk_keys[i]); return MTS_E_MISS; }
+        return MTS_OK;
+    };
+    if (miss.empty()) return all_resident();
+    const int m = (int)miss.size();
+    std::vector<long> coff(m), clen(m), rows(m), ooff(m);
+    std::vector<int> st(m);
+    u64 ctot = 0, otot = 0;
+    for (int k = 0; k < m; k++) {
+        const int i = miss[k];
+        clen[k] = c_lengths[i]; rows[k] = n_rows[i];
+        coff[k] = (long)ctot; ctot += align_up((u64)clen[k] + 8, 16);
+        ooff[k] = (long)otot; otot += align_up((u64)rows[k] * row_bytes, 256);
     }
+    if ((rc = E->h_in.ensure(ctot + 256))) return rc;
+    if ((rc = E->h_out.ensure(otot + 256))) return rc;
+    for (int k = 0; k < m; k++)
+        MTS_HIP(hipMemcpyAsync(E->h_in.as<u8>() + coff[k], cdata + c_offsets[miss[k]], (size_t)clen[k], hipMemcpyHostToDevice, nullptr));
+    rc = dev_decompress(*E, nullptr, E->h_in.as<u8>(), coff.data(), clen.data(), rows.data(), m, n_channels, itemsize, flags,
+                        E->h_out.as<u8>(), ooff.data(), st.data());
+    if (rc) return rc;
+    for (int k = 0; k < m; k++) {
+        const int i = miss[k];
+        chunk_status[i] = st[k];
+        if (st[k] != MTS_CHUNK_OK) continue;
+        const u64 size = (u64)rows[k] * row_bytes;
+        CacheEntry e;
+        c->make_room(align_up(size ? size : 1, 4096), call_stamp);
+        if ((rc = c->alloc(size, &e.d, &e.cap))) return rc;
+        e.size = size; e.rows = rows[k]; e.stamp = call_stamp;
+        if (size) MTS_HIP(hipMemcpyAsync(e.d, E->h_out.as<u8>() + ooff[k], (size_t)size, hipMemcpyDeviceToDevice, nullptr));
+        c->used += e.cap;
+        c->map[chunk_keys[i]] = e;
+    }
+    return all_resident();
+}
+
+int mts_cache_read_rows(long cache_id, int n_chunks, const long *chunk_keys, const unsigned char *cdata, const long *c_offsets,
+                        const long *c_lengths, const long *n_rows, int n_channels, int itemsize, int flags, long row_begin,
+                        long row_end, void *out, int *chunk_status)
+{
+    int dev = 0;
+    DevCache *c = find_cache(cache_id, &dev);
+    if (!c || n_chunks < 0 || n_channels <= 0 || row_begin < 0 || row_end < row_begin) return MTS_E_ARG;
+    Engine *E;
+    int rc = get_engine(dev, &E);
+    if (rc) return rc;
+    if (n_chunks == 0) return row_end == 0 ? MTS_OK : MTS_E_ARG;
+    std::lock_guard<std::mutex> lk(E->mu);
+    if (!cache_alive(cache_id, c)) return MTS_E_ARG;         // (destroyed while this call waited for the engine)
+    MTS_HIP(hipSetDevice(E->dev));
+    const u64 row_bytes = (u64)n_channels * itemsize;
+    const u64 call_stamp = ++c->clock;
+    long total_rows = 0;
+    if ((rc = cache_ensure(c, E, n_chunks, chunk_keys, cdata, c_offsets, c_lengths, n_rows, n_channels, itemsize, flags, chunk_status, call_stamp, &total_rows))) return rc;
+    if (row_end > total_rows) return MTS_E_ARG;
     // rows [row_begin, row_end) of the concatenation, straight from the resident chunks
     long r0 = 0;
     for (int i = 0; i < n_chunks; i++) {
@@ -910,6 +950,56 @@ int mts_cache_read_rows(long cache_id, int n_chunks, const long *chunk_keys, con
     }
     MTS_HIP(hipStreamSynchronize(nullptr));
     c->make_room(0, ~0ull);                         // back under the capacity (this call's chunks may go too)
+    return MTS_OK;
+}
+
+int mts_cache_read_slices(long cache_id, int n_chunks, const long *chunk_keys, const unsigned char *cdata, const long *c_offsets,
+                          const long *c_lengths, const long *n_rows, int n_channels, int itemsize, int flags, int n_req,
+                          const long *req, void *out, const long *out_offsets, long out_bytes, int *chunk_status)
+{
+    int dev = 0;
+    DevCache *c = find_cache(cache_id, &dev);
+    if (!c || n_chunks < 0 || n_channels <= 0 || n_req < 0 || out_bytes < 0) return MTS_E_ARG;
+    if (itemsize != 1 && itemsize != 2 && itemsize != 4 && itemsize != 8) return MTS_E_ARG;
+    Engine *E;
+    int rc = get_engine(dev, &E);
+    if (rc) return rc;
+    if (n_chunks == 0 || n_req == 0) return MTS_OK;
+    std::lock_guard<std::mutex> lk(E->mu);
+    if (!cache_alive(cache_id, c)) return MTS_E_ARG;
+    MTS_HIP(hipSetDevice(E->dev));
+    const u64 call_stamp = ++c->clock;
+    long total_rows = 0;
+    if ((rc = cache_ensure(c, E, n_chunks, chunk_keys, cdata, c_offsets, c_lengths, n_rows, n_channels, itemsize, flags, chunk_status, call_stamp, &total_rows))) return rc;
+    // descriptors: per chunk (first row, base pointer or null when it failed), per request its six numbers + output offset
+    std::vector<GatherChunk> gc(n_chunks);
+    long r0 = 0;
+    for (int i = 0; i < n_chunks; i++) {
+        gc[i].row0 = r0; r0 += n_rows[i];
+        gc[i].base = chunk_status[i] == MTS_CHUNK_OK ? c->map[chunk_keys[i]].d : nullptr;
+    }
+    std::vector<GatherReq> gr(n_req);
+    u64 max_items = 0;
+    for (int k = 0; k < n_req; k++) {
+        const long *q = req + 6 * k;
+        if (q[0] < 0 || q[1] < q[0] || q[1] > total_rows || q[2] < 1 || q[3] < 0 || q[4] < q[3] || q[4] > n_channels || q[5] < 1) return MTS_E_ARG;
+        GatherReq &g = gr[k];
+        g.rb = q[0]; g.rs = q[2]; g.cb = q[3]; g.cs = q[5];
+        g.nr = (q[1] - q[0] + q[2] - 1) / q[2]; g.ncol = (q[4] - q[3] + q[5] - 1) / q[5];
+        g.out_off = out_offsets[k];
+        if (out_offsets[k] < 0 || (u64)out_offsets[k] + (u64)g.nr * g.ncol * itemsize > (u64)out_bytes) return MTS_E_ARG;
+        if ((u64)g.nr * g.ncol > max_items) max_items = (u64)g.nr * g.ncol;
+    }
+    const size_t o_req = align_up(sizeof(GatherChunk) * n_chunks, 256), desc = o_req + align_up(sizeof(GatherReq) * n_req, 256);
+    if ((rc = E->misc.ensure(desc + 256))) return rc;
+    if ((rc = E->h_out.ensure((u64)out_bytes + 256))) return rc;
+    MTS_HIP(hipMemcpyAsync(E->misc.p, gc.data(), sizeof(GatherChunk) * n_chunks, hipMemcpyHostToDevice, nullptr));
+    MTS_HIP(hipMemcpyAsync(E->misc.as<u8>() + o_req, gr.data(), sizeof(GatherReq) * n_req, hipMemcpyHostToDevice, nullptr));
+    if (max_items && (rc = launch_gather_slices(nullptr, (const GatherChunk *)E->misc.p, n_chunks, (const GatherReq *)(E->misc.as<u8>() + o_req), n_req, max_items,
+                                                n_channels, itemsize, E->h_out.as<u8>()))) return rc;
+    if (out_bytes) MTS_HIP(hipMemcpyAsync(out, E->h_out.p, (size_t)out_bytes, hipMemcpyDeviceToHost, nullptr));      // the requested items, nothing else, in one copy
+    MTS_HIP(hipStreamSynchronize(nullptr));
+    c->make_room(0, ~0ull);
     return MTS_OK;
 }
 

@@ -128,6 +128,12 @@ int launch_synth_int16(hipStream_t st, int16_t *d_out, long t0, long t1, int n_c
 int launch_adler_stream(hipStream_t st, const u8 *d_stream, const u64 *d_stream_off, const u32 *d_n,
                         int n_chunks, u32 max_n, u64 *d_adler_acc);
 
+// pieces of decoded chunks gathered on the device (mts_cache_read_slices)
+struct GatherChunk { long row0; const u8 *base; };                      // first row in the concatenation; null = the chunk failed
+struct GatherReq { long rb, rs, cb, cs, nr, ncol, out_off; };           // rows rb + i * rs (i < nr), columns cb + j * cs (j < ncol) -> out_off
+int launch_gather_slices(hipStream_t st, const GatherChunk *d_chunks, int n_chunks, const GatherReq *d_req, int n_req, u64 max_items,
+                         int n_channels, int itemsize, u8 *d_out);
+
 // deflate.hip
 int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp,
                      u32 *d_sorted, u16 *d_sorted_nb, int want_nb /* chain lengths too (the kernel for budgets > 128 reads them) */,

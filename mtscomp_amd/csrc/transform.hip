@@ -785,4 +785,43 @@ int launch_synth_int16(hipStream_t st, int16_t *d_out, long t0, long t1, int n_c
     return MTS_OK;
 }
 
+// ================================================================================================
+// rectangular pieces of decoded chunks (Reader[rows, columns]; several requests per launch)
+// ================================================================================================
+// One thread per requested item; consecutive threads take consecutive columns of one row, so with a column step of 1 the
+// reads and the writes are both contiguous.  The chunks of the call are few: the owning chunk of a row is found by bisection.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_slices(const GatherChunk *__restrict__ chunks, int n_chunks, const GatherReq *__restrict__ req,
+                                                       int n_channels, u8 *__restrict__ out)
+{
+    const GatherReq q = req[blockIdx.y];
+    const u64 items = (u64)q.nr * (u64)q.ncol;
+    for (u64 e = (u64)blockIdx.x * 256 + threadIdx.x; e < items; e += (u64)gridDim.x * 256) {
+        const long i = (long)(e / (u64)q.ncol), j = (long)(e % (u64)q.ncol);
+        const long row = q.rb + i * q.rs, col = q.cb + j * q.cs;
+        int lo = 0, hi = n_chunks - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (chunks[mid].row0 <= row) lo = mid; else hi = mid - 1; }
+        const GatherChunk c = chunks[lo];
+        if (!c.base) continue;                                         // (a chunk that failed to decode: its rows are not written)
+        ((T *)(out + q.out_off))[e] = ((const T *)c.base)[(u64)(row - c.row0) * (u64)n_channels + (u64)col];
+    }
+}
+
+int launch_gather_slices(hipStream_t st, const GatherChunk *d_chunks, int n_chunks, const GatherReq *d_req, int n_req, u64 max_items,
+                         int n_channels, int itemsize, u8 *d_out)
+{
+    if (n_req == 0 || max_items == 0) return MTS_OK;
+    const u64 nb = (max_items + 255) / 256;
+    dim3 grid((unsigned)(nb < 4096 ? nb : 4096), n_req);
+    switch (itemsize) {
+    case 1: hipLaunchKernelGGL(k_gather_slices<u8>, grid, dim3(256), 0, st, d_chunks, n_chunks, d_req, n_channels, d_out); break;
+    case 2: hipLaunchKernelGGL(k_gather_slices<u16>, grid, dim3(256), 0, st, d_chunks, n_chunks, d_req, n_channels, d_out); break;
+    case 4: hipLaunchKernelGGL(k_gather_slices<u32>, grid, dim3(256), 0, st, d_chunks, n_chunks, d_req, n_channels, d_out); break;
+    case 8: hipLaunchKernelGGL(k_gather_slices<u64>, grid, dim3(256), 0, st, d_chunks, n_chunks, d_req, n_channels, d_out); break;
+    default: return MTS_E_ARG;
+    }
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
 }  // namespace mts

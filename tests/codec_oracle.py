@@ -79,6 +79,37 @@ class CachingOracleCodec(OracleCodec):
     def cache_query(self, cid, keys):
         return np.array([k in self.caches[cid] for k in keys], dtype=bool)
 
+    def _ensure(self, cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, what):
+        from mtscomp_amd import hip
+        cache = self.caches[cid]
+        if self.drop_before_next_read:
+            self.drop_before_next_read = False
+            cache.clear()
+        self.calls.append((what, sum(1 for n in lens if n)))
+        status = []
+        for k, o, n, nr in zip(keys, offs, lens, n_rows):
+            if k in cache:
+                status.append(0)
+                continue
+            if not n:
+                raise hip.HipError(hip.E_MISS, 'mts_cache_read_rows', 'chunk key %d is not resident' % k)
+            st, arrs = self.decompress([bytes(cdata[o:o + n])], [nr], n_channels, dtype, flags)
+            self.calls.pop()                         # (the inner decompress call is not a codec call of its own)
+            status.append(st[0])
+            if st[0] == 0:
+                cache[k] = arrs[0]
+        return cache, status
+
+    def cache_read_slices(self, cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, requests):
+        """mts_cache_read_slices restated: rectangles of the concatenation of the listed chunks."""
+        cache, status = self._ensure(cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, 'cache_slices')
+        whole = np.concatenate([cache[k] if st == 0 else np.zeros((nr, n_channels), dtype=dtype)
+                                for k, nr, st in zip(keys, n_rows, status)], axis=0)
+        arrays = [np.ascontiguousarray(whole[rb:re:rs, cb:ce:cs]) for rb, re, rs, cb, ce, cs in requests]
+        while len(cache) > self.capacity_chunks:
+            cache.pop(next(iter(cache)))
+        return status, arrays
+
     def cache_read_rows(self, cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, row_begin, row_end):
         from mtscomp_amd import hip
         cache = self.caches[cid]

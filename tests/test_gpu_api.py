@@ -398,3 +398,34 @@ def test_sort_order_guard_repeats_the_stage(monkeypatch):
     monkeypatch.delenv('MTS_SORT_INJECT_DISORDER')
     assert hip.compress_chunks(x, [0, 3000], flags, 6, device=0)[0] == want6
     assert 'hash_sort_retry' not in [n for n, _ in hip.last_stage_times(0)]
+
+
+def test_read_slices_gathers_on_the_device(tmp_cfg):
+    """Reader[rows, columns] and Reader.read_slices on a 385-channel file with 23.1 MB chunks (BASELINE configs[2] shape): the
+    rows and columns are picked on the device (mts_cache_read_slices) and must be numpy's."""
+    arr = synth_int16(0, 4 * 30000, 385, 2)
+    raw = tmp_cfg / 'np.bin'
+    arr.tofile(raw)
+    mtscomp_amd.compress(raw, tmp_cfg / 'np.cbin', tmp_cfg / 'np.ch', sample_rate=30000., n_channels=385, dtype=np.int16,
+                         check_after_compress=False)
+    r = mtscomp_amd.decompress(tmp_cfg / 'np.cbin', tmp_cfg / 'np.ch')
+    items = [(slice(100, 30100), slice(0, 385)), (slice(29990, 60010, 3), slice(10, 300, 7)), (slice(119000, None), 384),
+             (slice(45000, 45001), slice(None)), slice(60000, 60010), (slice(5, 5), slice(2, 9))]
+    got = r.read_slices(items)
+    for g, it in zip(got, items):
+        want = arr[it]
+        assert g.shape == want.shape and g.dtype == want.dtype and np.array_equal(g, want), it
+    assert np.array_equal(r[31000:32000, 5:50:5], arr[31000:32000, 5:50:5])
+    assert np.array_equal(r[31000:32000, -1], arr[31000:32000, -1])
+    assert np.array_equal(r[1000:90000:1000, :], arr[1000:90000:1000, :])
+    # other dtypes / itemsizes through the same gather
+    for dtype in ('uint8', 'int32', 'int64'):
+        a2 = np.random.RandomState(3).randint(0, 200, size=(5000, 7)).astype(dtype)
+        p = tmp_cfg / ('g_%s.bin' % dtype)
+        a2.tofile(p)
+        mtscomp_amd.compress(p, p.with_suffix('.cbin'), p.with_suffix('.ch'), sample_rate=1000., n_channels=7, dtype=a2.dtype,
+                             check_after_compress=False)
+        r2 = mtscomp_amd.decompress(p.with_suffix('.cbin'), p.with_suffix('.ch'))
+        assert np.array_equal(r2[10:4000:3, 1:6:2], a2[10:4000:3, 1:6:2]) and np.array_equal(r2[:, 6], a2[:, 6])
+        r2.close()
+    r.close()

@@ -267,7 +267,7 @@ def test_slices_through_the_decoded_chunk_cache_interface(tmp_cfg):
     assert np.array_equal(r[-10:], arr[-10:]) and np.array_equal(r[3000], arr[3000])
     codec.drop_before_next_read = True                                               # evicted between query and read
     assert np.array_equal(r[2600:2700, 1:4], arr[2600:2700, 1:4])
-    assert codec.calls[-2:] == [('cache_read', 0), ('cache_read', 1)]                # first try without bytes, then with
+    assert codec.calls[-2:] == [('cache_slices', 0), ('cache_slices', 1)]            # first try without bytes, then with
     assert np.array_equal(r[:], arr)                                                 # all six chunks: within DEVICE_CACHE_MAX_CHUNKS
     b = bytearray((tmp_cfg / 'data.cbin').read_bytes())
     b[r.chunk_offsets[4] + 20] ^= 0xff
@@ -276,5 +276,15 @@ def test_slices_through_the_decoded_chunk_cache_interface(tmp_cfg):
     with pytest.raises(IOError, match='#4'):
         r2[4936:4950]
     assert np.array_equal(r2[0:100], arr[0:100])
+    # several rectangles in one codec call (Reader.read_slices): chunks 0, 2, 3 and 5 -- two separate reads of missing bytes
+    codec.calls.clear()
+    items = [(slice(10, 50), slice(1, 5)), (slice(2500, 4000, 7), slice(None, None, 2)), slice(6990, None), (slice(3000, 3010), 4),
+             (slice(40, 40), slice(0, 3))]
+    got = r.read_slices(items)
+    assert len(got) == len(items) and all(np.array_equal(g, arr[it]) and g.shape == arr[it].shape for g, it in zip(got, items))
+    assert [c[0] for c in codec.calls] == ['cache_slices']
+    # what the gather does not serve goes through __getitem__ (numpy semantics kept)
+    assert np.array_equal(r[100:200, ::-1], arr[100:200, ::-1]) and np.array_equal(r[100:200, [1, 3]], arr[100:200, [1, 3]])
+    assert r[200:100:-1].shape == arr[200:100:-1][0:0].shape          # (like the reference: a negative row step gives nothing)
     r.close(); r2.close()
     assert codec.caches == {}
