@@ -107,39 +107,37 @@ def read_config(**kwargs):
 
 
 def write_config(**kwargs):
-    """mtscomp.py:203-209."""
-    config = read_config(**kwargs)
-    CONFIG_PATH.parent.mkdir(exist_ok=True, parents=True)
-    with CONFIG_PATH.open('w') as f:
-        json.dump(config, f, indent=2, sort_keys=True)
-    return config
+    """Merge kwargs into the user's configuration file and return what it now holds (mtscomp.py:203-209)."""
+    merged = read_config(**kwargs)
+    CONFIG_PATH.parent.mkdir(parents=True, exist_ok=True)
+    CONFIG_PATH.write_text(json.dumps(merged, indent=2, sort_keys=True))
+    return merged
 
 
 # ------------------------------------------------------------------------------------------------
 # raw I/O (mtscomp.py:115-140)
 # ------------------------------------------------------------------------------------------------
 def load_raw_data(path=None, n_channels=None, dtype=None, offset=None, mmap=True):
-    """Memmap (or read) a flat binary file as an (n_samples, n_channels) array."""
+    """A flat binary file as an (n_samples, n_channels) array, memory mapped unless mmap=False (mtscomp.py:115-140).
+    Contract: AssertionError for a missing file or dtype, ValueError when the size is no whole number of rows, an empty
+    (0, n_channels) array for an empty file."""
     path = Path(path)
     assert path.exists(), "File %s does not exist." % path
     assert dtype, "The data type must be provided."
-    n_channels = n_channels or 1
-    itemsize = np.dtype(dtype).itemsize
-    offset = offset or 0
-    f_size = op.getsize(str(path))
-    n_samples = (f_size - offset) // (itemsize * n_channels)
-    if n_samples * n_channels * itemsize != f_size - offset:
+    n_channels, offset = n_channels or 1, offset or 0
+    f_size = path.stat().st_size
+    n_samples, rest = divmod(f_size - offset, np.dtype(dtype).itemsize * n_channels)
+    if rest:
         raise ValueError(
             "The file size (%d bytes) is incompatible with the specified parameters "
             "(n_channels=%d, dtype=%s, offset=%d)" % (f_size, n_channels, dtype, offset))
-    if n_samples * n_channels == 0:
+    if n_samples <= 0:
         return np.zeros((0, n_channels), dtype=dtype)
-    shape = (n_samples, n_channels)
-    if mmap:
-        return np.memmap(str(path), dtype=dtype, shape=shape, offset=offset)
-    if offset > 0:  # pragma: no cover
-        raise NotImplementedError()
-    return np.fromfile(str(path), dtype).reshape(shape)
+    if not mmap:
+        if offset > 0:  # pragma: no cover
+            raise NotImplementedError()
+        return np.fromfile(str(path), dtype).reshape((n_samples, n_channels))
+    return np.memmap(str(path), dtype=dtype, shape=(n_samples, n_channels), offset=offset)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -305,65 +303,59 @@ class Writer:
     ``batch_chunks`` (chunks per device call) and ``codec`` (defaults to the MI355X codec).
     """
 
+    # configuration keys a Writer keeps as attributes of the same name
+    _CONFIG_ATTRS = ('chunk_duration', 'algorithm', 'comp_level', 'do_time_diff', 'do_spatial_diff', 'n_threads',
+                     'check_after_compress', 'chunk_order')
+
     def __init__(self, before_check=None, codec=None, **kwargs):
         self.pool = None
         self.quiet = kwargs.pop('quiet', False)
-        config = read_config(**kwargs)
-        self.config = config
-        self.chunk_duration = config.chunk_duration
-        self.algorithm = config.algorithm
+        self.config = read_config(**kwargs)
+        for key in self._CONFIG_ATTRS:
+            setattr(self, key, self.config[key])
         assert self.algorithm == 'zlib', "Only zlib is currently supported."
-        self.comp_level = config.comp_level
-        self.do_time_diff = config.do_time_diff
-        self.do_spatial_diff = config.do_spatial_diff
-        self.n_threads = config.n_threads
-        self.before_check = before_check or (lambda x: None)
-        self.check_after_compress = config.check_after_compress
-        self.chunk_order = config.chunk_order
-        self.batch_chunks = int(config.get('batch_chunks', None) or DEFAULT_BATCH_CHUNKS)
+        self.before_check = before_check if before_check is not None else (lambda x: None)
+        self.batch_chunks = int(self.config.get('batch_chunks', None) or DEFAULT_BATCH_CHUNKS)
         self._codec = codec
 
     @property
     def codec(self):
         return self._codec or get_codec()
 
+    def _need(self, given, key, message):
+        """A parameter from the call or the configuration; ValueError(message) when neither has it."""
+        value = given or self.config.get(key, None)
+        if not value:
+            raise ValueError(message)
+        return value
+
     def open(self, data_path, sample_rate=None, n_channels=None, dtype=None, offset=None, mmap=True):
-        """mtscomp.py:257-322."""
+        """Open the raw file and lay out the chunks (mtscomp.py:257-322).  A .npy file brings its own shape and dtype
+        (arrays of 3 and more dimensions are flattened to (-1, last axis), the header keeps the original shape); a flat file
+        needs n_channels and dtype.  ValueError for a missing sample rate / n_channels / dtype, AssertionError for no data."""
         self.data_path = Path(data_path)
-        sample_rate = sample_rate or self.config.get('sample_rate', None)
-        if not sample_rate:
-            raise ValueError("Please provide a sample rate (-s option in the command-line).")
+        sample_rate = self._need(sample_rate, 'sample_rate', "Please provide a sample rate (-s option in the command-line).")
         if str(data_path).endswith('.npy'):
-            self.data = np.load(data_path, mmap_mode='r')
-            self.shape = self.data.shape
-            if self.data.ndim >= 3:
-                self.data = np.reshape(self.data, (-1, self.data.shape[-1]))
-            self.dtype = dtype = self.data.dtype
-            self.n_channels = n_channels = self.data.shape[1]
+            data = np.load(data_path, mmap_mode='r')
+            self.shape = data.shape
+            self.data = data if data.ndim < 3 else np.reshape(data, (-1, data.shape[-1]))
+            self.dtype = self.data.dtype
+            n_channels = self.data.shape[1]
         else:
-            n_channels = n_channels or self.config.get('n_channels', None)
-            if not n_channels:
-                raise ValueError("Please provide n_channels (-n option in the command-line).")
-            dtype = dtype or self.config.get('dtype', None)
-            if not dtype:
-                raise ValueError("Please provide a dtype (-d option in the command-line).")
-            self.dtype = np.dtype(dtype)
+            n_channels = self._need(n_channels, 'n_channels', "Please provide n_channels (-n option in the command-line).")
+            self.dtype = np.dtype(self._need(dtype, 'dtype', "Please provide a dtype (-d option in the command-line)."))
             self.data = load_raw_data(data_path, n_channels=n_channels, dtype=self.dtype)
             self.shape = self.data.shape
-        self.sample_rate = float(sample_rate)
-        assert sample_rate > 0
-        assert n_channels > 0
-        self.file_size = self.data.size * self.data.itemsize
+        assert sample_rate > 0 and n_channels > 0
         assert self.data.ndim == 2
+        self.sample_rate = float(sample_rate)
         self.n_samples, self.n_channels = self.data.shape
-        assert self.n_samples > 0
-        assert self.n_channels > 0
-        assert n_channels == self.n_channels
-        logger.info("Opening %s, duration %.1fs, %d channels.", data_path,
-                    self.data.shape[0] / self.sample_rate, self.n_channels)
+        assert self.n_samples > 0 and self.n_channels > 0
+        assert self.n_channels == n_channels
+        self.file_size = self.data.size * self.data.itemsize
+        logger.info("Opening %s, duration %.1fs, %d channels.", data_path, self.n_samples / self.sample_rate, self.n_channels)
         self._compute_chunk_bounds()
-        self.sha1_compressed = hashlib.sha1()
-        self.sha1_uncompressed = hashlib.sha1()
+        self.sha1_compressed, self.sha1_uncompressed = hashlib.sha1(), hashlib.sha1()
 
     def _compute_chunk_bounds(self):
         """mtscomp.py:324-339 (np.round: half to even)."""
@@ -522,25 +514,23 @@ class Reader:
     def codec(self):
         return self._codec or get_codec()
 
+    # header fields a Reader keeps as attributes of the same name
+    _HEADER_ATTRS = ('n_channels', 'sample_rate', 'chunk_offsets', 'chunk_bounds', 'chunk_order')
+
     def open(self, cdata, cmeta=None):
-        """mtscomp.py:536-580."""
-        if cmeta is None:
-            cmeta = Path(cdata).with_suffix('.ch')
-        if not isinstance(cmeta, dict):
-            with open(cmeta, 'r') as f:
-                cmeta = json.load(f)
-        assert isinstance(cmeta, dict)
-        self.cmeta = Bunch(cmeta)
-        self.n_channels = self.cmeta.n_channels
-        self.sample_rate = self.cmeta.sample_rate
+        """Attach a compressed file (path or open binary file object) and its header: a dict, a path, or -- by default --
+        the .ch file next to a .cbin path (mtscomp.py:536-580)."""
+        header = cmeta if cmeta is not None else Path(cdata).with_suffix('.ch')
+        if not isinstance(header, dict):
+            header = json.loads(Path(header).read_text())
+        assert isinstance(header, dict)
+        self.cmeta = Bunch(header)
+        for key in self._HEADER_ATTRS:
+            setattr(self, key, self.cmeta[key])
         self.dtype = np.dtype(self.cmeta.dtype)
-        self.chunk_offsets = self.cmeta.chunk_offsets
-        self.chunk_bounds = self.cmeta.chunk_bounds
-        self.chunk_order = self.cmeta.chunk_order
-        self.n_samples = self.chunk_bounds[-1]
         self.n_chunks = len(self.chunk_bounds) - 1
-        self.shape = (self.n_samples, self.n_channels)
-        self.ndim = 2
+        self.n_samples = self.chunk_bounds[-1]
+        self.shape, self.ndim = (self.n_samples, self.n_channels), 2
         self.batch_size = max(1, self.batch_chunks * max(1, len(getattr(self.codec, 'devices', [0]))))
         self.n_batches = int(np.ceil(self.n_chunks / self.batch_size))
         if isinstance(cdata, (str, Path)):
@@ -617,19 +607,23 @@ class Reader:
             if idx in self._cache:
                 self._cache.move_to_end(idx)
                 result[idx] = self._cache[idx]
-        # the arrays of one call are views of one buffer: what stays cached after a big batch is copied, so that a
-        # few cached chunks do not keep the whole batch alive
-        big = len(todo) > self.cache_size
         for idx, arr in result.items():
             self._cache[idx] = arr
             self._cache.move_to_end(idx)
+        self._trim_cache()
+        return result
+
+    def _trim_cache(self):
+        """Back to cache_size entries.  The arrays of one codec call are views of one buffer: an entry that would keep a
+        buffer several times its own size alive (what is left of a big batch) is replaced by a copy of itself."""
         while len(self._cache) > self.cache_size:
             self._cache.popitem(last=False)
-        if big:
-            for idx in list(self._cache):
-                if self._cache[idx].base is not None:
-                    self._cache[idx] = self._cache[idx].copy()
-        return result
+        for idx, arr in list(self._cache.items()):
+            root = arr
+            while isinstance(root.base, np.ndarray):
+                root = root.base
+            if root is not arr and root.nbytes > 2 * arr.nbytes:
+                self._cache[idx] = arr.copy()
 
     def _slice_from_device_cache(self, first, last, i0, i1):
         """Rows [i0, i1) -- inside chunks first..last -- through the codec's decoded-chunk cache in HBM: chunks that are
@@ -803,19 +797,15 @@ class Reader:
                 out = self._decode(triples)
             finally:
                 self.cache_size = keep
-                while len(self._cache) > self.cache_size:
-                    self._cache.popitem(last=False)
+                self._trim_cache()
         assert set(out.keys()) == set(ids)
         return out
 
     def _validate_index(self, i, value_for_none=0):
-        """mtscomp.py:652-659."""
+        """A slice bound as a sample index in [0, n_samples]: None -> the default, negative -> from the end (mtscomp.py:652-659)."""
         if i is None:
-            i = value_for_none
-        elif i < 0:
-            i += self.n_samples
-        i = _clip(i, 0, self.n_samples)
-        return int(i)
+            return int(_clip(value_for_none, 0, self.n_samples))
+        return int(_clip(i + self.n_samples if i < 0 else i, 0, self.n_samples))
 
     def _chunks_for_interval(self, i0, i1):
         """First and last chunk to load for samples [i0, i1] -- i1 is treated as inclusive, exactly
@@ -877,32 +867,27 @@ class Reader:
             self.cdata.close()
 
     def chop(self, n_chunks, out=None):
-        """Keep the first n_chunks chunks, without decoding (mtscomp.py:750-796)."""
+        """Write the first n_chunks chunks as a new .cbin/.ch pair without decoding anything: the byte range up to
+        chunk_offsets[n_chunks], a header cut to match, sha1s dropped and 'chopped' set (mtscomp.py:750-796)."""
         assert n_chunks > 0
         if n_chunks >= self.n_chunks:  # pragma: no cover
             logger.warning("Cannot chop more chunks than there are in the original file.")
             return
         assert out is not None, "The output path must be specified."
         out = Path(out)
-        assert out.suffix == '.cbin'
-        if out.exists():  # pragma: no cover
-            raise IOError("File %s already exists." % out)
-        out.parent.mkdir(exist_ok=True, parents=True)
-        end = self.chunk_offsets[n_chunks]
-        with open(out, 'wb') as f:
-            f.write(self._pread(end, 0))
         outmeta = out.with_suffix('.ch')
-        if outmeta.exists():  # pragma: no cover
-            raise IOError("File %s already exists." % outmeta)
-        cmeta = Bunch(self.cmeta.copy())
-        cmeta['chunk_bounds'] = cmeta['chunk_bounds'][:n_chunks + 1]
-        cmeta['chunk_offsets'] = cmeta['chunk_offsets'][:n_chunks + 1]
-        assert cmeta['chunk_offsets'][-1] == end
-        cmeta['sha1_compressed'] = None
-        cmeta['sha1_uncompressed'] = None
-        cmeta['chopped'] = True
-        with open(outmeta, 'w') as f:
-            json.dump(cmeta, f, indent=2, sort_keys=True)
+        assert out.suffix == '.cbin'
+        for target in (out, outmeta):
+            if target.exists():  # pragma: no cover
+                raise IOError("File %s already exists." % target)
+        out.parent.mkdir(parents=True, exist_ok=True)
+        n_bytes = self.chunk_offsets[n_chunks]
+        out.write_bytes(self._pread(n_bytes, 0))
+        header = dict(self.cmeta)
+        header.update(chunk_bounds=self.cmeta['chunk_bounds'][:n_chunks + 1], chunk_offsets=self.cmeta['chunk_offsets'][:n_chunks + 1],
+                      sha1_compressed=None, sha1_uncompressed=None, chopped=True)
+        assert header['chunk_offsets'][-1] == n_bytes
+        outmeta.write_text(json.dumps(header, indent=2, sort_keys=True))
 
     def __getitem__(self, item):
         """NumPy-style slicing (mtscomp.py:798-856).  All chunks a slice touches are decoded in one
@@ -950,8 +935,7 @@ class Reader:
                     decoded = self._decode(triples)
                 finally:
                     self.cache_size = keep
-                    while len(self._cache) > self.cache_size:
-                        self._cache.popitem(last=False)
+                    self._trim_cache()
             chunks = [decoded[i] for i in range(first, last + 1)]
             arr = _join_rows(chunks)
             a = i0 - self.chunk_bounds[first]

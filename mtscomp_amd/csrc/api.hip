@@ -254,15 +254,12 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     MTS_HIP(hipMemcpyAsync(d_blk_chunk, h_blk_chunk.data(), 4 * (size_t)nblk, hipMemcpyHostToDevice, st));
     MTS_HIP(hipMemsetAsync(d_cout, 0, sizeof(ChunkOut) * n_chunks, st));
     MTS_HIP(hipMemsetAsync(pb.changed, 0, 8, st));           // + the match stage's flag word behind it
-    // zero the output slots (the packer ORs bits into them)
+    // zero the output slots (the packer ORs bits into them): exactly the compress_bound() bytes the header promises each
+    // slot has, never what lies between two slots (one launch, after the descriptors are on the device)
     {
-        u64 lo = ~0ull, hi = 0;
-        for (int i = 0; i < n_chunks; i++) {
-            const u64 a = cd[i].out_off, b = a + align_up((u64)compress_bound(cd[i].n), 16);
-            if (a < lo) lo = a;
-            if (b > hi) hi = b;
-        }
-        if (n_chunks) MTS_HIP(hipMemsetAsync(d_out + lo, 0, hi - lo, st));
+        u32 max_n = 0;
+        for (int i = 0; i < n_chunks; i++) if (cd[i].n > max_n) max_n = cd[i].n;
+        if ((rc = launch_zero_slots(st, d_chunks, n_chunks, max_n, d_out))) return rc;
     }
     // the host copies above must be complete before the std::vectors go away; they are pageable
     // copies, which hipMemcpyAsync finishes staging before returning.

@@ -2149,4 +2149,23 @@ int launch_block_pack(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chu
     return MTS_OK;
 }
 
+// the output slots of a batch, zeroed over exactly compress_bound(n) bytes each (16-byte aligned starts)
+__global__ __launch_bounds__(256) void k_zero_slots(const ChunkDesc *__restrict__ chunks, u8 *__restrict__ out)
+{
+    const ChunkDesc ch = chunks[blockIdx.y];
+    const u64 n = ch.n, bound = n + (n >> 12) + (n >> 14) + (n >> 25) + 13;
+    u8 *o = out + ch.out_off;
+    const u64 nv = bound / 16;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nv; i += (u64)gridDim.x * 256) ((uint4 *)o)[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x < (bound & 15)) o[nv * 16 + threadIdx.x] = 0;
+}
+int launch_zero_slots(hipStream_t st, const ChunkDesc *d_chunks, int n_chunks, u32 max_n, u8 *d_out)
+{
+    if (n_chunks == 0) return MTS_OK;
+    const u64 nv = ((u64)max_n + (max_n >> 12) + 64) / 16 / 256 / 8 + 1;
+    hipLaunchKernelGGL(k_zero_slots, dim3((unsigned)(nv < 2048 ? nv : 2048), n_chunks), dim3(256), 0, st, d_chunks, d_out);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
 }  // namespace mts
