@@ -1268,17 +1268,45 @@ __device__ __forceinline__ u32 fast_walk(const u8 *__restrict__ s, const ChunkDe
         const u32 myhash = hash_of(gld_u32_unaligned(s, pos));
         u32 j = fb.inv[ch.stream_off + pos];
         u32 best = MIN_MATCH - 1, bstart = 0, examined = 0;
-        while (j > 0) {
-            j--;
-            const u32 q = td.w + (sk[j] & REL_MASK);
-            if (hash_of(gld_u32_unaligned(s, q)) != myhash) break;    // the run ends
-            if (!inserted(q)) continue;                               // not in the chain
-            if (examined == 0) { if (q == 0 || pos - q > (u32)MAX_DIST) break; }       // hash_head != NIL && strstart - hash_head <= MAX_DIST
-            else if (q <= limit) break;                               // cur_match > limit
-            examined++;
-            const u32 len = common_len(s, pos, q, maxlen);
-            if (len > best) { best = len; bstart = q; if (len >= nice) break; }
-            if (examined == (u32)cfg.chain) break;
+        const u32 own4 = gld_u32_unaligned(s, pos);
+        bool more = true;
+        while (more && j > 0) {
+            // The walk is a chain of dependent memory round trips (slot -> position -> bytes, insertion bit), one lane per
+            // segment: the next FAST_FETCH slots are fetched together -- keys, then the candidates' first bytes and
+            // everything the insertion test may need (entry of the candidate's segment, its bitmap word, the spill word
+            // of the segment before) -- and only then looked at one after the other.
+            constexpr int FAST_FETCH = 4;
+            u32 q[FAST_FETCH], c4[FAST_FETCH], ent[FAST_FETCH], bw[FAST_FETCH], sw[FAST_FETCH];
+            const u32 nb = j < (u32)FAST_FETCH ? j : (u32)FAST_FETCH;
+#pragma unroll
+            for (int c = 0; c < FAST_FETCH; c++) q[c] = td.w + (sk[j - 1 - ((u32)c < nb ? (u32)c : nb - 1)] & REL_MASK);
+#pragma unroll
+            for (int c = 0; c < FAST_FETCH; c++) {
+                c4[c] = gld_u32_unaligned(s, q[c]);
+                const u32 kq = q[c] / SEG, gq = ch.seg0 + kq, r = q[c] - kq * SEG;
+                ent[c] = seg_entry[gq];
+                bw[c] = bmc[q[c] >> 5];
+                sw[c] = fb.spill[(u64)(gq > ch.seg0 ? gq - 1 : gq) * FAST_SPILL_WORDS + (r >> 5 < (u32)FAST_SPILL_WORDS ? r >> 5 : 0)];
+            }
+#pragma unroll
+            for (int c = 0; c < FAST_FETCH; c++) {
+                if (!more || (u32)c >= nb) continue;
+                const u32 qq = q[c];
+                if (hash_of(c4[c]) != myhash) { more = false; continue; }                 // the run ends
+                bool ins;
+                if (qq >= seg_s) ins = inserted(qq);                                       // own segment: this walk's own bits (or the spill before it)
+                else ins = qq >= ent[c] ? (bw[c] >> (qq & 31)) & 1 : (sw[c] >> ((qq % SEG) & 31)) & 1;
+                if (!ins) continue;                                                       // not in the chain
+                if (examined == 0) { if (qq == 0 || pos - qq > (u32)MAX_DIST) { more = false; continue; } }      // hash_head != NIL && strstart - hash_head <= MAX_DIST
+                else if (qq <= limit) { more = false; continue; }                         // cur_match > limit
+                examined++;
+                const u32 x0 = c4[c] ^ own4;
+                u32 len = x0 ? (u32)__builtin_ctz(x0) >> 3 : 4 + common_len(s, pos + 4, qq + 4, maxlen > 4 ? maxlen - 4 : 0);
+                len = len < maxlen ? len : maxlen;
+                if (len > best) { best = len; bstart = qq; if (len >= nice) more = false; }
+                if (examined == (u32)cfg.chain) more = false;
+            }
+            j -= nb;
         }
         if (best >= (u32)MIN_MATCH) {
             put(((best - MIN_MATCH) << 16) | (pos - bstart), pos);
