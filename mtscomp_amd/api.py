@@ -759,11 +759,17 @@ class Reader:
                 raise IOError("Compressed chunk #%d is corrupted." % k)
         return [a[:, 0] if r[6] else a for a, r in zip(arrays, reqs)]
 
-    def _decode_into(self, b0, b1, dst):
-        """Chunks b0 .. b1-1 (consecutive in the file) decoded straight into `dst` (their rows, C-contiguous): one read, one
-        codec call, no copy on the host and nothing left in the chunk cache."""
+    def _read_range(self, b0, b1):
+        """The compressed bytes of chunks b0 .. b1-1 in one read."""
         base = self.chunk_offsets[b0]
-        buf = self._pread(self.chunk_offsets[b1] - base, base)
+        return self._pread(self.chunk_offsets[b1] - base, base)
+
+    def _decode_into(self, b0, b1, dst, buf=None):
+        """Chunks b0 .. b1-1 (consecutive in the file) decoded straight into `dst` (their rows, C-contiguous): one read (or
+        the bytes read ahead by the caller), one codec call, no copy on the host and nothing left in the chunk cache."""
+        base = self.chunk_offsets[b0]
+        if buf is None:
+            buf = self._read_range(b0, b1)
         offs = [self.chunk_offsets[i] - base for i in range(b0, b1)]
         lens = [self.chunk_offsets[i + 1] - self.chunk_offsets[i] for i in range(b0, b1)]
         rows = [self.chunk_bounds[i + 1] - self.chunk_bounds[i] for i in range(b0, b1)]
@@ -913,16 +919,25 @@ class Reader:
                 # whole slice in device memory, and the chunk cache could not hold it anyway)
                 r0 = self.chunk_bounds[first]
                 whole = np.empty((self.chunk_bounds[last + 1] - r0, self.n_channels), dtype=self.dtype)   # whole chunks first..last
-                for b0 in range(first, last + 1, self.batch_size):
+                direct = getattr(self.codec, 'takes_out', False) and len(getattr(self.codec, 'devices', [0])) == 1
+                starts = list(range(first, last + 1, self.batch_size))
+                ahead = ThreadPool(1) if direct and len(starts) > 1 else None      # the next batch's bytes are read while this one is on the device
+                nxt = ahead.apply_async(self._read_range, (starts[0], min(starts[0] + self.batch_size, last + 1))) if ahead else None
+                for k, b0 in enumerate(starts):
                     b1 = min(b0 + self.batch_size, last + 1)
                     dst = whole[self.chunk_bounds[b0] - r0:self.chunk_bounds[b1] - r0]
-                    if getattr(self.codec, 'takes_out', False) and len(getattr(self.codec, 'devices', [0])) == 1:
-                        self._decode_into(b0, b1, dst)
+                    if direct:
+                        buf = nxt.get() if nxt is not None else None
+                        nxt = ahead.apply_async(self._read_range, (starts[k + 1], min(starts[k + 1] + self.batch_size, last + 1))) \
+                            if ahead and k + 1 < len(starts) else None
+                        self._decode_into(b0, b1, dst, buf)
                     else:
                         chunks = self.decompress_chunks(range(b0, b1))
                         for idx in range(b0, b1):
                             dst[self.chunk_bounds[idx] - self.chunk_bounds[b0]:self.chunk_bounds[idx + 1] - self.chunk_bounds[b0]] = chunks[idx]
                         del chunks
+                if ahead:
+                    ahead.close()
                 out = whole[i0 - r0:i1 - r0:item.step, :]
                 assert out.shape[0] == len(range(i0, i1, item.step or 1))
                 return out

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <string>
 #include <vector>
@@ -75,6 +76,12 @@ struct Engine {
     DBuf stream, sort_a, sort_b, tables, tokens, marks, segbuf, blk, blkcodes, blkhdr, desc, adler, misc;
     // host-API staging
     DBuf h_in, h_out;
+    // pinned pieces the host entry points move user memory through (pageable memory crosses the bus at a fraction of the
+    // link's rate, and a fresh destination array takes its page faults on the copying thread): two pieces, so that the
+    // DMA of one overlaps the host threads copying the other
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    hipStream_t copy_st = nullptr;
     // inflate workspace
     DBuf inf_scratch, inf_desc, segsums;
     // stage timing
@@ -115,6 +122,9 @@ struct Engine {
         DBuf *all[] = {&stream, &sort_a, &sort_b, &tables, &tokens, &marks, &segbuf, &blk, &blkcodes, &blkhdr, &desc,
                        &adler, &misc, &h_in, &h_out, &inf_scratch, &inf_desc, &segsums};
         for (DBuf *b : all) b->release();
+        for (int k = 0; k < 2; k++) { if (pin[k]) (void)hipHostFree(pin[k]); pin[k] = nullptr; if (pin_ev[k]) (void)hipEventDestroy(pin_ev[k]); pin_ev[k] = nullptr; }
+        if (copy_st) (void)hipStreamDestroy(copy_st);
+        copy_st = nullptr;
     }
 };
 
@@ -381,6 +391,92 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
             *tap->n_tokens = nt;
         }
     }
+    return MTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// user memory <-> device through pinned pieces
+// ------------------------------------------------------------------------------------------------
+constexpr size_t PIN_PIECE = (size_t)32 << 20;
+
+static int host_threads()
+{
+    static const int n = [] { const char *e = getenv("MTS_HOST_THREADS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : v > 64 ? 64 : v; }();
+    return n;
+}
+
+// memcpy by several threads (a fresh destination is faulted in by all of them at once)
+static void par_memcpy(void *dst, const void *src, size_t n)
+{
+    const int nt = n < ((size_t)4 << 20) ? 1 : host_threads();
+    if (nt == 1) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n / nt + 4095) & ~(size_t)4095;
+    for (int t = 1; t < nt; t++) {
+        const size_t a = (size_t)t * per;
+        if (a >= n) break;
+        th.emplace_back([=] { memcpy((u8 *)dst + a, (const u8 *)src + a, n - a < per ? n - a : per); });
+    }
+    memcpy(dst, src, n < per ? n : per);
+    for (auto &t : th) t.join();
+}
+
+static int pin_init(Engine &E)
+{
+    if (E.pin[0]) return MTS_OK;
+    for (int k = 0; k < 2; k++) {
+        if (hipHostMalloc(&E.pin[k], PIN_PIECE, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); E.pin[k] = nullptr; }
+        if (E.pin[k] && hipEventCreateWithFlags(&E.pin_ev[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(E.pin[k]); E.pin[k] = nullptr; }
+    }
+    if (E.pin[0] && E.pin[1] && hipStreamCreateWithFlags(&E.copy_st, hipStreamNonBlocking) == hipSuccess) return MTS_OK;
+    (void)hipGetLastError();
+    for (int k = 0; k < 2; k++) { if (E.pin[k]) (void)hipHostFree(E.pin[k]); E.pin[k] = nullptr; }
+    return MTS_E_NOMEM;           // (the callers fall back to plain copies)
+}
+
+// device -> user memory, any number of pieces (dst, src, bytes).  The device data must be complete (the caller synchronised the
+// stream that produced it).  The DMA of the next piece runs while the host threads copy the one before out of its pinned buffer.
+struct CopyItem { void *dst; const void *src; size_t n; };
+static int staged_d2h_multi(Engine &E, const std::vector<CopyItem> &segs)
+{
+    size_t total = 0;
+    for (auto &s : segs) total += s.n;
+    if (total < ((size_t)8 << 20) || pin_init(E) != MTS_OK) {
+        for (auto &s : segs) if (s.n) MTS_HIP(hipMemcpy(s.dst, s.src, s.n, hipMemcpyDeviceToHost));
+        return MTS_OK;
+    }
+    std::vector<CopyItem> items;                      // cut to pinned-piece size
+    for (auto &s : segs)
+        for (size_t o = 0; o < s.n; o += PIN_PIECE) items.push_back({(u8 *)s.dst + o, (const u8 *)s.src + o, s.n - o < PIN_PIECE ? s.n - o : PIN_PIECE});
+    auto issue = [&](size_t k) -> int {
+        MTS_HIP(hipMemcpyAsync(E.pin[k & 1], items[k].src, items[k].n, hipMemcpyDeviceToHost, E.copy_st));
+        MTS_HIP(hipEventRecord(E.pin_ev[k & 1], E.copy_st));
+        return MTS_OK;
+    };
+    int rc;
+    if (!items.empty() && (rc = issue(0))) return rc;
+    for (size_t k = 0; k < items.size(); k++) {
+        if (k + 1 < items.size() && (rc = issue(k + 1))) return rc;
+        MTS_HIP(hipEventSynchronize(E.pin_ev[k & 1]));
+        par_memcpy(items[k].dst, E.pin[k & 1], items[k].n);
+    }
+    return MTS_OK;
+}
+static int staged_d2h(Engine &E, void *dst, const void *d_src, size_t n) { return staged_d2h_multi(E, {{dst, d_src, n}}); }
+
+// user memory -> device; complete on return
+static int staged_h2d(Engine &E, void *d_dst, const void *src, size_t n)
+{
+    if (n < ((size_t)8 << 20) || pin_init(E) != MTS_OK) { MTS_HIP(hipMemcpy(d_dst, src, n, hipMemcpyHostToDevice)); return MTS_OK; }
+    const size_t np = (n + PIN_PIECE - 1) / PIN_PIECE;
+    auto len = [&](size_t k) { return k + 1 < np ? PIN_PIECE : n - k * PIN_PIECE; };
+    for (size_t k = 0; k < np; k++) {
+        if (k >= 2) MTS_HIP(hipEventSynchronize(E.pin_ev[k & 1]));       // the DMA out of this piece two rounds ago
+        par_memcpy(E.pin[k & 1], (const u8 *)src + k * PIN_PIECE, len(k));
+        MTS_HIP(hipMemcpyAsync((u8 *)d_dst + k * PIN_PIECE, E.pin[k & 1], len(k), hipMemcpyHostToDevice, E.copy_st));
+        MTS_HIP(hipEventRecord(E.pin_ev[k & 1], E.copy_st));
+    }
+    MTS_HIP(hipStreamSynchronize(E.copy_st));
     return MTS_OK;
 }
 
@@ -677,7 +773,7 @@ int mts_compress_chunks(int device, const void *raw, int n_channels, int itemsiz
     }
     if ((rc = E->h_in.ensure(raw_bytes + 256))) return rc;
     if ((rc = E->h_out.ensure(total + 256))) return rc;
-    MTS_HIP(hipMemcpy(E->h_in.p, raw, raw_bytes, hipMemcpyHostToDevice));
+    if ((rc = staged_h2d(*E, E->h_in.p, raw, raw_bytes))) return rc;
     rc = dev_compress(*E, nullptr, E->h_in.p, n_channels, itemsize, chunk_bounds, n_chunks, flags, level, E->h_out.as<u8>(),
                       slots.data(), out_sizes);
     if (rc) return rc;
@@ -792,17 +888,31 @@ int mts_decompress_chunks(int device, const unsigned char *cdata, const long *c_
         coff[i] = (long)ctot; ctot += align_up((u64)c_lengths[i] + 8, 16);
         ooff[i] = (long)otot; otot += align_up((u64)n_rows[i] * row_bytes, 256);
     }
+    // the compressed bytes: when the chunks lie (nearly) back to back in the caller's buffer -- a range read from a .cbin --
+    // the whole range crosses the bus in one staged copy and the chunks keep their distances; otherwise chunk by chunk
+    long lo = c_offsets[0], hi = c_offsets[0] + c_lengths[0];
+    u64 sum = 0;
+    for (int i = 0; i < n_chunks; i++) {
+        if (c_offsets[i] < lo) lo = c_offsets[i];
+        if (c_offsets[i] + c_lengths[i] > hi) hi = c_offsets[i] + c_lengths[i];
+        sum += (u64)c_lengths[i];
+    }
+    const bool one_range = lo >= 0 && (u64)(hi - lo) <= sum + sum / 4 + 4096;
+    if (one_range) { ctot = (u64)(hi - lo) + 16; for (int i = 0; i < n_chunks; i++) coff[i] = c_offsets[i] - lo; }
     if ((rc = E->h_in.ensure(ctot + 256))) return rc;
     if ((rc = E->h_out.ensure(otot + 256))) return rc;
-    for (int i = 0; i < n_chunks; i++)
-        if (c_lengths[i]) MTS_HIP(hipMemcpyAsync(E->h_in.as<u8>() + coff[i], cdata + c_offsets[i], (size_t)c_lengths[i], hipMemcpyHostToDevice, nullptr));
+    if (one_range) { if ((rc = staged_h2d(*E, E->h_in.p, cdata + lo, (size_t)(hi - lo)))) return rc; }
+    else
+        for (int i = 0; i < n_chunks; i++)
+            if (c_lengths[i]) MTS_HIP(hipMemcpyAsync(E->h_in.as<u8>() + coff[i], cdata + c_offsets[i], (size_t)c_lengths[i], hipMemcpyHostToDevice, nullptr));
     rc = dev_decompress(*E, nullptr, E->h_in.as<u8>(), coff.data(), c_lengths, n_rows, n_chunks, n_channels, itemsize, flags,
                         E->h_out.as<u8>(), ooff.data(), chunk_status);
     if (rc) return rc;
+    std::vector<CopyItem> segs;
     for (int i = 0; i < n_chunks; i++)
         if (chunk_status[i] == MTS_CHUNK_OK && n_rows[i])
-            MTS_HIP(hipMemcpy((u8 *)out + out_offsets[i], E->h_out.as<u8>() + ooff[i], (size_t)((u64)n_rows[i] * row_bytes), hipMemcpyDeviceToHost));
-    return MTS_OK;
+            segs.push_back({(u8 *)out + out_offsets[i], E->h_out.as<u8>() + ooff[i], (size_t)((u64)n_rows[i] * row_bytes)});
+    return staged_d2h_multi(*E, segs);
 }
 
 // ---- decoded-chunk cache: entry points (state above mts_release) ----------------------------------
