@@ -2,7 +2,8 @@
 points, every chunk compared byte for byte with the reference's statement sequence on numpy + stdlib zlib (oracle.ref_*:
 compressed bytes, status, decoded bytes).  Found the pass-B staging bug on run-length streams.
 
-    python tools/fuzz_gpu.py [seed] [seconds]          (FUZZ_LEVELS=1: zlib levels 4..9 instead of 6 only)
+    python tools/fuzz_gpu.py [seed] [seconds]          (FUZZ_LEVELS=1: zlib levels 4..9 instead of 6 only; FUZZ_LEVELS=2: levels 1..9,
+                                                        i.e. deflate_fast too; MTS_FAST_OPEN_ROUNDS=0 runs its windowed rounds alone)
 """
 import os
 import sys
@@ -82,7 +83,8 @@ def main():
         b = np.concatenate(([0], np.cumsum(rows)))
         if os.environ.get('FUZZ_TRACE'):
             print('case dtype %s nc %d rows %s kind %d flags %d' % (dt, nc, rows, kind, fl), flush=True)
-        level = int(r.choice([6, 6, 6, 4, 5, 7, 8, 9])) if os.environ.get('FUZZ_LEVELS') else 6
+        lv = os.environ.get('FUZZ_LEVELS')
+        level = int(r.choice([1, 2, 3, 1, 2, 3, 6, 9])) if lv == '2' else int(r.choice([6, 6, 6, 4, 5, 7, 8, 9])) if lv else 6
         z = hip.compress_chunks(x, b, fl, level)
         st, arrs = hip.decompress_chunks(z, rows, nc, dt, fl)
         for i in range(len(rows)):
