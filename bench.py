@@ -221,12 +221,15 @@ def extra_level_sweep(torch, hip, L, dev, seconds=60, levels=(1, 6, 9)):
             dt = time.perf_counter() - t0
             assert rc == 0, L.mts_last_error()
             best = dt if best is None else min(best, dt)
-        t0 = time.perf_counter()
-        rc = L.mts_dev_decompress_chunks(dev, None, C.c_void_p(cbuf.data_ptr()), lp(slots), lp(sizes), lp(nrows), n, nc, 2, flags,
-                                         C.c_void_p(back.data_ptr()), lp(ooffs), status.ctypes.data_as(C.POINTER(C.c_int)))
-        torch.cuda.synchronize()
-        dt_d = time.perf_counter() - t0
-        assert rc == 0 and not status.any()
+        dt_d = None
+        for rep in range(2):                                  # (the first call at a new shape also allocates the inflate workspace)
+            t0 = time.perf_counter()
+            rc = L.mts_dev_decompress_chunks(dev, None, C.c_void_p(cbuf.data_ptr()), lp(slots), lp(sizes), lp(nrows), n, nc, 2, flags,
+                                             C.c_void_p(back.data_ptr()), lp(ooffs), status.ctypes.data_as(C.POINTER(C.c_int)))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert rc == 0 and not status.any()
+            dt_d = dt if dt_d is None else min(dt_d, dt)
         ident = cbuf[:int(sizes[0])].cpu().numpy().tobytes() == zlib.compress(stream0, level)
         out[str(level)] = {'ratio': float(sizes.sum()) / (n * rows * nc * 2), 'compress_gbps': n * rows * nc * 2 / best / 1e9,
                            'decompress_gbps': n * rows * nc * 2 / dt_d / 1e9, 'round_trip_ok': bool(torch.equal(back, raw)),

@@ -598,7 +598,7 @@ __global__ __launch_bounds__(1024, 2) void k_match4(const u8 *__restrict__ strea
 // scored candidates is about the number of times the best length improves.
 // ------------------------------------------------------------------------------------------------
 constexpr int M5_WAVES = 8;
-constexpr int M5_SLICES = 32;                        // workgroups per tile (MTS_MATCH_SLICES overrides: experiments)
+constexpr int M5_SLICES = 64;                        // workgroups per tile (MTS_MATCH_SLICES overrides: experiments)
 constexpr int M5_RING = 256;
 constexpr int M5_ROWS = 32;
 constexpr int M5_LEVELS = 4;                         // tables for prefix lengths 4, 5, 6, 7
