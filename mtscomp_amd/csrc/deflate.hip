@@ -842,10 +842,63 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         MTS_WALK(3, qpart);
         const u32 qbest = best, qdist = bdist;
         if (qpart != 0xffffffffu) MTS_WALK(3, ~qpart);
-        MTS_WALK(2, 0xffffffffu);
-        MTS_WALK(1, 0xffffffffu);
-        MTS_WALK(0, 0xffffffffu);
 #undef MTS_WALK
+        {
+            // The other 96 candidates in ONE loop (a lane takes its own next candidate, whichever of the three words it is in):
+            // word by word the wave ran as many rounds as the busiest lane of EACH word needed -- 4.4 rounds per group at 10 % lane
+            // use; together it is the busiest lane over all three.
+            auto pickw = [&](const int w) __attribute__((always_inline)) -> u32 {
+                u32 r = best >= 3 ? A4[w] : V[w];
+                asm volatile("" : "+v"(r));
+                r = best >= 4 ? A5[w] : r;
+                asm volatile("" : "+v"(r));
+                r = best >= 5 ? A6[w] : r;
+                asm volatile("" : "+v"(r));
+                return best >= 6 ? A7[w] : r;
+            };
+            u32 f2 = stop ? 0u : pickw(2), f1 = stop ? 0u : pickw(1), f0 = stop ? 0u : pickw(0);
+            while (__any((f2 | f1 | f0) != 0)) {
+                if (f2 | f1 | f0) {
+                    const bool t2 = f2 != 0, t1 = f1 != 0;
+                    const u32 cur = t2 ? f2 : t1 ? f1 : f0;
+                    const u32 tb = t2 ? 64u : t1 ? 32u : 0u;
+                    const u32 b = 31 - __builtin_clz(cur);
+                    const u32 clr = ~(1u << b);
+                    f2 = t2 ? f2 & clr : f2;
+                    f1 = (!t2 && t1) ? f1 & clr : f1;
+                    f0 = (!t2 && !t1) ? f0 & clr : f0;
+                    const u32 slot = (lo + tb + b) & (M5_RING - 1);
+                    const u64 c = SE[slot];
+                    const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
+                    const u32 rel_c = c0 & REL_MASK;
+                    if ((int)rel_c > limn) {
+                        const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
+                        if ((x0 & 0x1ff) == 0) {
+                            u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
+                            if (x1 == 0 && (x0 >> 9) == 0) {
+                                const u64 y = SX[slot] ^ ex;
+                                if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
+                                else {
+                                    len = 13;
+                                    while (len < maxlen) {
+                                        const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
+                                        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+                                        len += 4;
+                                    }
+                                }
+                            }
+                            len = len < maxlen ? len : maxlen;
+                            if (len > best) {
+                                best = len; bdist = rel_p - rel_c;
+                                if (len >= nice) stop = true;
+                                f2 &= pickw(2); f1 &= pickw(1); f0 &= pickw(0);      // fewer candidates can still win now
+                            }
+                        }
+                    } else stop = true;                 // out of range: so is everything older
+                    if (stop) { f2 = 0; f1 = 0; f0 = 0; }
+                }
+            }
+        }
         if (own) T[p_abs] = table_entry(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0, own_lo & 0xff);
     }
 }
