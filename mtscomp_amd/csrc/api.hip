@@ -84,6 +84,10 @@ struct Engine {
     hipStream_t copy_st = nullptr;
     // inflate workspace
     DBuf inf_scratch, inf_desc, segsums;
+    // geometry of the last compress batch whose per-segment / per-block / per-tile descriptors are on the device (a recording is
+    // compressed batch after batch of the same shape: the 10 MB of index arrays need not be rebuilt and copied every call)
+    std::vector<u32> geo_n;
+    const void *geo_seg = nullptr, *geo_blk = nullptr, *geo_desc = nullptr;
     // stage timing
     hipEvent_t ev[MAX_STAGES + 1];
     bool ev_ok = false;
@@ -250,18 +254,30 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     u32 *d_blk_chunk = (u32 *)(d_blocks + nblk + 1);
     u32 *d_blk_in_start = d_blk_chunk + nblk + 1;
 
-    std::vector<u32> h_seg(2 * (size_t)nseg), h_blk_chunk(nblk + 1);
-    for (int i = 0; i < n_chunks; i++) {
-        for (u32 k = 0; k < cd[i].nseg; k++) { h_seg[cd[i].seg0 + k] = (u32)i; h_seg[nseg + cd[i].seg0 + k] = k * SEG; }
-        for (u32 k = 0; k < cd[i].blk_cap; k++) h_blk_chunk[cd[i].blk0 + k] = (u32)i;
-    }
     MTS_HIP(hipMemcpyAsync(d_chunks, cd.data(), sizeof(ChunkDesc) * n_chunks, hipMemcpyHostToDevice, st));
-    if (!tiles.empty()) MTS_HIP(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice, st));
-    if (nseg) {
-        MTS_HIP(hipMemcpyAsync(pb.seg_chunk, h_seg.data(), 4 * (size_t)nseg, hipMemcpyHostToDevice, st));
-        MTS_HIP(hipMemcpyAsync(pb.seg_start, h_seg.data() + nseg, 4 * (size_t)nseg, hipMemcpyHostToDevice, st));
+    {
+        // the index arrays depend on the chunk sizes only: kept on the device while the next batch has the same sizes and
+        // the buffers have not moved
+        std::vector<u32> sizes_now(n_chunks);
+        for (int i = 0; i < n_chunks; i++) sizes_now[i] = cd[i].n;
+        const bool same = sizes_now == E.geo_n && E.geo_seg == E.segbuf.p && E.geo_blk == E.blk.p && E.geo_desc == E.desc.p;
+        if (!same) {
+            E.geo_n.clear();                                      // (not valid again until everything below is on its way)
+            std::vector<u32> h_seg(2 * (size_t)nseg), h_blk_chunk(nblk + 1);
+            for (int i = 0; i < n_chunks; i++) {
+                for (u32 k = 0; k < cd[i].nseg; k++) { h_seg[cd[i].seg0 + k] = (u32)i; h_seg[nseg + cd[i].seg0 + k] = k * SEG; }
+                for (u32 k = 0; k < cd[i].blk_cap; k++) h_blk_chunk[cd[i].blk0 + k] = (u32)i;
+            }
+            if (!tiles.empty()) MTS_HIP(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice, st));
+            if (nseg) {
+                MTS_HIP(hipMemcpyAsync(pb.seg_chunk, h_seg.data(), 4 * (size_t)nseg, hipMemcpyHostToDevice, st));
+                MTS_HIP(hipMemcpyAsync(pb.seg_start, h_seg.data() + nseg, 4 * (size_t)nseg, hipMemcpyHostToDevice, st));
+            }
+            MTS_HIP(hipMemcpyAsync(d_blk_chunk, h_blk_chunk.data(), 4 * (size_t)nblk, hipMemcpyHostToDevice, st));
+            // (pageable copies: staged before hipMemcpyAsync returns, so the vectors may go)
+            E.geo_n = sizes_now; E.geo_seg = E.segbuf.p; E.geo_blk = E.blk.p; E.geo_desc = E.desc.p;
+        }
     }
-    MTS_HIP(hipMemcpyAsync(d_blk_chunk, h_blk_chunk.data(), 4 * (size_t)nblk, hipMemcpyHostToDevice, st));
     MTS_HIP(hipMemsetAsync(d_cout, 0, sizeof(ChunkOut) * n_chunks, st));
     MTS_HIP(hipMemsetAsync(pb.changed, 0, 8, st));           // + the match stage's flag word behind it
     // zero the output slots (the packer ORs bits into them): exactly the compress_bound() bytes the header promises each
