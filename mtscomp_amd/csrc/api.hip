@@ -303,7 +303,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         MTS_HIP(hipMemcpyAsync(d_so, so.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
         MTS_HIP(hipMemcpyAsync(d_nn, nn.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
         u32 max_n = 0; for (int i = 0; i < n_chunks; i++) if (cd[i].n > max_n) max_n = cd[i].n;
-        if ((rc = launch_adler_stream(st, d_stream, d_so, d_nn, n_chunks, max_n, d_adler))) return rc;
+        if ((rc = launch_adler_stream(st, d_stream, d_so, d_nn, n_chunks, max_n, d_adler, nullptr, 0))) return rc;
     } else {
         if ((rc = launch_delta_transpose(st, d_raw, E.stream.p, d_chunks, n_chunks, max_rows, nc, sz, flags, d_adler))) return rc;
         d_stream = E.stream.as<u8>();

@@ -126,7 +126,8 @@ int launch_cumsum_transpose(hipStream_t st, const void *d_stream, void *d_out, c
 size_t cumsum_scratch_bytes(int n_chunks, u32 max_rows, int n_channels);
 int launch_synth_int16(hipStream_t st, int16_t *d_out, long t0, long t1, int n_channels, long seed);
 int launch_adler_stream(hipStream_t st, const u8 *d_stream, const u64 *d_stream_off, const u32 *d_n,
-                        int n_chunks, u32 max_n, u64 *d_adler_acc);
+                        int n_chunks, u32 max_n, u64 *d_adler_acc,
+                        const u32 *d_skip /* null, or per chunk (stride in words): >= 2 = already summed; the sums are then NOT zeroed here */, u32 skip_stride);
 
 // pieces of decoded chunks gathered on the device (mts_cache_read_slices)
 struct GatherChunk { long row0; const u8 *base; };                      // first row in the concatenation; null = the chunk failed

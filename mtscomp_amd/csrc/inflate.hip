@@ -2018,9 +2018,11 @@ __global__ __launch_bounds__(1024) void k_inf_windows(const InfChunk *__restrict
 }
 
 // cells -> bytes: 16 cells per lane
+// (also sums the bytes for the adler32 check -- A = sum b_i, B = sum (n - i) b_i, reduced per workgroup -- while they are in
+// registers: the separate pass over the finished stream is skipped for the chunks that come through here)
 __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restrict__ chunks, const InfResult *__restrict__ res,
                                                        const LzPlan *__restrict__ plan, const u16 *__restrict__ sym,
-                                                       const u8 *__restrict__ win, u8 *__restrict__ stream)
+                                                       const u8 *__restrict__ win, u8 *__restrict__ stream, u64 *__restrict__ adler_acc)
 {
     const int ci = blockIdx.y;
     const InfResult r = res[ci];
@@ -2028,8 +2030,27 @@ __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restric
     const LzPlan *pl = plan + ci;
     const u32 nseg = pl->nseg;
     if (nseg < 2) return;
-    const u32 p = (blockIdx.x * 256 + threadIdx.x) * 16;
-    if (p >= r.n_out) return;
+    constexpr u32 TR_STEPS = 4;                                        // 4 x 4 KiB per workgroup: a quarter of the atomics on the chunk's two sums
+    if (blockIdx.x * 256u * 16u * TR_STEPS >= r.n_out) return;
+    __shared__ u64 red[8];
+    u64 sa = 0, sb = 0;
+    const u64 nn = chunks[ci].n_expect;                                // (= r.n_out for a chunk whose status is OK)
+    auto finish = [&]() {
+        for (int d = 32; d; d >>= 1) {                                  // (32-bit halves: the sums do not fit one shuffle)
+            sa += ((u64)(u32)__shfl_xor((u32)(sa >> 32), d) << 32) | (u32)__shfl_xor((u32)sa, d);
+            sb += ((u64)(u32)__shfl_xor((u32)(sb >> 32), d) << 32) | (u32)__shfl_xor((u32)sb, d);
+        }
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sa; red[4 + (threadIdx.x >> 6)] = sb; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const u64 a = red[0] + red[1] + red[2] + red[3], b = red[4] + red[5] + red[6] + red[7];
+            atomicAdd((unsigned long long *)&adler_acc[2 * ci], (unsigned long long)(a % 65521u));
+            atomicAdd((unsigned long long *)&adler_acc[2 * ci + 1], (unsigned long long)(b % 65521u));
+        }
+    };
+    // (every thread of the workgroup reaches finish() together: its shuffles and its barrier want whole waves)
+    for (u32 step = 0; step < TR_STEPS; step++) {
+    const u32 p = ((blockIdx.x * TR_STEPS + step) * 256 + threadIdx.x) * 16;
     const u16 *cells = sym + chunks[ci].stream_off;
     u8 *out = stream + chunks[ci].stream_off;
     const u8 *W = win + (size_t)ci * LZ_MAXSEG * LZ_WIN;
@@ -2038,25 +2059,32 @@ __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restric
         while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (q >= pl->b0[mid]) lo = mid; else hi = mid - 1; }
         return lo;
     };
-    if (p + 16 <= r.n_out) {
+    if (p >= r.n_out) {
+    } else if (p + 16 <= r.n_out) {
         const uint4 a = *(const uint4 *)(cells + p), b = *(const uint4 *)(cells + p + 8);
         const u32 cw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         const u32 k_lo = seg_of(p), k_hi = seg_of(p + 15);
-        u32 ow[4] = {0, 0, 0, 0};
+        u32 ow[4] = {0, 0, 0, 0}, s1 = 0, s2 = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const u32 c = (cw[j >> 1] >> (16 * (j & 1))) & 0xffff;
             u32 v = c;
             if (c >= 256) { const u32 k = (k_lo == k_hi) ? k_lo : seg_of(p + j); v = W[(size_t)k * LZ_WIN + ((c - 256) & (LZ_WIN - 1))]; }
             ow[j >> 2] |= (v & 0xff) << (8 * (j & 3));
+            s1 += v & 0xff; s2 += (u32)j * (v & 0xff);
         }
         *(uint4 *)(out + p) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        sa += s1; sb += (nn - p) * (u64)s1 - s2;                        // sum (n - p - j) b_j with 32-bit sums inside the loop
     } else {
         for (u32 q = p; q < r.n_out; q++) {
             const u32 c = cells[q];
-            out[q] = (u8)(c < 256 ? c : W[(size_t)seg_of(q) * LZ_WIN + ((c - 256) & (LZ_WIN - 1))]);
+            const u8 v = (u8)(c < 256 ? c : W[(size_t)seg_of(q) * LZ_WIN + ((c - 256) & (LZ_WIN - 1))]);
+            out[q] = v;
+            sa += v; sb += (nn - q) * (u64)v;
         }
     }
+    }
+    finish();
 }
 
 __global__ __launch_bounds__(64) void k_inf_finish(const InfChunk *__restrict__ chunks, InfResult *__restrict__ res,
@@ -2231,11 +2259,12 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
                                (const LzPlan *)(S + l.plan), (u16 *)(S + l.sym), pass ? 1 : lz_workers, pass ? 1 : first_pass);
     }
     hipLaunchKernelGGL(k_inf_lz_settle, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_res, n_chunks);
+    MTS_HIP(hipMemsetAsync(d_adler_acc, 0, sizeof(u64) * 2 * n_chunks, st));      // (the translation of segmented chunks adds their byte sums)
     if (l.nseg > 1 && max_n > 0) {
         hipLaunchKernelGGL(k_inf_windows, dim3(n_chunks), dim3(1024), 0, st, d_chunks, d_res, (const LzPlan *)(S + l.plan),
                            (const u16 *)(S + l.sym), (u8 *)(S + l.win));
-        hipLaunchKernelGGL(k_inf_translate, dim3((max_n + 4095) / 4096, n_chunks), dim3(256), 0, st, d_chunks, d_res,
-                           (const LzPlan *)(S + l.plan), (const u16 *)(S + l.sym), (const u8 *)(S + l.win), d_stream);
+        hipLaunchKernelGGL(k_inf_translate, dim3((max_n + 16383) / 16384, n_chunks), dim3(256), 0, st, d_chunks, d_res,
+                           (const LzPlan *)(S + l.plan), (const u16 *)(S + l.sym), (const u8 *)(S + l.win), d_stream, d_adler_acc);
     }
     MTS_HIP(hipGetLastError());
     if (d_prof) {
@@ -2249,7 +2278,9 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
                         (double)a[0] / nw, (double)a[1] / nw, (double)a[2] / nw, (double)a[3] / nw, (double)a[5] / nw, (double)a[4] / a[5], (double)a[0] / a[5], (double)a[6] / nw, (double)a[7] / nw);
     }
     inflate_mark(engine, st, "inflate_lz");
-    int rc = launch_adler_stream(st, d_stream, (const u64 *)(S + l.so), (const u32 *)(S + l.nn), n_chunks, max_n, d_adler_acc);
+    // byte sums of the chunks that did not go through the translation (resolved as bytes by k_inf_lz)
+    int rc = launch_adler_stream(st, d_stream, (const u64 *)(S + l.so), (const u32 *)(S + l.nn), n_chunks, max_n, d_adler_acc,
+                                 (const u32 *)(S + l.plan), (u32)(sizeof(LzPlan) / 4));
     if (rc) return rc;
     hipLaunchKernelGGL(k_inf_finish, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_chunks, d_res, d_adler_acc, n_chunks,
                        d_status_out);

@@ -293,9 +293,10 @@ int launch_delta_transpose(hipStream_t st, const void *d_raw, void *d_stream, co
 // adler32 partial sums of plain streams (inflate side: verify the trailer)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_adler_stream(const u8 *__restrict__ stream, const u64 *__restrict__ stream_off,
-                                                      const u32 *__restrict__ n_arr, u64 *adler_acc)
+                                                      const u32 *__restrict__ n_arr, u64 *adler_acc, const u32 *__restrict__ skip, u32 skip_stride)
 {
     const int chunk = blockIdx.y;
+    if (skip && skip[(size_t)chunk * skip_stride] >= 2) return;         // (summed where its bytes were made: k_inf_translate)
     const u64 n = n_arr[chunk];
     const u64 base = (u64)blockIdx.x * (256 * 64);
     if (base >= n) return;
@@ -326,13 +327,13 @@ __global__ __launch_bounds__(256) void k_adler_stream(const u8 *__restrict__ str
 }
 
 int launch_adler_stream(hipStream_t st, const u8 *d_stream, const u64 *d_stream_off, const u32 *d_n,
-                        int n_chunks, u32 max_n, u64 *d_adler_acc)
+                        int n_chunks, u32 max_n, u64 *d_adler_acc, const u32 *d_skip, u32 skip_stride)
 {
     if (n_chunks == 0) return MTS_OK;
-    MTS_HIP(hipMemsetAsync(d_adler_acc, 0, sizeof(u64) * 2 * n_chunks, st));
+    if (!d_skip) MTS_HIP(hipMemsetAsync(d_adler_acc, 0, sizeof(u64) * 2 * n_chunks, st));      // (with d_skip the caller zeroed the sums before the chunks that are skipped here added theirs)
     if (max_n == 0) return MTS_OK;
     dim3 grid((max_n + 256 * 64 - 1) / (256 * 64), n_chunks), block(256);
-    hipLaunchKernelGGL(k_adler_stream, grid, block, 0, st, d_stream, d_stream_off, d_n, d_adler_acc);
+    hipLaunchKernelGGL(k_adler_stream, grid, block, 0, st, d_stream, d_stream_off, d_n, d_adler_acc, d_skip, skip_stride);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
