@@ -31,14 +31,15 @@ constexpr int STREAM_PAD = 512;
 constexpr int STREAM_ALIGN = 256;
 
 // ---- match stage tiling ---------------------------------------------------------------------------
-// A tile's history (HALO) is sorted and staged again by the next tile, so bigger tiles mean less work -- but the
-// match kernel reads the tile's window (TILE + HALO bytes) at random, two workgroups per CU: measured on MI355X,
-// 64..96 Ki tiles cost the same (41-42 ms: less work balances worse locality), 160 Ki 53 ms, 224 Ki 60 ms.
+// A tile's history (HALO) is sorted and staged again by the next tile, so bigger tiles mean less work.  While every
+// workgroup read its own window through L2, big tiles lost to locality (round 1: 64..96 Ki 41-42 ms, 160 Ki 53, 224 Ki 60);
+// with the workgroups of an XCD sharing a tile the window is L2 resident whatever its size and the biggest tile the 18-bit
+// window-relative positions allow wins (match 31 -> 28.5 ms, sort 12.9 -> 11.4 from 96 Ki to 224 Ki).
 // The 32-bit sort keys hold the window-relative position (REL_BITS allow windows up to 2^18) and the 7 hash bits
 // the second radix pass still needs; the first pass takes its 8 bits straight from the bytes.
 constexpr int TILE = 229376;               // positions a match-stage workgroup owns
 constexpr int HALO = 32768;                // history it additionally needs (>= MAX_DIST)
-constexpr int WIN = TILE + HALO;           // 131072
+constexpr int WIN = TILE + HALO;           // 262144 = 2^REL_BITS
 constexpr int REL_BITS = 18;
 constexpr u32 REL_MASK = (1u << REL_BITS) - 1;
 

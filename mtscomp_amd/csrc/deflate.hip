@@ -1,4 +1,5 @@
-// Bit-exact zlib-1.2.11 DEFLATE (levels 4..9, i.e. deflate_slow) on gfx950.
+// Bit-exact zlib-1.2.11 DEFLATE on gfx950: levels 4..9 (deflate_slow) by the stages below, levels 1..3 (deflate_fast) by
+// the sort + section F (its walks replace M and P).
 //
 // Replaces `zlib.compress(chunkd.tobytes(order))` (/root/reference/mtscomp.py:394).  The algorithm is
 // the parallel formulation of SURVEY.md Appendix A.3, checked stage by stage against
@@ -7,12 +8,16 @@
 //   S  k_hash_sort     per tile (TILE owned positions + HALO history): stable 2-pass radix sort of the
 //                      positions by their 15-bit zlib hash -> every hash chain becomes a contiguous,
 //                      position-ordered run (parse independent because deflate_slow inserts every
-//                      position).  Ranking by lane-ordered LDS atomics (probed), ballots as fallback.
+//                      position).  Ranking by lane-ordered LDS atomics (probed, and checked where the order is used),
+//                      ballots as fallback.
 //   M  k_match5        (budgets <= 128) per tile: a wave walks contiguous 64-slot groups of the sorted order
 //                      with a ring of per-slot entries in LDS; one lane per position scores, newest
 //                      first, only the candidates its looked-up filter masks let through, and records
 //                      the best match within the full budget and within budget>>2 (the
-//                      prev_length >= good_match case).  k_match4: budgets > 128, SWAR key compares.
+//                      prev_length >= good_match case).  The workgroups of one XCD share a tile (its window stays
+//                      in that XCD's L2).  k_match4: budgets > 128, SWAR key compares.
+//   F  k_fast_*        levels 1..3: greedy walks that skip the positions the parse did not insert into the chains (one
+//                      insertion bit per position, written by the walks), rounds to the unique fixed point.
 //   P  k_parse_*       lazy-evaluation state machine over the tables; one lane per SEG positions,
 //                      speculative entry, iterated to a fixed point (walks re-converge after a few
 //                      tokens); then count + emit tokens (LDS rows, written out coalesced).

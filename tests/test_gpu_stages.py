@@ -332,7 +332,7 @@ def test_inflate_full_size_streams_without_dynamic_blocks():
         st, out, dt = _timed_inflate(z, n)
         assert st == 0 and out == want, name
         print('inflate %s: %.1f ms' % (name, dt * 1e3))
-        assert dt < budget, (name, dt)          # (host copies of 23 MB each way included; the one-lane decoder took seconds to minutes)
+        assert dt < budget, (name, dt)          # (host copies of 23 MB each way included; round 1's one-lane decoder took seconds to minutes)
 
 
 def test_inflate_full_size_damage_is_refused_quickly():
