@@ -74,6 +74,7 @@ struct Engine {
     hipStream_t own = nullptr;
     // compress workspace
     DBuf stream, sort_a, sort_b, tables, tokens, marks, segbuf, blk, blkcodes, blkhdr, desc, adler, misc;
+    DBuf fast_lists, fast_state;         // levels 1..3: candidate lists of one phase, per-chunk state of the in-order walk
     // host-API staging
     DBuf h_in, h_out;
     // pinned pieces the host entry points move user memory through (pageable memory crosses the bus at a fraction of the
@@ -124,7 +125,7 @@ struct Engine {
     void release_all()
     {
         DBuf *all[] = {&stream, &sort_a, &sort_b, &tables, &tokens, &marks, &segbuf, &blk, &blkcodes, &blkhdr, &desc,
-                       &adler, &misc, &h_in, &h_out, &inf_scratch, &inf_desc, &segsums};
+                       &adler, &misc, &h_in, &h_out, &inf_scratch, &inf_desc, &segsums, &fast_lists, &fast_state};
         for (DBuf *b : all) b->release();
         for (int k = 0; k < 2; k++) { if (pin[k]) (void)hipHostFree(pin[k]); pin[k] = nullptr; if (pin_ev[k]) (void)hipEventDestroy(pin_ev[k]); pin_ev[k] = nullptr; }
         if (copy_st) (void)hipStreamDestroy(copy_st);
@@ -165,7 +166,6 @@ static int get_engine(int device, Engine **out)
     return MTS_OK;
 }
 
-constexpr int FAST_PARALLEL_ROUNDS = 1 << 20;     // levels 1..3: rounds of the speculative greedy walk before the in-order pass (one lane per chunk: slow, but exact whatever the data)
 constexpr int PARSE_PARALLEL_ROUNDS = 96;     // parallel correction rounds of the speculative parse (~40 us each) before the in-order pass:
                                               // chains of a few dozen segments (a dead channel) are cheaper in parallel, whole-chunk chains are not
 
@@ -316,39 +316,35 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     u32 *d_tokens = E.tokens.as<u32>();
     int force_ballot = getenv("MTS_SORT_INJECT_DISORDER") ? 2 : 0;      // (test hook: the first sort of the call is deliberately mis-ranked)
     const bool fast = level < 4;                              // deflate_fast: no candidate tables, the walk itself searches (deflate.hip, section F)
-    // levels 1..3 keep their per-position data where the other levels keep the candidate tables (8 bytes per stream byte):
-    // inverse map (4 bytes per byte), insertion bitmap (1 bit), per segment spill words and change stamps
-    u32 *d_inv = (u32 *)d_tables;
-    u32 *d_bm = d_inv + align_up(stream_bytes, 64);
-    u32 *d_spill = d_bm + align_up(stream_bytes / 32 + 2, 64);
-    u32 *d_stamp = d_spill + (size_t)(nseg + 1) * FAST_SPILL_WORDS_H;
-    u32 *d_front = d_stamp + 2 * ((size_t)nseg + 1);           // (the rounds of the segments' last walks sit behind the stamps)
-    if (fast && (size_t)((u8 *)(d_front + n_chunks + 1) - (u8 *)d_tables) > (stream_bytes + 64) * sizeof(uint2)) { set_error("internal: fast-level workspace"); return MTS_E_INTERNAL; }
+    u32 *d_inv = (u32 *)d_tables;                             // levels 1..3: the inverse map lives where the other levels keep the candidate tables
     for (;;) {
         if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, srt_nb, cfg.chain > 128 && !fast, force_ballot, d_flags))) return rc;
         E.t_mark(st, force_ballot == 1 ? "hash_sort_retry" : "hash_sort");
         int round = 0;
         bool resort = false;
         if (fast) {
+            // one in-order pass per chunk over candidate lists made a phase (W positions of every chunk) at a time
             if ((rc = launch_inverse_map(st, d_stream, d_tiles, (int)tiles.size(), srt_k, d_inv, d_flags))) return rc;
-            MTS_HIP(hipMemsetAsync(d_bm, 0xff, (size_t)((u8 *)d_stamp - (u8 *)d_bm), st));      // everything counts as inserted until a walk says otherwise
-            MTS_HIP(hipMemsetAsync(d_stamp, 0, 4 * (2 * ((size_t)nseg + 1) + n_chunks + 1), st));      // + walk rounds + the fronts
-            if ((rc = launch_fast_init(st, d_chunks, pb, (int)nseg))) return rc;
             E.t_mark(st, "inverse_map");
-            for (;;) {
-                if ((rc = launch_fast_round(st, d_stream, d_chunks, d_tiles, srt_k, pb, d_inv, d_bm, d_spill, d_stamp, d_front, (int)nseg, n_chunks, cfg, round))) return rc;
-                round++;
-                int hflags[2] = {0, 0};                          // {changed, sort-order flag}
-                MTS_HIP(hipMemcpyAsync(hflags, pb.changed, 8, hipMemcpyDeviceToHost, st));
-                MTS_HIP(hipStreamSynchronize(st));
-                if (hflags[1] & 1) { resort = true; break; }
-                if (!hflags[0]) break;
-                MTS_HIP(hipMemsetAsync(pb.changed, 0, 4, st));
-                if (round >= FAST_PARALLEL_ROUNDS) {
-                    if ((rc = launch_fast_serial(st, d_stream, d_chunks, d_tiles, srt_k, pb, d_inv, d_bm, d_spill, d_stamp, n_chunks, cfg, round))) return rc;
-                    break;
-                }
+            u32 max_n = 0;
+            for (int i = 0; i < n_chunks; i++) if (cd[i].n > max_n) max_n = cd[i].n;
+            const u64 K = (u64)fast_list_rows(level);
+            const char *be = getenv("MTS_FAST_LIST_BYTES");      // (tests: a tiny budget = many phases)
+            const u64 budget = be ? strtoull(be, nullptr, 10) : (u64)8 << 30;
+            u64 W = budget / ((u64)n_chunks * K * 4) / 256 * 256;
+            if (W < 256) W = 256;
+            if (W > align_up(max_n, 256)) W = align_up(max_n, 256);
+            if (max_n) {
+                if ((rc = E.fast_lists.ensure((size_t)n_chunks * W * K * 4))) return rc;
+                if ((rc = E.fast_state.ensure(fast_seq_state_bytes(n_chunks)))) return rc;
+                for (u64 ph = 0; ph * W < max_n; ph++)
+                    if ((rc = launch_fast_phase(st, d_stream, d_chunks, d_tiles, srt_k, d_inv, E.fast_lists.as<u32>(), (u32)W, (u32)ph, E.fast_state.p, n_chunks,
+                                                level, cfg, d_tokens, d_blk_in_start, d_cout))) return rc;
             }
+            int hflags[2] = {0, 0};                              // {-, sort-order flag}
+            MTS_HIP(hipMemcpyAsync(hflags, pb.changed, 8, hipMemcpyDeviceToHost, st));
+            MTS_HIP(hipStreamSynchronize(st));
+            if (hflags[1] & 1) resort = true;
         } else {
         if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, srt_nb, d_tables, cfg, d_flags))) return rc;
         E.t_mark(st, "match");
@@ -376,10 +372,11 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         MTS_HIP(hipMemsetAsync(pb.changed, 0, 8, st));
     }
     // after an odd number of fix rounds the current exits live in exit_b; nothing downstream needs them
-    E.t_mark(st, "parse_fixpoint");
-    if ((rc = launch_parse_count(st, d_tables, d_chunks, pb, (int)nseg, n_chunks, cfg, d_cout))) return rc;
-    if (fast) { if ((rc = launch_fast_emit(st, d_stream, d_chunks, d_tiles, srt_k, pb, d_inv, d_bm, d_spill, (int)nseg, cfg, d_tokens, d_blk_in_start))) return rc; }
-    else if ((rc = launch_parse_emit(st, d_stream, d_tables, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start, d_cout))) return rc;
+    E.t_mark(st, fast ? "fast_walk" : "parse_fixpoint");
+    if (!fast) {                                              // (levels 1..3: the in-order walk has written tokens and counts)
+        if ((rc = launch_parse_count(st, d_tables, d_chunks, pb, (int)nseg, n_chunks, cfg, d_cout))) return rc;
+        if ((rc = launch_parse_emit(st, d_stream, d_tables, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start, d_cout))) return rc;
+    }
     E.t_mark(st, "parse_emit");
     if ((rc = launch_block_trees(st, d_chunks, d_blk_chunk, (int)nblk, d_tokens, d_blk_in_start, d_cout, d_blocks,
                                  E.blkcodes.as<u32>(), E.blkhdr.as<u32>(), fast ? 1 : 0))) return rc;

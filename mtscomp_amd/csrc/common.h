@@ -166,15 +166,12 @@ int launch_block_trees(hipStream_t st, const ChunkDesc *d_chunks, const u32 *d_b
                        BlockRec *d_blocks, u32 *d_blk_codes, u32 *d_blk_hdr, int fast /* levels 1..3: deflate_fast's flush points */);
 // levels 1..3 (deflate_fast): inverse map of the sorted order, the rounds of the speculative greedy walk, its in-order completion, the token pass
 int launch_inverse_map(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, u32 *d_inv, u32 *d_flags);
-int launch_fast_init(hipStream_t st, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs);
-int launch_fast_round(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, ParseBufs pb,
-                      const u32 *d_inv, u32 *d_bm, u32 *d_spill, u32 *d_stamp, u32 *d_front /* per chunk: segments already final */, int n_segs,
-                      int n_chunks, LevelCfg cfg, int round);
-int launch_fast_serial(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, ParseBufs pb,
-                       const u32 *d_inv, u32 *d_bm, u32 *d_spill, u32 *d_stamp, int n_chunks, LevelCfg cfg, int rounds_done);
-int launch_fast_emit(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, ParseBufs pb,
-                     const u32 *d_inv, u32 *d_bm, u32 *d_spill, int n_segs, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start);
-constexpr int FAST_SPILL_WORDS_H = 9;   // (= FAST_SPILL_WORDS of deflate.hip: spill words per parse segment)
+size_t fast_seq_state_bytes(int n_chunks);
+int fast_list_len(int level);           // members per position in the candidate lists of levels 1..3
+int fast_list_rows(int level);          // words per position (members + masks + header)
+int launch_fast_phase(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, const u32 *d_inv,
+                      u32 *d_lists, u32 W, u32 phase, void *d_state, int n_chunks, int level, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start,
+                      ChunkOut *d_cout);
 int launch_block_layout(hipStream_t st, const ChunkDesc *d_chunks, int n_chunks, BlockRec *d_blocks,
                         ChunkOut *d_cout, const u64 *d_adler_acc);
 int launch_block_pack(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const u32 *d_blk_chunk,

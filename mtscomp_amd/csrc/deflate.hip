@@ -1226,33 +1226,15 @@ int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables,
 // F: levels 1..3 (zlib's deflate_fast) -- orc_deflate()'s fast branch is the oracle
 // ================================================================================================
 // deflate_fast is greedy (no lazy evaluation) and it does NOT enter the inside of a match longer than max_insert_length
-// (= the level's `lazy` field) into the hash chains, so the chains -- unlike deflate_slow's -- depend on the parse and
-// there are no parse-independent candidate tables.  What stays parse independent is the ORDER: the same hash sort as for
-// the other levels lists every position of a hash run newest-last; a decision point p finds its own slot through an
-// inverse map (k_inverse_map) and walks the run backwards, skipping the positions the parse did not insert.  Which
-// positions were inserted is one bit per position, written by the walk itself:
-//   * one lane per SEG positions walks its segment from an assumed entry (first: the segment start), greedily, and
-//     records its exit, its token count and the insertion bits of the positions it covered (its own segment's 32 words
-//     in the chunk's bitmap; the tail of a last match that reaches into the next segment in 9 spill words);
-//   * a position q is looked up in the bitmap word of its segment when q >= that segment's entry, in the spill words of
-//     the segment before otherwise (every word has one writer);
-//   * rounds repeat -- a segment walks again when its entry (= exit of its left neighbour) or anything within the
-//     32 KiB it can see changed in the round before -- until nothing changes.  The system is causal (what a segment does
-//     depends only on what lies to its left), so the fixed point is unique and is zlib's parse: segment 0 is right after
-//     round 0, every later one as soon as everything to its left is.  Local damage heals locally (walks re-synchronise,
-//     only the newest `chain` inserted members of a run matter), so a few rounds do; after FAST_PARALLEL_ROUNDS the rest
-//     is walked in order.
-constexpr int FAST_SPILL_WORDS = 9;            // insertion bits of [segment end, segment end + 288): a match is at most 258 long
-constexpr int FAST_DEP_SEGS = 34;              // segments to the left a walk can read (32 KiB of window + the spill of one more)
-
-struct FastBufs {
-    const u32 *inv;      // per stream byte: slot of the position in its tile's sorted order
-    u32 *bm;             // per stream byte one bit: position inserted into its hash chain
-    u32 *spill;          // per segment FAST_SPILL_WORDS
-    u32 *stamp;          // per segment: round (+2) in which its outputs last changed; [n_segs + 1 ...): round (+2) of its last walk, 0 = never
-    u32 *walked;
-};
-
+// (= the level's `lazy` field) into the hash chains, so the chains -- unlike deflate_slow's -- depend on the parse.  What
+// stays parse independent is the ORDER: the same hash sort as for the other levels lists every position of a hash run
+// newest-last, a position finds its own slot through an inverse map (k_inverse_map), and the older members of its run with
+// the common prefix each would give can be listed for every position at once (k_fast_cands).  Which of them the parse
+// entered into the chain is one bit per position that only the parse so far can tell: the state of deflate_fast is the exact
+// insertion pattern of the last 32 KiB, and a chunk is a sequential computation.  k_fast_seq walks every chunk in order
+// with one wave, speculating only inside the 64 positions the wave looks at together.
+// (Round 2 first had speculative walks of 1024-position segments iterated to the fixed point: wrong guesses about the
+// insertion pattern healed in ~450 rounds at levels 1 and 3 and not at all at level 2 on the 385-channel workload.)
 // (also checks what the walks rely on -- positions ascending inside a hash run -- like k_match5 does for the other levels)
 __global__ __launch_bounds__(256) void k_inverse_map(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, const u32 *__restrict__ sorted,
                                                      u32 *__restrict__ inv, u32 *__restrict__ flags)
@@ -1282,222 +1264,364 @@ __device__ __forceinline__ u32 common_len(const u8 *__restrict__ s, u32 a, u32 b
     return len < maxlen ? len : maxlen;
 }
 
-// One segment, walked from `entry`.  EMIT: tokens are written (k = first token index); otherwise the insertion bits are.
-// lb: this lane's LDS words (32 own-segment words + FAST_SPILL_WORDS), element e at lb[e * 64].
-template <bool EMIT>
-__device__ __forceinline__ u32 fast_walk(const u8 *__restrict__ s, const ChunkDesc &ch, const TileDesc *__restrict__ tiles, const u32 *__restrict__ sorted,
-                                         const FastBufs &fb, const u32 *__restrict__ seg_entry, u32 g, u32 seg_s, u32 entry, LevelCfg cfg,
-                                         u32 *lb, u32 &cnt_out, u32 *__restrict__ tk, u32 *__restrict__ bis, u32 k)
+// One wave per chunk, 64 positions (a window) at a time:
+//   * every lane decides for its own position, as if it were a decision point, from its list: members before the window are
+//     looked up in a bitmap of the last 32 KiB kept in LDS (final), members inside the window count as inserted unless the
+//     wave already knows better (`nonins`); the lane remembers which in-window members it relied on (`dep`).  The decision
+//     is mask arithmetic: E = members that count, C = the first `chain` of them, X = C up to the first nice one, the result
+//     the maximum of the keys in X;
+//   * a scalar loop hops from decision point to decision point with v_readlane (about ten scalar instructions per plain
+//     token).  A match longer than max_insert_length leaves its inside out of the chains: lanes behind it that relied on
+//     one of those positions are marked dirty and decide again when the loop reaches one of them (then exactly:
+//     everything before it is final);
+//   * a list that ends before the decision does (long runs of skipped members, more than FQ_KW members inside the window,
+//     a member at exactly MAX_DIST) is finished by all 64 lanes scanning the sorted run itself (fast_exact);
+//   * the window's tokens are written side by side, its insertion bits go into the LDS bitmap.
+// The lists are made in phases of W positions per chunk so that they fit a fixed workspace whatever the batch; the walk's
+// state (position, token count, bitmap) is parked in memory between phases.
+constexpr u32 FQ_NEED = 1u << 10, FQ_LONG = 1u << 9;
+constexpr int FQ_KW = 8;                        // list members inside the window a lane follows itself (more: fast_exact)
+
+struct FastSeqState { u32 pos, k, carry_long, pad; u32 ring[1024]; };
+
+template <int K> struct FqMask { typedef u32 type; };
+template <> struct FqMask<48> { typedef u64 type; };
+template <int K> constexpr int fq_rows() { return K + (K > 32 ? 3 : 2); }      // K members + N mask word(s) + header
+
+// List member k of position p: len << 22 | (63 - k) << 16 | dist -- the maximum over a set of members is the longest, among
+// equals the first, and carries its distance.  Behind the members: the mask of those with len >= nice_match and a header
+// (members | members inside the 64-aligned window << 8 | "the list is not the whole story" << 16).
+template <int K>
+__global__ __launch_bounds__(256) void k_fast_cands(const u8 *__restrict__ stream, const ChunkDesc *__restrict__ chunks, const TileDesc *__restrict__ tiles,
+                                                    const u32 *__restrict__ sorted, const u32 *__restrict__ inv, u32 *__restrict__ tab, u32 W, u32 phase,
+                                                    LevelCfg cfg)
 {
-    const u32 n = ch.n, segend = min(seg_s + (u32)SEG, n);
-    const u32 *bmc = fb.bm + (ch.stream_off >> 5);
-    for (int e = 0; e < 32 + FAST_SPILL_WORDS; e++) lb[e * 64] = 0;
-    auto set_bit = [&](u32 q) { const u32 r = q - seg_s; lb[(r >> 5) * 64] |= 1u << (r & 31); };      // (r < 1024 + 288)
-    auto inserted = [&](u32 q) -> bool {
-        if (q >= seg_s) {
-            if (q >= entry) return (lb[((q - seg_s) >> 5) * 64] >> ((q - seg_s) & 31)) & 1;
-            const u32 r = q - seg_s;                                  // decided by the walk of the segment before
-            return (fb.spill[(u64)(g - 1) * FAST_SPILL_WORDS + (r >> 5)] >> (r & 31)) & 1;
-        }
-        const u32 kq = q / SEG, gq = ch.seg0 + kq;
-        if (q >= seg_entry[gq]) return (bmc[q >> 5] >> (q & 31)) & 1;
-        const u32 r = q - kq * SEG;
-        return (fb.spill[(u64)(gq - 1) * FAST_SPILL_WORDS + (r >> 5)] >> (r & 31)) & 1;
-    };
-    u32 kmod = EMIT ? k % BLOCK_TOKENS : 0;
-    auto put = [&](u32 v, u32 at) {
-        if (EMIT) {
-            if (kmod == 0) bis[k / BLOCK_TOKENS] = at;                // first token of a block: where its input starts
-            kmod = kmod + 1 == (u32)BLOCK_TOKENS ? 0 : kmod + 1;
-            tk[k] = v;
-            k++;
-        }
-    };
-    u32 pos = entry, cnt = 0;
-    while (pos < segend) {
-        const u32 look = n - pos;
-        if (look < (u32)MIN_MATCH) { put((u32)s[pos] << 16, pos); cnt++; pos++; continue; }      // (no hash: nothing inserted, no match)
-        set_bit(pos);
-        const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
-        const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
-        const u32 limit = pos > (u32)MAX_DIST ? pos - MAX_DIST : 0;
-        const TileDesc &td = tiles[ch.tile0 + pos / TILE];
-        const u32 *sk = sorted + td.sorted_off;
-        const u32 myhash = hash_of(gld_u32_unaligned(s, pos));
-        u32 j = fb.inv[ch.stream_off + pos];
-        u32 best = MIN_MATCH - 1, bstart = 0, examined = 0;
-        const u32 own4 = gld_u32_unaligned(s, pos);
-        bool more = true;
-        while (more && j > 0) {
-            // The walk is a chain of dependent memory round trips (slot -> position -> bytes, insertion bit), one lane per
-            // segment: the next FAST_FETCH slots are fetched together -- keys, then the candidates' first bytes and
-            // everything the insertion test may need (entry of the candidate's segment, its bitmap word, the spill word
-            // of the segment before) -- and only then looked at one after the other.
-            constexpr int FAST_FETCH = 4;
-            u32 q[FAST_FETCH], c4[FAST_FETCH], ent[FAST_FETCH], bw[FAST_FETCH], sw[FAST_FETCH];
-            const u32 nb = j < (u32)FAST_FETCH ? j : (u32)FAST_FETCH;
+    constexpr int R = fq_rows<K>();
+    const u32 ci = blockIdx.y;
+    const ChunkDesc ch = chunks[ci];
+    const u32 pl = blockIdx.x * 256 + threadIdx.x;
+    const u64 p64 = (u64)phase * W + pl;
+    if (p64 >= ch.n) return;
+    const u32 p = (u32)p64, n = ch.n, look = n - p, lane = pl & 63;
+    u32 *row = tab + (((u64)ci * (W / 64) + pl / 64) * R) * 64 + lane;
+    if (look < (u32)MIN_MATCH) { row[(R - 1) * 64] = 0; return; }
+    const u8 *s = stream + ch.stream_off;
+    const TileDesc &td = tiles[ch.tile0 + p / TILE];
+    const u32 *sk = sorted + td.sorted_off;
+    const u32 j = inv[ch.stream_off + p];
+    const u32 own4 = gld_u32_unaligned(s, p), myhash = hash_of(own4);
+    const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
+    const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
+    u32 q[K], c4[K];
 #pragma unroll
-            for (int c = 0; c < FAST_FETCH; c++) q[c] = td.w + (sk[j - 1 - ((u32)c < nb ? (u32)c : nb - 1)] & REL_MASK);
+    for (int k = 0; k < K; k++) q[k] = (u32)k < j ? td.w + (sk[j - 1 - k] & REL_MASK) : 0xffffffffu;
 #pragma unroll
-            for (int c = 0; c < FAST_FETCH; c++) {
-                c4[c] = gld_u32_unaligned(s, q[c]);
-                const u32 kq = q[c] / SEG, gq = ch.seg0 + kq, r = q[c] - kq * SEG;
-                ent[c] = seg_entry[gq];
-                bw[c] = bmc[q[c] >> 5];
-                sw[c] = fb.spill[(u64)(gq > ch.seg0 ? gq - 1 : gq) * FAST_SPILL_WORDS + (r >> 5 < (u32)FAST_SPILL_WORDS ? r >> 5 : 0)];
-            }
+    for (int k = 0; k < K; k++) c4[k] = q[k] != 0xffffffffu ? gld_u32_unaligned(s, q[k]) : 0;
+    bool run = true;
+    u32 nlist = 0, kin = 0, inc = 0;
+    u64 nm = 0;
 #pragma unroll
-            for (int c = 0; c < FAST_FETCH; c++) {
-                if (!more || (u32)c >= nb) continue;
-                const u32 qq = q[c];
-                if (hash_of(c4[c]) != myhash) { more = false; continue; }                 // the run ends
-                bool ins;
-                if (qq >= seg_s) ins = inserted(qq);                                       // own segment: this walk's own bits (or the spill before it)
-                else ins = qq >= ent[c] ? (bw[c] >> (qq & 31)) & 1 : (sw[c] >> ((qq % SEG) & 31)) & 1;
-                if (!ins) continue;                                                       // not in the chain
-                if (examined == 0) { if (qq == 0 || pos - qq > (u32)MAX_DIST) { more = false; continue; } }      // hash_head != NIL && strstart - hash_head <= MAX_DIST
-                else if (qq <= limit) { more = false; continue; }                         // cur_match > limit
-                examined++;
-                const u32 x0 = c4[c] ^ own4;
-                u32 len = x0 ? (u32)__builtin_ctz(x0) >> 3 : 4 + common_len(s, pos + 4, qq + 4, maxlen > 4 ? maxlen - 4 : 0);
+    for (int k = 0; k < K; k++) {
+        if (run) {
+            const u32 dist = p - q[k];
+            // the run ends, the window ends, or position 0 (zlib's NIL): nothing behind it counts
+            if (q[k] == 0xffffffffu || hash_of(c4[k]) != myhash || dist > (u32)MAX_DIST || dist == p) run = false;
+            else if (dist == (u32)MAX_DIST) { run = false; inc = 1; }      // (allowed as the chain's head only: fast_exact knows)
+            else {
+                const u32 x0 = c4[k] ^ own4;
+                u32 len = x0 ? (u32)__builtin_ctz(x0) >> 3 : 4 + common_len(s, p + 4, q[k] + 4, maxlen > 4 ? maxlen - 4 : 0);
                 len = len < maxlen ? len : maxlen;
-                if (len > best) { best = len; bstart = qq; if (len >= nice) more = false; }
-                if (examined == (u32)cfg.chain) more = false;
+                row[k * 64] = (len << 22) | ((u32)(63 - k) << 16) | dist;
+                nlist = k + 1;
+                if (dist <= lane) kin = k + 1;
+                if (len >= nice) nm |= 1ull << k;
             }
-            j -= nb;
         }
-        if (best >= (u32)MIN_MATCH) {
-            put(((best - MIN_MATCH) << 16) | (pos - bstart), pos);
-            cnt++;
-            if (best <= (u32)cfg.lazy && look - best >= (u32)MIN_MATCH)      // short match: its inside is inserted too
-                for (u32 q = pos + 1; q < pos + best; q++) set_bit(q);
-            pos += best;
-        } else { put((u32)s[pos] << 16, pos); cnt++; pos++; }
     }
-    cnt_out = cnt;
-    return pos;
+    if (run) inc = 1;                                             // K members and the run goes on
+    row[K * 64] = (u32)nm;
+    if (K > 32) row[(K + 1) * 64] = (u32)(nm >> 32);
+    row[(R - 1) * 64] = nlist | (kin << 8) | (inc << 16);
 }
 
-// What a walk does depends on the exact insertion pattern of the 32 KiB before it.  On some parameter sets a wrong guess
-// there heals (the walks of segments far apart settle side by side: levels 1 and 3 on the 385-channel workload need ~450
-// rounds for chunks of 22 500 segments), on others it does not (level 2 there: every error breeds new ones, and only what
-// lies right behind the part that is already final comes out right).  So per chunk a FRONT is kept -- segments
-// [0, front) are final: the first segment behind the front walks on final inputs and becomes final, and so does every
-// further one for as long as the segments before it came out of the round unchanged (k_fast_front) -- and after
-// FAST_OPEN_ROUNDS rounds in which every segment may walk, only the `window` segments behind the front still do: the
-// work per round is then bounded and the front moves at least one segment per round whatever the data.
-constexpr u32 FAST_WINDOW = 128;
-
-__global__ __launch_bounds__(64) void k_fast_round(const u8 *__restrict__ stream, const ChunkDesc *__restrict__ chunks, const TileDesc *__restrict__ tiles,
-                                                   const u32 *__restrict__ sorted, ParseBufs pb, FastBufs fb, const u32 *__restrict__ front, int n_segs,
-                                                   LevelCfg cfg, int round, u32 window)
+// One position's decision from its list, given which members count as inserted (E).  X: the members the chain walk looks at.
+template <int K>
+__device__ __forceinline__ void fast_decide(const u32 (&c)[K], typename FqMask<K>::type oldE, typename FqMask<K>::type listm, typename FqMask<K>::type nicem,
+                                            u32 kin, u32 inc, const u32 (&bk)[FQ_KW], u64 nonins, u32 look, const LevelCfg &cfg,
+                                            u32 &vbest, u32 &vdist, u64 &dep, u32 &vinfo)
 {
-    __shared__ u32 lds[64 * (32 + FAST_SPILL_WORDS)];
-    const int g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= n_segs) return;
-    const u32 *exit_in = (round & 1) ? pb.exit_b : pb.exit_a;
-    u32 *exit_out = (round & 1) ? pb.exit_a : pb.exit_b;
-    const u32 ci = pb.seg_chunk[g];
+    typedef typename FqMask<K>::type M;
+    // members inside the window: inserted unless the wave knows better
+    u32 notw = 0;
+#pragma unroll
+    for (int j = 0; j < FQ_KW; j++) notw |= ((u32)(nonins >> bk[j]) & 1u) << j;
+    const u32 kw = kin < (u32)FQ_KW ? kin : (u32)FQ_KW;
+    const M E = oldE | ((M)(~notw & ((1u << kw) - 1)) & listm);
+    // the first `chain` of them ...
+    M C;
+    if (K > 32) {
+        C = E;
+        while (__popcll((u64)C) > cfg.chain) C &= ~((M)1 << (63 - __builtin_clzll((u64)C)));
+    } else {
+        M r = E;
+        for (int i = 0; i < cfg.chain; i++) r &= r - 1;
+        C = E ^ r;
+    }
+    // ... up to and including the first that is nice enough
+    const M En = C & nicem;
+    const M X = En ? C & (En ^ (En - 1)) : C;
+    const bool ended = En != 0 || (K > 32 ? __popcll((u64)X) : __popc((u32)X)) == cfg.chain;
+    u32 key = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const u32 m = (u32)((X >> k) & 1);
+        key = max(key, c[k] & (0u - m));
+    }
+    u64 d = 0;
+    const u32 xw = (u32)X & ((1u << kw) - 1);
+#pragma unroll
+    for (int j = 0; j < FQ_KW; j++) d |= (u64)((xw >> j) & 1u) << bk[j];
+    const u32 best = key >> 22;
+    const bool is_match = best >= (u32)MIN_MATCH;
+    vbest = is_match ? best : (u32)MIN_MATCH - 1; vdist = key & 0xffff; dep = d;
+    const bool lng = is_match && !(best <= (u32)cfg.lazy && look - best >= (u32)MIN_MATCH);
+    const bool need = kin > (u32)FQ_KW || (!ended && inc);
+    vinfo = (is_match ? best : 1u) | (lng ? FQ_LONG : 0u) | (need ? FQ_NEED : 0u);
+}
+
+// the decision at pq by the whole wave from the sorted run itself (everything before pq is final)
+__device__ __forceinline__ void fast_exact(const u8 *__restrict__ s, const ChunkDesc &ch, const TileDesc *__restrict__ tiles, const u32 *__restrict__ sorted,
+                                           const u32 *__restrict__ inv, const u32 *ring, u32 ws, u64 nonins, u32 pq, const LevelCfg &cfg, u32 lane,
+                                           u32 &obest, u32 &odist)
+{
+    const u32 n = ch.n, look = n - pq;
+    const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
+    const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
+    const TileDesc &td = tiles[ch.tile0 + pq / TILE];
+    const u32 *sk = sorted + td.sorted_off;
+    const u32 tw = td.w;
+    u32 j = (u32)__builtin_amdgcn_readfirstlane((int)inv[ch.stream_off + pq]);      // (uniform: the scalar loop of the caller stays scalar)
+    const u32 own4 = (u32)__builtin_amdgcn_readfirstlane((int)gld_u32_unaligned(s, pq)), myhash = hash_of(own4);
+    const bool farp = pq > (u32)MAX_DIST;
+    u32 best = MIN_MATCH - 1, bdist = 0, examined = 0;
+    bool done = false;
+    while (!done && j > 0) {
+        const bool have = lane < j;
+        u32 qq = 0, c4 = 0;
+        if (have) { qq = tw + (sk[j - 1 - lane] & REL_MASK); c4 = gld_u32_unaligned(s, qq); }
+        const u32 dist = pq - qq;
+        const bool ends = !have || hash_of(c4) != myhash || dist > (u32)MAX_DIST;
+        const u64 em = __ballot(ends);
+        const u32 cut = em ? (u32)__ffsll((long long)em) - 1 : 64u;
+        bool ins = false;
+        if (lane < cut) ins = qq >= ws ? !((nonins >> (qq - ws)) & 1) : (ring[(qq >> 5) & 1023] >> (qq & 31)) & 1;
+        u32 len = 0;
+        if (ins) {
+            const u32 x0 = c4 ^ own4;
+            len = x0 ? (u32)__builtin_ctz(x0) >> 3 : 4 + common_len(s, pq + 4, qq + 4, maxlen > 4 ? maxlen - 4 : 0);
+            len = len < maxlen ? len : maxlen;
+        }
+        u64 im = __ballot(ins);
+        while (im && !done) {
+            const int i = __ffsll((long long)im) - 1;
+            im &= im - 1;
+            const u32 d = (u32)__builtin_amdgcn_readlane((int)dist, i), l = (u32)__builtin_amdgcn_readlane((int)len, i);
+            const bool stop = (examined == 0 || !farp) ? d == pq : d >= (u32)MAX_DIST;
+            if (stop) { done = true; break; }
+            examined++;
+            if (l > best) { best = l; bdist = d; if (l >= nice) done = true; }
+            if (examined == (u32)cfg.chain) done = true;
+        }
+        if (cut < 64) done = true;
+        j = j > 64 ? j - 64 : 0;
+    }
+    obest = (u32)__builtin_amdgcn_readfirstlane((int)best); odist = (u32)__builtin_amdgcn_readfirstlane((int)bdist);
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void k_fast_seq(const u8 *__restrict__ stream, const ChunkDesc *__restrict__ chunks, const TileDesc *__restrict__ tiles,
+                                                 const u32 *__restrict__ sorted, const u32 *__restrict__ inv, const u32 *__restrict__ tab, u32 W, u32 phase,
+                                                 FastSeqState *__restrict__ state, LevelCfg cfg, u32 *__restrict__ tokens, u32 *__restrict__ blk_in_start,
+                                                 ChunkOut *__restrict__ cout)
+{
+    __shared__ u32 ring[1024];
+    const u32 ci = blockIdx.x, lane = threadIdx.x;
     const ChunkDesc ch = chunks[ci];
-    const u32 seg_s = pb.seg_start[g];
-    const u32 kseg = (u32)g - ch.seg0, fr = front[ci];
-    if (kseg < fr || kseg - fr >= window) { exit_out[g] = exit_in[g]; return; }
-    const u32 entry = kseg == 0 ? 0u : exit_in[g - 1];
-    const u32 my_walk = fb.walked[g];                              // round (+2) of this segment's last walk, 0 = never
-    const bool walked = my_walk != 0;
-    if (walked) {
-        // walk again when the entry moved or something in sight changed in or after the round of the last walk
-        bool dirty = entry != pb.entry[g];
-        const u32 lo = kseg >= (u32)FAST_DEP_SEGS ? (u32)g - FAST_DEP_SEGS : ch.seg0;
-        for (u32 q = lo; q < (u32)g && !dirty; q++) dirty = fb.stamp[q] >= my_walk;
-        if (!dirty) { exit_out[g] = exit_in[g]; return; }
+    const u32 n = ch.n;
+    const u64 pb64 = (u64)phase * W;
+    if (pb64 >= n) return;
+    const u32 p_begin = (u32)pb64, p_end = (u64)p_begin + W < n ? p_begin + W : n;
+    const u8 *s = stream + ch.stream_off;
+    FastSeqState *S = state + ci;
+    u32 pos = 0, k = 0, carry_long = 0;
+    if (phase == 0) { for (int i = lane; i < 1024; i += 64) ring[i] = 0; }
+    else {
+        pos = S->pos; k = S->k; carry_long = S->carry_long;
+        for (int i = lane; i < 1024; i += 64) ring[i] = S->ring[i];
     }
-    fb.walked[g] = (u32)round + 2;
-    u32 *lb = lds + threadIdx.x;
-    u32 cnt;
-    bool changed = !walked || entry != pb.entry[g];
-    pb.entry[g] = entry;
-    const u32 e = fast_walk<false>(stream + ch.stream_off, ch, tiles, sorted, fb, pb.entry, (u32)g, seg_s, entry, cfg, lb, cnt, nullptr, nullptr, 0);
-    // outputs: exit, count, the segment's bitmap words, its spill words; `changed` when any of them is new
-    changed = changed || e != exit_in[g];
-    exit_out[g] = e;
-    pb.cnt[g] = cnt;
-    u32 *bmw = fb.bm + ((ch.stream_off + seg_s) >> 5);
-    const u32 nw = (min(seg_s + (u32)SEG, ch.n) - seg_s + 31) / 32;
-    for (u32 w = 0; w < nw; w++) { const u32 v = lb[w * 64]; if (bmw[w] != v) { bmw[w] = v; changed = true; } }
-    u32 *sp = fb.spill + (u64)g * FAST_SPILL_WORDS;
-    for (u32 w = 0; w < (u32)FAST_SPILL_WORDS; w++) { const u32 v = lb[(32 + w) * 64]; if (sp[w] != v) { sp[w] = v; changed = true; } }
-    if (changed) fb.stamp[g] = (u32)round + 2;
-}
-
-// after a round: the front of every chunk moves past the first window segment whose outputs changed in this round (that
-// one walked on final inputs: it is final now; what follows it saw its old outputs); *pb.changed = some chunk is not done
-__global__ __launch_bounds__(64) void k_fast_front(const ChunkDesc *__restrict__ chunks, ParseBufs pb, FastBufs fb, u32 *__restrict__ front, int n_chunks, int round,
-                                                   u32 window)
-{
-    const int ci = blockIdx.x, lane = threadIdx.x;
-    if (ci >= n_chunks) return;
-    const ChunkDesc ch = chunks[ci];
-    u32 fr = front[ci];
-    if (fr >= ch.nseg) return;
-    const u32 hi = ch.nseg - fr > window ? fr + window : ch.nseg;
-    u32 nf = hi;
-    for (u32 k0 = fr; k0 < hi; k0 += 64) {
-        const u32 k = k0 + lane;
-        const bool ch_now = k < hi && fb.stamp[ch.seg0 + k] == (u32)round + 2;
-        const u64 m = __ballot(ch_now);
-        if (m) { nf = k0 + (u32)__ffsll((long long)m); break; }      // the changed one is final too: + 1
+    __syncthreads();
+    pos = (u32)__builtin_amdgcn_readfirstlane((int)pos); k = (u32)__builtin_amdgcn_readfirstlane((int)k);
+    carry_long = (u32)__builtin_amdgcn_readfirstlane((int)carry_long);
+    u32 *tk = tokens + ch.tok_off;
+    u32 *bis = blk_in_start + ch.blk0;
+    constexpr int R = fq_rows<K>();
+    typedef typename FqMask<K>::type M;
+    const u8 *ringb = (const u8 *)ring;
+    const u32 *trow = tab + ((u64)ci * (W / 64)) * R * 64 + lane;
+    // the lists of G windows at a time: fetched into registers a group ahead (one wave alone hides no latency), parked in
+    // LDS while the group is worked on
+    constexpr int G = K <= 12 ? 4 : 2;
+    __shared__ u32 stage[G][R + 1][64];
+    u32 pre[G][R + 1];
+    auto fetch = [&](u32 wsg) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+#pragma unroll
+            for (int i = 0; i < R; i++) pre[g][i] = trow[(g * R + i) * 64];
+            pre[g][R] = wsg + g * 64 + lane < n ? s[wsg + g * 64 + lane] : 0;
+        }
+        trow += G * R * 64;
+    };
+    fetch(p_begin);
+    for (u32 wsg = p_begin; wsg < p_end; wsg += 64 * G) {
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int i = 0; i <= R; i++) stage[g][i][lane] = pre[g][i];
+    if (wsg + 64 * G < p_end) fetch(wsg + 64 * G);
+#pragma unroll 1
+    for (u32 g = 0; g < (u32)G; g++) {
+        const u32 ws = wsg + g * 64;
+        if (ws >= p_end) break;
+        const u32 p = ws + lane;
+        const u32 look = p < n ? n - p : 0;
+        const bool valid = look >= (u32)MIN_MATCH;
+        const u32 byte = stage[g][R][lane];
+        const u32 lim = n - ws < 64 ? n - ws : 64;
+        const u32 e0 = (u32)__builtin_amdgcn_readfirstlane((int)(pos - ws));
+        const u64 vm = __ballot(valid);
+        u64 nonins = ~vm;
+        if (carry_long) nonins |= e0 >= 64 ? ~0ull : ((1ull << e0) - 1);
+        u64 B = 0;
+        u32 vbest = MIN_MATCH - 1, vdist = 0;
+        if (e0 < lim) {
+            u32 c[K];
+#pragma unroll
+            for (int i = 0; i < K; i++) c[i] = stage[g][i][lane];
+            const u32 hdr = valid ? stage[g][R - 1][lane] : 0;
+            const u32 nlist = hdr & 0xff, kin = (hdr >> 8) & 0xff, inc = (hdr >> 16) & 1;
+            const M listm = nlist >= (u32)(8 * sizeof(M)) ? ~(M)0 : ((M)1 << nlist) - 1;
+            M nicem = stage[g][K][lane];
+            if (K > 32) nicem |= (M)((u64)stage[g][K + 1][lane] << 32);
+            nicem &= listm;
+            u32 bk[FQ_KW];
+#pragma unroll
+            for (int j = 0; j < FQ_KW; j++) bk[j] = (lane - (c[j] & 0xffff)) & 63;
+            // members before the window: the bitmap of the last 32 KiB has them
+            M oldE = 0;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const u32 q = p - (c[i] & 0xffff);
+                oldE |= (M)((ringb[(q >> 3) & 4095] >> (q & 7)) & 1) << i;
+            }
+            const u32 kw = kin < (u32)FQ_KW ? kin : (u32)FQ_KW;
+            oldE &= listm & ~(M)((1u << kw) - 1);
+            u64 dep; u32 vinfo;
+            fast_decide<K>(c, oldE, listm, nicem, kin, inc, bk, nonins, look, cfg, vbest, vdist, dep, vinfo);
+            u32 q = (u32)__builtin_amdgcn_readfirstlane((int)e0), lastlong = 0;
+            u64 slow = __ballot(vinfo > 0x1ffu);                // lanes whose token is not a plain one: a long match, fast_exact, dirty
+            u64 dirty = 0;                                      // lanes that relied on a position a later long match left out
+            for (;;) {
+                // literals and short matches: a handful of scalar instructions each
+                while (!((slow >> q) & 1)) {
+                    const u32 xp = (u32)__builtin_amdgcn_readlane((int)vinfo, (int)q);
+                    B |= 1ull << q;
+                    q = (u32)__builtin_amdgcn_readfirstlane((int)(q + xp));
+                    lastlong = 0;
+                    if (q >= lim) break;
+                }
+                if (q >= lim) break;
+                if ((dirty >> q) & 1) {
+                    // decide again, now that everything before q is final (the other dirty lanes too: most will not change again)
+                    if ((dirty >> lane) & 1) fast_decide<K>(c, oldE, listm, nicem, kin, inc, bk, nonins, look, cfg, vbest, vdist, dep, vinfo);
+                    dirty = 0;
+                    slow = __ballot(vinfo > 0x1ffu);
+                } else {
+                    u32 x = (u32)__builtin_amdgcn_readlane((int)vinfo, (int)q);
+                    if (x & FQ_NEED) {
+                        u32 ob, od;
+                        fast_exact(s, ch, tiles, sorted, inv, ring, ws, nonins, ws + q, cfg, lane, ob, od);
+                        const u32 lk = n - (ws + q);
+                        const bool im = ob >= (u32)MIN_MATCH;
+                        const bool lg = im && !(ob <= (u32)cfg.lazy && lk - ob >= (u32)MIN_MATCH);
+                        x = (im ? ob : 1u) | (lg ? FQ_LONG : 0u);
+                        if (lane == q) { vbest = ob; vdist = od; vinfo = x; }
+                        x = (u32)__builtin_amdgcn_readfirstlane((int)x);
+                    }
+                    B |= 1ull << q;
+                    const u32 adv = x & 0x1ff;
+                    lastlong = (x >> 9) & 1;
+                    if (lastlong) {
+                        const u32 hi = q + adv < 64 ? q + adv : 64;
+                        const u64 below = hi >= 64 ? ~0ull : (1ull << hi) - 1;
+                        const u64 nb = below & ~((2ull << q) - 1);            // positions (q, q + adv)
+                        nonins |= nb;
+                        const u64 dn = __ballot((dep & nb) != 0) & ~below;
+                        dirty |= dn; slow |= dn;
+                    }
+                    q = (u32)__builtin_amdgcn_readfirstlane((int)(q + adv));
+                    if (q >= lim) break;
+                }
+            }
+            pos = (u32)__builtin_amdgcn_readfirstlane((int)(ws + q));
+            carry_long = (u32)__builtin_amdgcn_readfirstlane((int)(q > 64 ? lastlong : 0));
+        }
+        // the window's insertion bits
+        const u64 ins = ~nonins;
+        if (lane == 0) { ring[(ws >> 5) & 1023] = (u32)ins; ring[((ws >> 5) + 1) & 1023] = (u32)(ins >> 32); }
+        __syncthreads();
+        // its tokens, side by side
+        if (B) {
+            const bool base = (B >> lane) & 1;
+            const u32 rank = (u32)__popcll(B & ((1ull << lane) - 1));
+            if (base) {
+                const u32 kk = k + rank;
+                if (kk % BLOCK_TOKENS == 0) bis[kk / BLOCK_TOKENS] = p;
+                tk[kk] = vbest >= (u32)MIN_MATCH ? ((vbest - MIN_MATCH) << 16) | vdist : byte << 16;
+            }
+            k += (u32)__popcll(B);
+        }
     }
-    if (lane == 0) { front[ci] = nf; if (nf < ch.nseg) *pb.changed = 1; }
-}
-
-__global__ __launch_bounds__(256) void k_fast_init(const ChunkDesc *__restrict__ chunks, ParseBufs pb, int n_segs)
-{
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= n_segs) return;
-    const ChunkDesc ch = chunks[pb.seg_chunk[g]];
-    const u32 e = min(pb.seg_start[g] + (u32)SEG, ch.n);          // a segment that has not walked yet hands over at its end
-    pb.exit_a[g] = e; pb.exit_b[g] = e; pb.entry[g] = pb.seg_start[g]; pb.cnt[g] = 0;
-}
-
-// in-order completion (one lane per chunk) for data whose walks do not settle in parallel rounds
-__global__ __launch_bounds__(64) void k_fast_serial(const u8 *__restrict__ stream, const ChunkDesc *__restrict__ chunks, const TileDesc *__restrict__ tiles,
-                                                    const u32 *__restrict__ sorted, ParseBufs pb, FastBufs fb, int n_chunks, LevelCfg cfg, u32 *__restrict__ exits)
-{
-    __shared__ u32 lds[64 * (32 + FAST_SPILL_WORDS)];
-    const int ci = blockIdx.x * 64 + threadIdx.x;
-    if (ci >= n_chunks) return;
-    const ChunkDesc ch = chunks[ci];
-    u32 *lb = lds + threadIdx.x;
-    u32 entry = 0;
-    for (u32 g = ch.seg0; g < ch.seg0 + ch.nseg; g++) {
-        const u32 seg_s = pb.seg_start[g];
-        u32 cnt;
-        pb.entry[g] = entry;
-        const u32 e = fast_walk<false>(stream + ch.stream_off, ch, tiles, sorted, fb, pb.entry, g, seg_s, entry, cfg, lb, cnt, nullptr, nullptr, 0);
-        exits[g] = e; pb.cnt[g] = cnt;
-        u32 *bmw = fb.bm + ((ch.stream_off + seg_s) >> 5);
-        const u32 nw = (min(seg_s + (u32)SEG, ch.n) - seg_s + 31) / 32;
-        for (u32 w = 0; w < nw; w++) bmw[w] = lb[w * 64];
-        u32 *sp = fb.spill + (u64)g * FAST_SPILL_WORDS;
-        for (u32 w = 0; w < (u32)FAST_SPILL_WORDS; w++) sp[w] = lb[(32 + w) * 64];
-        __threadfence();
-        entry = e;
     }
+    if (lane == 0) {
+        S->pos = pos; S->k = k; S->carry_long = carry_long;
+        if (p_end == n) cout[ci].ntok = k;
+    }
+    for (int i = lane; i < 1024; i += 64) S->ring[i] = ring[i];
 }
 
-__global__ __launch_bounds__(64) void k_fast_emit(const u8 *__restrict__ stream, const ChunkDesc *__restrict__ chunks, const TileDesc *__restrict__ tiles,
-                                                  const u32 *__restrict__ sorted, ParseBufs pb, FastBufs fb, int n_segs, LevelCfg cfg,
-                                                  u32 *__restrict__ tokens, u32 *__restrict__ blk_in_start)
+size_t fast_seq_state_bytes(int n_chunks) { return sizeof(FastSeqState) * (size_t)n_chunks; }
+int fast_list_len(int level) { return level <= 1 ? 12 : level == 2 ? 24 : 48; }
+int fast_list_rows(int level) { const int K = fast_list_len(level); return K + (K > 32 ? 3 : 2); }
+
+int launch_fast_phase(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, const u32 *d_inv,
+                      u32 *d_tab, u32 W, u32 phase, void *d_state, int n_chunks, int level, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start,
+                      ChunkOut *d_cout)
 {
-    __shared__ u32 lds[64 * (32 + FAST_SPILL_WORDS)];
-    const int g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= n_segs) return;
-    const ChunkDesc ch = chunks[pb.seg_chunk[g]];
-    u32 cnt;
-    fast_walk<true>(stream + ch.stream_off, ch, tiles, sorted, fb, pb.entry, (u32)g, pb.seg_start[g], pb.entry[g], cfg, lds + threadIdx.x, cnt,
-                    tokens + ch.tok_off, blk_in_start + ch.blk0, pb.tokbase[g]);
+    if (n_chunks == 0) return MTS_OK;
+    FastSeqState *S = (FastSeqState *)d_state;
+    const dim3 gc(W / 256, n_chunks);
+#define MTS_FAST_PHASE(K)                                                                                                                      \
+    hipLaunchKernelGGL(k_fast_cands<K>, gc, dim3(256), 0, st, d_stream, d_chunks, d_tiles, d_sorted, d_inv, d_tab, W, phase, cfg);                 \
+    hipLaunchKernelGGL(k_fast_seq<K>, dim3(n_chunks), dim3(64), 0, st, d_stream, d_chunks, d_tiles, d_sorted, d_inv, d_tab, W, phase, S, cfg,  \
+                       d_tokens, d_blk_in_start, d_cout)
+    const int K = fast_list_len(level);
+    if (K == 12) { MTS_FAST_PHASE(12); } else if (K == 24) { MTS_FAST_PHASE(24); } else { MTS_FAST_PHASE(48); }
+#undef MTS_FAST_PHASE
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
 }
+
 
 int launch_inverse_map(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, u32 *d_inv, u32 *d_flags)
 {
@@ -1506,46 +1630,6 @@ int launch_inverse_map(hipStream_t st, const u8 *d_stream, const TileDesc *d_til
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
-int launch_fast_init(hipStream_t st, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs)
-{
-    if (n_segs == 0) return MTS_OK;
-    hipLaunchKernelGGL(k_fast_init, dim3((n_segs + 255) / 256), dim3(256), 0, st, d_chunks, pb, n_segs);
-    MTS_HIP(hipGetLastError());
-    return MTS_OK;
-}
-int launch_fast_round(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, ParseBufs pb,
-                      const u32 *d_inv, u32 *d_bm, u32 *d_spill, u32 *d_stamp, u32 *d_front, int n_segs, int n_chunks, LevelCfg cfg, int round)
-{
-    if (n_segs == 0) return MTS_OK;
-    static const int open_rounds = getenv("MTS_FAST_OPEN_ROUNDS") ? atoi(getenv("MTS_FAST_OPEN_ROUNDS")) : 640;      // (tests force the windowed rounds with 0)
-    const u32 window = round < open_rounds ? 0x7fffffffu : FAST_WINDOW;
-    FastBufs fb; fb.inv = d_inv; fb.bm = d_bm; fb.spill = d_spill; fb.stamp = d_stamp; fb.walked = d_stamp + n_segs + 1;
-    hipLaunchKernelGGL(k_fast_round, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_stream, d_chunks, d_tiles, d_sorted, pb, fb, d_front, n_segs, cfg, round, window);
-    hipLaunchKernelGGL(k_fast_front, dim3(n_chunks), dim3(64), 0, st, d_chunks, pb, fb, d_front, n_chunks, round, window);
-    MTS_HIP(hipGetLastError());
-    return MTS_OK;
-}
-int launch_fast_serial(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, ParseBufs pb,
-                       const u32 *d_inv, u32 *d_bm, u32 *d_spill, u32 *d_stamp, int n_chunks, LevelCfg cfg, int rounds_done)
-{
-    if (n_chunks == 0) return MTS_OK;
-    FastBufs fb; fb.inv = d_inv; fb.bm = d_bm; fb.spill = d_spill; fb.stamp = d_stamp; fb.walked = nullptr;
-    u32 *exits = ((rounds_done - 1) & 1) ? pb.exit_a : pb.exit_b;
-    hipLaunchKernelGGL(k_fast_serial, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_stream, d_chunks, d_tiles, d_sorted, pb, fb, n_chunks, cfg, exits);
-    MTS_HIP(hipGetLastError());
-    return MTS_OK;
-}
-int launch_fast_emit(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, ParseBufs pb,
-                     const u32 *d_inv, u32 *d_bm, u32 *d_spill, int n_segs, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start)
-{
-    if (n_segs == 0) return MTS_OK;
-    FastBufs fb; fb.inv = d_inv; fb.bm = d_bm; fb.spill = d_spill; fb.stamp = nullptr; fb.walked = nullptr;
-    hipLaunchKernelGGL(k_fast_emit, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_stream, d_chunks, d_tiles, d_sorted, pb, fb, n_segs, cfg, d_tokens,
-                       d_blk_in_start);
-    MTS_HIP(hipGetLastError());
-    return MTS_OK;
-}
-
 // ================================================================================================
 // T: per-block Huffman trees (zlib trees.c, exact) -- flush_block() in the oracle
 // ================================================================================================

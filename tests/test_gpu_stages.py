@@ -132,11 +132,40 @@ def test_deflate_multi_tile():
     assert hip.debug_deflate(data, 6) == zlib.compress(data, 6)
 
 
+def _fast_edge_cases():
+    """Inputs picked for the in-order walk of levels 1..3 (deflate.hip, section F): windows of 64 positions, lists of a
+    fixed length, a 32 KiB bitmap, the block buffer of 16383 tokens."""
+    r = np.random.RandomState(11)
+    out = {}
+    for n in (0, 1, 2, 3, 4, 5, 63, 64, 65, 66, 67, 127, 128, 129, 191, 193, 257, 258, 259, 260, 261, 262):
+        out['zeros_%d' % n] = bytes(n)                                    # matches of 258 across window ends, every member in the window
+        out['rand_%d' % n] = r.randint(0, 4, size=n).astype(np.uint8).tobytes()
+    out['zeros_100k'] = bytes(100000)
+    out['ab_70k'] = b'ab' * 35000
+    out['abc_70k'] = b'abc' * 23334
+    per = r.randint(0, 256, size=32506).astype(np.uint8).tobytes()
+    out['period_max_dist'] = per * 3 + per[:1000]                          # every candidate at exactly MAX_DIST
+    per = r.randint(0, 256, size=32505).astype(np.uint8).tobytes()
+    out['period_max_dist_m1'] = per * 3
+    per = r.randint(0, 256, size=32507).astype(np.uint8).tobytes()
+    out['period_max_dist_p1'] = per * 3
+    out['period_32768'] = r.randint(0, 256, size=32768).astype(np.uint8).tobytes() * 3
+    # many members of one hash run that the parse did not insert: long matches of one byte value, then short repeats of it
+    blk = bytes([7]) * 300 + r.randint(0, 256, size=40).astype(np.uint8).tobytes()
+    out['long_runs_then_probe'] = blk * 150 + bytes([7]) * 5 + b'x' + bytes([7]) * 4 + b'y' + bytes([7]) * 3
+    # few distinct trigrams: long lists, chains that reach their budget
+    out['rand2_200k'] = r.randint(0, 2, size=200000).astype(np.uint8).tobytes()
+    out['rand3_64k'] = r.randint(0, 3, size=65536).astype(np.uint8).tobytes()
+    # exactly a multiple of the block buffer in tokens (all literals): deflate_fast closes with an empty block
+    out['literals_16383'] = r.permutation(np.arange(16383) % 251).astype(np.uint8).tobytes()
+    return out
+
+
 @pytest.mark.parametrize('level', [1, 2, 3])
 def test_deflate_fast_levels(level):
     """Levels 1..3 are zlib's deflate_fast: greedy, and the inside of a long match is not entered into the hash chains, so
     the chains depend on the parse (deflate.hip, section F).  Byte identity on every small case, multi-tile streams and
-    a dead channel between live ones (walks that do not re-synchronise for dozens of segments)."""
+    a dead channel between live ones."""
     for name, data in sorted(CASES.items()):
         got = hip.debug_deflate(data, level)
         want = zlib.compress(data, level)
@@ -146,14 +175,23 @@ def test_deflate_fast_levels(level):
         assert hip.debug_deflate(data, level) == zlib.compress(data, level), len(data)
 
 
-def test_deflate_fast_windowed_rounds(monkeypatch):
-    # after a number of rounds in which every segment may walk, only the segments right behind the settled front still do
-    # (data on which wrong guesses do not heal); MTS_FAST_OPEN_ROUNDS=0 (read once per process) is set by the fuzz tool; here the
-    # windowed phase is reached by a stream long enough for the default: not affordable in a unit test, so the small cases
-    # above stand for the logic and tools/fuzz_gpu.py runs the windowed phase alone
-    data = ar1_stream(6000, 16, seed=9)
+@pytest.mark.parametrize('level', [1, 2, 3])
+def test_deflate_fast_edge_cases(level):
+    for name, data in sorted(_fast_edge_cases().items()):
+        got = hip.debug_deflate(data, level)
+        want = zlib.compress(data, level)
+        assert got == want, (name, len(got), len(want), _first_diff(np.frombuffer(got, np.uint8), np.frombuffer(want, np.uint8)))
+
+
+def test_deflate_fast_many_phases(monkeypatch):
+    # the candidate lists are made W positions at a time to fit a fixed workspace; the walk's state (position, token count,
+    # the 32 KiB insertion bitmap, a long match in flight) is parked in memory in between: W = 256 here
+    monkeypatch.setenv('MTS_FAST_LIST_BYTES', '1')
+    cases = _fast_edge_cases()
     for level in (1, 2, 3):
-        assert hip.debug_deflate(data, level) == zlib.compress(data, level)
+        for data in (ar1_stream(6000, 16, seed=9), cases['zeros_100k'][:70000], cases['long_runs_then_probe'], cases['rand3_64k'],
+                     cases['period_max_dist'][:70000]):
+            assert hip.debug_deflate(data, level) == zlib.compress(data, level), (level, len(data))
 
 
 def test_deflate_fast_sort_guard(monkeypatch):

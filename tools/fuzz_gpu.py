@@ -3,7 +3,7 @@ points, every chunk compared byte for byte with the reference's statement sequen
 compressed bytes, status, decoded bytes).  Found the pass-B staging bug on run-length streams.
 
     python tools/fuzz_gpu.py [seed] [seconds]          (FUZZ_LEVELS=1: zlib levels 4..9 instead of 6 only; FUZZ_LEVELS=2: levels 1..9,
-                                                        i.e. deflate_fast too; MTS_FAST_OPEN_ROUNDS=0 runs its windowed rounds alone)
+                                                        i.e. deflate_fast too; MTS_FAST_LIST_BYTES=1 makes its candidate lists 256 positions at a time)
 """
 import os
 import sys
