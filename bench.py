@@ -16,7 +16,7 @@ The JSON line carries, next to the contract's keys:
   cpu_baseline         the reference's ThreadPool path restated (numpy + stdlib zlib: the oracle) on ALL host cores and on 1
   extras (N = 1 only, after the timed region; --no-extras skips them)
     random_read        BASELINE configs[2]: a 600 s file, 1000 windows of 1 s at splitmix(i) starts through Reader[a:b]
-    level_sweep        BASELINE configs[4] shape (1024 ch, 0.25 s chunks) at levels 1, 6, 9: ratio and GB/s
+    level_sweep        BASELINE configs[4] shape (1024 ch, 0.25 s chunks) at levels 1, 2, 3, 6, 9: ratio and GB/s
 """
 import argparse
 import ctypes as C
@@ -188,9 +188,9 @@ def extra_random_read(torch, hip, L, dev, seconds, n_windows=1000):
             'reader': 'Reader[a:b] through the decoded-chunk cache in HBM (MTSCOMP_DEVICE_CACHE_GB, default 32); pread + H2D + decode on first touch, one D2H of the rows after'}
 
 
-def extra_level_sweep(torch, hip, L, dev, seconds=60, levels=(1, 6, 9)):
+def extra_level_sweep(torch, hip, L, dev, seconds=60, levels=(1, 2, 3, 6, 9)):
     """BASELINE configs[4] shape: 1024 ch @ 30 kHz, chunk = 0.25 s (7500 rows); `seconds` s of it, compressed on the device at
-    levels 1 (deflate_fast), 6 and 9; chunk 0 of every level checked against stdlib zlib."""
+    levels 1, 2, 3 (deflate_fast), 6 and 9; chunk 0 of every level checked against stdlib zlib."""
     import zlib
     from oracle import oracle as O
     nc, rows = 1024, 7500
@@ -212,7 +212,7 @@ def extra_level_sweep(torch, hip, L, dev, seconds=60, levels=(1, 6, 9)):
     out = {}
     for level in levels:
         best = None
-        for rep in range(2 if level >= 4 else 1):
+        for rep in range(2):                                  # (the first call at a level also allocates its workspace)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             rc = L.mts_dev_compress_chunks(dev, None, C.c_void_p(raw.data_ptr()), nc, 2, lp(bounds), n, flags, level, C.c_void_p(cbuf.data_ptr()),

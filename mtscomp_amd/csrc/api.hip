@@ -74,7 +74,9 @@ struct Engine {
     hipStream_t own = nullptr;
     // compress workspace
     DBuf stream, sort_a, sort_b, tables, tokens, marks, segbuf, blk, blkcodes, blkhdr, desc, adler, misc;
-    DBuf fast_lists, fast_state;         // levels 1..3: candidate lists of one phase, per-chunk state of the in-order walk
+    DBuf fast_lists, fast_state;         // levels 1..3: candidate lists of two phases, per-chunk state of the in-order walk
+    hipStream_t fast_st = nullptr;       // ... and the stream the lists are made on, with its events (lists ready x2, lists read x2, inputs ready)
+    hipEvent_t fast_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // host-API staging
     DBuf h_in, h_out;
     // pinned pieces the host entry points move user memory through (pageable memory crosses the bus at a fraction of the
@@ -105,6 +107,13 @@ struct Engine {
         ev_ok = true;
         return MTS_OK;
     }
+    int init_fast_streams()
+    {
+        if (fast_st) return MTS_OK;
+        MTS_HIP(hipStreamCreateWithFlags(&fast_st, hipStreamNonBlocking));
+        for (auto &e : fast_ev) MTS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return MTS_OK;
+    }
     void t_begin(hipStream_t st) { n_stage = 0; (void)hipEventRecord(ev[0], st); }
     void t_mark(hipStream_t st, const char *name)
     {
@@ -130,6 +139,9 @@ struct Engine {
         for (int k = 0; k < 2; k++) { if (pin[k]) (void)hipHostFree(pin[k]); pin[k] = nullptr; if (pin_ev[k]) (void)hipEventDestroy(pin_ev[k]); pin_ev[k] = nullptr; }
         if (copy_st) (void)hipStreamDestroy(copy_st);
         copy_st = nullptr;
+        if (fast_st) (void)hipStreamDestroy(fast_st);
+        fast_st = nullptr;
+        for (auto &e : fast_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     }
 };
 
@@ -331,15 +343,30 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
             const u64 K = (u64)fast_list_rows(level);
             const char *be = getenv("MTS_FAST_LIST_BYTES");      // (tests: a tiny budget = many phases)
             const u64 budget = be ? strtoull(be, nullptr, 10) : (u64)8 << 30;
-            u64 W = budget / ((u64)n_chunks * K * 4) / 256 * 256;
+            // two list buffers: the lists of phase k + 1 are made on a second stream while phase k is walked (the walk keeps
+            // one wave per chunk busy, the rest of the device is free)
+            u64 W = budget / 2 / ((u64)n_chunks * K * 4) / 256 * 256;
             if (W < 256) W = 256;
             if (W > align_up(max_n, 256)) W = align_up(max_n, 256);
+            if (W > 1024 && W * 8 > max_n) W = align_up((max_n + 7) / 8, 256);      // at least 8 phases: only the first lists are waited for
             if (max_n) {
-                if ((rc = E.fast_lists.ensure((size_t)n_chunks * W * K * 4))) return rc;
+                const size_t list_words = (size_t)n_chunks * W * K;
+                if ((rc = E.fast_lists.ensure(2 * list_words * 4))) return rc;
                 if ((rc = E.fast_state.ensure(fast_seq_state_bytes(n_chunks)))) return rc;
-                for (u64 ph = 0; ph * W < max_n; ph++)
-                    if ((rc = launch_fast_phase(st, d_stream, d_chunks, d_tiles, srt_k, d_inv, E.fast_lists.as<u32>(), (u32)W, (u32)ph, E.fast_state.p, n_chunks,
-                                                level, cfg, d_tokens, d_blk_in_start, d_cout))) return rc;
+                if ((rc = E.init_fast_streams())) return rc;
+                u32 *lists[2] = {E.fast_lists.as<u32>(), E.fast_lists.as<u32>() + list_words};
+                MTS_HIP(hipEventRecord(E.fast_ev[4], st));       // the sort and the inverse map
+                MTS_HIP(hipStreamWaitEvent(E.fast_st, E.fast_ev[4], 0));
+                for (u64 ph = 0; ph * W < max_n; ph++) {
+                    const int b = (int)(ph & 1);
+                    if (ph >= 2) MTS_HIP(hipStreamWaitEvent(E.fast_st, E.fast_ev[2 + b], 0));      // the walk that read this buffer
+                    if ((rc = launch_fast_cands(E.fast_st, d_stream, d_chunks, d_tiles, srt_k, d_inv, lists[b], (u32)W, (u32)ph, n_chunks, level, cfg))) return rc;
+                    MTS_HIP(hipEventRecord(E.fast_ev[b], E.fast_st));
+                    MTS_HIP(hipStreamWaitEvent(st, E.fast_ev[b], 0));
+                    if ((rc = launch_fast_seq(st, d_stream, d_chunks, d_tiles, srt_k, d_inv, lists[b], (u32)W, (u32)ph, E.fast_state.p, n_chunks, level, cfg,
+                                              d_tokens, d_blk_in_start, d_cout))) return rc;
+                    MTS_HIP(hipEventRecord(E.fast_ev[2 + b], st));
+                }
             }
             int hflags[2] = {0, 0};                              // {-, sort-order flag}
             MTS_HIP(hipMemcpyAsync(hflags, pb.changed, 8, hipMemcpyDeviceToHost, st));

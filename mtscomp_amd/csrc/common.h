@@ -169,9 +169,11 @@ int launch_inverse_map(hipStream_t st, const u8 *d_stream, const TileDesc *d_til
 size_t fast_seq_state_bytes(int n_chunks);
 int fast_list_len(int level);           // members per position in the candidate lists of levels 1..3
 int fast_list_rows(int level);          // words per position (members + masks + header)
-int launch_fast_phase(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, const u32 *d_inv,
-                      u32 *d_lists, u32 W, u32 phase, void *d_state, int n_chunks, int level, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start,
-                      ChunkOut *d_cout);
+int launch_fast_cands(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, const u32 *d_inv,
+                      u32 *d_lists, u32 W, u32 phase, int n_chunks, int level, LevelCfg cfg);
+int launch_fast_seq(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, const u32 *d_inv,
+                    const u32 *d_lists, u32 W, u32 phase, void *d_state, int n_chunks, int level, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start,
+                    ChunkOut *d_cout);
 int launch_block_layout(hipStream_t st, const ChunkDesc *d_chunks, int n_chunks, BlockRec *d_blocks,
                         ChunkOut *d_cout, const u64 *d_adler_acc);
 int launch_block_pack(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const u32 *d_blk_chunk,

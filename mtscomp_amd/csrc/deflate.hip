@@ -1579,7 +1579,7 @@ __global__ __launch_bounds__(64) void k_fast_seq(const u8 *__restrict__ stream, 
         // the window's insertion bits
         const u64 ins = ~nonins;
         if (lane == 0) { ring[(ws >> 5) & 1023] = (u32)ins; ring[((ws >> 5) + 1) & 1023] = (u32)(ins >> 32); }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();                        // (one wave: its LDS accesses are in order; no s_barrier, no wait for the stores in flight)
         // its tokens, side by side
         if (B) {
             const bool base = (B >> lane) & 1;
@@ -1604,25 +1604,6 @@ size_t fast_seq_state_bytes(int n_chunks) { return sizeof(FastSeqState) * (size_
 int fast_list_len(int level) { return level <= 1 ? 12 : level == 2 ? 24 : 48; }
 int fast_list_rows(int level) { const int K = fast_list_len(level); return K + (K > 32 ? 3 : 2); }
 
-int launch_fast_phase(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, const u32 *d_inv,
-                      u32 *d_tab, u32 W, u32 phase, void *d_state, int n_chunks, int level, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start,
-                      ChunkOut *d_cout)
-{
-    if (n_chunks == 0) return MTS_OK;
-    FastSeqState *S = (FastSeqState *)d_state;
-    const dim3 gc(W / 256, n_chunks);
-#define MTS_FAST_PHASE(K)                                                                                                                      \
-    hipLaunchKernelGGL(k_fast_cands<K>, gc, dim3(256), 0, st, d_stream, d_chunks, d_tiles, d_sorted, d_inv, d_tab, W, phase, cfg);                 \
-    hipLaunchKernelGGL(k_fast_seq<K>, dim3(n_chunks), dim3(64), 0, st, d_stream, d_chunks, d_tiles, d_sorted, d_inv, d_tab, W, phase, S, cfg,  \
-                       d_tokens, d_blk_in_start, d_cout)
-    const int K = fast_list_len(level);
-    if (K == 12) { MTS_FAST_PHASE(12); } else if (K == 24) { MTS_FAST_PHASE(24); } else { MTS_FAST_PHASE(48); }
-#undef MTS_FAST_PHASE
-    MTS_HIP(hipGetLastError());
-    return MTS_OK;
-}
-
-
 int launch_inverse_map(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, u32 *d_inv, u32 *d_flags)
 {
     if (n_tiles == 0) return MTS_OK;
@@ -1630,6 +1611,36 @@ int launch_inverse_map(hipStream_t st, const u8 *d_stream, const TileDesc *d_til
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
+
+int launch_fast_cands(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, const u32 *d_inv,
+                      u32 *d_lists, u32 W, u32 phase, int n_chunks, int level, LevelCfg cfg)
+{
+    if (n_chunks == 0) return MTS_OK;
+    const dim3 gc(W / 256, n_chunks);
+    const int K = fast_list_len(level);
+#define MTS_FAST_CANDS(K) hipLaunchKernelGGL(k_fast_cands<K>, gc, dim3(256), 0, st, d_stream, d_chunks, d_tiles, d_sorted, d_inv, d_lists, W, phase, cfg)
+    if (K == 12) { MTS_FAST_CANDS(12); } else if (K == 24) { MTS_FAST_CANDS(24); } else { MTS_FAST_CANDS(48); }
+#undef MTS_FAST_CANDS
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
+int launch_fast_seq(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chunks, const TileDesc *d_tiles, const u32 *d_sorted, const u32 *d_inv,
+                    const u32 *d_lists, u32 W, u32 phase, void *d_state, int n_chunks, int level, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start,
+                    ChunkOut *d_cout)
+{
+    if (n_chunks == 0) return MTS_OK;
+    FastSeqState *S = (FastSeqState *)d_state;
+    const int K = fast_list_len(level);
+#define MTS_FAST_SEQ(K)                                                                                                                        \
+    hipLaunchKernelGGL(k_fast_seq<K>, dim3(n_chunks), dim3(64), 0, st, d_stream, d_chunks, d_tiles, d_sorted, d_inv, d_lists, W, phase, S, cfg, \
+                       d_tokens, d_blk_in_start, d_cout)
+    if (K == 12) { MTS_FAST_SEQ(12); } else if (K == 24) { MTS_FAST_SEQ(24); } else { MTS_FAST_SEQ(48); }
+#undef MTS_FAST_SEQ
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
 // ================================================================================================
 // T: per-block Huffman trees (zlib trees.c, exact) -- flush_block() in the oracle
 // ================================================================================================
