@@ -520,7 +520,9 @@ static int staged_h2d(Engine &E, void *d_dst, const void *src, size_t n)
     return MTS_OK;
 }
 
-// split a call into sub-batches that fit the workspace budget (stream bytes per sub-batch)
+// split a call into sub-batches that fit the workspace budget (stream bytes per sub-batch) and the grid (several kernels
+// take the chunk index from blockIdx.y, which ends at 65535)
+constexpr int MAX_BATCH_CHUNKS = 32768;
 static size_t batch_budget_bytes()
 {
     const char *e = getenv("MTS_BATCH_BYTES");               // read per call: tests force small sub-batches with it
@@ -547,7 +549,7 @@ static int dev_compress(Engine &E, hipStream_t st, const void *d_raw, int nc, in
         size_t acc = 0;
         while (j < n_chunks) {
             const size_t n = (size_t)(bounds[j + 1] - bounds[j]) * row_bytes;
-            if (j > i && acc + n > budget) break;
+            if (j > i && (acc + n > budget || j - i >= MAX_BATCH_CHUNKS)) break;
             acc += n; j++;
         }
         const u8 *raw = (const u8 *)d_raw + (u64)(bounds[i] - bounds[0]) * row_bytes;
@@ -648,7 +650,7 @@ static int dev_decompress(Engine &E, hipStream_t st, const u8 *d_cdata, const lo
         size_t acc = 0;
         while (j < n_chunks) {
             const size_t n = (size_t)n_rows[j] * row_bytes;
-            if (j > i && acc + n > budget) break;
+            if (j > i && (acc + n > budget || j - i >= MAX_BATCH_CHUNKS)) break;
             acc += n; j++;
         }
         int rc = decompress_batch(E, st, d_cdata, c_off + i, c_len + i, n_rows + i, j - i, nc, sz, flags, d_out, out_off + i,

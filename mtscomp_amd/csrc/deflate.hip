@@ -1236,18 +1236,20 @@ int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables,
 // (Round 2 first had speculative walks of 1024-position segments iterated to the fixed point: wrong guesses about the
 // insertion pattern healed in ~450 rounds at levels 1 and 3 and not at all at level 2 on the 385-channel workload.)
 // (also checks what the walks rely on -- positions ascending inside a hash run -- like k_match5 does for the other levels)
-__global__ __launch_bounds__(256) void k_inverse_map(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, const u32 *__restrict__ sorted,
-                                                     u32 *__restrict__ inv, u32 *__restrict__ flags)
+__global__ __launch_bounds__(256) void k_inverse_map(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles,
+                                                     const u32 *__restrict__ sorted, u32 *__restrict__ inv, u32 *__restrict__ flags)
 {
-    const TileDesc td = tiles[blockIdx.y];
-    const u32 halo = td.a - td.w;
-    const u8 *s = stream + td.stream_off + td.w;
-    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < td.wlen; i += gridDim.x * 256) {
-        const u32 rel = sorted[td.sorted_off + i] & REL_MASK;
-        if (rel >= halo) inv[td.stream_off + td.w + rel] = i;
-        if (i > 0) {
-            const u32 prev = sorted[td.sorted_off + i - 1] & REL_MASK;
-            if (prev >= rel && hash_of(gld_u32_unaligned(s, prev)) == hash_of(gld_u32_unaligned(s, rel))) atomicOr(flags, 1u);
+    for (int ti = blockIdx.y; ti < n_tiles; ti += gridDim.y) {
+        const TileDesc td = tiles[ti];
+        const u32 halo = td.a - td.w;
+        const u8 *s = stream + td.stream_off + td.w;
+        for (u32 i = blockIdx.x * 256 + threadIdx.x; i < td.wlen; i += gridDim.x * 256) {
+            const u32 rel = sorted[td.sorted_off + i] & REL_MASK;
+            if (rel >= halo) inv[td.stream_off + td.w + rel] = i;
+            if (i > 0) {
+                const u32 prev = sorted[td.sorted_off + i - 1] & REL_MASK;
+                if (prev >= rel && hash_of(gld_u32_unaligned(s, prev)) == hash_of(gld_u32_unaligned(s, rel))) atomicOr(flags, 1u);
+            }
         }
     }
 }
@@ -1297,9 +1299,10 @@ __global__ __launch_bounds__(256) void k_fast_cands(const u8 *__restrict__ strea
                                                     LevelCfg cfg)
 {
     constexpr int R = fq_rows<K>();
-    const u32 ci = blockIdx.y;
+    const u32 bpc = W / 256;                                      // blocks per chunk (a 1-D grid: any number of chunks)
+    const u32 ci = blockIdx.x / bpc;
     const ChunkDesc ch = chunks[ci];
-    const u32 pl = blockIdx.x * 256 + threadIdx.x;
+    const u32 pl = (blockIdx.x - ci * bpc) * 256 + threadIdx.x;
     const u64 p64 = (u64)phase * W + pl;
     if (p64 >= ch.n) return;
     const u32 p = (u32)p64, n = ch.n, look = n - p, lane = pl & 63;
@@ -1607,7 +1610,7 @@ int fast_list_rows(int level) { const int K = fast_list_len(level); return K + (
 int launch_inverse_map(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, u32 *d_inv, u32 *d_flags)
 {
     if (n_tiles == 0) return MTS_OK;
-    hipLaunchKernelGGL(k_inverse_map, dim3(64, n_tiles), dim3(256), 0, st, d_stream, d_tiles, d_sorted, d_inv, d_flags);
+    hipLaunchKernelGGL(k_inverse_map, dim3(64, n_tiles < 65535 ? n_tiles : 65535), dim3(256), 0, st, d_stream, d_tiles, n_tiles, d_sorted, d_inv, d_flags);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
@@ -1616,7 +1619,7 @@ int launch_fast_cands(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chu
                       u32 *d_lists, u32 W, u32 phase, int n_chunks, int level, LevelCfg cfg)
 {
     if (n_chunks == 0) return MTS_OK;
-    const dim3 gc(W / 256, n_chunks);
+    const dim3 gc((W / 256) * (u32)n_chunks);                    // (bounded by the list workspace: W * n_chunks * rows * 4 bytes)
     const int K = fast_list_len(level);
 #define MTS_FAST_CANDS(K) hipLaunchKernelGGL(k_fast_cands<K>, gc, dim3(256), 0, st, d_stream, d_chunks, d_tiles, d_sorted, d_inv, d_lists, W, phase, cfg)
     if (K == 12) { MTS_FAST_CANDS(12); } else if (K == 24) { MTS_FAST_CANDS(24); } else { MTS_FAST_CANDS(48); }

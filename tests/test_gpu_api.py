@@ -212,6 +212,24 @@ def test_wide_batch_with_tiny_chunks():
     assert st == [0] * 5 and all(np.array_equal(arrs[i], x[b[i]:b[i + 1]]) for i in range(5))
 
 
+def test_more_chunks_than_a_grid_dimension():
+    """70 000 chunks of one row in one call: several kernels take the chunk from blockIdx.y (at most 65 535), so the entry
+    points split such a call; levels 6 and 1, and back."""
+    import zlib
+    n = 70000
+    x = synth_int16(0, n, 3, 4)
+    b = np.arange(n + 1)
+    flags = hip.make_flags(True, False, 'F')
+    for level in (6, 1):
+        z = hip.compress_chunks(x, b, flags, level)
+        assert len(z) == n
+        for i in (0, 1, 32767, 32768, 65535, 65536, n - 1):
+            assert z[i] == zlib.compress(x[i:i + 1].tobytes(), level), (level, i)
+        st, arrs = hip.decompress_chunks(z, [1] * n, 3, 'int16', flags)
+        assert not any(st)
+        assert np.array_equal(np.concatenate([a for a in arrs]), x)
+
+
 def test_dependent_copy_chains_do_not_starve_the_resolver():
     """int64 items of small magnitude, no differencing: the stream is literal + 7-byte match at distance 8, each match
     reading what the one before it wrote.  Fourteen resolver waves polling the LDS for their sources used to leave the
