@@ -15,9 +15,9 @@
 //                      first, only the candidates its looked-up filter masks let through, and records
 //                      the best match within the full budget and within budget>>2 (the
 //                      prev_length >= good_match case).  The workgroups of one XCD share a tile (its window stays
-//                      in that XCD's L2).  k_match4: budgets > 128, SWAR key compares.
-//   F  k_fast_*        levels 1..3: greedy walks that skip the positions the parse did not insert into the chains (one
-//                      insertion bit per position, written by the walks), rounds to the unique fixed point.
+//                      in that XCD's L2).  k_match6: budgets > 128, the same masks from a ring the workgroup shares.
+//   F  k_fast_*        levels 1..3 (deflate_fast: the chains depend on the parse): per position the older members of its run
+//                      with their match lengths, all at once; then one wave per chunk walks the chunk in order.
 //   P  k_parse_*       lazy-evaluation state machine over the tables; one lane per SEG positions,
 //                      speculative entry, iterated to a fixed point (walks re-converge after a few
 //                      tokens); then count + emit tokens (LDS rows, written out coalesced).
@@ -231,35 +231,57 @@ __global__ __launch_bounds__(1024) void k_probe_lds_order(u32 *bad, int iters)
     if (nbad) atomicAdd(bad, nbad);
 }
 
-// third phase: sorted keys -> number of same-hash predecessors of each slot (the chain behind it), capped
+// third phase: sorted keys -> number of same-hash predecessors of each slot (the chain behind it), capped.
+// Every wave takes one contiguous part of the sorted order and scans it alone (index + 1 of the latest run start, carried in
+// a register); the slots before a part's first run start belong to a run that began in an earlier part: they are filled in
+// after the one barrier that tells every wave where the parts before it left off.
 __device__ __forceinline__ void chain_lengths(const u8 *__restrict__ s, const u32 *__restrict__ sk, u16 *__restrict__ nb, u32 wlen, u32 *wmax,
                                               u32 *carry_p, u32 *__restrict__ flags)
 {
+    (void)carry_p;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) *carry_p = 0;
-    __syncthreads();
-    for (u32 base = 0; base < wlen; base += SORT_NT) {
-        const u32 i = base + threadIdx.x;
-        const bool act = i < wlen;
-        // (the keys only hold 7 hash bits: the hash is recomputed from the bytes; only budgets > 128 come here)
-        const u32 pos = act ? sk[i] & REL_MASK : 0, pos_prev = (act && i > 0) ? sk[i - 1] & REL_MASK : 0;
-        const u32 h = act ? hash_of(gld_u32_unaligned(s, pos)) : 0xffffu;
-        const u32 hprev = (act && i > 0) ? hash_of(gld_u32_unaligned(s, pos_prev)) : 0xfffeu;
-        if (act && h == hprev && pos <= pos_prev) atomicOr(flags, 1u);      // a run out of position order (see k_match5)
-        // bucket start index + 1 where a bucket starts here, else 0; running max = start of my bucket
-        u32 v = (act && h != hprev) ? i + 1 : 0;
+    const u32 per = (((wlen + SORT_WAVES - 1) / SORT_WAVES) + 63) & ~63u;
+    const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
+    u32 carry = 0, first = end;
+    // the slot before the one lane 0 looks at (its position and hash): the neighbour lane's values inside a step, carried here
+    // from step to step; only a part's first slot costs a fetch
+    u32 last_pos = 0, last_h = 0xfffeu;
+    if (beg > 0 && beg < end) { last_pos = sk[beg - 1] & REL_MASK; last_h = hash_of(gld_u32_unaligned(s, last_pos)); }
+    constexpr int CL_DEPTH = 4;                                     // steps whose (random) byte loads are in flight together
+    for (u32 base0 = beg; base0 < end; base0 += CL_DEPTH * 64) {
+        u32 posv[CL_DEPTH], hv[CL_DEPTH];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(v, off, 64); if (lane >= off) v = max(v, y); }
-        if (lane == 63) wmax[wave] = v;
-        __syncthreads();
-        u32 pre = *carry_p;
-        for (int w = 0; w < wave; w++) pre = max(pre, wmax[w]);
-        v = max(v, pre);
-        __syncthreads();
-        if (threadIdx.x == SORT_NT - 1) *carry_p = v;
-        if (act) { const u32 c = i + 1 - v; nb[i] = (u16)(c < 65535u ? c : 65535u); }
-        __syncthreads();
+        for (int k = 0; k < CL_DEPTH; k++) { const u32 i = base0 + k * 64 + lane; posv[k] = i < end ? sk[i] & REL_MASK : 0; }
+        // (the keys only hold 7 hash bits: the hash is recomputed from the bytes; only budgets > 128 come here)
+#pragma unroll
+        for (int k = 0; k < CL_DEPTH; k++) hv[k] = hash_of(gld_u32_unaligned(s, posv[k]));
+#pragma unroll
+        for (int k = 0; k < CL_DEPTH; k++) {
+            const u32 base = base0 + k * 64;
+            if (base >= end) break;                                 // (uniform)
+            const u32 i = base + lane;
+            const bool act = i < end;
+            const u32 pos = posv[k];
+            const u32 h = act ? hv[k] : 0xffffu;
+            u32 pos_prev = __shfl_up(pos, 1, 64), hprev = __shfl_up(h, 1, 64);
+            if (lane == 0) { pos_prev = last_pos; hprev = last_h; }
+            last_pos = (u32)__builtin_amdgcn_readlane((int)pos, 63); last_h = (u32)__builtin_amdgcn_readlane((int)h, 63);
+            if (act && h == hprev && pos <= pos_prev) atomicOr(flags, 1u);      // a run out of position order (see k_match5)
+            // run start index + 1 where a run starts here, else 0; running max = start of my run
+            u32 v = (act && h != hprev) ? i + 1 : 0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(v, off, 64); if (lane >= off) v = max(v, y); }
+            v = max(v, carry);
+            if (carry == 0) { const u64 m = __ballot(v != 0); if (m) first = base + (u32)__builtin_ctzll(m); }
+            carry = (u32)__builtin_amdgcn_readlane((int)v, 63);
+            if (act && v) { const u32 c = i + 1 - v; nb[i] = (u16)(c < 65535u ? c : 65535u); }
+        }
     }
+    wmax[wave] = carry;
+    __syncthreads();
+    u32 pre = 0;
+    for (int w = 0; w < wave; w++) pre = max(pre, wmax[w]);
+    for (u32 i = beg + lane; i < first; i += 64) { const u32 c = i + 1 - pre; nb[i] = (u16)(c < 65535u ? c : 65535u); }
 }
 
 __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
@@ -412,187 +434,13 @@ __device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
 
 // ------------------------------------------------------------------------------------------------
 // The walk is filtered: it produces exactly what the plain newest-first walk produces, scoring far fewer candidates:
-// a candidate can only replace the current best if it can be LONGER than it.  Its length is bounded from
-// the two byte keys alone: byte 3 differs -> at most 3, byte 3 equal but the (3,4) mix differs -> at most
-// 4.  So once best >= 3 only byte-3-equal candidates are scored, once best >= 4 only mix-equal ones; all
-// others are skipped -- which changes nothing, because zlib's walk would have compared and rejected them
-// (they still count against the chain budget: budgets are positions in the run, not candidates scored).
-// The keys of 8 candidates are tested per LDS read with SWAR byte compares.
+// a candidate can only replace the current best if it can be LONGER than it, so once the best length is L only candidates
+// whose first L + 1 bytes may equal the position's own are looked at; all others are skipped -- which changes nothing,
+// because zlib's walk would have compared and rejected them (they still count against the chain budget: budgets are
+// positions in the run, not candidates scored).
 // ------------------------------------------------------------------------------------------------
-constexpr int ST4_N = 256;                          // slots staged per wave (ring)
-constexpr int ST4_BYTES = ST4_N * 8 + 2 * ST4_N;    // entries + two key arrays
-constexpr int MATCH4_LDS = 16 * ST4_BYTES;
-
-// bit k of the result = byte k of v is zero (k = 0..3)
-__device__ __forceinline__ u32 zero_bytes4(u32 v)
-{
-    const u32 t = ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v | 0x7f7f7f7fu;      // bit 7 of a byte clear iff the byte is 0
-    return ((((~t) >> 7) & 0x01010101u) * 0x01020408u) >> 24;
-}
-__device__ __forceinline__ u32 zero_bytes8(u64 v) { return zero_bytes4((u32)v) | (zero_bytes4((u32)(v >> 32)) << 4); }
-// bits [lo, hi] (inclusive, may lie outside 0..31) of a 32-bit word
-__device__ __forceinline__ u32 bit_range(int lo, int hi)
-{
-    if (hi < 0 || lo > 31 || hi < lo) return 0;
-    const u32 l = lo < 0 ? 0 : (u32)lo, h = hi > 31 ? 31 : (u32)hi;
-    return (0xffffffffu >> (31 - h)) & (0xffffffffu << l);
-}
-
-// k_match4: chain budgets > 128 (levels 7..9).  A wave takes every 16th group and restages 192 slots per 128
-// candidates; the filter masks come from SWAR compares of two byte keys per candidate.  (Budgets <= 128 go to
-// k_match5 below, which keeps a sliding ring per wave and looks the masks up.)
-constexpr bool SLIDE = false;
-__global__ __launch_bounds__(1024, 2) void k_match4(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
-                                                    const u32 *__restrict__ sorted, const u16 *__restrict__ sorted_nb,
-                                                    uint2 *__restrict__ tables, LevelCfg cfg)
-{
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const TileDesc td = tiles[blockIdx.x];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    u8 *wbase = smem + wave * ST4_BYTES;
-    const u8 *gwin = stream + td.stream_off + td.w;
-    auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
-    u64 *SE = (u64 *)wbase;
-    u64 *SK3 = (u64 *)(wbase + ST4_N * 8);
-    u64 *SK34 = (u64 *)(wbase + ST4_N * 8 + ST4_N);
-    u8 *SK3b = (u8 *)SK3, *SK34b = (u8 *)SK34;
-    uint2 *T = tables + td.stream_off;
-    if (threadIdx.x < 2) {
-        const u32 hashed_end = td.w + td.wlen;
-        const u32 p = hashed_end + threadIdx.x;
-        if (p >= td.a && p < td.own_end) T[p] = table_entry(0, 0, stream[td.stream_off + p]);
-    }
-    if (td.wlen == 0) return;
-    const u32 *sk = sorted + td.sorted_off;
-    const u16 *snb = sorted_nb + td.sorted_off;
-    const u32 wlen = td.wlen, n = td.n;
-    const u32 ngroups = (wlen + 63) / 64;
-    const u32 halo = td.a - td.w;
-    const u32 chain = (u32)cfg.chain, qchain = (u32)cfg.chain >> 2;
-    const int r8 = lane & 7, g8 = lane >> 3;
-    // slot -> position -> its 8 bytes -> entry + the two filter keys, written to stage index `at`
-    auto build = [&](int idx, int at) -> u64 {
-        u64 ce = ~0ull;
-        u32 k3 = 0, k34 = 0;
-        if (idx >= 0 && (u32)idx < wlen) {
-            const u32 rc = sk[idx] & REL_MASK;
-            const u32 lo = wread(rc), hi = wread(rc + 4);
-            ce = make_entry(rc, lo, hi);
-            k3 = lo >> 24;
-            k34 = ((hi & 0xff) ^ ((k3 << 3) | (k3 >> 5))) & 0xff;
-        }
-        SE[at] = ce;
-        SK3b[at] = (u8)k3;
-        SK34b[at] = (u8)k34;
-        return ce;
-    };
-    const u32 gpw = SLIDE ? (ngroups + 15) / 16 : 1;
-    const u32 g_begin = SLIDE ? wave * gpw : wave, g_end = SLIDE ? min(ngroups, g_begin + gpw) : ngroups;
-    const u32 g_step = SLIDE ? 1 : 16;
-    if (SLIDE && g_begin < g_end) {
-        const int i0 = (int)g_begin * 64;
-        build(i0 - 128 + lane, (i0 - 128 + lane) & 255);
-        build(i0 - 64 + lane, (i0 - 64 + lane) & 255);
-    }
-    for (u32 g = g_begin; g < g_end; g += g_step) {
-        const u32 i0 = g * 64, i = i0 + lane;
-        u64 e;
-        u32 own_lo = 0;
-        if (SLIDE) { __builtin_amdgcn_wave_barrier(); e = build((int)i, (int)(i & 255)); __builtin_amdgcn_wave_barrier(); }
-        else { const u32 rp = i < wlen ? sk[i] & REL_MASK : 0; own_lo = wread(rp); e = make_entry(rp, own_lo, wread(rp + 4)); }
-        const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
-        const u32 rel_p = e0 & REL_MASK;
-        const bool own = i < wlen && rel_p >= halo;
-        if (!__any(own)) continue;
-        const u32 p_abs = td.w + rel_p;
-        const u32 look = n - p_abs;
-        const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
-        const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
-        const int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
-        const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
-        u32 nbv = own ? (u32)snb[i] : 0;
-        nbv = nbv < chain ? nbv : chain;
-        const u32 rep3 = (e1 & 0xff) * 0x01010101u;
-        const u32 b3 = e1 & 0xff, b4 = (e1 >> 8) & 0xff;
-        const u32 rep34 = ((b4 ^ ((b3 << 3) | (b3 >> 5))) & 0xff) * 0x01010101u;
-        u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
-        bool stop = false, qtaken = false;
-        const u32 jmax = __reduce_max_sync_u32(nbv);
-        for (u32 jbase = 0; jbase < jmax; jbase += 128) {
-            // the candidates of this block live in slots sb .. sb + 191
-            const int sb = (int)i0 - (int)jbase - 128;
-            if (!SLIDE) {
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int k = 0; k < 3; k++) build(sb + lane + 64 * k, lane + 64 * k);
-                __builtin_amdgcn_wave_barrier();
-            }
-            const int gbase = SLIDE ? (sb >> 3) : 0;                         // 8-slot key group of slot sb in the stage
-            const u32 nbl = nbv > jbase ? (nbv - jbase < 128 ? nbv - jbase : 128) : 0;      // candidates of this lane in the block
-            // candidate jj (1 = newest) of this lane sits in slot sb + 128 + lane - jj = sb + 8*g8 + m with
-            // m = 128 + r8 - jj; the masks below are indexed by m (5 words), scanned from high m to low
-            const int lo_m = 128 + r8 - (int)nbl, hi_m = 127 + r8;
-#pragma unroll
-            for (int w = 4; w >= 0; w--) {
-                const u32 V = bit_range(lo_m - 32 * w, hi_m - 32 * w);
-                u32 M8 = 0, M5 = 0;
-#pragma unroll
-                for (int tt = 0; tt < 4; tt++) {
-                    const int t = 4 * w + tt;
-                    if (t > 16) continue;
-                    const int G = SLIDE ? ((gbase + g8 + t) & 31) : (g8 + t);
-                    const u64 a3 = SK3[G], a34 = SK34[G];
-                    const u32 z3 = zero_bytes8(a3 ^ ((u64)rep3 | ((u64)rep3 << 32)));
-                    const u32 z34 = zero_bytes8(a34 ^ ((u64)rep34 | ((u64)rep34 << 32)));
-                    M8 |= z3 << (8 * tt);
-                    M5 |= (z3 & z34) << (8 * tt);
-                }
-                M8 &= V; M5 &= V;
-                u32 el = stop ? 0 : (best < 3 ? V : best < 4 ? M8 : M5);
-                while (__any(el != 0)) {
-                    if (el) {
-                        const u32 b = 31 - __builtin_clz(el);
-                        el &= ~(1u << b);
-                        const int m = 32 * w + (int)b;
-                        const u32 j = jbase + (u32)(128 + r8 - m);
-                        const u64 c = SE[SLIDE ? ((sb + 8 * g8 + m) & 255) : (8 * g8 + m)];
-                        const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
-                        const u32 rel_c = c0 & REL_MASK;
-                        if (!qtaken && j > qchain) { qbest = best; qdist = bdist; qtaken = true; }
-                        if ((int)rel_c > (j == 1 ? lim1 : limn)) {
-                            const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
-                            if ((x0 & 0x1ff) == 0) {
-                                u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
-                                if (x1 == 0 && (x0 >> 9) == 0) {
-                                    while (len < maxlen) {
-                                        const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
-                                        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
-                                        len += 4;
-                                    }
-                                }
-                                len = len < maxlen ? len : maxlen;
-                                if (len > best) {
-                                    best = len; bdist = rel_p - rel_c;
-                                    if (len >= nice) stop = true;
-                                    // fewer candidates can still win now
-                                    el &= best < 4 ? M8 : M5;
-                                }
-                            }
-                        } else stop = true;                 // out of range: so is everything older
-                        if (stop) el = 0;
-                    }
-                }
-            }
-            if (!__any(!stop && nbv > jbase + 128)) break;
-        }
-        if (!qtaken) { qbest = best; qdist = bdist; }
-        if (own) T[p_abs] = table_entry(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0, own_lo & 0xff);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// k_match5 (chain budget <= 128): the same filtered walk, but the filter masks are not computed by comparing
-// keys -- they are looked up, and they go deeper.  Every wave keeps, next to its 256-slot ring of
+// k_match5 (chain budget <= 128): the filter masks are looked up.  Every wave keeps, next to its 256-slot ring of
 // entries, four tables of 32 rows x 256 bits: row k of table d (d = 4..7) has bit r set iff the slot at
 // ring position r has key_d = k, where key_d is a 5-bit hash of bytes 3 .. d-1 of the slot's string.  A
 // slot entering the ring clears the bits of the slot it replaces and sets its own (8 LDS atomics per 64
@@ -908,6 +756,233 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_match6 (chain budget > 128: levels 7..9): k_match5's looked-up filter masks and walk, block after block of 128
+// candidates, with the chain lengths from the sort (sorted_nb).  The eight waves of a workgroup take eight consecutive groups
+// of 64 slots and go through the blocks together: what their lanes' candidates of block b lie in is 640 consecutive slots of
+// the sorted order, 128 slots older with every block -- ONE ring of 1024 slots per workgroup (entries, bytes 7..12, the bits
+// of the four key tables) into which two waves enter the 128 new slots of the next block (fetched while the current block is
+// walked) while nothing is ever staged twice.  (Round 1's kernel for these levels restaged 192 slots per wave and block and compared two byte
+// keys per candidate with SWAR arithmetic: ~840 instructions per block before the first candidate was looked at.)
+// The quarter-budget result is what the walk holds when it has seen chain/4 candidates: at a block boundary for chain
+// 1024 and 4096, between the two halves of the first block for chain 256.
+// ------------------------------------------------------------------------------------------------
+constexpr int M6_RING = 1024;
+constexpr int M6_ROW_WORDS = M6_RING / 32 + 1;
+constexpr int M6_TABLE = M5_ROWS * M6_ROW_WORDS * 4;
+constexpr int MATCH6_LDS = 2 * M6_RING * 8 + M5_LEVELS * M6_TABLE;      // 33280 per workgroup
+
+__global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, int nsl,
+                                                          const u32 *__restrict__ sorted, const u16 *__restrict__ sorted_nb,
+                                                          uint2 *__restrict__ tables, LevelCfg cfg)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const u32 xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const u32 tile_id = (jb / (u32)nsl) * 8 + xcd, slice = jb % (u32)nsl;
+    if (tile_id >= (u32)n_tiles) return;
+    const TileDesc td = tiles[tile_id];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u8 *gwin = stream + td.stream_off + td.w;
+    auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
+    u64 *SE = (u64 *)smem;
+    u64 *SX = SE + M6_RING;
+    u32 *TB = (u32 *)(smem + 2 * M6_RING * 8);                     // [level][row][32 words + 1]
+    uint2 *T = tables + td.stream_off;
+    if (threadIdx.x < 2 && slice == 0) {
+        const u32 hashed_end = td.w + td.wlen;
+        const u32 p = hashed_end + threadIdx.x;
+        if (p >= td.a && p < td.own_end) T[p] = table_entry(0, 0, stream[td.stream_off + p]);
+    }
+    if (td.wlen == 0) return;
+    const u32 *sk = sorted + td.sorted_off;
+    const u16 *snb = sorted_nb + td.sorted_off;
+    const u32 wlen = td.wlen, n = td.n;
+    const u32 ngroups = (wlen + 63) / 64;
+    const u32 halo = td.a - td.w;
+    const u32 chain = (u32)cfg.chain, qchain = (u32)cfg.chain >> 2;
+    const u32 gpb = ((ngroups + (u32)nsl - 1) / (u32)nsl + M5_WAVES - 1) / M5_WAVES * M5_WAVES;      // groups per workgroup: whole sets of eight
+    const u32 gb_begin = slice * gpb, gb_end = min(ngroups, gb_begin + gpb);
+    if (gb_begin >= gb_end) return;                                // (the whole workgroup)
+    for (int k = threadIdx.x; k < M5_LEVELS * M6_TABLE / 4; k += M5_WAVES * 64) TB[k] = 0;
+    u32 inv[5];                                                    // lane r (< 32) builds row r of the first table: bit j of r clear -> all ones
+#pragma unroll
+    for (int j = 0; j < 5; j++) inv[j] = ((lane >> j) & 1) ? 0u : 0xffffffffu;
+    typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    auto load16 = [&](u32 r, u32 &lo, u32 &hi, u64 &x) {
+        const u8 *q = gwin + (r & ~3u);
+        const u32x4_a4 w = *(const u32x4_a4 *)q;
+        lo = alignbyte(w.y, w.x, r);
+        hi = alignbyte(w.z, w.y, r);
+        const u32 b8 = alignbyte(w.w, w.z, r), b12 = alignbyte(0u, w.w, r) & 0xffu;
+        x = (u64)(hi >> 24) | ((u64)b8 << 8) | ((u64)b12 << 40);                    // bytes 7..12
+    };
+    // a batch = 64 consecutive slots from idx0 (a multiple of 64, possibly negative or beyond the window: no bits then)
+    struct Batch { bool valid; u32 rc, lo, hi; u64 x; };
+    auto fetch = [&](int idx0, Batch &bt) {
+        const int idx = idx0 + lane;
+        bt.valid = idx >= 0 && (u32)idx < wlen;
+        bt.rc = bt.valid ? sk[idx] & REL_MASK : 0;
+        load16(bt.rc, bt.lo, bt.hi, bt.x);
+    };
+    // it takes word pair (idx0 / 32) mod 32 of every table row: cleared and set again (first table from five ballots by the
+    // lane that owns the row, the others by atomic OR, as in k_match5)
+    auto commit = [&](int idx0, const Batch &bt) {
+        const u32 rp = (u32)(idx0 + lane) & (M6_RING - 1), word = rp >> 5, bit = 1u << (rp & 31);
+        const u64 ce = bt.valid ? make_entry(bt.rc, bt.lo, bt.hi) : ~0ull;
+        u32 key[M5_LEVELS];
+        m5_keys((u32)(ce >> 32), key);
+        const u32 wp = word & ~1u;
+        u32 *t1 = TB + (M6_TABLE / 4) + lane * M6_ROW_WORDS + wp;           // rows of tables 1..3 are contiguous: 96 rows
+        t1[0] = 0; t1[1] = 0;
+        if (lane < 32) { t1[64 * M6_ROW_WORDS] = 0; t1[64 * M6_ROW_WORDS + 1] = 0; }
+        const u64 vm = __ballot(bt.valid);
+        u32 m0 = (u32)vm, m1 = (u32)(vm >> 32);
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const u64 B = __ballot((key[0] >> j) & 1);
+            m0 &= (u32)B ^ inv[j]; m1 &= (u32)(B >> 32) ^ inv[j];
+        }
+        if (lane < 32) { u32 *t0 = TB + lane * M6_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int d = 1; d < M5_LEVELS; d++)
+            if (bt.valid) atomicOr(&TB[d * (M6_TABLE / 4) + key[d] * M6_ROW_WORDS + word], bit);
+        SE[rp] = ce;
+        SX[rp] = bt.x;
+    };
+    for (u32 gs = gb_begin; gs < gb_end; gs += M5_WAVES) {
+        const int G0 = (int)gs * 64;
+        const u32 g = gs + (u32)wave;
+        const bool active = g < gb_end;
+        const u32 i = g * 64 + lane;
+        const u32 rp0 = (active && i < wlen) ? sk[i] & REL_MASK : 0;
+        u32 own_lo, own_hi;
+        u64 ex;
+        load16(rp0, own_lo, own_hi, ex);
+        // block 0 needs slots G0 - 128 .. G0 + 511: ten batches, wave v enters batches v and v + 8
+        Batch ba, bb;
+        fetch(G0 - 128 + 64 * wave, ba);
+        if (wave < 2) fetch(G0 - 128 + 64 * (wave + 8), bb);
+        const u64 e = make_entry(rp0, own_lo, own_hi);
+        const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
+        const u32 rel_p = e0 & REL_MASK;
+        const bool own = active && i < wlen && rel_p >= halo;
+        u32 key[M5_LEVELS];
+        m5_keys(e1, key);
+        const u32 p_abs = td.w + rel_p;
+        const u32 look = n - p_abs;
+        const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
+        const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
+        const int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
+        const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
+        u32 nbv = own ? (u32)snb[i] : 0;
+        nbv = nbv < chain ? nbv : chain;
+        u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
+        bool stop = false, qtaken = false;
+        __syncthreads();                                           // the ring is free (first set: the tables are zero)
+        commit(G0 - 128 + 64 * wave, ba);
+        if (wave < 2) commit(G0 - 128 + 64 * (wave + 8), bb);
+        __syncthreads();
+        for (u32 jbase = 0;; jbase += 128) {
+            // the 128 slots the next block adds, on their way while this one is walked
+            if (wave < 2) fetch(G0 - (int)jbase - 256 + 64 * wave, ba);
+            if (jbase == qchain && !qtaken) { qbest = best; qdist = bdist; qtaken = true; }      // (chain / 4 a multiple of 128)
+            const u32 nbl = nbv > jbase ? (nbv - jbase < 128 ? nbv - jbase : 128) : 0;          // candidates of this lane in the block
+            if (__any(nbl != 0 && !stop)) {
+                // candidate jj (1 = newest) of this lane is slot i - jbase - jj: bit 128 - jj of the 128 ring positions from lo
+                const u32 lo = (u32)((int)i - (int)jbase - 128) & (M6_RING - 1), w0 = lo >> 5, sh = lo & 31;
+                u32 V[4], A4[4], A5[4], A6[4], A7[4];                 // V = inside the budget; A_d = V & "first d bytes may match"
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int s = 32 * k + (int)nbl - 96;           // candidates of word k: bits >= 32 - s
+                    V[k] = s <= 0 ? 0u : s >= 32 ? 0xffffffffu : 0xffffffffu << (32 - s);
+                }
+                auto rowmask = [&](const int d, const u32 (&in)[4], u32 (&out)[4]) __attribute__((always_inline)) {
+                    const u32 *row = TB + d * (M6_TABLE / 4) + key[d] * M6_ROW_WORDS;
+                    const u32 W0 = row[w0], W1 = row[(w0 + 1) & 31], W2 = row[(w0 + 2) & 31], W3 = row[(w0 + 3) & 31], W4 = row[(w0 + 4) & 31];
+                    out[0] = in[0] & __builtin_amdgcn_alignbit(W1, W0, sh);
+                    out[1] = in[1] & __builtin_amdgcn_alignbit(W2, W1, sh);
+                    out[2] = in[2] & __builtin_amdgcn_alignbit(W3, W2, sh);
+                    out[3] = in[3] & __builtin_amdgcn_alignbit(W4, W3, sh);
+                };
+                rowmask(0, V, A4);
+                rowmask(1, A4, A5);
+                rowmask(2, A5, A6);
+                rowmask(3, A6, A7);
+                auto pickw = [&](const int w) __attribute__((always_inline)) -> u32 {
+                    u32 r = best >= 3 ? A4[w] : V[w];
+                    asm volatile("" : "+v"(r));
+                    r = best >= 4 ? A5[w] : r;
+                    asm volatile("" : "+v"(r));
+                    r = best >= 5 ? A6[w] : r;
+                    asm volatile("" : "+v"(r));
+                    return best >= 6 ? A7[w] : r;
+                };
+                const bool first = jbase == 0;
+                // a lane takes its own next candidate, newest first, whichever of the enabled words it is in
+                auto walk = [&](const bool u3, const bool u2, const bool u1, const bool u0) __attribute__((always_inline)) {
+                    u32 f3 = (stop || !u3) ? 0u : pickw(3), f2 = (stop || !u2) ? 0u : pickw(2);
+                    u32 f1 = (stop || !u1) ? 0u : pickw(1), f0 = (stop || !u0) ? 0u : pickw(0);
+                    while (__any((f3 | f2 | f1 | f0) != 0)) {
+                        if (f3 | f2 | f1 | f0) {
+                            const bool t3 = f3 != 0, t2 = f2 != 0, t1 = f1 != 0;
+                            const u32 cur = t3 ? f3 : t2 ? f2 : t1 ? f1 : f0;
+                            const u32 tb = t3 ? 96u : t2 ? 64u : t1 ? 32u : 0u;
+                            const u32 b = 31 - __builtin_clz(cur);
+                            const u32 clr = ~(1u << b);
+                            f3 = t3 ? f3 & clr : f3;
+                            f2 = (!t3 && t2) ? f2 & clr : f2;
+                            f1 = (!t3 && !t2 && t1) ? f1 & clr : f1;
+                            f0 = (!t3 && !t2 && !t1) ? f0 & clr : f0;
+                            const u32 t = tb + b;
+                            const u32 slot = (lo + t) & (M6_RING - 1);
+                            const u64 c = SE[slot];
+                            const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
+                            const u32 rel_c = c0 & REL_MASK;
+                            if ((int)rel_c > ((first && t == 127) ? lim1 : limn)) {
+                                const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
+                                if ((x0 & 0x1ff) == 0) {
+                                    u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
+                                    if (x1 == 0 && (x0 >> 9) == 0) {
+                                        const u64 y = SX[slot] ^ ex;
+                                        if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
+                                        else {
+                                            len = 13;
+                                            while (len < maxlen) {
+                                                const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
+                                                if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+                                                len += 4;
+                                            }
+                                        }
+                                    }
+                                    len = len < maxlen ? len : maxlen;
+                                    if (len > best) {
+                                        best = len; bdist = rel_p - rel_c;
+                                        if (len >= nice) stop = true;
+                                        f3 &= pickw(3); f2 &= pickw(2); f1 &= pickw(1); f0 &= pickw(0);      // fewer candidates can still win now
+                                    }
+                                }
+                            } else stop = true;                 // out of range: so is everything older
+                            if (stop) { f3 = 0; f2 = 0; f1 = 0; f0 = 0; }
+                        }
+                    }
+                };
+                if (first && qchain == 64) {
+                    walk(true, true, false, false);
+                    qbest = best; qdist = bdist; qtaken = true;
+                    walk(false, false, true, true);
+                } else walk(true, true, true, true);
+            } else if (jbase == 0 && qchain == 64) { qbest = best; qdist = bdist; qtaken = true; }
+            // another block while any lane of the workgroup has candidates left (this is also where everybody is done reading)
+            if (!__syncthreads_or(!stop && nbv > jbase + 128)) break;
+            if (wave < 2) commit(G0 - (int)jbase - 256 + 64 * wave, ba);
+            __syncthreads();
+        }
+        if (!qtaken) { qbest = best; qdist = bdist; }
+        if (own) T[p_abs] = table_entry(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0, own_lo & 0xff);
+    }
+}
+
 int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted,
                  const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg, u32 *d_flags)
 {
@@ -918,8 +993,12 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
         if (const char *e = getenv("MTS_MATCH_SLICES")) nsl = atoi(e) > 0 ? atoi(e) : nsl;
         const int grid = (n_tiles + 7) / 8 * 8 * nsl;
         hipLaunchKernelGGL(k_match5, dim3(grid), dim3(M5_WAVES * 64), MATCH5_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, cfg, d_flags);
-    } else
-        hipLaunchKernelGGL(k_match4, dim3(n_tiles), dim3(1024), MATCH4_LDS, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_tables, cfg);
+    } else {
+        if (cfg.chain != 256 && (cfg.chain >> 2) % 128 != 0) { set_error("match: chain budget %d unsupported", cfg.chain); return MTS_E_INTERNAL; }
+        const int nsl = M5_SLICES;
+        const int grid = (n_tiles + 7) / 8 * 8 * nsl;
+        hipLaunchKernelGGL(k_match6, dim3(grid), dim3(M5_WAVES * 64), MATCH6_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_sorted_nb, d_tables, cfg);
+    }
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
