@@ -761,8 +761,8 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
 // candidates, with the chain lengths from the sort (sorted_nb).  The eight waves of a workgroup take eight consecutive groups
 // of 64 slots and go through the blocks together: what their lanes' candidates of block b lie in is 640 consecutive slots of
 // the sorted order, 128 slots older with every block -- ONE ring of 1024 slots per workgroup (entries, bytes 7..12, the bits
-// of the four key tables) into which two waves enter the 128 new slots of the next block (fetched while the current block is
-// walked) while nothing is ever staged twice.  (Round 1's kernel for these levels restaged 192 slots per wave and block and compared two byte
+// of the four key tables) into which two waves enter the 128 new slots of the next block while the current block is walked;
+// nothing is ever staged twice.  (Round 1's kernel for these levels restaged 192 slots per wave and block and compared two byte
 // keys per candidate with SWAR arithmetic: ~840 instructions per block before the first candidate was looked at.)
 // The quarter-budget result is what the walk holds when it has seen chain/4 candidates: at a block boundary for chain
 // 1024 and 4096, between the two halves of the first block for chain 256.
@@ -883,9 +883,13 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
         commit(G0 - 128 + 64 * wave, ba);
         if (wave < 2) commit(G0 - 128 + 64 * (wave + 8), bb);
         __syncthreads();
-        for (u32 jbase = 0;; jbase += 128) {
-            // the 128 slots the next block adds, on their way while this one is walked
-            if (wave < 2) fetch(G0 - (int)jbase - 256 + 64 * wave, ba);
+        // The 128 slots block b + 1 adds lie just below what block b reads (other ring positions, other table words, and what
+        // they replace in the ring is 1024 slots newer: beyond anything still read), so they are entered DURING block b, by the
+        // wave pair (b mod 4), which fetched them during block b - 1: one barrier per block, and entering overlaps walking.
+        if (wave < 2) fetch(G0 - 256 + 64 * wave, ba);
+        for (u32 jbase = 0, blk = 0;; jbase += 128, blk++) {
+            if ((u32)(wave >> 1) == (blk & 3)) commit(G0 - (int)jbase - 256 + 64 * (wave & 1), ba);
+            if ((u32)(wave >> 1) == ((blk + 1) & 3)) fetch(G0 - (int)jbase - 384 + 64 * (wave & 1), ba);
             if (jbase == qchain && !qtaken) { qbest = best; qdist = bdist; qtaken = true; }      // (chain / 4 a multiple of 128)
             const u32 nbl = nbv > jbase ? (nbv - jbase < 128 ? nbv - jbase : 128) : 0;          // candidates of this lane in the block
             if (__any(nbl != 0 && !stop)) {
@@ -975,8 +979,6 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
             } else if (jbase == 0 && qchain == 64) { qbest = best; qdist = bdist; qtaken = true; }
             // another block while any lane of the workgroup has candidates left (this is also where everybody is done reading)
             if (!__syncthreads_or(!stop && nbv > jbase + 128)) break;
-            if (wave < 2) commit(G0 - (int)jbase - 256 + 64 * wave, ba);
-            __syncthreads();
         }
         if (!qtaken) { qbest = best; qdist = bdist; }
         if (own) T[p_abs] = table_entry(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0, own_lo & 0xff);
