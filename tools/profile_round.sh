@@ -4,6 +4,8 @@
 #   <tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command (per-kernel totals / averages)
 #   <tag>_bench_pmc_hbm_bytes.csv  FETCH_SIZE / WRITE_SIZE per kernel (two separate --pmc passes, no trace domains)
 #   <tag>_traffic.json             HBM bytes per launch of the dominant kernel, read by bench.py
+#   <tag>_levels_kernel_stats.csv  rocprofv3 --kernel-trace --stats of tools/level_sweep.py (levels 1, 2, 3, 6, 7, 8, 9 on 240 chunks of 15.36 MB)
+#   <tag>_levels.json              its output line
 tag=${1:-r2}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/profile_$tag
@@ -14,9 +16,13 @@ python3 bench.py > $out/${tag}_bench_default.jsonl 2> $out/bench_stderr.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline --no-extras > $out/stats_stdout.txt 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 0 > $out/pmc_fetch_stdout.txt 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 0 > $out/pmc_write_stdout.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/levels -- python3 tools/level_sweep.py > $out/${tag}_levels.json 2> $out/levels_stderr.txt
 python3 - <<PY
 import csv, glob, json, collections
 out, tag = "$out", "$tag"
+f = glob.glob(out + "/levels/**/*kernel_stats.csv", recursive=True)
+if f:
+    open(out + "/%s_levels_kernel_stats.csv" % tag, "w").write(open(f[0]).read())
 f = glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)
 if f:
     open(out + "/%s_bench_kernel_stats.csv" % tag, "w").write(open(f[0]).read())
