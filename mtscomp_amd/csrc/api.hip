@@ -234,8 +234,8 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     // ---- workspace ----
     int rc;
     if (!raw_is_stream) { if ((rc = E.stream.ensure(stream_bytes))) return rc; }
-    const size_t sort_n = align_up(sorted_off + 64, 64);          // 32-bit keys; sort_a also holds the u16 chain lengths
-    if ((rc = E.sort_a.ensure(sort_n * 6))) return rc;
+    const size_t sort_n = align_up(sorted_off + 64, 64);          // 32-bit keys
+    if ((rc = E.sort_a.ensure(sort_n * 4))) return rc;
     if ((rc = E.sort_b.ensure(sort_n * 4))) return rc;
     if ((rc = E.tables.ensure((stream_bytes + 64) * sizeof(uint2)))) return rc;
     if ((rc = E.tokens.ensure((toff + 64) * 4))) return rc;
@@ -322,7 +322,6 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     }
     E.t_mark(st, "delta_transpose");
     u32 *tmp_k = E.sort_a.as<u32>(), *srt_k = E.sort_b.as<u32>();
-    u16 *srt_nb = (u16 *)(tmp_k + sort_n);
     uint2 *d_tables = E.tables.as<uint2>();
     u32 *d_flags = (u32 *)(pb.changed + 1);                   // [0] bit 0: the match stage found a hash run out of position order
     u32 *d_tokens = E.tokens.as<u32>();
@@ -330,7 +329,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     const bool fast = level < 4;                              // deflate_fast: no candidate tables, the walk itself searches (deflate.hip, section F)
     u32 *d_inv = (u32 *)d_tables;                             // levels 1..3: the inverse map lives where the other levels keep the candidate tables
     for (;;) {
-        if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, srt_nb, cfg.chain > 128 && !fast, force_ballot, d_flags))) return rc;
+        if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, force_ballot))) return rc;
         E.t_mark(st, force_ballot == 1 ? "hash_sort_retry" : "hash_sort");
         int round = 0;
         bool resort = false;
@@ -373,7 +372,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
             MTS_HIP(hipStreamSynchronize(st));
             if (hflags[1] & 1) resort = true;
         } else {
-        if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, srt_nb, d_tables, cfg, d_flags))) return rc;
+        if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, d_tables, cfg, d_flags))) return rc;
         E.t_mark(st, "match");
         if ((rc = launch_parse_spec(st, d_tables, d_chunks, pb, (int)nseg, cfg))) return rc;
         for (;;) {

@@ -137,13 +137,10 @@ int launch_gather_slices(hipStream_t st, const GatherChunk *d_chunks, int n_chun
                          int n_channels, int itemsize, u8 *d_out);
 
 // deflate.hip
-int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp,
-                     u32 *d_sorted, u16 *d_sorted_nb, int want_nb /* chain lengths too (the kernel for budgets > 128 reads them) */,
-                     int force_ballot /* 1: rank with wave ballots whatever the probe said; 2: test hook, damages the order */,
-                     u32 *d_flags /* [0] |= 1: a hash run out of position order (budgets > 128: checked with the chain lengths) */);
-int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles,
-                 const u32 *d_sorted, const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg,
-                 u32 *d_flags /* [0] |= 1: the sorted order was not position-ordered inside a hash run */);
+int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp, u32 *d_sorted,
+                     int force_ballot /* 1: ballot ranking, 2 (test hook): sort, then damage the run order */);
+int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, uint2 *d_tables, LevelCfg cfg,
+                 u32 *d_flags /* [0] |= 1: a hash run out of position order */);
 struct ParseBufs {
     u32 *entry, *exit_a, *exit_b, *cnt, *tokbase;   // per segment
     u32 *cp;                                        // per segment 16 words: 7 checkpoint positions, 7 token counts

@@ -231,62 +231,8 @@ __global__ __launch_bounds__(1024) void k_probe_lds_order(u32 *bad, int iters)
     if (nbad) atomicAdd(bad, nbad);
 }
 
-// third phase: sorted keys -> number of same-hash predecessors of each slot (the chain behind it), capped.
-// Every wave takes one contiguous part of the sorted order and scans it alone (index + 1 of the latest run start, carried in
-// a register); the slots before a part's first run start belong to a run that began in an earlier part: they are filled in
-// after the one barrier that tells every wave where the parts before it left off.
-__device__ __forceinline__ void chain_lengths(const u8 *__restrict__ s, const u32 *__restrict__ sk, u16 *__restrict__ nb, u32 wlen, u32 *wmax,
-                                              u32 *carry_p, u32 *__restrict__ flags)
-{
-    (void)carry_p;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 per = (((wlen + SORT_WAVES - 1) / SORT_WAVES) + 63) & ~63u;
-    const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
-    u32 carry = 0, first = end;
-    // the slot before the one lane 0 looks at (its position and hash): the neighbour lane's values inside a step, carried here
-    // from step to step; only a part's first slot costs a fetch
-    u32 last_pos = 0, last_h = 0xfffeu;
-    if (beg > 0 && beg < end) { last_pos = sk[beg - 1] & REL_MASK; last_h = hash_of(gld_u32_unaligned(s, last_pos)); }
-    constexpr int CL_DEPTH = 4;                                     // steps whose (random) byte loads are in flight together
-    for (u32 base0 = beg; base0 < end; base0 += CL_DEPTH * 64) {
-        u32 posv[CL_DEPTH], hv[CL_DEPTH];
-#pragma unroll
-        for (int k = 0; k < CL_DEPTH; k++) { const u32 i = base0 + k * 64 + lane; posv[k] = i < end ? sk[i] & REL_MASK : 0; }
-        // (the keys only hold 7 hash bits: the hash is recomputed from the bytes; only budgets > 128 come here)
-#pragma unroll
-        for (int k = 0; k < CL_DEPTH; k++) hv[k] = hash_of(gld_u32_unaligned(s, posv[k]));
-#pragma unroll
-        for (int k = 0; k < CL_DEPTH; k++) {
-            const u32 base = base0 + k * 64;
-            if (base >= end) break;                                 // (uniform)
-            const u32 i = base + lane;
-            const bool act = i < end;
-            const u32 pos = posv[k];
-            const u32 h = act ? hv[k] : 0xffffu;
-            u32 pos_prev = __shfl_up(pos, 1, 64), hprev = __shfl_up(h, 1, 64);
-            if (lane == 0) { pos_prev = last_pos; hprev = last_h; }
-            last_pos = (u32)__builtin_amdgcn_readlane((int)pos, 63); last_h = (u32)__builtin_amdgcn_readlane((int)h, 63);
-            if (act && h == hprev && pos <= pos_prev) atomicOr(flags, 1u);      // a run out of position order (see k_match5)
-            // run start index + 1 where a run starts here, else 0; running max = start of my run
-            u32 v = (act && h != hprev) ? i + 1 : 0;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(v, off, 64); if (lane >= off) v = max(v, y); }
-            v = max(v, carry);
-            if (carry == 0) { const u64 m = __ballot(v != 0); if (m) first = base + (u32)__builtin_ctzll(m); }
-            carry = (u32)__builtin_amdgcn_readlane((int)v, 63);
-            if (act && v) { const u32 c = i + 1 - v; nb[i] = (u16)(c < 65535u ? c : 65535u); }
-        }
-    }
-    wmax[wave] = carry;
-    __syncthreads();
-    u32 pre = 0;
-    for (int w = 0; w < wave; w++) pre = max(pre, wmax[w]);
-    for (u32 i = beg + lane; i < first; i += 64) { const u32 c = i + 1 - pre; nb[i] = (u16)(c < 65535u ? c : 65535u); }
-}
-
 __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
-                                                    u32 *__restrict__ tmp, u32 *__restrict__ sorted, u16 *__restrict__ sorted_nb, int lane_ordered,
-                                                    int want_nb, u32 *__restrict__ flags)
+                                                    u32 *__restrict__ tmp, u32 *__restrict__ sorted, int lane_ordered)
 {
     const TileDesc td = tiles[blockIdx.x];
     __shared__ u32 cnt[SORT_WAVES][256];
@@ -338,16 +284,6 @@ __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ st
         bin_offsets<5>(cnt, tot);
         rank_pass<5, false, 5, 0>(s, tmp_t, out_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);
     }
-    if (want_nb) chain_lengths(s, sorted + td.sorted_off, sorted_nb + td.sorted_off, wlen, tot, tot + 32, flags);      // (k_match5 derives them itself)
-}
-
-__global__ __launch_bounds__(SORT_NT) void k_chain_lengths(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, const u32 *__restrict__ sorted,
-                                                        u16 *__restrict__ sorted_nb, u32 *__restrict__ flags)
-{
-    const TileDesc td = tiles[blockIdx.x];
-    __shared__ u32 tot[64];
-    if (td.wlen == 0) return;
-    chain_lengths(stream + td.stream_off + td.w, sorted + td.sorted_off, sorted_nb + td.sorted_off, td.wlen, tot, tot + 32, flags);
 }
 
 // 1 if this device's LDS retires same-address atomics of a wave instruction in lane order (probed once per device)
@@ -372,8 +308,7 @@ static int lds_lane_ordered()
     return cached[dev];
 }
 
-// test hook: swaps the first two neighbours of the first tile's sorted order that belong to one hash run (before the chain
-// lengths are taken), i.e. what a failure of the lane-ordered ranking would look like to the stages downstream
+// test hook: swaps the first two neighbours of the first tile's sorted order that belong to one hash run, i.e. what a failure of the lane-ordered ranking would look like to the stages downstream
 __global__ void k_inject_disorder(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, u32 *__restrict__ sorted)
 {
     const TileDesc td = tiles[0];
@@ -385,17 +320,12 @@ __global__ void k_inject_disorder(const u8 *__restrict__ stream, const TileDesc 
     }
 }
 
-int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp, u32 *d_sorted,
-                     u16 *d_sorted_nb, int want_nb, int force_ballot, u32 *d_flags)
+int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp, u32 *d_sorted, int force_ballot)
 {
     if (n_tiles == 0) return MTS_OK;
     const int ordered = (force_ballot == 1 || getenv("MTS_SORT_BALLOT")) ? 0 : lds_lane_ordered();      // MTS_SORT_BALLOT=1: force the ballot ranking (tests)
-    if (force_ballot == 2) {       // (test hook) sort, damage the order, then take the chain lengths in a second launch that only does that
-        hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(SORT_NT), 0, st, d_stream, d_tiles, d_tmp, d_sorted, d_sorted_nb, ordered, 0, d_flags);
-        hipLaunchKernelGGL(k_inject_disorder, dim3(1), dim3(1), 0, st, d_stream, d_tiles, d_sorted);
-        if (want_nb) hipLaunchKernelGGL(k_chain_lengths, dim3(n_tiles), dim3(SORT_NT), 0, st, d_stream, d_tiles, d_sorted, d_sorted_nb, d_flags);
-    } else
-        hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(SORT_NT), 0, st, d_stream, d_tiles, d_tmp, d_sorted, d_sorted_nb, ordered, want_nb, d_flags);
+    hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(SORT_NT), 0, st, d_stream, d_tiles, d_tmp, d_sorted, ordered);
+    if (force_ballot == 2) hipLaunchKernelGGL(k_inject_disorder, dim3(1), dim3(1), 0, st, d_stream, d_tiles, d_sorted);      // (test hook: damage the order)
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
@@ -758,7 +688,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
 
 // ------------------------------------------------------------------------------------------------
 // k_match6 (chain budget > 128: levels 7..9): k_match5's looked-up filter masks and walk, block after block of 128
-// candidates, with the chain lengths from the sort (sorted_nb).  The eight waves of a workgroup take eight consecutive groups
+// candidates.  The eight waves of a workgroup take eight consecutive groups
 // of 64 slots and go through the blocks together: what their lanes' candidates of block b lie in is 640 consecutive slots of
 // the sorted order, 128 slots older with every block -- ONE ring of 1024 slots per workgroup (entries, bytes 7..12, the bits
 // of the four key tables) into which two waves enter the 128 new slots of the next block while the current block is walked;
@@ -773,10 +703,11 @@ constexpr int M6_TABLE = M5_ROWS * M6_ROW_WORDS * 4;
 constexpr int MATCH6_LDS = 2 * M6_RING * 8 + M5_LEVELS * M6_TABLE;      // 33280 per workgroup
 
 __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, int nsl,
-                                                          const u32 *__restrict__ sorted, const u16 *__restrict__ sorted_nb,
-                                                          uint2 *__restrict__ tables, LevelCfg cfg)
+                                                          const u32 *__restrict__ sorted, uint2 *__restrict__ tables, LevelCfg cfg,
+                                                          u32 *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    __shared__ u32 wg_h[M5_WAVES], wg_rc[M5_WAVES], wg_tail[M5_WAVES], wg_min;      // per group of the set: hash and position of its last slot, slots since its last run start (0: none starts in it)
     const u32 xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const u32 tile_id = (jb / (u32)nsl) * 8 + xcd, slice = jb % (u32)nsl;
     if (tile_id >= (u32)n_tiles) return;
@@ -795,7 +726,6 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
     }
     if (td.wlen == 0) return;
     const u32 *sk = sorted + td.sorted_off;
-    const u16 *snb = sorted_nb + td.sorted_off;
     const u32 wlen = td.wlen, n = td.n;
     const u32 ngroups = (wlen + 63) / 64;
     const u32 halo = td.a - td.w;
@@ -850,6 +780,27 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
         SE[rp] = ce;
         SX[rp] = bt.x;
     };
+    // The chain behind a slot = the slots back to the start of its hash run (the sorted order lists a run's positions in a row):
+    // inside a group from the ballot of the run starts, across groups carried along -- c_tail = slots since the last run start
+    // before the set's first group (capped), c_h / c_rc = hash and position of the slot before it; the same in every wave.
+    // Before the workgroup's first group the whole workgroup looks back for the start of that run.
+    u32 c_h = 0xfffffffdu, c_rc = 0, c_tail = 0;
+    if (gb_begin > 0) {
+        const u32 i1 = gb_begin * 64 - 1;
+        c_rc = sk[i1] & REL_MASK;
+        c_h = hash_of(wread(c_rc));
+        if (threadIdx.x == 0) wg_min = 0xffffffffu;
+        __syncthreads();
+        for (u32 r = 0; r * (M5_WAVES * 64) < chain; r++) {
+            const u32 t = 1 + threadIdx.x + r * (M5_WAVES * 64);            // is slot i1 - t still in the run of slot i1?
+            const bool mism = t > i1 || hash_of(wread(sk[i1 - (t > i1 ? 0 : t)] & REL_MASK)) != c_h;
+            if (mism) atomicMin(&wg_min, t);
+            __syncthreads();
+            if (wg_min != 0xffffffffu) break;
+        }
+        c_tail = wg_min < chain ? wg_min : chain;
+        __syncthreads();
+    }
     for (u32 gs = gb_begin; gs < gb_end; gs += M5_WAVES) {
         const int G0 = (int)gs * 64;
         const u32 g = gs + (u32)wave;
@@ -875,14 +826,35 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
         const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
         const int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
         const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
-        u32 nbv = own ? (u32)snb[i] : 0;
-        nbv = nbv < chain ? nbv : chain;
         u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
         bool stop = false, qtaken = false;
+        const bool have = active && i < wlen;
+        const u32 h_own = have ? hash_of(own_lo) : 0xfffffffeu;
+        if (lane == 63) { wg_h[wave] = h_own; wg_rc[wave] = rel_p; }
         __syncthreads();                                           // the ring is free (first set: the tables are zero)
         commit(G0 - 128 + 64 * wave, ba);
         if (wave < 2) commit(G0 - 128 + 64 * (wave + 8), bb);
-        __syncthreads();
+        u32 nbv;
+        {
+            u32 hp = __shfl_up(h_own, 1, 64), rcp = __shfl_up(rel_p, 1, 64);
+            if (lane == 0) { hp = wave ? wg_h[wave - 1] : c_h; rcp = wave ? wg_rc[wave - 1] : c_rc; }
+            const bool starts_run = h_own != hp;
+            if (__any(have && !starts_run && rel_p <= rcp)) { if (lane == 0) atomicOr(flags, 1u); }      // positions must increase inside a run (see k_match5)
+            const u64 sr = __ballot(starts_run);
+            if (lane == 0) wg_tail[wave] = sr ? (u32)__builtin_clzll(sr) + 1u : 0u;
+            __syncthreads();
+            u32 t = c_tail;                                         // slots since the last run start before this wave's group
+            for (int w = 0; w < wave; w++) { const u32 x = wg_tail[w]; t = x ? x : (t + 64u < chain ? t + 64u : chain); }
+            const u32 le_lo = lane >= 31 ? 0xffffffffu : (2u << lane) - 1, le_hi = lane < 32 ? 0u : lane == 63 ? 0xffffffffu : (2u << (lane - 32)) - 1;
+            const u32 mlo = (u32)sr & le_lo, mhi = (u32)(sr >> 32) & le_hi;
+            const u32 top = mhi ? 63u - (u32)__builtin_clz(mhi) : 31u - (u32)__builtin_clz(mlo | 1u);
+            nbv = (mlo | mhi) ? (u32)lane - top : (u32)lane + t;
+            nbv = own ? (nbv < chain ? nbv : chain) : 0;
+            // what the next set starts from (every wave works it out for itself)
+            u32 tt = c_tail;
+            for (int w = 0; w < M5_WAVES; w++) { const u32 x = wg_tail[w]; tt = x ? x : (tt + 64u < chain ? tt + 64u : chain); }
+            c_tail = tt; c_h = wg_h[M5_WAVES - 1]; c_rc = wg_rc[M5_WAVES - 1];
+        }
         // The 128 slots block b + 1 adds lie just below what block b reads (other ring positions, other table words, and what
         // they replace in the ring is 1024 slots newer: beyond anything still read), so they are entered DURING block b, by the
         // wave pair (b mod 4), which fetched them during block b - 1: one barrier per block, and entering overlaps walking.
@@ -985,8 +957,8 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
     }
 }
 
-int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted,
-                 const u16 *d_sorted_nb, uint2 *d_tables, LevelCfg cfg, u32 *d_flags)
+int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, uint2 *d_tables, LevelCfg cfg,
+                 u32 *d_flags)
 {
     if (n_tiles == 0) return MTS_OK;
     if (cfg.chain <= 128) {
@@ -999,7 +971,7 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
         if (cfg.chain != 256 && (cfg.chain >> 2) % 128 != 0) { set_error("match: chain budget %d unsupported", cfg.chain); return MTS_E_INTERNAL; }
         const int nsl = M5_SLICES;
         const int grid = (n_tiles + 7) / 8 * 8 * nsl;
-        hipLaunchKernelGGL(k_match6, dim3(grid), dim3(M5_WAVES * 64), MATCH6_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_sorted_nb, d_tables, cfg);
+        hipLaunchKernelGGL(k_match6, dim3(grid), dim3(M5_WAVES * 64), MATCH6_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, cfg, d_flags);
     }
     MTS_HIP(hipGetLastError());
     return MTS_OK;
