@@ -371,8 +371,9 @@ __device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
 // ------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------
 // k_match5 (chain budget <= 128): the filter masks are looked up.  Every wave keeps, next to its 256-slot ring of
-// entries, four tables of 32 rows x 256 bits: row k of table d (d = 4..7) has bit r set iff the slot at
-// ring position r has key_d = k, where key_d is a 5-bit hash of bytes 3 .. d-1 of the slot's string.  A
+// entries, four tables of 32 rows x 256 bits (the first one 64 rows): row k of table d (d = 4..7) has bit r set iff the slot at
+// ring position r has key_d = k, where key_d is a 5-bit hash of bytes 3 .. d-1 of the slot's string (6 bits of byte 3 for the
+// first table, which the walk consults most: with 32 rows a lane met ~4 candidates per group that only shared the row).  A
 // slot entering the ring clears the bits of the slot it replaces and sets its own (8 LDS atomics per 64
 // slots).  A lane reads the rows of its OWN keys and funnel-shifts out the 128 bits of the slots before
 // it: M_d = candidates whose first d bytes may equal its own (hash + bytes 3..d-1; a superset, which is
@@ -387,7 +388,9 @@ constexpr int M5_ROWS = 32;
 constexpr int M5_LEVELS = 4;                         // tables for prefix lengths 4, 5, 6, 7
 constexpr int M5_ROW_WORDS = M5_RING / 32 + 1;       // a row is 8 words of bits + 1 of padding, so that rows start in different LDS banks
 constexpr int M5_TABLE = M5_ROWS * M5_ROW_WORDS * 4; // bytes per table
-constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_LEVELS * M5_TABLE;     // 8704: entries, bytes 7..12, tables
+constexpr int M5_SLOTS = M5_LEVELS + 1;                // the first table has 64 rows (a 6-bit key of byte 3): two table slots
+constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_SLOTS * M5_TABLE;      // 9856: entries, bytes 7..12, tables
+__device__ __forceinline__ constexpr int m5_slot(int d) { return d ? d + 1 : 0; }
 // requested LDS is padded so that TWO workgroups share a CU, not three (16 waves per CU keep the vector units busy)
 constexpr int MATCH5_LDS = M5_WAVES * M5_WAVE_LDS > 56 * 1024 ? M5_WAVES * M5_WAVE_LDS : 56 * 1024;
 
@@ -395,7 +398,7 @@ constexpr int MATCH5_LDS = M5_WAVES * M5_WAVE_LDS > 56 * 1024 ? M5_WAVES * M5_WA
 __device__ __forceinline__ u32 m5_hash24(u32 x) { return (__umul24(x, 0x9E3779u) >> 19) & 31; }
 __device__ __forceinline__ void m5_keys(u32 e1, u32 (&k)[M5_LEVELS])
 {
-    k[0] = m5_hash24(e1 & 0xff);
+    k[0] = (__umul24(e1 & 0xff, 0x9E3779u) >> 18) & 63;
     k[1] = m5_hash24(e1 & 0xffff);
     k[2] = m5_hash24(e1 & 0xffffff);
     k[3] = m5_hash24((e1 ^ (e1 >> 11)) & 0xffffff);
@@ -439,15 +442,15 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     const u32 g_begin = (slice * M5_WAVES + wave) * gpw, g_end = min(ngroups, g_begin + gpw);
     if (g_begin >= g_end) return;
     // the tables start empty (the entry ring may hold anything: it is only read where table bits point)
-    for (int k = lane; k < M5_LEVELS * M5_TABLE / 16; k += 64) ((uint4 *)TB)[k] = make_uint4(0, 0, 0, 0);
+    for (int k = lane; k < M5_SLOTS * M5_TABLE / 16; k += 64) ((uint4 *)TB)[k] = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_wave_barrier();
     u32 h_carry = 0xffffffffu;                                     // hash of the slot before the one lane 0 commits next
     u32 rc_carry = 0;                                              // its position
     u32 run_carry = 0;                                             // slots between the newest run start and lane 0 of the group being committed (capped)
     const u32 le_lo = lane >= 31 ? 0xffffffffu : (2u << lane) - 1, le_hi = lane < 32 ? 0u : lane == 63 ? 0xffffffffu : (2u << (lane - 32)) - 1;      // lanes <= this one
-    u32 inv[5];                                                    // lane r (< 32) builds row r of the first table: bit j of r clear -> all ones
+    u32 inv[6];                                                    // lane r builds row r of the first table: bit j of r clear -> all ones
 #pragma unroll
-    for (int j = 0; j < 5; j++) inv[j] = ((lane >> j) & 1) ? 0u : 0xffffffffu;
+    for (int j = 0; j < 6; j++) inv[j] = ((lane >> j) & 1) ? 0u : 0xffffffffu;
     // slot idx -> position -> its 13 bytes -> entry; enters the ring at idx & 255, replacing slot idx - 256.  The ring
     // positions of a 64-slot group are two whole words of every table row: they are cleared and set again (the first table,
     // whose keys repeat most -- 32 lanes adding the same bit to the same word would be serialised by the LDS -- is rebuilt
@@ -474,22 +477,22 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         m5_keys((u32)(ce >> 32), key);
         const u32 wp = word & ~1u;                                 // the group's word pair
         {
-            u32 *t1 = TB + (M5_TABLE / 4) + lane * M5_ROW_WORDS + wp;       // rows of tables 1..3 are contiguous: 96 rows
+            u32 *t1 = TB + 2 * (M5_TABLE / 4) + lane * M5_ROW_WORDS + wp;   // rows of tables 1..3 are contiguous: 96 rows
             t1[0] = 0; t1[1] = 0;
             if (lane < 32) { t1[64 * M5_ROW_WORDS] = 0; t1[64 * M5_ROW_WORDS + 1] = 0; }
             const u64 vm = __ballot(valid);
             u32 m0 = (u32)vm, m1 = (u32)(vm >> 32);
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
+            for (int j = 0; j < 6; j++) {
                 const u64 B = __ballot((key[0] >> j) & 1);
                 m0 &= (u32)B ^ inv[j]; m1 &= (u32)(B >> 32) ^ inv[j];
             }
-            if (lane < 32) { u32 *t0 = TB + lane * M5_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
+            { u32 *t0 = TB + lane * M5_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int d = 1; d < M5_LEVELS; d++)
-            if (valid) atomicOr(&TB[d * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS + word], bit);
+            if (valid) atomicOr(&TB[m5_slot(d) * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS + word], bit);
         SE[rp] = ce;
         SX[rp] = x;
         return ce;
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
             V[k] = s <= 0 ? 0u : s >= 32 ? 0xffffffffu : 0xffffffffu << (32 - s);
         }
         auto rowmask = [&](const int d, const u32 (&in)[4], u32 (&out)[4]) __attribute__((always_inline)) {
-            const u32 *row = TB + d * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS;
+            const u32 *row = TB + m5_slot(d) * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS;
             const u32 W0 = row[w0 & 7], W1 = row[(w0 + 1) & 7], W2 = row[(w0 + 2) & 7], W3 = row[(w0 + 3) & 7], W4 = row[(w0 + 4) & 7];
             out[0] = in[0] & __builtin_amdgcn_alignbit(W1, W0, sh);
             out[1] = in[1] & __builtin_amdgcn_alignbit(W2, W1, sh);
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
 constexpr int M6_RING = 1024;
 constexpr int M6_ROW_WORDS = M6_RING / 32 + 1;
 constexpr int M6_TABLE = M5_ROWS * M6_ROW_WORDS * 4;
-constexpr int MATCH6_LDS = 2 * M6_RING * 8 + M5_LEVELS * M6_TABLE;      // 33280 per workgroup
+constexpr int MATCH6_LDS = 2 * M6_RING * 8 + M5_SLOTS * M6_TABLE;       // 37504 per workgroup
 
 __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, int nsl,
                                                           const u32 *__restrict__ sorted, uint2 *__restrict__ tables, LevelCfg cfg,
@@ -733,10 +736,10 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
     const u32 gpb = ((ngroups + (u32)nsl - 1) / (u32)nsl + M5_WAVES - 1) / M5_WAVES * M5_WAVES;      // groups per workgroup: whole sets of eight
     const u32 gb_begin = slice * gpb, gb_end = min(ngroups, gb_begin + gpb);
     if (gb_begin >= gb_end) return;                                // (the whole workgroup)
-    for (int k = threadIdx.x; k < M5_LEVELS * M6_TABLE / 4; k += M5_WAVES * 64) TB[k] = 0;
-    u32 inv[5];                                                    // lane r (< 32) builds row r of the first table: bit j of r clear -> all ones
+    for (int k = threadIdx.x; k < M5_SLOTS * M6_TABLE / 4; k += M5_WAVES * 64) TB[k] = 0;
+    u32 inv[6];                                                    // lane r builds row r of the first table: bit j of r clear -> all ones
 #pragma unroll
-    for (int j = 0; j < 5; j++) inv[j] = ((lane >> j) & 1) ? 0u : 0xffffffffu;
+    for (int j = 0; j < 6; j++) inv[j] = ((lane >> j) & 1) ? 0u : 0xffffffffu;
     typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     auto load16 = [&](u32 r, u32 &lo, u32 &hi, u64 &x) {
         const u8 *q = gwin + (r & ~3u);
@@ -762,21 +765,21 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
         u32 key[M5_LEVELS];
         m5_keys((u32)(ce >> 32), key);
         const u32 wp = word & ~1u;
-        u32 *t1 = TB + (M6_TABLE / 4) + lane * M6_ROW_WORDS + wp;           // rows of tables 1..3 are contiguous: 96 rows
+        u32 *t1 = TB + 2 * (M6_TABLE / 4) + lane * M6_ROW_WORDS + wp;       // rows of tables 1..3 are contiguous: 96 rows
         t1[0] = 0; t1[1] = 0;
         if (lane < 32) { t1[64 * M6_ROW_WORDS] = 0; t1[64 * M6_ROW_WORDS + 1] = 0; }
         const u64 vm = __ballot(bt.valid);
         u32 m0 = (u32)vm, m1 = (u32)(vm >> 32);
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
+        for (int j = 0; j < 6; j++) {
             const u64 B = __ballot((key[0] >> j) & 1);
             m0 &= (u32)B ^ inv[j]; m1 &= (u32)(B >> 32) ^ inv[j];
         }
-        if (lane < 32) { u32 *t0 = TB + lane * M6_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
+        { u32 *t0 = TB + lane * M6_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int d = 1; d < M5_LEVELS; d++)
-            if (bt.valid) atomicOr(&TB[d * (M6_TABLE / 4) + key[d] * M6_ROW_WORDS + word], bit);
+            if (bt.valid) atomicOr(&TB[m5_slot(d) * (M6_TABLE / 4) + key[d] * M6_ROW_WORDS + word], bit);
         SE[rp] = ce;
         SX[rp] = bt.x;
     };
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
                     V[k] = s <= 0 ? 0u : s >= 32 ? 0xffffffffu : 0xffffffffu << (32 - s);
                 }
                 auto rowmask = [&](const int d, const u32 (&in)[4], u32 (&out)[4]) __attribute__((always_inline)) {
-                    const u32 *row = TB + d * (M6_TABLE / 4) + key[d] * M6_ROW_WORDS;
+                    const u32 *row = TB + m5_slot(d) * (M6_TABLE / 4) + key[d] * M6_ROW_WORDS;
                     const u32 W0 = row[w0], W1 = row[(w0 + 1) & 31], W2 = row[(w0 + 2) & 31], W3 = row[(w0 + 3) & 31], W4 = row[(w0 + 4) & 31];
                     out[0] = in[0] & __builtin_amdgcn_alignbit(W1, W0, sh);
                     out[1] = in[1] & __builtin_amdgcn_alignbit(W2, W1, sh);
