@@ -237,7 +237,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     const size_t sort_n = align_up(sorted_off + 64, 64);          // 32-bit keys
     if ((rc = E.sort_a.ensure(sort_n * 4))) return rc;
     if ((rc = E.sort_b.ensure(sort_n * 4))) return rc;
-    if ((rc = E.tables.ensure((stream_bytes + 64) * sizeof(uint2)))) return rc;
+    if ((rc = E.tables.ensure((stream_bytes + 64) * (level < 4 ? sizeof(u32) : sizeof(uint2))))) return rc;      // (levels 1..3: the inverse map only)
     if ((rc = E.tokens.ensure((toff + 64) * 4))) return rc;
     if ((rc = E.segbuf.ensure((size_t)(nseg + 64) * 4 * (7 + 16) + 256))) return rc;
     if ((rc = E.blk.ensure((size_t)(nblk + 1) * (sizeof(BlockRec) + 8) + 256))) return rc;
@@ -522,10 +522,12 @@ static int staged_h2d(Engine &E, void *d_dst, const void *src, size_t n)
 // split a call into sub-batches that fit the workspace budget (stream bytes per sub-batch) and the grid (several kernels
 // take the chunk index from blockIdx.y, which ends at 65535)
 constexpr int MAX_BATCH_CHUNKS = 32768;
-static size_t batch_budget_bytes()
+static size_t batch_budget_bytes(bool in_order_walk = false)
 {
     const char *e = getenv("MTS_BATCH_BYTES");               // read per call: tests force small sub-batches with it
-    size_t v = e ? (size_t)atoll(e) : ((size_t)3 << 30);     // 3 GiB of stream -> ~75 GiB of workspace
+    // 3 GiB of stream -> ~75 GiB of workspace.  Levels 1..3: 6 GiB (17 bytes of workspace per byte + the candidate lists: ~110
+    // GiB) -- their in-order walk takes as long for one chunk as for 256, so fewer, larger sub-batches are what counts there
+    size_t v = e ? (size_t)atoll(e) : ((size_t)(in_order_walk ? 6 : 3) << 30);
     if (v < (1u << 20)) v = 1u << 20;
     return v;
 }
@@ -539,7 +541,7 @@ static int dev_compress(Engine &E, hipStream_t st, const void *d_raw, int nc, in
     if ((flags & MTS_FLAG_FLOAT) && sz != 4 && sz != 8) { set_error("float items of %d bytes unsupported", sz); return MTS_E_ARG; }
     if (nc <= 0 || n_chunks < 0) return MTS_E_ARG;
     MTS_HIP(hipSetDevice(E.dev));
-    const size_t budget = batch_budget_bytes();
+    const size_t budget = batch_budget_bytes(level < 4);
     const u64 row_bytes = (u64)nc * sz;
     int i = 0;
     bool first = true;
