@@ -176,6 +176,20 @@ def test_deflate_fast_levels(level):
 
 
 @pytest.mark.parametrize('level', [1, 2, 3])
+def test_fast_level_tokens(level):
+    """The token sequence of the in-order walk against the oracle's deflate_fast (oracle.deflate(report=True)), token by token:
+    a wrong decision shows here where it is made, not as a different byte somewhere in a Huffman block."""
+    cases = dict(CASES)
+    cases.update({k: v for k, v in _fast_edge_cases().items() if k in ('zeros_100k', 'long_runs_then_probe', 'rand3_64k', 'zeros_259', 'period_max_dist')})
+    for name in TABLE_CASES + ['empty', 'one', 'two', 'zeros_100k', 'long_runs_then_probe', 'rand3_64k', 'zeros_259', 'period_max_dist']:
+        data = cases[name]
+        _, toks, _, _ = O.deflate(data, level, report=True)
+        got = hip.debug_tokens(data, level)
+        assert got.shape == toks.shape, (name, got.shape, toks.shape, _first_diff(got, toks))
+        assert np.array_equal(got, toks), (name, _first_diff(got, toks))
+
+
+@pytest.mark.parametrize('level', [1, 2, 3])
 def test_deflate_fast_edge_cases(level):
     for name, data in sorted(_fast_edge_cases().items()):
         got = hip.debug_deflate(data, level)
