@@ -13,9 +13,11 @@
  * MTS_E_NODEV.
  *
  * `flags`: bit0 do_time_diff, bit1 do_spatial_diff, bit2 chunk_order=='F'   (reference config keys,
- * mtscomp.py:52-55).  `level`: zlib level 4..9 or -1; the reference always compresses at zlib's
- * default (6) whatever `comp_level` says (mtscomp.py:394), so 6/-1 is the drop-in value.
- * Supported item types: integer dtypes of 1, 2, 4 or 8 bytes (two's complement wrap, like numpy).
+ * mtscomp.py:52-55), bit3 items are IEEE floats.  `level`: zlib level 1..9 or -1 (= 6), every one
+ * byte-identical to zlib.compress(stream, level) of libz 1.2.11; the reference always compresses at
+ * zlib's default (6) whatever `comp_level` says (mtscomp.py:394), so 6/-1 is the drop-in value.
+ * Supported item types: integer dtypes of 1, 2, 4 or 8 bytes (two's complement wrap, like numpy) and,
+ * with MTS_FLAG_FLOAT, float32 / float64 (np.diff / np.cumsum in the item type, bit for bit).
  */
 #ifndef MTSCOMP_HIP_H
 #define MTSCOMP_HIP_H
@@ -29,7 +31,7 @@ extern "C" {
 #define MTS_E_NODEV (-2)       /* no usable gfx950 device / HIP runtime */
 #define MTS_E_HIP (-3)         /* HIP runtime error (see mts_last_error) */
 #define MTS_E_NOMEM (-4)       /* device or host allocation failed */
-#define MTS_E_UNSUPPORTED (-5) /* valid request this build does not implement (e.g. level 1..3) */
+#define MTS_E_UNSUPPORTED (-5) /* valid request this build does not implement (e.g. the match-table tap at levels 1..3) */
 #define MTS_E_INTERNAL (-6)    /* internal consistency check failed */
 #define MTS_E_MISS (-7)        /* mts_cache_read_rows: a chunk given without bytes is not resident (any more) */
 

@@ -614,16 +614,25 @@ class Reader:
         return result
 
     def _trim_cache(self):
-        """Back to cache_size entries.  The arrays of one codec call are views of one buffer: an entry that would keep a
-        buffer several times its own size alive (what is left of a big batch) is replaced by a copy of itself."""
+        """Back to cache_size entries.  The arrays of one codec call are views of one buffer: entries that would keep a
+        buffer several times the size of everything cached from it alive (what is left of a big batch) are replaced by
+        copies of themselves; views that still account for most of their buffer stay views (no copy, and neighbours keep
+        sharing a base, which lets a slice over several cached chunks be joined without copying)."""
         while len(self._cache) > self.cache_size:
             self._cache.popitem(last=False)
-        for idx, arr in list(self._cache.items()):
+        roots = {}
+        for idx, arr in self._cache.items():
             root = arr
             while isinstance(root.base, np.ndarray):
                 root = root.base
-            if root is not arr and root.nbytes > 2 * arr.nbytes:
-                self._cache[idx] = arr.copy()
+            if root is not arr:
+                entry = roots.setdefault(id(root), [root, 0, []])
+                entry[1] += arr.nbytes
+                entry[2].append(idx)
+        for root, cached_bytes, ids in roots.values():
+            if root.nbytes > 2 * cached_bytes:
+                for idx in ids:
+                    self._cache[idx] = self._cache[idx].copy()
 
     def _slice_from_device_cache(self, first, last, i0, i1):
         """Rows [i0, i1) -- inside chunks first..last -- through the codec's decoded-chunk cache in HBM: chunks that are

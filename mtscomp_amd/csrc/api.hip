@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -48,9 +49,11 @@ void drop_device_caches();      // frees the decoded-chunk caches of the current
 struct DBuf {
     void *p = nullptr;
     size_t cap = 0;
+    u64 gen = 0;              // bumped whenever the buffer is (re)allocated, freed or an allocation fails: what it held is gone
     int ensure(size_t bytes)
     {
         if (bytes <= cap) return MTS_OK;
+        gen++;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         const size_t want = bytes + bytes / 8 + 4096;
         hipError_t e = hipMalloc(&p, want);
@@ -62,7 +65,7 @@ struct DBuf {
         } else cap = want;
         return MTS_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; gen++; }
     template <typename T> T *as() { return (T *)p; }
 };
 
@@ -89,8 +92,10 @@ struct Engine {
     DBuf inf_scratch, inf_desc, segsums;
     // geometry of the last compress batch whose per-segment / per-block / per-tile descriptors are on the device (a recording is
     // compressed batch after batch of the same shape: the 10 MB of index arrays need not be rebuilt and copied every call)
+    // (valid while the three buffers are the allocations the arrays were copied into: DBuf::gen, not the address -- a buffer
+    // freed by mts_release() and allocated again usually comes back at the same address with nothing in it)
     std::vector<u32> geo_n;
-    const void *geo_seg = nullptr, *geo_blk = nullptr, *geo_desc = nullptr;
+    u64 geo_seg = ~0ull, geo_blk = ~0ull, geo_desc = ~0ull;
     // stage timing
     hipEvent_t ev[MAX_STAGES + 1];
     bool ev_ok = false;
@@ -136,6 +141,7 @@ struct Engine {
         DBuf *all[] = {&stream, &sort_a, &sort_b, &tables, &tokens, &marks, &segbuf, &blk, &blkcodes, &blkhdr, &desc,
                        &adler, &misc, &h_in, &h_out, &inf_scratch, &inf_desc, &segsums, &fast_lists, &fast_state};
         for (DBuf *b : all) b->release();
+        geo_n.clear();
         for (int k = 0; k < 2; k++) { if (pin[k]) (void)hipHostFree(pin[k]); pin[k] = nullptr; if (pin_ev[k]) (void)hipEventDestroy(pin_ev[k]); pin_ev[k] = nullptr; }
         if (copy_st) (void)hipStreamDestroy(copy_st);
         copy_st = nullptr;
@@ -272,7 +278,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         // the buffers have not moved
         std::vector<u32> sizes_now(n_chunks);
         for (int i = 0; i < n_chunks; i++) sizes_now[i] = cd[i].n;
-        const bool same = sizes_now == E.geo_n && E.geo_seg == E.segbuf.p && E.geo_blk == E.blk.p && E.geo_desc == E.desc.p;
+        const bool same = sizes_now == E.geo_n && E.geo_seg == E.segbuf.gen && E.geo_blk == E.blk.gen && E.geo_desc == E.desc.gen;
         if (!same) {
             E.geo_n.clear();                                      // (not valid again until everything below is on its way)
             std::vector<u32> h_seg(2 * (size_t)nseg), h_blk_chunk(nblk + 1);
@@ -287,7 +293,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
             }
             MTS_HIP(hipMemcpyAsync(d_blk_chunk, h_blk_chunk.data(), 4 * (size_t)nblk, hipMemcpyHostToDevice, st));
             // (pageable copies: staged before hipMemcpyAsync returns, so the vectors may go)
-            E.geo_n = sizes_now; E.geo_seg = E.segbuf.p; E.geo_blk = E.blk.p; E.geo_desc = E.desc.p;
+            E.geo_n = sizes_now; E.geo_seg = E.segbuf.gen; E.geo_blk = E.blk.gen; E.geo_desc = E.desc.gen;
         }
     }
     MTS_HIP(hipMemsetAsync(d_cout, 0, sizeof(ChunkOut) * n_chunks, st));
@@ -1017,6 +1023,11 @@ static int cache_ensure(DevCache *c, Engine *E, int n_chunks, const long *chunk_
     const u64 row_bytes = (u64)n_channels * itemsize;
     std::vector<int> miss;
     long total_rows = 0;
+    {   // every key once: a key listed twice would be decoded and accounted twice
+        std::vector<long> keys(chunk_keys, chunk_keys + n_chunks);
+        std::sort(keys.begin(), keys.end());
+        if (std::adjacent_find(keys.begin(), keys.end()) != keys.end()) { set_error("a chunk key is listed twice"); return MTS_E_ARG; }
+    }
     for (int i = 0; i < n_chunks; i++) {
         if (n_rows[i] < 0) return MTS_E_ARG;
         total_rows += n_rows[i];
@@ -1119,15 +1130,10 @@ int mts_cache_read_slices(long cache_id, int n_chunks, const long *chunk_keys, c
     if (!cache_alive(cache_id, c)) return MTS_E_ARG;
     MTS_HIP(hipSetDevice(E->dev));
     const u64 call_stamp = ++c->clock;
+    // the requests first: their sizes are known without the chunks, and every allocation of this call has to come BEFORE the
+    // residency check -- a workspace allocation that fails once drops this device's decoded chunks (DBuf::ensure)
     long total_rows = 0;
-    if ((rc = cache_ensure(c, E, n_chunks, chunk_keys, cdata, c_offsets, c_lengths, n_rows, n_channels, itemsize, flags, chunk_status, call_stamp, &total_rows))) return rc;
-    // descriptors: per chunk (first row, base pointer or null when it failed), per request its six numbers + output offset
-    std::vector<GatherChunk> gc(n_chunks);
-    long r0 = 0;
-    for (int i = 0; i < n_chunks; i++) {
-        gc[i].row0 = r0; r0 += n_rows[i];
-        gc[i].base = chunk_status[i] == MTS_CHUNK_OK ? c->map[chunk_keys[i]].d : nullptr;
-    }
+    for (int i = 0; i < n_chunks; i++) { if (n_rows[i] < 0) return MTS_E_ARG; total_rows += n_rows[i]; }
     std::vector<GatherReq> gr(n_req);
     u64 max_items = 0;
     for (int k = 0; k < n_req; k++) {
@@ -1138,11 +1144,21 @@ int mts_cache_read_slices(long cache_id, int n_chunks, const long *chunk_keys, c
         g.nr = (q[1] - q[0] + q[2] - 1) / q[2]; g.ncol = (q[4] - q[3] + q[5] - 1) / q[5];
         g.out_off = out_offsets[k];
         if (out_offsets[k] < 0 || (u64)out_offsets[k] + (u64)g.nr * g.ncol * itemsize > (u64)out_bytes) return MTS_E_ARG;
+        if (out_offsets[k] % itemsize) { set_error("request %d: output offset %ld is not a multiple of the item size", k, out_offsets[k]); return MTS_E_ARG; }
         if ((u64)g.nr * g.ncol > max_items) max_items = (u64)g.nr * g.ncol;
     }
     const size_t o_req = align_up(sizeof(GatherChunk) * n_chunks, 256), desc = o_req + align_up(sizeof(GatherReq) * n_req, 256);
     if ((rc = E->misc.ensure(desc + 256))) return rc;
     if ((rc = E->h_out.ensure((u64)out_bytes + 256))) return rc;
+    long total_rows_seen = 0;
+    if ((rc = cache_ensure(c, E, n_chunks, chunk_keys, cdata, c_offsets, c_lengths, n_rows, n_channels, itemsize, flags, chunk_status, call_stamp, &total_rows_seen))) return rc;
+    // (cache_ensure ends with the residency check and nothing below allocates: the base pointers stay valid)
+    std::vector<GatherChunk> gc(n_chunks);
+    long r0 = 0;
+    for (int i = 0; i < n_chunks; i++) {
+        gc[i].row0 = r0; r0 += n_rows[i];
+        gc[i].base = chunk_status[i] == MTS_CHUNK_OK ? c->map[chunk_keys[i]].d : nullptr;
+    }
     MTS_HIP(hipMemcpyAsync(E->misc.p, gc.data(), sizeof(GatherChunk) * n_chunks, hipMemcpyHostToDevice, nullptr));
     MTS_HIP(hipMemcpyAsync(E->misc.as<u8>() + o_req, gr.data(), sizeof(GatherReq) * n_req, hipMemcpyHostToDevice, nullptr));
     if (max_items && (rc = launch_gather_slices(nullptr, (const GatherChunk *)E->misc.p, n_chunks, (const GatherReq *)(E->misc.as<u8>() + o_req), n_req, max_items,

@@ -813,13 +813,17 @@ int launch_gather_slices(hipStream_t st, const GatherChunk *d_chunks, int n_chun
 {
     if (n_req == 0 || max_items == 0) return MTS_OK;
     const u64 nb = (max_items + 255) / 256;
-    dim3 grid((unsigned)(nb < 4096 ? nb : 4096), n_req);
-    switch (itemsize) {
-    case 1: hipLaunchKernelGGL(k_gather_slices<u8>, grid, dim3(256), 0, st, d_chunks, n_chunks, d_req, n_channels, d_out); break;
-    case 2: hipLaunchKernelGGL(k_gather_slices<u16>, grid, dim3(256), 0, st, d_chunks, n_chunks, d_req, n_channels, d_out); break;
-    case 4: hipLaunchKernelGGL(k_gather_slices<u32>, grid, dim3(256), 0, st, d_chunks, n_chunks, d_req, n_channels, d_out); break;
-    case 8: hipLaunchKernelGGL(k_gather_slices<u64>, grid, dim3(256), 0, st, d_chunks, n_chunks, d_req, n_channels, d_out); break;
-    default: return MTS_E_ARG;
+    if (itemsize != 1 && itemsize != 2 && itemsize != 4 && itemsize != 8) return MTS_E_ARG;
+    // grid.y (one request per row of workgroups) is limited to 65535: slabs of requests
+    for (int r0 = 0; r0 < n_req; r0 += 65535) {
+        const int nr = n_req - r0 < 65535 ? n_req - r0 : 65535;
+        dim3 grid((unsigned)(nb < 4096 ? nb : 4096), (unsigned)nr);
+        switch (itemsize) {
+        case 1: hipLaunchKernelGGL(k_gather_slices<u8>, grid, dim3(256), 0, st, d_chunks, n_chunks, d_req + r0, n_channels, d_out); break;
+        case 2: hipLaunchKernelGGL(k_gather_slices<u16>, grid, dim3(256), 0, st, d_chunks, n_chunks, d_req + r0, n_channels, d_out); break;
+        case 4: hipLaunchKernelGGL(k_gather_slices<u32>, grid, dim3(256), 0, st, d_chunks, n_chunks, d_req + r0, n_channels, d_out); break;
+        default: hipLaunchKernelGGL(k_gather_slices<u64>, grid, dim3(256), 0, st, d_chunks, n_chunks, d_req + r0, n_channels, d_out); break;
+        }
     }
     MTS_HIP(hipGetLastError());
     return MTS_OK;

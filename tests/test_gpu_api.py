@@ -447,3 +447,66 @@ def test_read_slices_gathers_on_the_device(tmp_cfg):
         assert np.array_equal(r2[10:4000:3, 1:6:2], a2[10:4000:3, 1:6:2]) and np.array_equal(r2[:, 6], a2[:, 6])
         r2.close()
     r.close()
+
+
+def test_release_then_same_shape_again():
+    """mts_release() frees the workspaces; the next batch of the SAME shape must upload its tile / segment / block
+    descriptors again (they are cached per allocation, not per address: a freed buffer usually comes back where it was)."""
+    x = synth_int16(0, 6000, 24, 11)
+    bounds = [0, 1500, 3000, 4500, 6000]
+    flags = hip.make_flags()
+    first = hip.compress_chunks(x, bounds, flags, 6)
+    again = hip.compress_chunks(x, bounds, flags, 6)                 # (descriptors reused)
+    hip.lib().mts_release()
+    after = hip.compress_chunks(x, bounds, flags, 6)
+    want = [O.ref_compress_chunk(x[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
+    assert first == want and again == want and after == want
+    hip.lib().mts_release()
+    y = synth_int16(0, 6000, 24, 12)                                 # same shape, other bytes, fresh buffers
+    assert hip.compress_chunks(y, bounds, flags, 6) == [O.ref_compress_chunk(y[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
+    st, arrs = hip.decompress_chunks(after, [1500] * 4, 24, 'int16', flags)
+    assert st == [0] * 4 and np.array_equal(np.concatenate(arrs), x)
+
+
+def test_read_slices_argument_checks_and_many_requests():
+    """mts_cache_read_slices: a key listed twice and an output offset that is not a multiple of the item size are refused;
+    more requests than one grid dimension holds (65535) are served in slabs."""
+    import ctypes as C
+    x = synth_int16(0, 3000, 8, 5)
+    z = hip.compress_chunks(x, [0, 1000, 2000, 3000], hip.make_flags(), 6)
+    flags = hip.make_flags()
+    buf = b''.join(z)
+    lens = [len(c) for c in z]
+    offs = list(np.concatenate(([0], np.cumsum(lens)))[:-1])
+    cid = hip.cache_create(1 << 20)
+    try:
+        with pytest.raises(hip.HipError) as e:
+            hip.cache_read_slices(cid, [0, 1, 0], buf, [offs[0], offs[1], offs[0]], [lens[0], lens[1], lens[0]], [1000] * 3, 8, np.int16, flags,
+                                  [(0, 10, 1, 0, 8, 1)])
+        assert e.value.code == -1
+        n_req = 70000
+        rng = np.random.RandomState(1)
+        r0 = rng.randint(0, 2990, size=n_req)
+        c0 = rng.randint(0, 7, size=n_req)
+        reqs = [(int(a), int(a) + 3, 1, int(c), int(c) + 2, 1) for a, c in zip(r0, c0)]
+        st, got = hip.cache_read_slices(cid, [0, 1, 2], buf, offs, lens, [1000] * 3, 8, np.int16, flags, reqs)
+        assert st == [0, 0, 0] and len(got) == n_req
+        for k in (0, 1, 65534, 65535, 65536, n_req - 1):
+            assert np.array_equal(got[k], x[r0[k]:r0[k] + 3, c0[k]:c0[k] + 2]), k
+        # a misaligned output offset straight through the C ABI
+        L = hip.lib()
+        keys = np.array([0], dtype=np.int64)
+        zero = np.zeros(1, dtype=np.int64)
+        rows = np.array([1000], dtype=np.int64)
+        req = np.array([0, 4, 1, 0, 8, 1], dtype=np.int64)
+        out = np.zeros(256, dtype=np.uint8)
+        status = np.zeros(1, dtype=np.int32)
+        lp = lambda a: a.ctypes.data_as(C.POINTER(C.c_long))  # noqa: E731
+        for off, want_rc in ((1, -1), (2, 0)):
+            ooff = np.array([off], dtype=np.int64)
+            rc = L.mts_cache_read_slices(cid, 1, lp(keys), out.ctypes.data_as(C.c_void_p), lp(zero), lp(zero), lp(rows), 8, 2, flags, 1, lp(req),
+                                         out.ctypes.data_as(C.c_void_p), lp(ooff), 200, status.ctypes.data_as(C.POINTER(C.c_int)))
+            assert rc == want_rc, (off, rc)
+        assert np.array_equal(out[2:2 + 64].view(np.int16).reshape(4, 8), x[0:4])
+    finally:
+        hip.cache_destroy(cid)

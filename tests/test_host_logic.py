@@ -288,3 +288,24 @@ def test_slices_through_the_decoded_chunk_cache_interface(tmp_cfg):
     assert r[200:100:-1].shape == arr[200:100:-1][0:0].shape          # (like the reference: a negative row step gives nothing)
     r.close(); r2.close()
     assert codec.caches == {}
+
+
+def test_trim_cache_copies_only_what_pins_a_big_buffer(tmp_cfg):
+    """Decoded chunks of one codec call are views of one buffer: while the cached views account for most of that buffer they
+    stay views (no host copy per chunk, neighbours keep a common base); what is left of a big batch is copied so that the
+    batch's buffer can go."""
+    arr = (np.random.RandomState(4).randn(6997, 5) * 300).astype(np.int16)
+    r, _ = _write(tmp_cfg, arr, check_after_compress=False)
+    r.set_cache_size(3)
+    r._cache.clear()
+    big = np.zeros((4000, 5), dtype=np.int16)
+    views = [big[i * 1000:(i + 1) * 1000] for i in range(4)]
+    for i in (0, 1, 2):
+        r._cache[i] = views[i]
+    r._trim_cache()
+    assert all(r._cache[i].base is big for i in (0, 1, 2))           # 3 of 4 quarters cached: views stay
+    r.set_cache_size(1)
+    r._trim_cache()
+    (idx, kept), = r._cache.items()
+    assert idx == 2 and kept.base is None and np.array_equal(kept, views[2])      # one quarter of the buffer left: copied
+    r.close()
