@@ -10,11 +10,20 @@ N=1: BASELINE.json configs[1] (385 ch @ 30 kHz, 60 s, 1 s chunks, level 6).  Wit
 N x 60 s recording are sharded round-robin (chunk i -> rank i mod N, no data-path collective; only the
 compressed sizes are gathered), so per-GPU work is fixed: weak scaling.
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process -- before it has made any HIP / torch.cuda call --
+starts the N ranks itself (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, the command the driver uses),
+relays rank 0's JSON line and exits with the child's status; fewer than N visible devices is an error, never a silent
+downgrade.  (`--dist-backend gloo --oversubscribe` lets the N ranks share the visible devices: a smoke test of the
+multi-rank path on a one-GPU box, not a measurement.)
+
 The JSON line carries, next to the contract's keys:
   roofline             the dominant kernel (k_match5): algorithmic bytes (R + C of the batch) / its launch time
   roofline_compress    (R + C) / time of the whole compress direction, roofline_decompress likewise (C + R)
   cpu_baseline         the reference's ThreadPool path restated (numpy + stdlib zlib: the oracle) on ALL host cores and on 1
+  byte_identical_chunks  how many of the recording's chunks are byte for byte what that CPU path produced (+ the .cbin sha1s)
   extras (N = 1 only, after the timed region; --no-extras skips them)
+    file_to_file       the drop-in calls compress() / decompress(out=...) on the 60 s recording as a file on tmpfs (PCIe, SHA-1
+                       and file I/O included; check_after_* off like the reference's benchmark.py:29,36), next to the CPU port's
     random_read        BASELINE configs[2]: a 600 s file, 1000 windows of 1 s at splitmix(i) starts through Reader[a:b]
     level_sweep        BASELINE configs[4] shape (1024 ch, 0.25 s chunks) at levels 1, 2, 3, 6, 9: ratio and GB/s
 """
@@ -35,7 +44,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/
 RATE = 30000
 
 
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=3)
@@ -46,18 +55,84 @@ def parse_args():
     p.add_argument('--cpu-chunks', type=int, default=0, help='chunks in the all-cores CPU sample (default: one per host cpu)')
     p.add_argument('--no-extras', action='store_true', help='skip the configs[2] / configs[4] measurements')
     p.add_argument('--extras-seconds', type=int, default=600, help='length of the random-read file (configs[2])')
-    return p.parse_args()
+    p.add_argument('--dist-backend', default='nccl', choices=('nccl', 'gloo'), help='process group backend (nccl = RCCL)')
+    p.add_argument('--oversubscribe', action='store_true',
+                   help='let ranks share devices (rank -> device rank mod visible): smoke test of the N > 1 path on fewer GPUs, not a measurement')
+    p.add_argument('--master-port', type=int, default=0, help='rendezvous port of the self-launched ranks (default: a free one)')
+    return p.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# the N > 1 path: ranks, shards, the one exchange (tests/test_distributed.py drives these same functions under gloo)
+# ------------------------------------------------------------------------------------------------
+def shard_ids(rank, world, n_total):
+    """Global chunk ids a rank owns: chunk i -> rank i mod N (the reference's batches, mtscomp.py:399-423)."""
+    return list(range(rank, n_total, world))
+
+
+def gather_chunk_offsets(local_sizes, rank, world, dist=None, device='cpu'):
+    """The only cross-rank step of the path (mtscomp.py:474-483): every rank's compressed sizes -> chunk_offsets of the whole
+    recording (exclusive prefix sum in global chunk order i = rank + k * world).  All ranks own the same number of chunks."""
+    local_sizes = np.asarray(local_sizes, dtype=np.int64)
+    if world == 1:
+        return np.concatenate(([0], np.cumsum(local_sizes)))
+    import torch
+    t = torch.from_numpy(local_sizes).to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    allsz = torch.stack(out, dim=1).reshape(-1).cpu().numpy()          # [k][rank] -> global order
+    return np.concatenate(([0], np.cumsum(allsz)))
+
+
+def visible_gpus():
+    """Devices torch sees, WITHOUT initialising the GPU in this process (device_count() does not, on this image)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, script, script_args, port=0, env=None, timeout=None):
+    """Start `n` ranks of `script` on this node the way the driver does (one process per GPU, torch.distributed.run,
+    rendezvous on 127.0.0.1) from a process that has NOT touched the GPU; relays the children's output and returns their
+    exit status."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port or free_port()), str(script)] + list(script_args)
+    e = dict(os.environ if env is None else env)
+    e.setdefault('MASTER_ADDR', '127.0.0.1')
+    e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.run(cmd, env=e, timeout=timeout).returncode
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1, not yet under torch.distributed): become the launcher."""
+    have = visible_gpus()
+    if have < args.gpus and not args.oversubscribe:
+        sys.stderr.write('bench.py: --gpus %d asked for, %d device(s) visible; refusing to measure fewer GPUs than asked '
+                         '(--oversubscribe shares devices between ranks for a smoke test)\n' % (args.gpus, have))
+        return 2
+    if have < 1:
+        sys.stderr.write('bench.py: no GPU visible\n')
+        return 2
+    return launch_ranks(args.gpus, Path(__file__).resolve(), argv, port=args.master_port)
 
 
 def cpu_baseline(x, nc, n_have, n_sample):
     """The reference's ThreadPool path restated on numpy + stdlib zlib (oracle.ref_*), timed on this box's host cores
-    over a bounded sample of the benchmarked recording: one chunk per host cpu (the recording's chunks, cycled), all of them
-    in flight at once like the reference's batch of n_threads chunks; and one core alone on two chunks."""
+    over a bounded sample of the benchmarked recording: one chunk per host cpu and at least the recording's own chunks
+    (cycled), all of them in flight at once like the reference's batch of n_threads chunks; and one core alone on two chunks.
+    Returns the record and the CPU path's compressed chunks 0 .. n_have-1 (the identity check of the GPU output)."""
     from multiprocessing.dummy import Pool as ThreadPool
     import zlib
     from oracle import oracle as O
     ncpu = os.cpu_count() or 1
-    n_sample = n_sample or ncpu
+    n_sample = n_sample or max(ncpu, n_have)
     cores = min(ncpu, n_sample)
     chunk = lambda i: x[(i % n_have) * RATE:(i % n_have + 1) * RATE]  # noqa: E731
     ids = list(range(n_sample))
@@ -68,6 +143,7 @@ def cpu_baseline(x, nc, n_have, n_sample):
         back = pool.map(lambda i: O.ref_decompress_chunk(cc[i], RATE, nc, 'int16'), ids)
         t2 = time.perf_counter()
     assert all(np.array_equal(back[i], chunk(i)) for i in (0, n_sample - 1))
+    del back
     gb = n_sample * RATE * nc * 2 / 1e9
     # one core
     m1 = 2
@@ -81,24 +157,36 @@ def cpu_baseline(x, nc, n_have, n_sample):
     return {
         'value': gb / (t2 - t0), 'unit': 'GB/s', 'cores': cores, 'kind': 'port',
         'sample': '%d chunks (%d ch x %d samples int16 each, %.0f MB; the recording\'s %d chunks cycled), numpy diff/tobytes + stdlib '
-                  'zlib %s level 6, ThreadPool(%d) of %d host cpus, every chunk in flight at once: compress %.3f GB/s, decompress %.3f GB/s; '
+                  'zlib %s level 6, ThreadPool(%d) of %d host cpus, every chunk in flight at once: compress %.3f GB/s, decompress %.3f GB/s '
+                  '(the threads share the GIL for the numpy part, as the reference\'s ThreadPool does: %.1f MB/s per thread against %.1f for one core alone); '
                   'one core on %d chunks: compress %.4f GB/s, decompress %.3f GB/s'
                   % (n_sample, nc, RATE, gb * 1e3, n_have, zlib.ZLIB_RUNTIME_VERSION, cores, ncpu, gb / (t1 - t0), gb / (t2 - t1),
-                     m1, gb1 / (a1 - a0), gb1 / (a2 - a1)),
+                     gb / (t1 - t0) / cores * 1e3, gb1 / (a1 - a0) * 1e3, m1, gb1 / (a1 - a0), gb1 / (a2 - a1)),
         'compress_gbps': gb / (t1 - t0), 'decompress_gbps': gb / (t2 - t1),
         'one_core': {'value': gb1 / (a2 - a0), 'compress_gbps': gb1 / (a1 - a0), 'decompress_gbps': gb1 / (a2 - a1), 'cores': 1, 'chunks': m1},
-    }
+    }, (cc[:n_have] if n_sample >= n_have else None)
 
 
-def measured_traffic(n_chunks, nc):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS round's profile
-    (profiles/r2_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this script; a counter pass cannot
-    run inside the timed process).  Only valid for the profiled workload (60 chunks x 385 ch); null otherwise."""
-    for name in ('r2_traffic.json', 'r1_traffic.json'):
+# stage of the library's timing hooks -> the kernel that stage is (one launch per step)
+STAGE_KERNEL = {'match': 'k_match5', 'hash_sort': 'k_hash_sort', 'delta_transpose': 'k_delta_rows', 'block_pack': 'k_block_pack',
+                'block_trees': 'k_block_trees'}
+
+
+def measured_traffic(kernel, n_chunks, nc):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of the newest profile (profiles/rN_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this script -- a counter pass cannot run inside the timed
+    process).  Only valid for the profiled workload (60 chunks x 385 ch) and for a kernel the profile lists; null otherwise."""
+    if n_chunks != 60 or nc != 385:
+        return None, None
+    for name in ('r3_traffic.json', 'r2_traffic.json', 'r1_traffic.json'):
         p = ROOT / 'profiles' / name
-        if p.exists() and n_chunks == 60 and nc == 385:
-            d = json.loads(p.read_text())
-            return d['traffic_bytes_per_launch'], 'profiles/' + name
+        if not p.exists():
+            continue
+        d = json.loads(p.read_text())
+        per = d.get('kernels', {d.get('kernel'): d.get('traffic_bytes_per_launch')})
+        if per.get(kernel) is not None:
+            return per[kernel], 'profiles/' + name
+        return None, None                     # the newest profile does not know this kernel: say nothing rather than something stale
     return None, None
 
 
@@ -114,21 +202,15 @@ def lp(a):
     return a.ctypes.data_as(C.POINTER(C.c_long))
 
 
-def extra_random_read(torch, hip, L, dev, seconds, n_windows=1000):
-    """BASELINE configs[2]: a `seconds` s 385-channel file (compressed on the device, written to tmpfs with its header), then
-    Reader[s:s+30000] at s = splitmix(i) mod (n_samples - 30000): first pass (chunks decoded on first touch, then resident in
-    the decoded-chunk cache in HBM) and second pass (every chunk resident); windows checked against the generator."""
-    import tempfile
-    import mtscomp_amd
-    nc, piece = 385, 60
-    tmp = Path(tempfile.mkdtemp(prefix='mtsbench_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None))
-    os.environ.setdefault('HOME', str(tmp))
+def build_synth_file(torch, hip, L, dev, seconds, tmp, nc=385):
+    """A `seconds` s recording of the synthetic generator as data.cbin + data.ch under `tmp`, compressed on the device a minute
+    at a time (the raw file is never materialised).  Returns (n_samples, compressed bytes)."""
+    piece = 60
     cb = (hip.compress_bound(RATE * nc * 2) + 255) // 256 * 256
     raw = torch.empty((piece * RATE, nc), dtype=torch.int16, device='cuda')
     cbuf = torch.empty(piece * cb, dtype=torch.uint8, device='cuda')
     flags = hip.make_flags(True, False, 'F')
     offsets = [0]
-    t_gen = time.perf_counter()
     with open(tmp / 'data.cbin', 'wb') as f:
         for p0 in range(0, seconds, piece):
             n = min(piece, seconds - p0)
@@ -151,9 +233,29 @@ def extra_random_read(torch, hip, L, dev, seconds, n_windows=1000):
               'n_channels': nc, 'sample_rate': float(RATE), 'chunk_bounds': list(range(0, n_samples + 1, RATE)), 'chunk_offsets': offsets,
               'chunk_order': 'F', 'sha1_compressed': None, 'sha1_uncompressed': None, 'shape': [n_samples, nc]}
     (tmp / 'data.ch').write_text(json.dumps(header))
+    return n_samples, offsets[-1]
+
+
+def window_starts(n_samples, n_windows):
+    """BASELINE configs[2]'s windows: start = splitmix64(i) mod (n_samples - 30000)  (SURVEY 8d)."""
+    return [int(splitmix(i) % (n_samples - RATE)) for i in range(n_windows)]
+
+
+def extra_random_read(torch, hip, L, dev, seconds, n_windows=1000):
+    """BASELINE configs[2]: a `seconds` s 385-channel file (compressed on the device, written to tmpfs with its header), then
+    Reader[s:s+30000] at s = splitmix(i) mod (n_samples - 30000): first pass (chunks decoded on first touch, then resident in
+    the decoded-chunk cache in HBM) and second pass (every chunk resident); windows checked against the generator."""
+    import tempfile
+    import mtscomp_amd
+    nc = 385
+    tmp = Path(tempfile.mkdtemp(prefix='mtsbench_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None))
+    os.environ.setdefault('HOME', str(tmp))
+    t_gen = time.perf_counter()
+    n_samples, cbytes = build_synth_file(torch, hip, L, dev, seconds, tmp, nc)
+    offsets = [0, cbytes]
     t_gen = time.perf_counter() - t_gen
     r = mtscomp_amd.decompress(tmp / 'data.cbin', tmp / 'data.ch')
-    starts = [int(splitmix(i) % (n_samples - RATE)) for i in range(n_windows)]
+    starts = window_starts(n_samples, n_windows)
     passes = []
     for _ in range(2):
         t0 = time.perf_counter()
@@ -238,8 +340,125 @@ def extra_level_sweep(torch, hip, L, dev, seconds=60, levels=(1, 2, 3, 6, 9)):
     return out
 
 
-def main():
-    args = parse_args()
+def cpu_file_to_file(raw_path, tmp, nc, n_threads):
+    """The reference's file-to-file calls restated (Writer.write mtscomp.py:461-495, Reader.tofile :717-738) on numpy + stdlib
+    zlib: batches of n_threads chunks through a ThreadPool, in-order write, both SHA-1s, JSON header; then the way back."""
+    import hashlib
+    from multiprocessing.dummy import Pool as ThreadPool
+    from oracle import oracle as O
+    data = np.memmap(raw_path, dtype=np.int16, mode='r').reshape(-1, nc)
+    n = data.shape[0]
+    bounds = list(range(0, n, RATE)) + ([n] if n % RATE else [n])
+    bounds = sorted(set(bounds))
+    ids = list(range(len(bounds) - 1))
+    out, outmeta, back = tmp / 'cpu.cbin', tmp / 'cpu.ch', tmp / 'cpu_back.bin'
+    s_raw, s_c = hashlib.sha1(), hashlib.sha1()
+    offs = [0]
+    t0 = time.perf_counter()
+    with open(out, 'wb') as f, ThreadPool(n_threads) as pool:
+        for b0 in range(0, len(ids), n_threads):
+            batch = ids[b0:b0 + n_threads]
+            cc = pool.map(lambda i: O.ref_compress_chunk(data[bounds[i]:bounds[i + 1]]), batch)
+            for i, c in zip(batch, cc):
+                f.write(c)
+                offs.append(offs[-1] + len(c))
+                s_raw.update(np.ascontiguousarray(data[bounds[i]:bounds[i + 1]]))
+                s_c.update(c)
+    outmeta.write_text(json.dumps({'chunk_offsets': offs, 'chunk_bounds': bounds, 'sha1_compressed': s_c.hexdigest(),
+                                   'sha1_uncompressed': s_raw.hexdigest()}, indent=2, sort_keys=True))
+    t1 = time.perf_counter()
+    fd = os.open(out, os.O_RDONLY)
+    with open(back, 'wb') as f, ThreadPool(n_threads) as pool:
+        for b0 in range(0, len(ids), n_threads):
+            batch = ids[b0:b0 + n_threads]
+            arrs = pool.map(lambda i: O.ref_decompress_chunk(os.pread(fd, offs[i + 1] - offs[i], offs[i]), bounds[i + 1] - bounds[i], nc, 'int16'), batch)
+            for a in arrs:
+                f.write(a)
+    os.close(fd)
+    t2 = time.perf_counter()
+    same = np.array_equal(np.memmap(back, dtype=np.int16, mode='r'), np.memmap(raw_path, dtype=np.int16, mode='r'))
+    res = {'compress_gbps': data.nbytes / (t1 - t0) / 1e9, 'decompress_gbps': data.nbytes / (t2 - t1) / 1e9, 'threads': n_threads,
+           'sha1_compressed': s_c.hexdigest(), 'round_trip_ok': bool(same)}
+    for q in (out, outmeta, back):
+        q.unlink()
+    return res
+
+
+def extra_file_to_file(x, nc, with_cpu):
+    """The drop-in calls on a file: mtscomp_amd.compress(raw, .cbin, .ch) and mtscomp_amd.decompress(.cbin, .ch, out) of the
+    benchmarked recording written to tmpfs -- pread, PCIe both ways, the two SHA-1s the .ch needs, file writes: everything
+    the reference's benchmark.py:26-45 times, check_after_* off as there (:29, :36).  Next to it the CPU port's same calls."""
+    import hashlib
+    import tempfile
+    import mtscomp_amd
+    tmp = Path(tempfile.mkdtemp(prefix='mtsbench_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None))
+    os.environ.setdefault('HOME', str(tmp))
+    raw, out, outmeta, back = tmp / 'data.bin', tmp / 'data.cbin', tmp / 'data.ch', tmp / 'back.bin'
+    try:
+        x.tofile(raw)
+        nbytes = raw.stat().st_size
+        best_c = best_d = None
+        for rep in range(2):                                # (the first call also allocates the engine's staging buffers)
+            t0 = time.perf_counter()
+            ratio = mtscomp_amd.compress(raw, out, outmeta, sample_rate=float(RATE), n_channels=nc, dtype=np.int16, check_after_compress=False)
+            t1 = time.perf_counter()
+            r = mtscomp_amd.decompress(out, outmeta, back, overwrite=True, check_after_decompress=False)
+            r.close()
+            t2 = time.perf_counter()
+            best_c = t1 - t0 if best_c is None else min(best_c, t1 - t0)
+            best_d = t2 - t1 if best_d is None else min(best_d, t2 - t1)
+        meta = json.loads(outmeta.read_text())
+        sha_c = hashlib.sha1(out.read_bytes()).hexdigest()
+        same = np.array_equal(np.memmap(back, dtype=np.int16, mode='r'), np.memmap(raw, dtype=np.int16, mode='r'))
+        res = {'workload': '%d ch @ 30 kHz, %.0f s int16 file on tmpfs (%.2f GB), chunk = 1 s, level 6; check_after_* off' % (nc, x.shape[0] / RATE, nbytes / 1e9),
+               'compress_gbps': nbytes / best_c / 1e9, 'decompress_gbps': nbytes / best_d / 1e9, 'ratio': ratio,
+               'header_sha1_matches_file': bool(meta['sha1_compressed'] == sha_c), 'round_trip_file_identical': bool(same),
+               'sha1_compressed': sha_c}
+        if with_cpu:
+            cpu = cpu_file_to_file(raw, tmp, nc, os.cpu_count() or 1)
+            res['cpu_port'] = cpu
+            res['cbin_identical_to_cpu_port'] = bool(cpu['sha1_compressed'] == sha_c)
+        return res
+    finally:
+        for q in (raw, out, outmeta, back, tmp / '.mtscomp'):
+            try:
+                q.unlink()
+            except OSError:
+                pass
+        try:
+            tmp.rmdir()
+        except OSError:
+            pass
+
+
+def extra_in_process_multi_gpu(hip, x, nc, n_dev):
+    """What a drop-in user of an N-GPU node gets without torch.distributed: HipCodec(devices=range(N)), one host thread per
+    GPU, chunk i -> GPU i mod N, host buffers in and out (PCIe included)."""
+    from mtscomp_amd.api import HipCodec
+    codec = HipCodec(devices=list(range(n_dev)))
+    chunks = [x[i * RATE:(i + 1) * RATE] for i in range(x.shape[0] // RATE)]
+    flags = hip.make_flags(True, False, 'F')
+    best_c = best_d = None
+    for rep in range(2):
+        t0 = time.perf_counter()
+        cc = codec.compress(chunks, flags, 6)
+        t1 = time.perf_counter()
+        st, arrs = codec.decompress(cc, [RATE] * len(cc), nc, np.int16, flags)
+        t2 = time.perf_counter()
+        best_c = t1 - t0 if best_c is None else min(best_c, t1 - t0)
+        best_d = t2 - t1 if best_d is None else min(best_d, t2 - t1)
+    ok = all(s == 0 for s in st) and all(np.array_equal(a, c) for a, c in zip(arrs, chunks))
+    nb = len(chunks) * RATE * nc * 2
+    return {'devices': n_dev, 'chunks': len(chunks), 'compress_gbps': nb / best_c / 1e9, 'decompress_gbps': nb / best_d / 1e9, 'round_trip_ok': bool(ok),
+            'path': 'HipCodec(devices=range(N)): host arrays in, bytes out, one host thread per GPU (rank 0 of the bench, the other ranks idle)'}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # not under torch.distributed yet: start the ranks (nothing in this process has touched the GPU)
+        sys.exit(self_launch(args, argv))
     import torch
     import torch.distributed as dist
     from mtscomp_amd import hip
@@ -247,11 +466,26 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != max(args.gpus, 1):
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
+        sys.exit(2)
+    have = visible_gpus()
+    if local_rank >= have and not args.oversubscribe:
+        sys.stderr.write('bench.py: rank %d has no device (%d visible)\n' % (local_rank, have))
+        sys.exit(2)
+    dev = local_rank % max(have, 1)
+    gloo = args.dist_backend == 'gloo'
+    xdev = 'cpu' if gloo else 'cuda'                     # where the few numbers that cross ranks live
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    dev = local_rank if world > 1 else 0
+        torch.cuda.set_device(dev)
+        if gloo:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
+        # (a host-side group for the last wait: an RCCL barrier would park a spinning kernel on every other GPU while rank 0
+        # runs its after-the-measurement extras)
+        host_group = dist.new_group(backend='gloo')
     torch.cuda.set_device(dev)
     hip.require_device()
     L = hip.lib()
@@ -264,10 +498,10 @@ def main():
     stream = torch.cuda.current_stream()
     sh = C.c_void_p(stream.cuda_stream)
 
-    # synthetic recording, generated on device: this rank owns global chunks rank, rank+world, ...
+    # synthetic recording, generated on device: this rank owns global chunks rank, rank + world, ... of a world x 60 s recording
+    mine = shard_ids(rank, world, n_chunks * world)
     raw = torch.empty((n_chunks * rate, nc), dtype=torch.int16, device='cuda')
-    for k in range(n_chunks):
-        g = rank + k * world
+    for k, g in enumerate(mine):
         rc = L.mts_dev_synth_int16(dev, sh, C.c_void_p(raw[k * rate:].data_ptr()), g * rate, (g + 1) * rate, nc, 0)
         assert rc == 0, hip.lib().mts_last_error()
     torch.cuda.synchronize()
@@ -296,14 +530,7 @@ def main():
         assert not status.any(), status
 
     def gather_sizes():
-        # the only cross-rank step of the path: compressed sizes -> chunk_offsets (host-side prefix sum)
-        if world == 1:
-            return sizes.copy()
-        t = torch.from_numpy(sizes).cuda()
-        out = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(out, t)
-        allsz = torch.stack(out, dim=1).reshape(-1).cpu().numpy()     # global chunk order: i = rank + k*world
-        return np.concatenate(([0], np.cumsum(allsz)))
+        return gather_chunk_offsets(sizes, rank, world, dist, xdev)
 
     stage = {}
 
@@ -329,20 +556,21 @@ def main():
         b = time.perf_counter()
         decompress()
         add_stages()
-        gather_sizes()
+        offsets = gather_sizes()
         c = time.perf_counter()
         t_c += b - a
         t_d += c - b
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed, t_c, t_d], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed, t_c, t_d], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, t_c, t_d = t.tolist()
 
-    # correctness of what was timed (outside the timed region): device round trip + oracle spot check
+    # correctness of what was timed (outside the timed region): device round trip on every rank + oracle spot check
     assert torch.equal(back, raw), 'round trip mismatch'
-    csize = int(sizes.sum())
+    csize_local = int(sizes.sum())
+    csize = int(offsets[-1]) if args.steps else csize_local
     ok_oracle = None
     if rank == 0:
         from oracle import oracle as O
@@ -355,10 +583,12 @@ def main():
         total_raw = raw_bytes * world * args.steps
         ms_step = elapsed / args.steps * 1e3
         sm = {k: float(np.mean(v)) for k, v in stage.items()}
-        match_ms = sm.get('match', 0.0)
-        algo = n_chunks * chunk_bytes + csize            # R + C per launch of the match kernel
-        achieved = algo / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(n_chunks, nc)
+        algo = n_chunks * chunk_bytes + csize_local      # R + C per launch (a launch = this rank's batch of chunks)
+        # the dominant kernel = the longest single-kernel stage
+        dom_stage = max((k for k in sm if k in STAGE_KERNEL), key=lambda k: sm[k], default='match')
+        dom_kernel, dom_ms = STAGE_KERNEL.get(dom_stage, 'k_match5'), sm.get(dom_stage, 0.0)
+        achieved = algo / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(dom_kernel, n_chunks, nc)
         comp_names = ('delta_transpose', 'hash_sort', 'match', 'parse_fixpoint', 'parse_emit', 'block_trees', 'block_pack')
         comp_ms = sum(sm.get(k, 0.0) for k in comp_names)
         dec_ms = sum(v for k, v in sm.items() if k not in comp_names and not k.startswith('hash_sort'))
@@ -369,6 +599,12 @@ def main():
             ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             return {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS,
                     'algorithmic_bytes_per_step': algo, 'device_ms_per_step': ms}
+
+        def transform(stage_name, kernel):                    # K1 / K2 alone: read R + write R
+            ms = sm.get(stage_name, 0.0)
+            ach = 2 * raw_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {'bound': 'hbm', 'kernel': kernel, 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS,
+                    'algorithmic_bytes_per_launch': 2 * raw_bytes, 'launch_ms': ms}
         res = {
             'metric': 'compress + decompress GB/s (raw int16)', 'value': total_raw / elapsed / 1e9, 'unit': 'GB/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
@@ -377,26 +613,48 @@ def main():
             'config': {'workload': '%d ch @ 30 kHz, %d s synthetic AR int16 per GPU, chunk=1 s, zlib level 6 '
                                    '(BASELINE configs[1])' % (nc, args.seconds),
                        'n_channels': nc, 'chunks_per_gpu': n_chunks, 'chunk_bytes': chunk_bytes,
-                       'sharding': 'chunk i -> rank i mod N (round robin), no collective on the data path'},
+                       'sharding': 'chunk i -> rank i mod N (round robin), no collective on the data path; the compressed sizes are '
+                                   'all-gathered (%s) and prefix-summed into chunk_offsets' % args.dist_backend,
+                       'rank_chunks': {str(r): shard_ids(r, world, n_chunks * world) for r in range(world)} if world > 1 else None,
+                       'oversubscribed': bool(args.oversubscribe and world > have)},
             'compress_gbps': raw_bytes * world * args.steps / t_c / 1e9,
             'decompress_gbps': raw_bytes * world * args.steps / t_d / 1e9,
-            'ratio': csize / raw_bytes, 'byte_identical_chunk0': ok_oracle,
+            'ratio': csize / (raw_bytes * world), 'byte_identical_chunk0': ok_oracle,
             'stage_ms': sm,
-            'roofline': {'bound': 'hbm', 'kernel': 'k_match5', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+            'roofline': {'bound': 'hbm', 'kernel': dom_kernel, 'stage': dom_stage, 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'algorithmic_bytes_per_launch': algo, 'launch_ms': match_ms},
+                         'algorithmic_bytes_per_launch': algo, 'launch_ms': dom_ms},
             'roofline_compress': direction(comp_ms),
             'roofline_decompress': dict(direction(dec_ms), dominant_stage=dec_dom[0], dominant_stage_ms=dec_dom[1]),
+            'roofline_k1': transform('delta_transpose', 'k_delta_rows'),
+            'roofline_k2': transform('cumsum_transpose', 'k_cumsum_rows'),
         }
+        x_host = None
+        cpu_chunks = None
+        if (not args.no_cpu_baseline or not args.no_extras) and world == 1:
+            x_host = raw.cpu().numpy()
         if not args.no_cpu_baseline and world == 1:             # (the CPU comparison is taken once, at N = 1)
             try:
-                res['cpu_baseline'] = cpu_baseline(raw.cpu().numpy(), nc, n_chunks, args.cpu_chunks)
+                res['cpu_baseline'], cpu_chunks = cpu_baseline(x_host, nc, n_chunks, args.cpu_chunks)
             except Exception as e:  # noqa: BLE001  -- the headline line must come out whatever happens here
                 res['cpu_baseline'] = {'error': repr(e)}
+        if cpu_chunks is not None:
+            # the whole recording, not chunk 0 alone: every chunk the timed region produced against the CPU path's bytes
+            import hashlib
+            host = cbuf.cpu().numpy()
+            mine_c = [host[int(slots[k]):int(slots[k]) + int(sizes[k])].tobytes() for k in range(n_chunks)]
+            same = [a == b for a, b in zip(mine_c, cpu_chunks)]
+            res['byte_identical_chunks'] = '%d/%d' % (sum(same), n_chunks)
+            res['cbin_sha1'] = hashlib.sha1(b''.join(mine_c)).hexdigest()
+            res['cbin_sha1_cpu'] = hashlib.sha1(b''.join(cpu_chunks)).hexdigest()
+            del host, mine_c
+            assert all(same), 'chunks %s differ from zlib level 6' % [i for i, ok in enumerate(same) if not ok][:8]
         if not args.no_extras and world == 1:
-            back = cbuf = None                      # (room for the extras' buffers)
+            back = cbuf = raw = None                # (room for the extras' buffers)
+            torch.cuda.empty_cache()
             extras = {}
-            for name, fn in (('random_read', lambda: extra_random_read(torch, hip, L, dev, args.extras_seconds)),
+            for name, fn in (('file_to_file', lambda: extra_file_to_file(x_host, nc, not args.no_cpu_baseline)),
+                             ('random_read', lambda: extra_random_read(torch, hip, L, dev, args.extras_seconds)),
                              ('level_sweep', lambda: extra_level_sweep(torch, hip, L, dev))):
                 t1 = time.perf_counter()
                 try:
@@ -405,8 +663,16 @@ def main():
                     extras[name] = {'error': repr(e)}
                 extras[name]['wall_s'] = time.perf_counter() - t1
             res['extras'] = extras
-        print(json.dumps(res))
+        if not args.no_extras and world > 1 and not args.oversubscribe:
+            t1 = time.perf_counter()
+            try:
+                res['extras'] = {'in_process_multi_gpu': extra_in_process_multi_gpu(hip, raw.cpu().numpy(), nc, world)}
+            except Exception as e:  # noqa: BLE001
+                res['extras'] = {'in_process_multi_gpu': {'error': repr(e)}}
+            res['extras']['in_process_multi_gpu']['wall_s'] = time.perf_counter() - t1
+        print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier(group=host_group)              # (the other ranks keep their devices free until rank 0 is done)
         dist.destroy_process_group()
 
 
