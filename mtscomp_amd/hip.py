@@ -10,7 +10,10 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / 'libmtscomp_hip.so'
+import os
+
+# (MTSCOMP_HIP_LIB: another build of the same library, for A/B measurements -- tools/ab_stage_times.py)
+LIB_PATH = Path(os.environ.get('MTSCOMP_HIP_LIB') or _HERE / 'libmtscomp_hip.so')
 
 FLAG_TIME_DIFF = 1
 FLAG_SPATIAL_DIFF = 2

@@ -11,6 +11,7 @@ import ctypes as C
 import hashlib
 import json
 import os
+import shutil
 import tempfile
 import zlib
 from multiprocessing.dummy import Pool as ThreadPool
@@ -27,6 +28,13 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 RATE = 30000
 
+# These tests hold their recordings in torch tensors.  torch brings its own HIP / HSA runtime libraries: they must be the first
+# ones this process initialises (a second runtime opening the device after libmtscomp_hip.so's finds no GPU), so the device is
+# initialised here, at collection time, before any test has called into the library.
+if os.path.exists('/dev/kfd'):
+    import torch
+    torch.cuda.init()
+
 
 @pytest.fixture
 def shm(monkeypatch):
@@ -34,9 +42,7 @@ def shm(monkeypatch):
     monkeypatch.setenv('HOME', str(tmp))
     monkeypatch.setattr(mtscomp_amd.api, 'CONFIG_PATH', tmp / '.mtscomp', raising=False)
     yield tmp
-    for q in tmp.iterdir():
-        q.unlink()
-    tmp.rmdir()
+    shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _lp(a):
@@ -51,7 +57,6 @@ def _synth_host(torch, t0, t1, nc):
 
 
 def test_config1_whole_recording_byte_identical(shm):
-    import torch
     nc, seconds = 385, 60
     x = np.concatenate([_synth_host(torch, s * RATE, (s + 1) * RATE, nc) for s in range(seconds)])
     raw, out, outmeta, back = shm / 'data.bin', shm / 'data.cbin', shm / 'data.ch', shm / 'back.bin'
@@ -80,7 +85,6 @@ def test_config1_whole_recording_byte_identical(shm):
 
 @pytest.mark.parametrize('cache_gb', [None, '1'])          # default (32 GiB: the whole decoded file stays in HBM) / 1 GiB (43 chunks: evicts all the time)
 def test_config2_random_windows_600s(shm, monkeypatch, cache_gb):
-    import torch
     nc, seconds = 385, 600
     n_windows = 1000 if cache_gb is None else 150
     if cache_gb is not None:
@@ -105,7 +109,6 @@ def test_config2_random_windows_600s(shm, monkeypatch, cache_gb):
 
 
 def test_config4_stress_shape_every_chunk_levels_1_6_9():
-    import torch
     nc, rows, n = 1024, 7500, 240
     L = hip.lib()
     raw = torch.empty((n * rows, nc), dtype=torch.int16, device='cuda')
