@@ -141,17 +141,33 @@ static int rows_tile(int nc, int itemsize)
     return 0;
 }
 
+// Row tiles that follow each other in time touch the same cache lines on the stream side (a channel's 64 items of a tile are
+// 128 bytes at a 32-byte phase): consecutive tiles of a chunk are given to ONE XCD (workgroup b runs on XCD b % 8), so that its
+// L2 merges the halves; with tile = blockIdx.x neighbours sat on different XCDs and every line crossed the fabric twice.
+// Linear workgroup b -> (chunk, tile); false when the tile does not exist.
+__device__ __forceinline__ bool xcd_row_tile(int ntile, int &tile, int &chunk)
+{
+    const u32 per = ((u32)ntile + 7) / 8;                      // tiles of a chunk per XCD
+    const u32 xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    chunk = (int)(j / per);
+    tile = (int)(xcd * per + j % per);
+    return tile < ntile;
+}
+static unsigned xcd_row_grid(int ntile, int n_chunks) { return 8u * (((unsigned)ntile + 7) / 8) * (unsigned)n_chunks; }
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_delta_rows(const u8 *__restrict__ raw, u8 *__restrict__ stream,
                                                     const ChunkDesc *__restrict__ chunks, int nc, int tt_rows, int pitch,
-                                                    u32 nc_magic, u64 *adler_acc)
+                                                    u32 nc_magic, u64 *adler_acc, int ntile_max)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem_rows[];
     T *tile = (T *)smem_rows;                                   // [tt_rows + 1][pitch]; row 0 = t0 - 1
     __shared__ u64 red[8];
-    const ChunkDesc ch = chunks[blockIdx.y];
+    int tile_x, chunk_y;
+    if (!xcd_row_tile(ntile_max, tile_x, chunk_y)) return;
+    const ChunkDesc ch = chunks[chunk_y];
     const long nt = ch.n_rows;
-    const long t0 = (long)blockIdx.x * tt_rows;
+    const long t0 = (long)tile_x * tt_rows;
     if (t0 >= nt) return;
     constexpr int EPD = 4 / (int)sizeof(T);
     const T *x = (const T *)(raw + ch.raw_off);
@@ -162,19 +178,37 @@ __global__ __launch_bounds__(256) void k_delta_rows(const u8 *__restrict__ raw, 
     const T *xs = x + t0 * nc;
     const long e_n = (long)nrow * nc;
     if ((((u64)xs) & 15) == 0) {
-        // 16 bytes (VW items) per lane and step
+        // 16 bytes (VW items) per lane and step, LOADS_IN_FLIGHT steps at a time: what bounds this kernel is the memory
+        // latency, i.e. how many bytes a CU has on their way (one load per lane and loop turn kept 12 KB per CU in flight and
+        // the kernel at 2.8 TB/s; the chip needs ~40 KB per CU to stream at its rate)
         constexpr int VW = 16 / (int)sizeof(T);
+        constexpr int LOADS_IN_FLIGHT = 7;
         const uint4 *xq = (const uint4 *)xs;
-        for (long i = threadIdx.x; i * VW < e_n; i += 256) {
-            u32 w[4] = {0, 0, 0, 0};
-            if ((i + 1) * VW <= e_n) { const uint4 q = xq[i]; w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; }
-            else for (int j = 0; (long)i * VW + j < e_n; j++) w[j / EPD] |= (u32)xs[i * VW + j] << (8 * sizeof(T) * (j % EPD));      // ragged end: never read past the rows
-            u32 r = __umulhi((u32)i * VW, nc_magic), c = (u32)i * VW - r * nc;
+        const long n_full = e_n / VW;                              // whole 16-byte pieces
+        for (long base = 0; base < n_full; base += 256 * LOADS_IN_FLIGHT) {
+            uint4 q[LOADS_IN_FLIGHT];
 #pragma unroll
-            for (int j = 0; j < VW; j++) {
-                if ((long)i * VW + j < e_n) tile[(r + 1) * pitch + c] = (T)(w[j / EPD] >> (8 * sizeof(T) * (j % EPD)));
-                if (++c == (u32)nc) { c = 0; r++; }
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                const long i = base + u * 256 + threadIdx.x;
+                q[u] = i < n_full ? xq[i] : make_uint4(0, 0, 0, 0);
             }
+#pragma unroll
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                const long i = base + u * 256 + threadIdx.x;
+                if (i < n_full) {
+                    const u32 w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                    u32 r = __umulhi((u32)i * VW, nc_magic), c = (u32)i * VW - r * nc;
+#pragma unroll
+                    for (int j = 0; j < VW; j++) {
+                        tile[(r + 1) * pitch + c] = (T)(w[j / EPD] >> (8 * sizeof(T) * (j % EPD)));
+                        if (++c == (u32)nc) { c = 0; r++; }
+                    }
+                }
+            }
+        }
+        for (long e = n_full * VW + threadIdx.x; e < e_n; e += 256) {     // ragged end: never read past the rows
+            const u32 r = __umulhi((u32)e, nc_magic), c = (u32)e - r * nc;
+            tile[(r + 1) * pitch + c] = xs[e];
         }
     } else {
         for (long i = threadIdx.x; i < e_n; i += 256) {
@@ -210,12 +244,16 @@ __global__ __launch_bounds__(256) void k_delta_rows(const u8 *__restrict__ raw, 
                     const T cur = tile[(tt + j + 1) * pitch + c];
                     const T d = (T)(cur - prev);
                     prev = cur;
-                    if (t0 + tt + j < nt) {
-                        w[j / EPD] |= (u32)d << (8 * sizeof(T) * (j % EPD));
-                        adler_item(d, (u64)c * nt + t0 + tt + j);
-                    }
+                    if (t0 + tt + j < nt) w[j / EPD] |= (u32)d << (8 * sizeof(T) * (j % EPD));      // (items past the chunk stay zero: no weight in the sums)
                 }
                 const u64 I = (u64)c * nt + t0 + tt;
+                {   // adler32 of the lane's 8 bytes: byte k of them is byte I * sizeof(T) + k of the stream
+                    u32 bs = 0, bw = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { const u32 b = (w[k >> 2] >> (8 * (k & 3))) & 0xff; bs += b; bw += k * b; }
+                    sa += bs;
+                    sb += (nbytes - I * sizeof(T)) * bs - bw;
+                }
                 if (t0 + tt + IPL <= nt) *(uint2 *)&out[I] = make_uint2(w[0], w[1]);
                 else for (int j = 0; t0 + tt + j < nt; j++) out[I + j] = (T)(w[j / EPD] >> (8 * sizeof(T) * (j % EPD)));
             }
@@ -237,8 +275,8 @@ __global__ __launch_bounds__(256) void k_delta_rows(const u8 *__restrict__ raw, 
     }
     block_sum2(sa, sb, red);
     if (threadIdx.x == 0) {
-        atomicAdd((unsigned long long *)&adler_acc[2 * blockIdx.y], (unsigned long long)(sa % 65521u));
-        atomicAdd((unsigned long long *)&adler_acc[2 * blockIdx.y + 1], (unsigned long long)(sb % 65521u));
+        atomicAdd((unsigned long long *)&adler_acc[2 * chunk_y], (unsigned long long)(sa % 65521u));
+        atomicAdd((unsigned long long *)&adler_acc[2 * chunk_y + 1], (unsigned long long)(sb % 65521u));
     }
 }
 
@@ -249,8 +287,9 @@ static void run_delta_rows(hipStream_t st, const u8 *raw, u8 *stream, const Chun
     const int tt = rows_tile(nc, (int)sizeof(T)), pitch = rows_pitch(nc, (int)sizeof(T));
     const size_t lds = (size_t)(tt + 1) * pitch * sizeof(T);
     (void)ensure_dynamic_lds((const void *)k_delta_rows<T>, 64 * 1024);
-    dim3 grid((max_rows + tt - 1) / tt, n_chunks);
-    hipLaunchKernelGGL(k_delta_rows<T>, grid, dim3(256), lds, st, raw, stream, d_chunks, nc, tt, pitch, 0xffffffffu / (u32)nc + 1, d_adler_acc);
+    const int ntile = (int)((max_rows + tt - 1) / tt);
+    hipLaunchKernelGGL(k_delta_rows<T>, dim3(xcd_row_grid(ntile, n_chunks)), dim3(256), lds, st, raw, stream, d_chunks, nc, tt, pitch, 0xffffffffu / (u32)nc + 1,
+                       d_adler_acc, ntile);
 }
 
 int launch_delta_transpose(hipStream_t st, const void *d_raw, void *d_stream, const ChunkDesc *d_chunks,
@@ -542,29 +581,37 @@ __global__ __launch_bounds__(256) void k_rows_sums(const u8 *__restrict__ stream
                                                    const u32 *__restrict__ rows, const int *__restrict__ status,
                                                    int nc, int tt_rows, int ntile_max, u32 *__restrict__ sums)
 {
-    const int chunk = blockIdx.y;
+    int tile_x, chunk;
+    if (!xcd_row_tile(ntile_max, tile_x, chunk)) return;
     if (status && status[chunk] != 0) return;
     const long nt = rows[chunk];
-    const long t0 = (long)blockIdx.x * tt_rows;
+    const long t0 = (long)tile_x * tt_rows;
     if (t0 >= nt) return;
     const T *d = (const T *)(stream + stream_off[chunk]);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    u32 *o = sums + ((u64)chunk * ntile_max + blockIdx.x) * nc;
+    u32 *o = sums + ((u64)chunk * ntile_max + tile_x) * nc;
     constexpr int EPD = 4 / (int)sizeof(T), IPL = 8 / (int)sizeof(T);
     if (tt_rows % IPL == 0 && ((u64)nt * sizeof(T)) % 8 == 0 && (((u64)d) & 7) == 0 && ((u64)t0 * sizeof(T)) % 8 == 0 && t0 + tt_rows <= nt) {
         // a lane reads IPL consecutive items (8 bytes) of one channel; the lanes of a channel are neighbours
         const int lpc = tt_rows / IPL, cpw = 64 / lpc;
         const int q = lane % lpc, cc = lane / lpc;
-        for (int c0 = wave * cpw; c0 < nc; c0 += 4 * cpw) {
-            const int c = min(c0 + cc, nc - 1);
-            const uint2 w = *(const uint2 *)&d[(u64)c * nt + t0 + q * IPL];
-            const u32 ww[2] = {w.x, w.y};
-            u32 v = 0;
+        constexpr int KU = 5;                                     // wave steps whose loads are in flight together
+        for (int c00 = wave * cpw; c00 < nc; c00 += 4 * cpw * KU) {
+            uint2 wq[KU];
 #pragma unroll
-            for (int j = 0; j < IPL; j++) v += (u32)(T)(ww[j / EPD] >> (8 * sizeof(T) * (j % EPD)));
-            v = wave_incl_scan_dpp32(v);
-            const u32 before = (u32)__shfl((int)v, (lane - q - 1) & 63, 64);   // total of the lanes before this channel's
-            if (q == lpc - 1 && c0 + cc < nc) o[c] = v - (lane - q ? before : 0u);
+            for (int k = 0; k < KU; k++) wq[k] = *(const uint2 *)&d[(u64)min(c00 + k * 4 * cpw + cc, nc - 1) * nt + t0 + q * IPL];
+#pragma unroll
+            for (int k = 0; k < KU; k++) {
+                const int c0 = c00 + k * 4 * cpw;
+                const int c = min(c0 + cc, nc - 1);
+                const u32 ww[2] = {wq[k].x, wq[k].y};
+                u32 v = 0;
+#pragma unroll
+                for (int j = 0; j < IPL; j++) v += (u32)(T)(ww[j / EPD] >> (8 * sizeof(T) * (j % EPD)));
+                v = wave_incl_scan_dpp32(v);
+                const u32 before = (u32)__shfl((int)v, (lane - q - 1) & 63, 64);   // total of the lanes before this channel's
+                if (q == lpc - 1 && c0 + cc < nc) o[c] = v - (lane - q ? before : 0u);
+            }
         }
     } else {
         for (int c = wave; c < nc; c += 4) {
@@ -603,33 +650,46 @@ __global__ __launch_bounds__(256) void k_cumsum_rows(const u8 *__restrict__ stre
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem_rows[];
     T *tile = (T *)smem_rows;                                   // [tt_rows][pitch]
-    const int chunk = blockIdx.y;
+    int tile_x, chunk;
+    if (!xcd_row_tile(ntile_max, tile_x, chunk)) return;
     if (status && status[chunk] != 0) return;
     const long nt = rows[chunk];
-    const long t0 = (long)blockIdx.x * tt_rows;
+    const long t0 = (long)tile_x * tt_rows;
     if (t0 >= nt) return;
     constexpr int EPD = 4 / (int)sizeof(T);
     const T *d = (const T *)(stream + stream_off[chunk]);
-    const u32 *carry = sums + ((u64)chunk * ntile_max + blockIdx.x) * nc;
+    const u32 *carry = sums + ((u64)chunk * ntile_max + tile_x) * nc;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int IPL = 8 / (int)sizeof(T);
     if (tt_rows % IPL == 0 && ((u64)nt * sizeof(T)) % 8 == 0 && (((u64)d) & 7) == 0 && ((u64)t0 * sizeof(T)) % 8 == 0 && t0 + tt_rows <= nt) {
         const int lpc = tt_rows / IPL, cpw = 64 / lpc;
         const int q = lane % lpc, cc = lane / lpc;
-        for (int c0 = wave * cpw; c0 < nc; c0 += 4 * cpw) {
-            const int c = min(c0 + cc, nc - 1);
-            const uint2 w = *(const uint2 *)&d[(u64)c * nt + t0 + q * IPL];
-            const u32 ww[2] = {w.x, w.y};
-            u32 x[IPL], tot = 0;
+        constexpr int KU = 5;                                     // wave steps whose loads are in flight together (see k_delta_rows)
+        for (int c00 = wave * cpw; c00 < nc; c00 += 4 * cpw * KU) {
+            uint2 wq[KU];
+            u32 cy[KU];
 #pragma unroll
-            for (int j = 0; j < IPL; j++) { tot += (u32)(T)(ww[j / EPD] >> (8 * sizeof(T) * (j % EPD))); x[j] = tot; }
-            const u32 v = wave_incl_scan_dpp32(tot);
-            const u32 prev = (u32)__shfl((int)v, (lane - q - 1) & 63, 64);      // (unconditional: a shuffle cannot read a lane that is masked off)
-            const u32 before = (lane - q) ? prev : 0u;                          // total of the lanes of the channels before this one
-            const u32 add = carry[c] + v - tot - before;
-            if (c0 + cc < nc) {
+            for (int k = 0; k < KU; k++) {
+                const int c = min(c00 + k * 4 * cpw + cc, nc - 1);
+                wq[k] = *(const uint2 *)&d[(u64)c * nt + t0 + q * IPL];
+                cy[k] = carry[c];
+            }
 #pragma unroll
-                for (int j = 0; j < IPL; j++) tile[(q * IPL + j) * pitch + c] = (T)(x[j] + add);
+            for (int k = 0; k < KU; k++) {
+                const int c0 = c00 + k * 4 * cpw;
+                const int c = min(c0 + cc, nc - 1);
+                const u32 ww[2] = {wq[k].x, wq[k].y};
+                u32 x[IPL], tot = 0;
+#pragma unroll
+                for (int j = 0; j < IPL; j++) { tot += (u32)(T)(ww[j / EPD] >> (8 * sizeof(T) * (j % EPD))); x[j] = tot; }
+                const u32 v = wave_incl_scan_dpp32(tot);
+                const u32 prev = (u32)__shfl((int)v, (lane - q - 1) & 63, 64);      // (unconditional: a shuffle cannot read a lane that is masked off)
+                const u32 before = (lane - q) ? prev : 0u;                          // total of the lanes of the channels before this one
+                const u32 add = cy[k] + v - tot - before;
+                if (c0 + cc < nc) {
+#pragma unroll
+                    for (int j = 0; j < IPL; j++) tile[(q * IPL + j) * pitch + c] = (T)(x[j] + add);
+                }
             }
         }
     } else {
@@ -648,8 +708,27 @@ __global__ __launch_bounds__(256) void k_cumsum_rows(const u8 *__restrict__ stre
     const int nrow = (int)min((long)tt_rows, nt - t0);
     T *out = (T *)(outb + out_off[chunk]) + t0 * nc;
     const long e_n = (long)nrow * nc;
-    if ((((u64)out) & 3) == 0) {
-        // the rows of the tile are one contiguous piece of memory: whole dwords (EPD items), except a ragged end
+    if ((((u64)out) & 15) == 0 && sizeof(T) <= 4) {
+        // the rows of the tile are one contiguous piece of memory: 16 bytes (VW items) per lane and store, except a ragged end
+        constexpr int VW = 16 / (int)sizeof(T);
+        const long n_full = e_n / VW;
+        uint4 *oq = (uint4 *)out;
+        for (long i = threadIdx.x; i < n_full; i += 256) {
+            u32 r = __umulhi((u32)i * VW, nc_magic), c = (u32)i * VW - r * nc;
+            u32 w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < VW; j++) {
+                w[j / EPD] |= (u32)tile[r * pitch + c] << (8 * sizeof(T) * (j % EPD));
+                if (++c == (u32)nc) { c = 0; r++; }
+            }
+            oq[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        for (long e = n_full * VW + threadIdx.x; e < e_n; e += 256) {
+            const u32 r = __umulhi((u32)e, nc_magic), c = (u32)e - r * nc;
+            out[e] = tile[r * pitch + c];
+        }
+    } else if ((((u64)out) & 3) == 0) {
+        // ... whole dwords (EPD items)
         u32 *od = (u32 *)out;
         for (long i = threadIdx.x; i * EPD < e_n; i += 256) {
             u32 v = 0;
@@ -681,7 +760,7 @@ static void run_cumsum_rows(hipStream_t st, const u8 *stream, u8 *out, const u64
     const size_t lds = (size_t)tt * pitch * sizeof(T);
     (void)ensure_dynamic_lds((const void *)k_cumsum_rows<T>, 64 * 1024);
     const int ntile = (max_rows + tt - 1) / tt;
-    dim3 grid(ntile, n_chunks);
+    dim3 grid(xcd_row_grid(ntile, n_chunks));
     hipLaunchKernelGGL(k_rows_sums<T>, grid, dim3(256), 0, st, stream, d_stream_off, d_rows, d_status, nc, tt, ntile, sums);
     hipLaunchKernelGGL(k_rows_scan, dim3((nc + 255) / 256, n_chunks), dim3(256), 0, st, d_rows, d_status, nc, tt, ntile, sums);
     hipLaunchKernelGGL(k_cumsum_rows<T>, grid, dim3(256), lds, st, stream, out, d_stream_off, d_out_off, d_rows, d_status, nc, tt, pitch,
