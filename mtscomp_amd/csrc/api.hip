@@ -380,7 +380,9 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         } else {
         if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, d_tables, cfg, d_flags))) return rc;
         E.t_mark(st, "match");
-        if ((rc = launch_parse_spec(st, d_tables, d_chunks, pb, (int)nseg, cfg))) return rc;
+        u32 max_nseg = 0;
+        for (int i = 0; i < n_chunks; i++) if (cd[i].nseg > max_nseg) max_nseg = cd[i].nseg;
+        if ((rc = launch_parse_spec(st, d_tables, d_chunks, pb, (int)nseg, cfg, n_chunks, max_nseg))) return rc;
         for (;;) {
             if ((rc = launch_parse_fix(st, d_tables, d_chunks, pb, (int)nseg, cfg, round))) return rc;
             round++;
@@ -407,7 +409,9 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     E.t_mark(st, fast ? "fast_walk" : "parse_fixpoint");
     if (!fast) {                                              // (levels 1..3: the in-order walk has written tokens and counts)
         if ((rc = launch_parse_count(st, d_tables, d_chunks, pb, (int)nseg, n_chunks, cfg, d_cout))) return rc;
-        if ((rc = launch_parse_emit(st, d_stream, d_tables, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start, d_cout))) return rc;
+        u32 max_nseg = 0;
+        for (int i = 0; i < n_chunks; i++) if (cd[i].nseg > max_nseg) max_nseg = cd[i].nseg;
+        if ((rc = launch_parse_emit(st, d_stream, d_tables, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start, d_cout, n_chunks, max_nseg))) return rc;
     }
     E.t_mark(st, "parse_emit");
     if ((rc = launch_block_trees(st, d_chunks, d_blk_chunk, (int)nblk, d_tokens, d_blk_in_start, d_cout, d_blocks,

@@ -148,7 +148,7 @@ struct ParseBufs {
     int *changed;                                   // device flag
 };
 int launch_parse_spec(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb,
-                      int n_segs, LevelCfg cfg);
+                      int n_segs, LevelCfg cfg, int n_chunks, u32 max_nseg /* segments of the longest chunk */);
 int launch_parse_fix(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb,
                      int n_segs, LevelCfg cfg, int round);
 int launch_parse_fix_serial(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_chunks,
@@ -157,7 +157,7 @@ int launch_parse_count(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d
                        int n_segs, int n_chunks, LevelCfg cfg, ChunkOut *d_cout);
 int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables,
                       const ChunkDesc *d_chunks, ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens,
-                      u32 *d_blk_in_start, ChunkOut *d_cout);
+                      u32 *d_blk_in_start, ChunkOut *d_cout, int n_chunks, u32 max_nseg);
 int launch_block_trees(hipStream_t st, const ChunkDesc *d_chunks, const u32 *d_blk_chunk, int total_blk_cap,
                        const u32 *d_tokens, const u32 *d_blk_in_start, const ChunkOut *d_cout,
                        BlockRec *d_blocks, u32 *d_blk_codes, u32 *d_blk_hdr, int fast /* levels 1..3: deflate_fast's flush points */);

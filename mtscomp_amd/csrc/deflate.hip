@@ -990,12 +990,14 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
 // every step looks at both, and for lanes that are each somewhere else in memory the number of load instructions
 // is what the address unit charges for
 typedef u32 u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-template <class RD>
-__device__ __forceinline__ u32 lazy_step(RD &&rd, const uint2 *T, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos, u32 &mlen, u32 &mdist,
+typedef u32 u32x4_v __attribute__((ext_vector_type(4)));
+// rdpair(p) = the entries of p and p + 1 (x, y, z, w), rd(q) = the entry of q
+template <class RDP, class RD>
+__device__ __forceinline__ u32 lazy_step(RDP &&rdpair, RD &&rd, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos, u32 &mlen, u32 &mdist,
                                          u32 &byte0, u32 &byte1)
 {
     u32 p = p0;
-    const u32x4_a8 pr = *(const u32x4_a8 *)&T[p];
+    const u32x4_v pr = rdpair(p);
     byte0 = entry_byte(pr.x, pr.y); byte1 = entry_byte(pr.z, pr.w);      // the bytes at p0 and p0 + 1
     const u32 c = pr.x & ENTRY_MASK;
     u32 len = c >> 16, dist = c & 0xffff;
@@ -1014,6 +1016,77 @@ __device__ __forceinline__ u32 lazy_step(RD &&rd, const uint2 *T, u32 p0, u32 n,
     mpos = p; mlen = len; mdist = dist;
     return p + len;
 }
+// the readers of a walker that goes straight to memory (one lane somewhere in its segment: the short re-walks)
+#define MTS_PARSE_GLOBAL_READERS(T)                                                                               \
+    auto rd = [&](u32 q) -> uint2 { return (T)[q]; };                                                             \
+    auto rdpair = [&](u32 q) -> u32x4_v { const u32x4_a8 v = *(const u32x4_a8 *)&(T)[q]; return u32x4_v{v.x, v.y, v.z, v.w}; };
+
+// ------------------------------------------------------------------------------------------------
+// Staged walkers.  A wave walks 64 segments, one lane each, and every lane is somewhere else in memory: read entry by entry,
+// each load instruction of the wave touched 64 different cache lines (the address unit takes a cycle per line: ~70 cycles per
+// load instruction and CU, measured by doubling the loads) and every step of the walk waited for memory (75 % of the wave
+// cycles).  So the table is brought in window by window: the wave loads, for every lane, the 32 entries that start at the lane's
+// current window base -- 16 bytes per lane and instruction with neighbouring lanes on neighbouring addresses, four lanes'
+// windows per instruction -- into LDS, and the lanes then walk PARSE_WIN positions in LDS (a window holds two entries more than
+// it is wide: the lazy evaluation looks one and two positions ahead; whatever lies farther comes from memory, rarely).  The loads
+// of the next window are in flight while the current one is walked.
+// ------------------------------------------------------------------------------------------------
+#ifndef MTS_PARSE_WIN_N
+#define MTS_PARSE_WIN_N 32
+#endif
+constexpr int PARSE_WIN_N = MTS_PARSE_WIN_N;        // entries staged per window (16 or 32)
+constexpr int PARSE_WIN = PARSE_WIN_N - 2;          // positions walked per window
+constexpr int PARSE_WIN_PITCH = PARSE_WIN_N + 1;    // LDS pitch in entries (an odd number of 8-byte words: the reads of 32 lanes fall into different banks)
+constexpr int PARSE_NWIN = (SEG + PARSE_WIN - 1) / PARSE_WIN;
+constexpr int PARSE_PIECES = PARSE_WIN_N / 2;       // 16-byte pieces per window = lanes per window = load instructions per window step
+
+// The 64 segments of a wave are consecutive segments of ONE chunk (the grid is laid out per chunk), so the window of lane l
+// starts at  base + (l * SEG + w * PARSE_WIN) entries: plain arithmetic, no pointer per lane.
+typedef const __attribute__((address_space(1))) u32x4_v *gptr_uint4;      // (a global pointer: a generic one makes flat loads, which LDS reads wait for)
+struct ParseStage {
+    uint2 *win;                 // LDS [64][PARSE_WIN_PITCH]
+    const uint2 *base;          // table entry of the first lane's segment start
+    int nlanes;                 // lanes that have a segment (the others' windows are not loaded)
+    u32x4_v pre[PARSE_PIECES];  // the pieces of the next window this lane has asked for
+    __device__ __forceinline__ void request(int w)              // ask for window w (of every lane)
+    {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int it = 0; it < PARSE_PIECES; it++) {
+            int wl = it * (64 / PARSE_PIECES) + lane / PARSE_PIECES;
+            wl = wl < nlanes ? wl : nlanes - 1;                 // (lanes without a segment load something harmless)
+            const uint2 *src = base + (size_t)wl * SEG + (size_t)w * PARSE_WIN + 2 * (lane % PARSE_PIECES);
+            pre[it] = *(gptr_uint4)(u64)src;
+        }
+    }
+    __device__ __forceinline__ void land()                      // the requested window goes to LDS
+    {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int it = 0; it < PARSE_PIECES; it++) {
+            uint2 *d = win + (it * (64 / PARSE_PIECES) + lane / PARSE_PIECES) * PARSE_WIN_PITCH + 2 * (lane % PARSE_PIECES);
+            d[0] = make_uint2(pre[it].x, pre[it].y);
+            d[1] = make_uint2(pre[it].z, pre[it].w);
+        }
+    }
+};
+// readers of a lane whose window starts at position wb (entries wb .. wb + PARSE_WIN_N - 1 are in LDS row `row`)
+typedef u32 u32x2_v __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) u32x2_v *gptr_uint2;
+typedef const __attribute__((address_space(1))) u32x4_a8 *gptr_uint4_a8;
+#define MTS_PARSE_STAGED_READERS(T, row, wb)                                                                      \
+    auto rd = [&](u32 q) -> uint2 {                                                                               \
+        const u32 o = q - (wb);                                                                                   \
+        if (o < (u32)PARSE_WIN_N) return (row)[o];                                                                \
+        const u32x2_v v = *(gptr_uint2)(u64)&(T)[q];            /* (global address space spelled out: no flat load) */ \
+        return make_uint2(v.x, v.y);                                                                              \
+    };                                                                                                            \
+    auto rdpair = [&](u32 q) -> u32x4_v {                                                                         \
+        const u32 o = q - (wb);                                                                                   \
+        if (o + 1 < (u32)PARSE_WIN_N) { const uint2 a = (row)[o], b = (row)[o + 1]; return u32x4_v{a.x, a.y, b.x, b.y}; }   \
+        const u32x4_a8 v = *(gptr_uint4_a8)(u64)&(T)[q];                                                          \
+        return u32x4_v{v.x, v.y, v.z, v.w};                                                                       \
+    };
 
 __device__ __forceinline__ u64 readlane_u64(u64 v, int k)
 {
@@ -1029,21 +1102,39 @@ constexpr int PARSE_CP = SEG / 8;
 __global__ __launch_bounds__(64) void k_parse_spec(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
                                                    ParseBufs pb, int n_segs, LevelCfg cfg)
 {
-    const int g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= n_segs) return;
-    const ChunkDesc ch = chunks[pb.seg_chunk[g]];
-    const u32 s = pb.seg_start[g], n = ch.n;
-    const u32 segend = min(s + (u32)SEG, n);
+    __shared__ uint2 win[64 * PARSE_WIN_PITCH];
+    const int lane = threadIdx.x;
+    const ChunkDesc ch = chunks[blockIdx.y];                    // grid: x = wave within the chunk, y = chunk
+    const u32 k0seg = blockIdx.x * 64;                          // the wave's first segment within the chunk
+    if (k0seg >= ch.nseg) return;
+    const int nlanes = (int)min(64u, ch.nseg - k0seg);
+    const bool valid = lane < nlanes;
+    const int gc = (int)(ch.seg0 + k0seg) + (valid ? lane : nlanes - 1), g = gc;
+    const u32 s = (k0seg + (u32)(valid ? lane : nlanes - 1)) * SEG, n = ch.n;
+    const u32 segend = valid ? min(s + (u32)SEG, n) : 0;
     const uint2 *T = tables + ch.stream_off;
-    auto rd = [&](u32 q) -> uint2 { return T[q]; };
-    u32 *cp = pb.cp + (u64)g * 16;
+    ParseStage st{win, T + (size_t)k0seg * SEG, nlanes};
+    const uint2 *row = win + lane * PARSE_WIN_PITCH;
+    u32 *cp = pb.cp + (u64)gc * 16;
     u32 pos = s, mp, ml, md, cnt = 0, k = 1, lb0, lb1;
-    while (pos < segend) {
-        while (k < 8 && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++; }
-        const u32 p0 = pos;
-        pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md, lb0, lb1);
-        cnt += mp - p0 + 1;
+    st.request(0);
+    for (int w = 0; w < PARSE_NWIN; w++) {
+        __syncthreads();                                         // (everybody is done with the window before)
+        st.land();
+        __syncthreads();
+        if (w + 1 < PARSE_NWIN) st.request(w + 1);
+        const u32 wb = s + (u32)w * PARSE_WIN;
+        const u32 wend = min(wb + (u32)PARSE_WIN, segend);
+        MTS_PARSE_STAGED_READERS(T, row, wb)
+        while (pos < wend) {
+            while (k < 8 && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++; }
+            const u32 p0 = pos;
+            pos = lazy_step(rdpair, rd, pos, n, cfg, mp, ml, md, lb0, lb1);
+            cnt += mp - p0 + 1;
+        }
+        if (!__any(pos < segend)) break;
     }
+    if (!valid) return;
     for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }      // checkpoints past the exit
     pb.entry[g] = s;
     pb.exit_a[g] = pos;
@@ -1058,7 +1149,7 @@ __device__ __forceinline__ u32 parse_rewalk(const uint2 *__restrict__ T, const C
     pb.entry[g] = ne;
     const u32 s = pb.seg_start[g], n = ch.n;
     const u32 segend = min(s + (u32)SEG, n);
-    auto rd = [&](u32 q) -> uint2 { return T[q]; };
+    MTS_PARSE_GLOBAL_READERS(T)
     u32 *cp = pb.cp + (u64)g * 16;
     const u32 old_cnt = pb.cnt[g];
     u32 pos = ne, mp, ml, md, cnt = 0, k = 1, lb0, lb1;
@@ -1076,7 +1167,7 @@ __device__ __forceinline__ u32 parse_rewalk(const uint2 *__restrict__ T, const C
             return old_exit;
         }
         const u32 p0 = pos;
-        pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md, lb0, lb1);
+        pos = lazy_step(rdpair, rd, pos, n, cfg, mp, ml, md, lb0, lb1);
         cnt += mp - p0 + 1;
     }
     for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }
@@ -1170,51 +1261,49 @@ __global__ __launch_bounds__(256) void k_seg_scan(const ChunkDesc *__restrict__ 
 // segments: stored one by one, every token would be a 4-byte partial write.  So the tokens of a round are
 // collected in a short LDS row per lane and the rows are written out one after the other (consecutive
 // lanes write consecutive tokens of ONE segment).
-constexpr int PTCAP = 32;                  // tokens buffered per lane and round
+#ifndef MTS_PTCAP
+#define MTS_PTCAP 32
+#endif
+constexpr int PTCAP = MTS_PTCAP;           // tokens buffered per lane and round (0: every token straight to memory)
 constexpr int PTROW = PTCAP + 1;
+constexpr int PTROWS_LDS = PTCAP ? 64 * PTROW : 1;
 
 __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream, const uint2 *__restrict__ tables,
                                                    const ChunkDesc *__restrict__ chunks, ParseBufs pb, int n_segs,
                                                    LevelCfg cfg, u32 *__restrict__ tokens, u32 *__restrict__ blk_in_start,
                                                    ChunkOut *__restrict__ cout)
 {
-    __shared__ u32 tokb[64 * PTROW];
+    __shared__ u32 tokb[PTROWS_LDS];
+    __shared__ uint2 win[64 * PARSE_WIN_PITCH];
     const int lane = threadIdx.x;
-    const int g = blockIdx.x * 64 + lane;
-    const bool valid = g < n_segs;
-    const int gc = valid ? g : n_segs - 1;
-    const u32 ci = pb.seg_chunk[gc];
+    const u32 ci = blockIdx.y;                                  // grid: x = wave within the chunk, y = chunk
     const ChunkDesc ch = chunks[ci];
-    const u32 s = pb.seg_start[gc], n = ch.n;
-    const u32 segend = min(s + (u32)SEG, n);
+    const u32 k0seg = blockIdx.x * 64;
+    if (k0seg >= ch.nseg) return;
+    const int nlanes = (int)min(64u, ch.nseg - k0seg);
+    const bool valid = lane < nlanes;
+    const int gc = (int)(ch.seg0 + k0seg) + (valid ? lane : nlanes - 1);
+    const u32 s = (k0seg + (u32)(valid ? lane : nlanes - 1)) * SEG, n = ch.n;
+    const u32 segend = valid ? min(s + (u32)SEG, n) : 0;
     const uint2 *T = tables + ch.stream_off;
-    const u8 *b = stream + ch.stream_off;
     u32 *tk = tokens + ch.tok_off;
     u32 *bis = blk_in_start + ch.blk0;
-    auto rd = [&](u32 q) -> uint2 { return T[q]; };
-    u32 pos = pb.entry[gc], mp, ml, md, k = pb.tokbase[gc];
+    // the staged windows are laid over [s, s + SEG) like the speculative walk's; the walk itself starts at the segment's entry,
+    // at or a little beyond s (the exit of the segment before)
+    ParseStage st{win, T + (size_t)k0seg * SEG, nlanes};
+    const uint2 *row = win + lane * PARSE_WIN_PITCH;
+    u32 pos = valid ? pb.entry[gc] : 0, mp, ml, md, k = pb.tokbase[gc];
     u32 kmod = k % BLOCK_TOKENS;                 // k mod BLOCK_TOKENS, kept by counting
-    for (;;) {
-        const bool act = valid && pos < segend;
-        if (!__any(act)) break;
-        const u32 k0 = k;
-        auto put = [&](u32 v, u32 at) {
-            if (kmod == 0) bis[k / BLOCK_TOKENS] = at;                           // first token of a block: where its input starts
-            kmod = kmod + 1 == (u32)BLOCK_TOKENS ? 0 : kmod + 1;
-            const u32 j = k - k0;
-            if (j < (u32)PTCAP) tokb[lane * PTROW + j] = v; else tk[k] = v;      // (a step longer than the row: straight to memory)
-            k++;
-        };
-        while (act && pos < segend && k - k0 < (u32)PTCAP) {
-            const u32 p0 = pos;
-            u32 lb0, lb1;
-            pos = lazy_step(rd, T, pos, n, cfg, mp, ml, md, lb0, lb1);
-            if (pos >= n) cout[ci].trailing = (ml == 0) ? 1u : 0u;       // last token of the chunk
-            const u32 nlit = ml ? mp - p0 : 1;
-            // the literals' bytes ride in the table entries the step loaded (a third literal in one step is rare)
-            for (u32 q = 0; q < nlit; q++) put((q == 0 ? lb0 : q == 1 ? lb1 : (u32)b[p0 + q]) << 16, p0 + q);
-            if (ml) put(((ml - MIN_MATCH) << 16) | md, mp);
-        }
+    u32 k0 = k;                                  // token index of the first token in this lane's LDS row
+    auto put = [&](u32 v, u32 at) {
+        if (kmod == 0) bis[k / BLOCK_TOKENS] = at;                           // first token of a block: where its input starts
+        kmod = kmod + 1 == (u32)BLOCK_TOKENS ? 0 : kmod + 1;
+        const u32 j = k - k0;
+        if (j < (u32)PTCAP) tokb[lane * PTROW + j] = v; else tk[k] = v;      // (a step longer than the row: straight to memory)
+        k++;
+    };
+    auto flush = [&]() {                         // the rows go to memory one after the other, the lanes side by side
+        if (PTCAP == 0) { k0 = k; return; }
         __builtin_amdgcn_wave_barrier();
         const u32 nloc = min(k - k0, (u32)PTCAP);
         const int sub = lane & 31, half = lane >> 5;
@@ -1226,20 +1315,55 @@ __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int r0 = rb + 2 * j;
-                u32 *d0 = (u32 *)readlane_u64((u64)(tk + k0), r0), *d1 = (u32 *)readlane_u64((u64)(tk + k0), r0 + 1);
+                typedef __attribute__((address_space(1))) u32 *gptr_u32;      // (a global pointer: a generic one makes flat stores)
+                gptr_u32 d0 = (gptr_u32)readlane_u64((u64)(tk + k0), r0), d1 = (gptr_u32)readlane_u64((u64)(tk + k0), r0 + 1);
                 const u32 c0 = (u32)__builtin_amdgcn_readlane((int)nloc, r0), c1 = (u32)__builtin_amdgcn_readlane((int)nloc, r0 + 1);
                 if ((u32)sub < (half ? c1 : c0)) (half ? d1 : d0)[sub] = v[j];
             }
         }
         __builtin_amdgcn_wave_barrier();
+        k0 = k;
+    };
+    st.request(0);
+    for (int w = 0; w < PARSE_NWIN; w++) {
+        __syncthreads();
+        st.land();
+        __syncthreads();
+        if (w + 1 < PARSE_NWIN) st.request(w + 1);
+        const u32 wb = s + (u32)w * PARSE_WIN;
+        const u32 wend = min(wb + (u32)PARSE_WIN, segend);
+        MTS_PARSE_STAGED_READERS(T, row, wb)
+        for (;;) {
+            while (pos < wend && (PTCAP == 0 || k - k0 < (u32)PTCAP)) {
+                const u32 p0 = pos;
+                u32 lb0, lb1;
+                pos = lazy_step(rdpair, rd, pos, n, cfg, mp, ml, md, lb0, lb1);
+                if (pos >= n) cout[ci].trailing = (ml == 0) ? 1u : 0u;       // last token of the chunk
+                const u32 nlit = ml ? mp - p0 : 1;
+                // the literals' bytes ride in the table entries (those of the first two came with the step; a third literal in one
+                // step is rare, but a load from memory that ONE lane of 64 needs is a memory latency for the whole wave: its entry,
+                // too, is in the window)
+                for (u32 q = 0; q < nlit; q++) {
+                    u32 byte = q == 0 ? lb0 : lb1;
+                    if (q >= 2) { const uint2 e = rd(p0 + q); byte = entry_byte(e.x, e.y); }
+                    put(byte << 16, p0 + q);
+                }
+                if (ml) put(((ml - MIN_MATCH) << 16) | md, mp);
+            }
+            if (!__any(pos < wend)) break;                       // (whoever stopped before the window's end has a full row)
+            flush();
+        }
+        if (PTCAP && __any(k - k0 >= (u32)PTCAP)) flush();      // a full row: make room before the next window
+        if (!__any(pos < segend)) break;
     }
+    flush();
 }
 
 int launch_parse_spec(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs,
-                      LevelCfg cfg)
+                      LevelCfg cfg, int n_chunks, u32 max_nseg)
 {
     if (n_segs == 0) return MTS_OK;
-    hipLaunchKernelGGL(k_parse_spec, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_tables, d_chunks, pb, n_segs, cfg);
+    hipLaunchKernelGGL(k_parse_spec, dim3((max_nseg + 63) / 64, n_chunks), dim3(64), 0, st, d_tables, d_chunks, pb, n_segs, cfg);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
@@ -1269,10 +1393,10 @@ int launch_parse_count(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d
     return MTS_OK;
 }
 int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables, const ChunkDesc *d_chunks,
-                      ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start, ChunkOut *d_cout)
+                      ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start, ChunkOut *d_cout, int n_chunks, u32 max_nseg)
 {
     if (n_segs == 0) return MTS_OK;
-    hipLaunchKernelGGL(k_parse_emit, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_stream, d_tables, d_chunks, pb, n_segs,
+    hipLaunchKernelGGL(k_parse_emit, dim3((max_nseg + 63) / 64, n_chunks), dim3(64), 0, st, d_stream, d_tables, d_chunks, pb, n_segs,
                        cfg, d_tokens, d_blk_in_start, d_cout);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
