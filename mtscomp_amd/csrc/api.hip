@@ -243,7 +243,10 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     const size_t sort_n = align_up(sorted_off + 64, 64);          // 32-bit keys
     if ((rc = E.sort_a.ensure(sort_n * 4))) return rc;
     if ((rc = E.sort_b.ensure(sort_n * 4))) return rc;
-    if ((rc = E.tables.ensure((stream_bytes + 64) * (level < 4 ? sizeof(u32) : sizeof(uint2))))) return rc;      // (levels 1..3: the inverse map only)
+    // one word per position (levels 1..3: the inverse map) + for levels 4..9 the side table of the quarter-budget results, which is
+    // written and read at a fraction of a percent of the positions only
+    const size_t table_words = align_up(stream_bytes + 64, 64);
+    if ((rc = E.tables.ensure(table_words * 4 * (level < 4 ? 1 : 2)))) return rc;
     if ((rc = E.tokens.ensure((toff + 64) * 4))) return rc;
     if ((rc = E.segbuf.ensure((size_t)(nseg + 64) * 4 * (7 + 16) + 256))) return rc;
     if ((rc = E.blk.ensure((size_t)(nblk + 1) * (sizeof(BlockRec) + 8) + 256))) return rc;
@@ -328,7 +331,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     }
     E.t_mark(st, "delta_transpose");
     u32 *tmp_k = E.sort_a.as<u32>(), *srt_k = E.sort_b.as<u32>();
-    uint2 *d_tables = E.tables.as<uint2>();
+    u32 *d_tables = E.tables.as<u32>(), *d_quarter = d_tables + table_words;
     u32 *d_flags = (u32 *)(pb.changed + 1);                   // [0] bit 0: the match stage found a hash run out of position order
     u32 *d_tokens = E.tokens.as<u32>();
     int force_ballot = getenv("MTS_SORT_INJECT_DISORDER") ? 2 : 0;      // (test hook: the first sort of the call is deliberately mis-ranked)
@@ -378,13 +381,13 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
             MTS_HIP(hipStreamSynchronize(st));
             if (hflags[1] & 1) resort = true;
         } else {
-        if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, d_tables, cfg, d_flags))) return rc;
+        if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, d_tables, d_quarter, cfg, d_flags, tap && tap->t_full ? 1 : 0))) return rc;
         E.t_mark(st, "match");
         u32 max_nseg = 0;
         for (int i = 0; i < n_chunks; i++) if (cd[i].nseg > max_nseg) max_nseg = cd[i].nseg;
-        if ((rc = launch_parse_spec(st, d_tables, d_chunks, pb, (int)nseg, cfg, n_chunks, max_nseg))) return rc;
+        if ((rc = launch_parse_spec(st, d_tables, d_quarter, d_chunks, pb, (int)nseg, cfg, n_chunks, max_nseg))) return rc;
         for (;;) {
-            if ((rc = launch_parse_fix(st, d_tables, d_chunks, pb, (int)nseg, cfg, round))) return rc;
+            if ((rc = launch_parse_fix(st, d_tables, d_quarter, d_chunks, pb, (int)nseg, cfg, round))) return rc;
             round++;
             int hflags[2] = {0, 0};                              // {changed, match-stage flags}
             MTS_HIP(hipMemcpyAsync(hflags, pb.changed, 8, hipMemcpyDeviceToHost, st));
@@ -393,7 +396,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
             if (!hflags[0]) break;
             MTS_HIP(hipMemsetAsync(pb.changed, 0, 4, st));
             if (round >= PARSE_PARALLEL_ROUNDS) {            // (runs, periodic data: the parse does not re-synchronise) the rest in order
-                if ((rc = launch_parse_fix_serial(st, d_tables, d_chunks, pb, n_chunks, cfg, round))) return rc;
+                if ((rc = launch_parse_fix_serial(st, d_tables, d_quarter, d_chunks, pb, n_chunks, cfg, round))) return rc;
                 break;
             }
         }
@@ -411,7 +414,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         if ((rc = launch_parse_count(st, d_tables, d_chunks, pb, (int)nseg, n_chunks, cfg, d_cout))) return rc;
         u32 max_nseg = 0;
         for (int i = 0; i < n_chunks; i++) if (cd[i].nseg > max_nseg) max_nseg = cd[i].nseg;
-        if ((rc = launch_parse_emit(st, d_stream, d_tables, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start, d_cout, n_chunks, max_nseg))) return rc;
+        if ((rc = launch_parse_emit(st, d_stream, d_tables, d_quarter, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start, d_cout, n_chunks, max_nseg))) return rc;
     }
     E.t_mark(st, "parse_emit");
     if ((rc = launch_block_trees(st, d_chunks, d_blk_chunk, (int)nblk, d_tokens, d_blk_in_start, d_cout, d_blocks,
@@ -430,9 +433,22 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         // single-chunk debug taps
         const u32 n = cd[0].n;
         if (tap->t_full && n) {
-            std::vector<uint2> h(n);
-            MTS_HIP(hipMemcpy(h.data(), d_tables + cd[0].stream_off, sizeof(uint2) * n, hipMemcpyDeviceToHost));
-            for (u32 i = 0; i < n; i++) { tap->t_full[i] = h[i].x & 0x01ffffffu; tap->t_quarter[i] = h[i].y & 0x01ffffffu; }      // (the spare bits carry the position's byte)
+            // (the tap had the match stage write the side table for every position)
+            std::vector<u32> hf(n), hq(n);
+            MTS_HIP(hipMemcpy(hf.data(), d_tables + cd[0].stream_off, 4 * (size_t)n, hipMemcpyDeviceToHost));
+            MTS_HIP(hipMemcpy(hq.data(), d_quarter + cd[0].stream_off, 4 * (size_t)n, hipMemcpyDeviceToHost));
+            auto unpack = [](u32 e) -> unsigned { return (e & 0x7fffu) ? ((((e >> 15) & 0xffu) + MIN_MATCH) << 16) | (e & 0x7fffu) : 0u; };
+            for (u32 i = 0; i < n; i++) {
+                tap->t_full[i] = unpack(hf[i]);
+                tap->t_quarter[i] = unpack(hq[i]);
+                // the flags must say what the two results say
+                const bool differs = hq[i] != (hf[i] & 0x7fffffu);
+                const u32 fl = hf[i] >> 23;
+                if ((fl != 0) != differs || (fl == 2) != (differs && (tap->t_quarter[i] >> 16) > (u32)cfg.good)) {
+                    set_error("table entry %u: flags %u do not describe full %08x / quarter %08x", i, fl, hf[i], hq[i]);
+                    return MTS_E_INTERNAL;
+                }
+            }
         }
         if (tap->tokens) {
             const u32 nt = h_cout[0].ntok;

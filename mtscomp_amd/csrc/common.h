@@ -139,23 +139,25 @@ int launch_gather_slices(hipStream_t st, const GatherChunk *d_chunks, int n_chun
 // deflate.hip
 int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp, u32 *d_sorted,
                      int force_ballot /* 1: ballot ranking, 2 (test hook): sort, then damage the run order */);
-int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, uint2 *d_tables, LevelCfg cfg,
-                 u32 *d_flags /* [0] |= 1: a hash run out of position order */);
+int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, u32 *d_tables, u32 *d_quarter,
+                 LevelCfg cfg, u32 *d_flags /* [0] |= 1: a hash run out of position order */,
+                 int all_quarters /* debug tap: write the side table for every position */);
 struct ParseBufs {
     u32 *entry, *exit_a, *exit_b, *cnt, *tokbase;   // per segment
     u32 *cp;                                        // per segment 16 words: 7 checkpoint positions, 7 token counts
     u32 *seg_chunk, *seg_start;                     // per segment: owning chunk / start position
     int *changed;                                   // device flag
 };
-int launch_parse_spec(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb,
+// d_tables: one word per stream position (deflate.hip: te_pack), d_quarter: the side table of the quarter-budget results
+int launch_parse_spec(hipStream_t st, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks, ParseBufs pb,
                       int n_segs, LevelCfg cfg, int n_chunks, u32 max_nseg /* segments of the longest chunk */);
-int launch_parse_fix(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb,
+int launch_parse_fix(hipStream_t st, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks, ParseBufs pb,
                      int n_segs, LevelCfg cfg, int round);
-int launch_parse_fix_serial(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_chunks,
+int launch_parse_fix_serial(hipStream_t st, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks, ParseBufs pb, int n_chunks,
                             LevelCfg cfg, int rounds_done);
-int launch_parse_count(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb,
+int launch_parse_count(hipStream_t st, const u32 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb,
                        int n_segs, int n_chunks, LevelCfg cfg, ChunkOut *d_cout);
-int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables,
+int launch_parse_emit(hipStream_t st, const u8 *d_stream, const u32 *d_tables, const u32 *d_quarter,
                       const ChunkDesc *d_chunks, ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens,
                       u32 *d_blk_in_start, ChunkOut *d_cout, int n_chunks, u32 max_nseg);
 int launch_block_trees(hipStream_t st, const ChunkDesc *d_chunks, const u32 *d_blk_chunk, int total_blk_cap,

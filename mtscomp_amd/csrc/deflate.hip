@@ -342,12 +342,30 @@ int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles
 //   w1         bytes 3..6
 // so the common prefix of two same-hash positions is known exactly up to 7 bytes from the entries alone;
 // only longer matches go back to the window bytes.
-// A table entry is two words (full budget, quarter budget) of  len << 16 | dist  (len <= 258: 25 bits).  The spare bits
-// carry the position's own byte (low 7 bits in x[31:25], top bit in y[31]), so the emitting walk, which loads the
-// entries of the literals it emits anyway, never touches the stream.
-__device__ __forceinline__ uint2 table_entry(u32 full, u32 quarter, u32 byte) { return make_uint2(full | ((byte & 0x7f) << 25), quarter | ((byte >> 7) << 31)); }
-__device__ __forceinline__ u32 entry_byte(u32 x, u32 y) { return (x >> 25) | ((y >> 31) << 7); }
-constexpr u32 ENTRY_MASK = 0x01ffffffu;
+// A table entry is ONE word per position:  [14:0] dist (0: no match), [22:15] len - 3  = the full-budget result, and two flags
+// for the quarter-budget result (what the walk looks at when it already holds a match of >= good_match bytes):
+//   neither   the same as the full-budget result
+//   TE_QNONE  another one that cannot matter: it is not longer than good_match, and the walk only takes what is LONGER than the
+//             match it holds
+//   TE_QSIDE  another one that can: it is in the side table quarter[p] (same packing), which is written for these positions
+//             only (0.4 % of them on the synthetic recordings; the debug tap of the tests has it written everywhere)
+// (Rounds 1-2 kept both results and the position's byte in 8 bytes per position: twice the table traffic in the match store
+// and in both parse walks, and half as many walkers per CU, whose windows of the table live in LDS.)
+constexpr u32 TE_DIST = 0x7fffu, TE_QNONE = 1u << 23, TE_QSIDE = 1u << 24;
+__device__ __forceinline__ u32 te_pack(u32 len, u32 dist) { return len >= (u32)MIN_MATCH ? dist | ((len - MIN_MATCH) << 15) : 0u; }
+__device__ __forceinline__ u32 te_dist(u32 e) { return e & TE_DIST; }
+__device__ __forceinline__ u32 te_len(u32 e) { return (e & TE_DIST) ? ((e >> 15) & 0xffu) + MIN_MATCH : 0u; }
+__device__ __forceinline__ void te_store(u32 *__restrict__ T, u32 *__restrict__ TQ, u32 p, u32 best, u32 bdist, u32 qbest, u32 qdist, u32 good, int all_quarters)
+{
+    const u32 f = te_pack(best, bdist), q = te_pack(qbest, qdist);
+    u32 e = f;
+    if (q != f) {
+        if (qbest > good) { e |= TE_QSIDE; TQ[p] = q; }
+        else e |= TE_QNONE;
+    }
+    T[p] = e;
+    if (all_quarters) TQ[p] = q;
+}
 __device__ __forceinline__ u64 make_entry(u32 rel, u32 lo, u32 hi)       // lo = bytes 0..3, hi = bytes 4..7
 {
     const u32 b0 = lo & 0xff, b1 = (lo >> 8) & 0xff;
@@ -410,8 +428,8 @@ __device__ __forceinline__ void m5_keys(u32 e1, u32 (&k)[M5_LEVELS])
 // flags[0] |= 1 when the sorted order is found NOT to be position-ordered inside a hash run (the sort's ranking relies on
 // a hardware property, see rank_pass): the caller then sorts again with the ballot ranking and repeats the stage.
 __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, int nsl,
-                                                          const u32 *__restrict__ sorted, uint2 *__restrict__ tables, LevelCfg cfg,
-                                                          u32 *__restrict__ flags)
+                                                          const u32 *__restrict__ sorted, u32 *__restrict__ tables, u32 *__restrict__ quarter, LevelCfg cfg,
+                                                          u32 *__restrict__ flags, int all_quarters)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u32 xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
@@ -425,11 +443,11 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     u64 *SE = (u64 *)wbase;
     u64 *SX = SE + M5_RING;                                        // bytes 7..12 of every slot: matches up to 13 never leave the LDS
     u32 *TB = (u32 *)(wbase + 2 * M5_RING * 8);                    // [level][row][8 words + 1]
-    uint2 *T = tables + td.stream_off;
+    u32 *T = tables + td.stream_off, *TQ = quarter + td.stream_off;
     if (threadIdx.x < 2 && slice == 0) {
         const u32 hashed_end = td.w + td.wlen;
         const u32 p = hashed_end + threadIdx.x;
-        if (p >= td.a && p < td.own_end) T[p] = table_entry(0, 0, stream[td.stream_off + p]);
+        if (p >= td.a && p < td.own_end) { T[p] = 0; if (all_quarters) TQ[p] = 0; }
     }
     if (td.wlen == 0) return;
     const u32 *sk = sorted + td.sorted_off;
@@ -532,7 +550,6 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         __builtin_amdgcn_wave_barrier();
         const u64 e = commit((int)i, rc_c, lo_c, hi_c, x_c, key, nbv);
         const u64 ex = x_c;
-        const u32 own_lo = lo_c;                                   // (byte 0 of this lane's own position rides along in its table entry)
         __builtin_amdgcn_wave_barrier();
         // next group's words, and the position of the one after
         rc_c = rc_n;
@@ -685,7 +702,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                 }
             }
         }
-        if (own) T[p_abs] = table_entry(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0, own_lo & 0xff);
+        if (own) te_store(T, TQ, p_abs, best, bdist, qbest, qdist, (u32)cfg.good, all_quarters);
     }
 }
 
@@ -706,8 +723,8 @@ constexpr int M6_TABLE = M5_ROWS * M6_ROW_WORDS * 4;
 constexpr int MATCH6_LDS = 2 * M6_RING * 8 + M5_SLOTS * M6_TABLE;       // 37504 per workgroup
 
 __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, int nsl,
-                                                          const u32 *__restrict__ sorted, uint2 *__restrict__ tables, LevelCfg cfg,
-                                                          u32 *__restrict__ flags)
+                                                          const u32 *__restrict__ sorted, u32 *__restrict__ tables, u32 *__restrict__ quarter, LevelCfg cfg,
+                                                          u32 *__restrict__ flags, int all_quarters)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     __shared__ u32 wg_h[M5_WAVES], wg_rc[M5_WAVES], wg_tail[M5_WAVES], wg_min;      // per group of the set: hash and position of its last slot, slots since its last run start (0: none starts in it)
@@ -721,11 +738,11 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
     u64 *SE = (u64 *)smem;
     u64 *SX = SE + M6_RING;
     u32 *TB = (u32 *)(smem + 2 * M6_RING * 8);                     // [level][row][32 words + 1]
-    uint2 *T = tables + td.stream_off;
+    u32 *T = tables + td.stream_off, *TQ = quarter + td.stream_off;
     if (threadIdx.x < 2 && slice == 0) {
         const u32 hashed_end = td.w + td.wlen;
         const u32 p = hashed_end + threadIdx.x;
-        if (p >= td.a && p < td.own_end) T[p] = table_entry(0, 0, stream[td.stream_off + p]);
+        if (p >= td.a && p < td.own_end) { T[p] = 0; if (all_quarters) TQ[p] = 0; }
     }
     if (td.wlen == 0) return;
     const u32 *sk = sorted + td.sorted_off;
@@ -956,12 +973,12 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
             if (!__syncthreads_or(!stop && nbv > jbase + 128)) break;
         }
         if (!qtaken) { qbest = best; qdist = bdist; }
-        if (own) T[p_abs] = table_entry(best >= 3 ? (best << 16) | bdist : 0, qbest >= 3 ? (qbest << 16) | qdist : 0, own_lo & 0xff);
+        if (own) te_store(T, TQ, p_abs, best, bdist, qbest, qdist, (u32)cfg.good, all_quarters);
     }
 }
 
-int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, uint2 *d_tables, LevelCfg cfg,
-                 u32 *d_flags)
+int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, u32 *d_tables, u32 *d_quarter,
+                 LevelCfg cfg, u32 *d_flags, int all_quarters)
 {
     if (n_tiles == 0) return MTS_OK;
     if (cfg.chain <= 128) {
@@ -969,12 +986,12 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
         int nsl = M5_SLICES;
         if (const char *e = getenv("MTS_MATCH_SLICES")) nsl = atoi(e) > 0 ? atoi(e) : nsl;
         const int grid = (n_tiles + 7) / 8 * 8 * nsl;
-        hipLaunchKernelGGL(k_match5, dim3(grid), dim3(M5_WAVES * 64), MATCH5_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, cfg, d_flags);
+        hipLaunchKernelGGL(k_match5, dim3(grid), dim3(M5_WAVES * 64), MATCH5_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, d_quarter, cfg, d_flags, all_quarters);
     } else {
         if (cfg.chain != 256 && (cfg.chain >> 2) % 128 != 0) { set_error("match: chain budget %d unsupported", cfg.chain); return MTS_E_INTERNAL; }
         const int nsl = M5_SLICES;
         const int grid = (n_tiles + 7) / 8 * 8 * nsl;
-        hipLaunchKernelGGL(k_match6, dim3(grid), dim3(M5_WAVES * 64), MATCH6_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, cfg, d_flags);
+        hipLaunchKernelGGL(k_match6, dim3(grid), dim3(M5_WAVES * 64), MATCH6_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, d_quarter, cfg, d_flags, all_quarters);
     }
     MTS_HIP(hipGetLastError());
     return MTS_OK;
@@ -989,27 +1006,36 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
 // the entries of positions p and p + 1 with one 16-byte load (8-byte aligned; the tables have slack past n): nearly
 // every step looks at both, and for lanes that are each somewhere else in memory the number of load instructions
 // is what the address unit charges for
-typedef u32 u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef u32 u32x4_v __attribute__((ext_vector_type(4)));
-// rdpair(p) = the entries of p and p + 1 (x, y, z, w), rd(q) = the entry of q
-template <class RDP, class RD>
-__device__ __forceinline__ u32 lazy_step(RDP &&rdpair, RD &&rd, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos, u32 &mlen, u32 &mdist,
-                                         u32 &byte0, u32 &byte1)
+typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef const __attribute__((address_space(1))) u32 *gptr_u32c;         // (global pointers spelled out: a generic pointer makes flat
+typedef const __attribute__((address_space(1))) u32x4_v *gptr_uint4;    //  loads, which count as LDS operations as well)
+typedef const __attribute__((address_space(1))) u32x4_a4 *gptr_uint4_a4;
+// rd(q) = the table entry of position q;  rdq(q) = its entry in the side table (TE_QSIDE positions only).
+// AHEAD: the entries of p0 + 1 .. p0 + 3 are read together with p0's (staged walkers: all four are in the LDS window, and
+// one LDS latency per step instead of one per position the lazy evaluation moves on matters when two waves share a SIMD)
+template <bool AHEAD, class RDU, class RD, class RDQ>
+__device__ __forceinline__ u32 lazy_step(RDU &&rdu /* p0 .. p0 + 3: no bounds check */, RD &&rd, RDQ &&rdq, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos, u32 &mlen, u32 &mdist)
 {
     u32 p = p0;
-    const u32x4_v pr = rdpair(p);
-    byte0 = entry_byte(pr.x, pr.y); byte1 = entry_byte(pr.z, pr.w);      // the bytes at p0 and p0 + 1
-    const u32 c = pr.x & ENTRY_MASK;
-    u32 len = c >> 16, dist = c & 0xffff;
+    const u32 e0 = rdu(p);
+    u32 e1 = 0, e2 = 0, e3 = 0;
+    if (AHEAD) { e1 = rdu(p + 1); e2 = rdu(p + 2); e3 = rdu(p + 3); }
+    u32 len = te_len(e0), dist = te_dist(e0);
     if (len == MIN_MATCH && dist > (u32)TOO_FAR) len = 0;
     if (len < MIN_MATCH) { mpos = p0; mlen = 0; mdist = 0; return p0 + 1; }
-    uint2 d2 = make_uint2(pr.z, pr.w);
     for (;;) {
         const u32 q = p + 1;
         if (q < n && len < (u32)cfg.lazy) {
-            if (q != p0 + 1) d2 = rd(q);
-            const u32 d = (len >= (u32)cfg.good ? d2.y : d2.x) & ENTRY_MASK;
-            if ((d >> 16) > len) { p = q; len = d >> 16; dist = d & 0xffff; continue; }
+            u32 d;
+            if (AHEAD) { d = q == p0 + 1 ? e1 : q == p0 + 2 ? e2 : e3; if (q > p0 + 3) d = rd(q); }
+            else d = rd(q);
+            if (len >= (u32)cfg.good) {                          // the quarter-budget result
+                if (d & TE_QNONE) d = 0;
+                else if (d & TE_QSIDE) d = rdq(q);
+            }
+            const u32 dl = te_len(d);
+            if (dl > len) { p = q; len = dl; dist = te_dist(d); continue; }
         }
         break;
     }
@@ -1017,36 +1043,37 @@ __device__ __forceinline__ u32 lazy_step(RDP &&rdpair, RD &&rd, u32 p0, u32 n, c
     return p + len;
 }
 // the readers of a walker that goes straight to memory (one lane somewhere in its segment: the short re-walks)
-#define MTS_PARSE_GLOBAL_READERS(T)                                                                               \
-    auto rd = [&](u32 q) -> uint2 { return (T)[q]; };                                                             \
-    auto rdpair = [&](u32 q) -> u32x4_v { const u32x4_a8 v = *(const u32x4_a8 *)&(T)[q]; return u32x4_v{v.x, v.y, v.z, v.w}; };
+#define MTS_PARSE_GLOBAL_READERS(T, TQ)                                 \
+    auto rd = [&](u32 q) -> u32 { return (T)[q]; };                     \
+    auto rdq = [&](u32 q) -> u32 { return (TQ)[q]; };
 
 // ------------------------------------------------------------------------------------------------
 // Staged walkers.  A wave walks 64 segments, one lane each, and every lane is somewhere else in memory: read entry by entry,
 // each load instruction of the wave touched 64 different cache lines (the address unit takes a cycle per line: ~70 cycles per
 // load instruction and CU, measured by doubling the loads) and every step of the walk waited for memory (75 % of the wave
-// cycles).  So the table is brought in window by window: the wave loads, for every lane, the 32 entries that start at the lane's
-// current window base -- 16 bytes per lane and instruction with neighbouring lanes on neighbouring addresses, four lanes'
-// windows per instruction -- into LDS, and the lanes then walk PARSE_WIN positions in LDS (a window holds two entries more than
-// it is wide: the lazy evaluation looks one and two positions ahead; whatever lies farther comes from memory, rarely).  The loads
-// of the next window are in flight while the current one is walked.
+// cycles).  So the table is brought in window by window: the wave loads, for every lane, the PARSE_WIN_N entries that start at
+// the lane's current window base -- 16 bytes per lane and instruction with neighbouring lanes on neighbouring addresses,
+// several lanes' windows per instruction -- into LDS, and the lanes then walk PARSE_WIN positions in LDS (a window holds four
+// entries more than it is wide: the lazy evaluation looks a position or two ahead; whatever lies farther comes from memory,
+// rarely).  The loads of the next window are in flight while the current one is walked.
+// The 64 segments of a wave are consecutive segments of ONE chunk (the grid is laid out per chunk), so the window of lane l
+// starts at  base + l * SEG + w * PARSE_WIN: plain arithmetic, no pointer per lane.
 // ------------------------------------------------------------------------------------------------
 #ifndef MTS_PARSE_WIN_N
 #define MTS_PARSE_WIN_N 32
 #endif
-constexpr int PARSE_WIN_N = MTS_PARSE_WIN_N;        // entries staged per window (16 or 32)
-constexpr int PARSE_WIN = PARSE_WIN_N - 2;          // positions walked per window
-constexpr int PARSE_WIN_PITCH = PARSE_WIN_N + 1;    // LDS pitch in entries (an odd number of 8-byte words: the reads of 32 lanes fall into different banks)
+constexpr int PARSE_WIN_N = MTS_PARSE_WIN_N;        // entries staged per window (32 or 64)
+constexpr int PARSE_WIN = PARSE_WIN_N - 4;          // positions walked per window (window bases stay 16-byte aligned)
+constexpr int PARSE_WIN_PITCH = PARSE_WIN_N + 1;    // LDS pitch in words: odd, so the lanes' reads fall into different banks
 constexpr int PARSE_NWIN = (SEG + PARSE_WIN - 1) / PARSE_WIN;
-constexpr int PARSE_PIECES = PARSE_WIN_N / 2;       // 16-byte pieces per window = lanes per window = load instructions per window step
+constexpr int PARSE_PIECES = PARSE_WIN_N / 4;       // 16-byte pieces per window = lanes per window = load instructions per window step
+constexpr int PARSE_BYTES_PITCH = PARSE_WIN_N / 4 + 1;      // words per lane of the staged stream bytes (emit walk)
+constexpr int PARSE_BPIECES = PARSE_WIN_N / 16;     // 16-byte pieces of a lane's PARSE_WIN_N stream bytes
 
-// The 64 segments of a wave are consecutive segments of ONE chunk (the grid is laid out per chunk), so the window of lane l
-// starts at  base + (l * SEG + w * PARSE_WIN) entries: plain arithmetic, no pointer per lane.
-typedef const __attribute__((address_space(1))) u32x4_v *gptr_uint4;      // (a global pointer: a generic one makes flat loads, which LDS reads wait for)
 struct ParseStage {
-    uint2 *win;                 // LDS [64][PARSE_WIN_PITCH]
-    const uint2 *base;          // table entry of the first lane's segment start
-    int nlanes;                 // lanes that have a segment (the others' windows are not loaded)
+    u32 *win;                   // LDS [64][PARSE_WIN_PITCH]
+    const u32 *base;            // table entry of the first lane's segment start
+    int nlanes;                 // lanes that have a segment (the others' windows hold something harmless)
     u32x4_v pre[PARSE_PIECES];  // the pieces of the next window this lane has asked for
     __device__ __forceinline__ void request(int w)              // ask for window w (of every lane)
     {
@@ -1054,8 +1081,8 @@ struct ParseStage {
 #pragma unroll
         for (int it = 0; it < PARSE_PIECES; it++) {
             int wl = it * (64 / PARSE_PIECES) + lane / PARSE_PIECES;
-            wl = wl < nlanes ? wl : nlanes - 1;                 // (lanes without a segment load something harmless)
-            const uint2 *src = base + (size_t)wl * SEG + (size_t)w * PARSE_WIN + 2 * (lane % PARSE_PIECES);
+            wl = wl < nlanes ? wl : nlanes - 1;
+            const u32 *src = base + (size_t)wl * SEG + (size_t)w * PARSE_WIN + 4 * (lane % PARSE_PIECES);
             pre[it] = *(gptr_uint4)(u64)src;
         }
     }
@@ -1064,29 +1091,50 @@ struct ParseStage {
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int it = 0; it < PARSE_PIECES; it++) {
-            uint2 *d = win + (it * (64 / PARSE_PIECES) + lane / PARSE_PIECES) * PARSE_WIN_PITCH + 2 * (lane % PARSE_PIECES);
-            d[0] = make_uint2(pre[it].x, pre[it].y);
-            d[1] = make_uint2(pre[it].z, pre[it].w);
+            u32 *d = win + (it * (64 / PARSE_PIECES) + lane / PARSE_PIECES) * PARSE_WIN_PITCH + 4 * (lane % PARSE_PIECES);
+            d[0] = pre[it].x; d[1] = pre[it].y; d[2] = pre[it].z; d[3] = pre[it].w;
         }
     }
 };
-// readers of a lane whose window starts at position wb (entries wb .. wb + PARSE_WIN_N - 1 are in LDS row `row`)
-typedef u32 u32x2_v __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(1))) u32x2_v *gptr_uint2;
-typedef const __attribute__((address_space(1))) u32x4_a8 *gptr_uint4_a8;
-#define MTS_PARSE_STAGED_READERS(T, row, wb)                                                                      \
-    auto rd = [&](u32 q) -> uint2 {                                                                               \
+// the same for the stream's bytes (the emitting walk: literals), PARSE_WIN_N bytes per lane and window at 4-byte alignment
+struct ParseStageBytes {
+    u32 *win;                   // LDS [64][PARSE_BYTES_PITCH]
+    const u8 *base;             // stream byte of the first lane's segment start
+    int nlanes;
+    u32x4_v pre[PARSE_BPIECES];
+    __device__ __forceinline__ void request(int w)
+    {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int it = 0; it < PARSE_BPIECES; it++) {
+            const int idx = it * 64 + lane;                     // piece idx of window-lane idx / PARSE_BPIECES
+            int wl = idx / PARSE_BPIECES;
+            wl = wl < nlanes ? wl : nlanes - 1;
+            const u8 *src = base + (size_t)wl * SEG + (size_t)w * PARSE_WIN + 16 * (idx % PARSE_BPIECES);
+            const u32x4_a4 v = *(gptr_uint4_a4)(u64)src;
+            pre[it] = u32x4_v{v.x, v.y, v.z, v.w};
+        }
+    }
+    __device__ __forceinline__ void land()
+    {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int it = 0; it < PARSE_BPIECES; it++) {
+            const int idx = it * 64 + lane;
+            u32 *d = win + (idx / PARSE_BPIECES) * PARSE_BYTES_PITCH + 4 * (idx % PARSE_BPIECES);
+            d[0] = pre[it].x; d[1] = pre[it].y; d[2] = pre[it].z; d[3] = pre[it].w;
+        }
+    }
+};
+// readers of a lane whose window starts at position wb (entries wb .. wb + PARSE_WIN_N - 1 are in the LDS row `row`)
+#define MTS_PARSE_STAGED_READERS(T, TQ, row, wb)                                                                  \
+    auto rdu = [&](u32 q) -> u32 { return (row)[q - (wb)]; };     /* (q within the window: a step's first four entries are) */ \
+    auto rd = [&](u32 q) -> u32 {                                                                                 \
         const u32 o = q - (wb);                                                                                   \
         if (o < (u32)PARSE_WIN_N) return (row)[o];                                                                \
-        const u32x2_v v = *(gptr_uint2)(u64)&(T)[q];            /* (global address space spelled out: no flat load) */ \
-        return make_uint2(v.x, v.y);                                                                              \
+        return *(gptr_u32c)(u64)&(T)[q];                                                                          \
     };                                                                                                            \
-    auto rdpair = [&](u32 q) -> u32x4_v {                                                                         \
-        const u32 o = q - (wb);                                                                                   \
-        if (o + 1 < (u32)PARSE_WIN_N) { const uint2 a = (row)[o], b = (row)[o + 1]; return u32x4_v{a.x, a.y, b.x, b.y}; }   \
-        const u32x4_a8 v = *(gptr_uint4_a8)(u64)&(T)[q];                                                          \
-        return u32x4_v{v.x, v.y, v.z, v.w};                                                                       \
-    };
+    auto rdq = [&](u32 q) -> u32 { return *(gptr_u32c)(u64)&(TQ)[q]; };
 
 __device__ __forceinline__ u64 readlane_u64(u64 v, int k)
 {
@@ -1099,24 +1147,24 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int k)
 // has to run until it lands on a recorded checkpoint: from there on the two walks are the same walk.
 constexpr int PARSE_CP = SEG / 8;
 
-__global__ __launch_bounds__(64) void k_parse_spec(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
+__global__ __launch_bounds__(64) void k_parse_spec(const u32 *__restrict__ tables, const u32 *__restrict__ quarter, const ChunkDesc *__restrict__ chunks,
                                                    ParseBufs pb, int n_segs, LevelCfg cfg)
 {
-    __shared__ uint2 win[64 * PARSE_WIN_PITCH];
+    __shared__ u32 win[64 * PARSE_WIN_PITCH];
     const int lane = threadIdx.x;
     const ChunkDesc ch = chunks[blockIdx.y];                    // grid: x = wave within the chunk, y = chunk
     const u32 k0seg = blockIdx.x * 64;                          // the wave's first segment within the chunk
     if (k0seg >= ch.nseg) return;
     const int nlanes = (int)min(64u, ch.nseg - k0seg);
     const bool valid = lane < nlanes;
-    const int gc = (int)(ch.seg0 + k0seg) + (valid ? lane : nlanes - 1), g = gc;
+    const int g = (int)(ch.seg0 + k0seg) + (valid ? lane : nlanes - 1);
     const u32 s = (k0seg + (u32)(valid ? lane : nlanes - 1)) * SEG, n = ch.n;
     const u32 segend = valid ? min(s + (u32)SEG, n) : 0;
-    const uint2 *T = tables + ch.stream_off;
+    const u32 *T = tables + ch.stream_off, *TQ = quarter + ch.stream_off;
     ParseStage st{win, T + (size_t)k0seg * SEG, nlanes};
-    const uint2 *row = win + lane * PARSE_WIN_PITCH;
-    u32 *cp = pb.cp + (u64)gc * 16;
-    u32 pos = s, mp, ml, md, cnt = 0, k = 1, lb0, lb1;
+    const u32 *row = win + lane * PARSE_WIN_PITCH;
+    u32 *cp = pb.cp + (u64)g * 16;
+    u32 pos = s, mp, ml, md, cnt = 0, k = 1;
     st.request(0);
     for (int w = 0; w < PARSE_NWIN; w++) {
         __syncthreads();                                         // (everybody is done with the window before)
@@ -1125,11 +1173,11 @@ __global__ __launch_bounds__(64) void k_parse_spec(const uint2 *__restrict__ tab
         if (w + 1 < PARSE_NWIN) st.request(w + 1);
         const u32 wb = s + (u32)w * PARSE_WIN;
         const u32 wend = min(wb + (u32)PARSE_WIN, segend);
-        MTS_PARSE_STAGED_READERS(T, row, wb)
+        MTS_PARSE_STAGED_READERS(T, TQ, row, wb)
         while (pos < wend) {
             while (k < 8 && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++; }
             const u32 p0 = pos;
-            pos = lazy_step(rdpair, rd, pos, n, cfg, mp, ml, md, lb0, lb1);
+            pos = lazy_step<true>(rdu, rd, rdq, pos, n, cfg, mp, ml, md);
             cnt += mp - p0 + 1;
         }
         if (!__any(pos < segend)) break;
@@ -1143,16 +1191,16 @@ __global__ __launch_bounds__(64) void k_parse_spec(const uint2 *__restrict__ tab
 
 // One segment walked again from the entry `ne` (the exit of the segment before it); returns its exit.  The walk stops early
 // when it lands on a checkpoint of the previous walk (from there on the two are the same walk).
-__device__ __forceinline__ u32 parse_rewalk(const uint2 *__restrict__ T, const ChunkDesc &ch, ParseBufs &pb, u32 g, u32 ne, u32 old_exit,
+__device__ __forceinline__ u32 parse_rewalk(const u32 *__restrict__ T, const u32 *__restrict__ TQ, const ChunkDesc &ch, ParseBufs &pb, u32 g, u32 ne, u32 old_exit,
                                             LevelCfg cfg)
 {
     pb.entry[g] = ne;
     const u32 s = pb.seg_start[g], n = ch.n;
     const u32 segend = min(s + (u32)SEG, n);
-    MTS_PARSE_GLOBAL_READERS(T)
+    MTS_PARSE_GLOBAL_READERS(T, TQ)
     u32 *cp = pb.cp + (u64)g * 16;
     const u32 old_cnt = pb.cnt[g];
-    u32 pos = ne, mp, ml, md, cnt = 0, k = 1, lb0, lb1;
+    u32 pos = ne, mp, ml, md, cnt = 0, k = 1;
     while (pos < segend) {
         bool merged = false;
         while (k < 8 && pos >= s + k * PARSE_CP) {
@@ -1167,7 +1215,7 @@ __device__ __forceinline__ u32 parse_rewalk(const uint2 *__restrict__ T, const C
             return old_exit;
         }
         const u32 p0 = pos;
-        pos = lazy_step(rdpair, rd, pos, n, cfg, mp, ml, md, lb0, lb1);
+        pos = lazy_step<false>(rd, rd, rdq, pos, n, cfg, mp, ml, md);
         cnt += mp - p0 + 1;
     }
     for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }
@@ -1175,7 +1223,7 @@ __device__ __forceinline__ u32 parse_rewalk(const uint2 *__restrict__ T, const C
     return pos;
 }
 
-__global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
+__global__ __launch_bounds__(64) void k_parse_fix(const u32 *__restrict__ tables, const u32 *__restrict__ quarter, const ChunkDesc *__restrict__ chunks,
                                                   ParseBufs pb, int n_segs, LevelCfg cfg, int round)
 {
     const int g = blockIdx.x * 64 + threadIdx.x;
@@ -1188,7 +1236,7 @@ __global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tabl
     const bool first = (u32)g == ch.seg0;
     const u32 ne = first ? 0 : exit_in[g - 1];
     if (ne == pb.entry[g]) { exit_out[g] = old_exit; return; }
-    const u32 e = parse_rewalk(tables + ch.stream_off, ch, pb, (u32)g, ne, old_exit, cfg);
+    const u32 e = parse_rewalk(tables + ch.stream_off, quarter + ch.stream_off, ch, pb, (u32)g, ne, old_exit, cfg);
     exit_out[g] = e;
     if (e != old_exit) *pb.changed = 1;
 }
@@ -1196,7 +1244,7 @@ __global__ __launch_bounds__(64) void k_parse_fix(const uint2 *__restrict__ tabl
 // Data whose parse never re-synchronises (a run of zeros is one 258-byte match after the other, in whatever phase the walk
 // starts) would need one parallel round per segment.  After PARSE_PARALLEL_ROUNDS rounds the rest is done in order
 // instead, each segment from the exit of the one before; a single pass is exact.
-__global__ __launch_bounds__(64) void k_parse_fix_serial(const uint2 *__restrict__ tables, const ChunkDesc *__restrict__ chunks,
+__global__ __launch_bounds__(64) void k_parse_fix_serial(const u32 *__restrict__ tables, const u32 *__restrict__ quarter, const ChunkDesc *__restrict__ chunks,
                                                          ParseBufs pb, int n_chunks, LevelCfg cfg, u32 *__restrict__ exits)
 {
     // one wave per chunk: 64 segments at a time are checked for an entry that is not the exit before it; the first such
@@ -1204,7 +1252,7 @@ __global__ __launch_bounds__(64) void k_parse_fix_serial(const uint2 *__restrict
     const int ci = blockIdx.x, lane = threadIdx.x;
     if (ci >= n_chunks) return;
     const ChunkDesc ch = chunks[ci];
-    const uint2 *T = tables + ch.stream_off;
+    const u32 *T = tables + ch.stream_off, *TQ = quarter + ch.stream_off;
     const u32 g_end = ch.seg0 + ch.nseg;
     u32 g0 = ch.seg0;
     while (g0 < g_end) {
@@ -1219,7 +1267,7 @@ __global__ __launch_bounds__(64) void k_parse_fix_serial(const uint2 *__restrict
                 const u32 ne = gg == ch.seg0 ? 0u : exits[gg - 1];
                 if (ne == pb.entry[gg]) break;                   // consistent again: back to scanning
                 const u32 old_exit = exits[gg];
-                exits[gg] = parse_rewalk(T, ch, pb, gg, ne, old_exit, cfg);
+                exits[gg] = parse_rewalk(T, TQ, ch, pb, gg, ne, old_exit, cfg);
             }
         }
         gg = (u32)__shfl((int)gg, 0);
@@ -1262,19 +1310,21 @@ __global__ __launch_bounds__(256) void k_seg_scan(const ChunkDesc *__restrict__ 
 // collected in a short LDS row per lane and the rows are written out one after the other (consecutive
 // lanes write consecutive tokens of ONE segment).
 #ifndef MTS_PTCAP
-#define MTS_PTCAP 32
+#define MTS_PTCAP 16
 #endif
-constexpr int PTCAP = MTS_PTCAP;           // tokens buffered per lane and round (0: every token straight to memory)
+constexpr int PTCAP = MTS_PTCAP;           // tokens buffered per lane (0: every token straight to memory).  Measured with the staged walk, whose
+                                           // LDS footprint sets how many waves a CU holds: 8: 4.0 ms, 12: 3.9, 16: 3.6, 24: 3.7, 32: 3.85, 0: 5.2
 constexpr int PTROW = PTCAP + 1;
 constexpr int PTROWS_LDS = PTCAP ? 64 * PTROW : 1;
 
-__global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream, const uint2 *__restrict__ tables,
+__global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream, const u32 *__restrict__ tables, const u32 *__restrict__ quarter,
                                                    const ChunkDesc *__restrict__ chunks, ParseBufs pb, int n_segs,
                                                    LevelCfg cfg, u32 *__restrict__ tokens, u32 *__restrict__ blk_in_start,
                                                    ChunkOut *__restrict__ cout)
 {
     __shared__ u32 tokb[PTROWS_LDS];
-    __shared__ uint2 win[64 * PARSE_WIN_PITCH];
+    __shared__ u32 win[64 * PARSE_WIN_PITCH];
+    __shared__ u32 bwin[64 * PARSE_BYTES_PITCH];
     const int lane = threadIdx.x;
     const u32 ci = blockIdx.y;                                  // grid: x = wave within the chunk, y = chunk
     const ChunkDesc ch = chunks[ci];
@@ -1285,13 +1335,16 @@ __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream
     const int gc = (int)(ch.seg0 + k0seg) + (valid ? lane : nlanes - 1);
     const u32 s = (k0seg + (u32)(valid ? lane : nlanes - 1)) * SEG, n = ch.n;
     const u32 segend = valid ? min(s + (u32)SEG, n) : 0;
-    const uint2 *T = tables + ch.stream_off;
+    const u32 *T = tables + ch.stream_off, *TQ = quarter + ch.stream_off;
+    const u8 *b = stream + ch.stream_off;
     u32 *tk = tokens + ch.tok_off;
     u32 *bis = blk_in_start + ch.blk0;
     // the staged windows are laid over [s, s + SEG) like the speculative walk's; the walk itself starts at the segment's entry,
     // at or a little beyond s (the exit of the segment before)
     ParseStage st{win, T + (size_t)k0seg * SEG, nlanes};
-    const uint2 *row = win + lane * PARSE_WIN_PITCH;
+    ParseStageBytes sb{bwin, b + (size_t)k0seg * SEG, nlanes};
+    const u32 *row = win + lane * PARSE_WIN_PITCH;
+    const u32 *brow = bwin + lane * PARSE_BYTES_PITCH;
     u32 pos = valid ? pb.entry[gc] : 0, mp, ml, md, k = pb.tokbase[gc];
     u32 kmod = k % BLOCK_TOKENS;                 // k mod BLOCK_TOKENS, kept by counting
     u32 k0 = k;                                  // token index of the first token in this lane's LDS row
@@ -1325,29 +1378,28 @@ __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream
         k0 = k;
     };
     st.request(0);
+    sb.request(0);
     for (int w = 0; w < PARSE_NWIN; w++) {
         __syncthreads();
         st.land();
+        sb.land();
         __syncthreads();
-        if (w + 1 < PARSE_NWIN) st.request(w + 1);
+        if (w + 1 < PARSE_NWIN) { st.request(w + 1); sb.request(w + 1); }
         const u32 wb = s + (u32)w * PARSE_WIN;
         const u32 wend = min(wb + (u32)PARSE_WIN, segend);
-        MTS_PARSE_STAGED_READERS(T, row, wb)
+        MTS_PARSE_STAGED_READERS(T, TQ, row, wb)
+        auto byte_at = [&](u32 q) -> u32 {                       // the stream's byte at q (a literal)
+            const u32 o = q - wb;
+            if (o < (u32)PARSE_WIN_N) return (brow[o >> 2] >> (8 * (o & 3))) & 0xffu;
+            return b[q];
+        };
         for (;;) {
             while (pos < wend && (PTCAP == 0 || k - k0 < (u32)PTCAP)) {
                 const u32 p0 = pos;
-                u32 lb0, lb1;
-                pos = lazy_step(rdpair, rd, pos, n, cfg, mp, ml, md, lb0, lb1);
+                pos = lazy_step<true>(rdu, rd, rdq, pos, n, cfg, mp, ml, md);
                 if (pos >= n) cout[ci].trailing = (ml == 0) ? 1u : 0u;       // last token of the chunk
                 const u32 nlit = ml ? mp - p0 : 1;
-                // the literals' bytes ride in the table entries (those of the first two came with the step; a third literal in one
-                // step is rare, but a load from memory that ONE lane of 64 needs is a memory latency for the whole wave: its entry,
-                // too, is in the window)
-                for (u32 q = 0; q < nlit; q++) {
-                    u32 byte = q == 0 ? lb0 : lb1;
-                    if (q >= 2) { const uint2 e = rd(p0 + q); byte = entry_byte(e.x, e.y); }
-                    put(byte << 16, p0 + q);
-                }
+                for (u32 q = 0; q < nlit; q++) put(byte_at(p0 + q) << 16, p0 + q);
                 if (ml) put(((ml - MIN_MATCH) << 16) | md, mp);
             }
             if (!__any(pos < wend)) break;                       // (whoever stopped before the window's end has a full row)
@@ -1359,32 +1411,32 @@ __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream
     flush();
 }
 
-int launch_parse_spec(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs,
+int launch_parse_spec(hipStream_t st, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs,
                       LevelCfg cfg, int n_chunks, u32 max_nseg)
 {
     if (n_segs == 0) return MTS_OK;
-    hipLaunchKernelGGL(k_parse_spec, dim3((max_nseg + 63) / 64, n_chunks), dim3(64), 0, st, d_tables, d_chunks, pb, n_segs, cfg);
+    hipLaunchKernelGGL(k_parse_spec, dim3((max_nseg + 63) / 64, n_chunks), dim3(64), 0, st, d_tables, d_quarter, d_chunks, pb, n_segs, cfg);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
-int launch_parse_fix(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs,
+int launch_parse_fix(hipStream_t st, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs,
                      LevelCfg cfg, int round)
 {
     if (n_segs == 0) return MTS_OK;
-    hipLaunchKernelGGL(k_parse_fix, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_tables, d_chunks, pb, n_segs, cfg, round);
+    hipLaunchKernelGGL(k_parse_fix, dim3((n_segs + 63) / 64), dim3(64), 0, st, d_tables, d_quarter, d_chunks, pb, n_segs, cfg, round);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
-int launch_parse_fix_serial(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_chunks, LevelCfg cfg,
+int launch_parse_fix_serial(hipStream_t st, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks, ParseBufs pb, int n_chunks, LevelCfg cfg,
                             int rounds_done)
 {
     if (n_chunks == 0) return MTS_OK;
     u32 *exits = ((rounds_done - 1) & 1) ? pb.exit_a : pb.exit_b;        // where the last parallel round left the exits
-    hipLaunchKernelGGL(k_parse_fix_serial, dim3(n_chunks), dim3(64), 0, st, d_tables, d_chunks, pb, n_chunks, cfg, exits);
+    hipLaunchKernelGGL(k_parse_fix_serial, dim3(n_chunks), dim3(64), 0, st, d_tables, d_quarter, d_chunks, pb, n_chunks, cfg, exits);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
-int launch_parse_count(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs,
+int launch_parse_count(hipStream_t st, const u32 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs,
                        int n_chunks, LevelCfg cfg, ChunkOut *d_cout)
 {
     (void)d_tables; (void)n_segs; (void)cfg;      // the counts come out of the spec/fix walks
@@ -1392,11 +1444,11 @@ int launch_parse_count(hipStream_t st, const uint2 *d_tables, const ChunkDesc *d
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
-int launch_parse_emit(hipStream_t st, const u8 *d_stream, const uint2 *d_tables, const ChunkDesc *d_chunks,
+int launch_parse_emit(hipStream_t st, const u8 *d_stream, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks,
                       ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start, ChunkOut *d_cout, int n_chunks, u32 max_nseg)
 {
     if (n_segs == 0) return MTS_OK;
-    hipLaunchKernelGGL(k_parse_emit, dim3((max_nseg + 63) / 64, n_chunks), dim3(64), 0, st, d_stream, d_tables, d_chunks, pb, n_segs,
+    hipLaunchKernelGGL(k_parse_emit, dim3((max_nseg + 63) / 64, n_chunks), dim3(64), 0, st, d_stream, d_tables, d_quarter, d_chunks, pb, n_segs,
                        cfg, d_tokens, d_blk_in_start, d_cout);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
