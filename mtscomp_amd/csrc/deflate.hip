@@ -2235,9 +2235,13 @@ __global__ __launch_bounds__(64) void k_block_trees(const ChunkDesc *__restrict_
             else { atomicAdd(&lfreq[257 + len_code(lc, ex)], 1u); atomicAdd(&dfreq[dist_code(dist - 1, ex)], 1u); }
         };
         const u32 nt4 = nt & ~3u;
-        for (u32 i = (u32)lane * 4; i < nt4; i += 256) {
-            const tok4 q = *(const tok4 *)(tk + i);
-            count(q.x); count(q.y); count(q.z); count(q.w);
+        constexpr int TA = 4;                                   // 16-byte loads in flight per lane
+        for (u32 i0 = (u32)lane * 4; i0 < nt4; i0 += 256 * TA) {
+            tok4 q[TA];
+#pragma unroll
+            for (int a = 0; a < TA; a++) { const u32 i = i0 + 256 * a; q[a] = i < nt4 ? *(const tok4 *)(tk + i) : tok4{0, 0, 0, 0}; }
+#pragma unroll
+            for (int a = 0; a < TA; a++) if (i0 + 256 * a < nt4) { count(q[a].x); count(q[a].y); count(q[a].z); count(q[a].w); }
         }
         if ((u32)lane < nt - nt4) count(tk[nt4 + lane]);
     }
@@ -2501,14 +2505,23 @@ __global__ __launch_bounds__(PACK_THREADS) void k_block_pack(const u8 *__restric
     const int wave = tid >> 6, lane = tid & 63;
     // token index ntok is the end-of-block symbol
     const u32 i_beg = (u32)wave * PACK_WTOK, i_end = min(i_beg + (u32)PACK_WTOK, r.ntok + 1);
-    auto code_at = [&](u32 i, u32 &nb) -> u64 {
-        if (i < r.ntok) return token_code(tk[i], lc_tab, dc_tab, nb);
+    // (the kernel was bound by the latency of its token loads, one per lane and step with the scan and the LDS work of the step
+    // behind it: the tokens of PACK_AHEAD steps are asked for together)
+    constexpr int PACK_AHEAD = 8;
+    auto code_of = [&](u32 i, u32 t, u32 &nb) -> u64 {
+        if (i < r.ntok) return token_code(t, lc_tab, dc_tab, nb);
         if (i == r.ntok) { const u32 c = lc_tab[256]; nb = c >> 16; return c & 0xffff; }
         nb = 0;
         return 0;
     };
     u32 mybits = 0;
-    for (u32 i = i_beg + lane; i < i_end; i += 64) { u32 nb; code_at(i, nb); mybits += nb; }
+    for (u32 i0 = i_beg; i0 < i_end; i0 += 64 * PACK_AHEAD) {
+        u32 t[PACK_AHEAD];
+#pragma unroll
+        for (int a = 0; a < PACK_AHEAD; a++) { const u32 i = i0 + 64 * a + lane; t[a] = i < r.ntok ? tk[i] : 0u; }
+#pragma unroll
+        for (int a = 0; a < PACK_AHEAD; a++) { const u32 i = i0 + 64 * a + lane; u32 nb; if (i < i_end) { code_of(i, t[a], nb); mybits += nb; } }
+    }
 #pragma unroll
     for (int o = 32; o; o >>= 1) mybits += __shfl_xor(mybits, o, 64);
     if (lane == 0) wsum[wave] = mybits;
@@ -2528,14 +2541,22 @@ __global__ __launch_bounds__(PACK_THREADS) void k_block_pack(const u8 *__restric
     __syncthreads();
     u64 pos = r.bit_start + 3 + r.hdr_bits;
     for (int w = 0; w < wave; w++) pos += wsum[w];
-    for (u32 i0 = i_beg; i0 < i_end; i0 += 64) {
-        u32 nb;
-        const u64 v = code_at(i0 + lane, nb);
-        u32 x = nb;
+    for (u32 i0 = i_beg; i0 < i_end; i0 += 64 * PACK_AHEAD) {
+        u32 t[PACK_AHEAD];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        or_bits(pos + x - nb, v, nb);
-        pos += __shfl(x, 63, 64);
+        for (int a = 0; a < PACK_AHEAD; a++) { const u32 i = i0 + 64 * a + lane; t[a] = i < r.ntok ? tk[i] : 0u; }
+#pragma unroll
+        for (int a = 0; a < PACK_AHEAD; a++) {
+            if (i0 + 64 * a >= i_end) break;                     // (wave uniform)
+            const u32 i = i0 + 64 * a + lane;
+            u32 nb = 0;
+            const u64 v = i < i_end ? code_of(i, t[a], nb) : 0ull;
+            u32 x = nb;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+            or_bits(pos + x - nb, v, nb);
+            pos += __shfl(x, 63, 64);
+        }
     }
     __syncthreads();
     for (u32 j = tid; j < nimg; j += PACK_THREADS) {
