@@ -54,6 +54,7 @@ DEFAULT_CONFIG = tuple(dict(
 CHECK_ATOL = 1e-16              # mtscomp.py:59
 CRITICAL_ERROR_URL = "https://github.com/int-brain-lab/mtscomp/issues/new?title=Critical+error"
 DEFAULT_BATCH_CHUNKS = 64       # chunks handed to one device call
+TOFILE_PIECE_CHUNKS = 8         # chunks per piece of Reader.tofile (decode of one piece under the file writes of the one before)
 DEFAULT_DEVICE_CACHE_GB = 32    # decoded chunks a Reader may keep in HBM for slicing (allocated as touched; env MTSCOMP_DEVICE_CACHE_GB, 0 = off)
 DEVICE_CACHE_MAX_CHUNKS = 8     # longer slices are streamed through the host path instead of the cache
 
@@ -856,19 +857,73 @@ class Reader:
                              "output path." % out)
         elif overwrite and out.exists():
             out.unlink()
-        with open(out, 'wb') as fb:
-            for batch in range(self.n_batches):
-                first = self.batch_size * batch
-                last = min(self.batch_size * (batch + 1), self.n_chunks)
-                chunks = self.decompress_chunks(range(first, last))
-                for idx in sorted(chunks.keys()):
-                    fb.write(chunks[idx])
-            dsize = fb.tell()
+        direct = getattr(self.codec, 'takes_out', False) and len(getattr(self.codec, 'devices', [0])) == 1
+        if direct and self.n_chunks > 1:
+            dsize = self._tofile_pipelined(out)
+        else:
+            with open(out, 'wb') as fb:
+                for batch in range(self.n_batches):
+                    first = self.batch_size * batch
+                    last = min(self.batch_size * (batch + 1), self.n_chunks)
+                    chunks = self.decompress_chunks(range(first, last))
+                    for idx in sorted(chunks.keys()):
+                        fb.write(chunks[idx])
+                dsize = fb.tell()
         assert dsize == self.chunk_bounds[-1] * self.n_channels * self.dtype.itemsize
         logger.info("Wrote %s (%.1f GB).", out, dsize / 1024 ** 3)
         if self.check_after_decompress:
             decompressed = load_raw_data(out, n_channels=self.n_channels, dtype=self.dtype)
             check(decompressed, self.cdata, self.cmeta, codec=self._codec)
+
+    def _tofile_pipelined(self, out):
+        """The file written piece by piece with three things in flight: the compressed bytes of piece k + 1 being read, piece k
+        on the device (decoded straight into one of two reused host buffers: no fresh pages per piece), piece k - 1 being
+        written by a few threads (pwrite on disjoint ranges; file writes, reads and ctypes calls all release the GIL).  A piece
+        is a fraction of a device batch so that even a one-batch file overlaps its copies with its writes.  Returns the size."""
+        piece = max(1, min(self.batch_size, TOFILE_PIECE_CHUNKS))
+        starts = list(range(0, self.n_chunks, piece))
+        row_bytes = self.n_channels * self.dtype.itemsize
+        max_rows = max(self.chunk_bounds[min(b0 + piece, self.n_chunks)] - self.chunk_bounds[b0] for b0 in starts)
+        bufs = [np.empty((max_rows, self.n_channels), dtype=self.dtype) for _ in range(min(2, len(starts)))]
+        n_writers = 8
+        fd = os.open(str(out), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+
+        def write_piece(arr, offset):
+            mv = memoryview(arr).cast('B')
+            per = (len(mv) + n_writers - 1) // n_writers
+            per = max(1 << 20, (per + 4095) & ~4095)
+
+            def one(k):
+                a, b = k * per, min((k + 1) * per, len(mv))
+                while a < b:
+                    a += os.pwrite(fd, mv[a:b], offset + a)
+            parts = [k for k in range(n_writers) if k * per < len(mv)]
+            if len(parts) == 1:
+                one(0)
+            else:
+                wpool.map(one, parts)
+
+        try:
+            with ThreadPool(n_writers) as wpool, ThreadPool(3) as aux:
+                nxt = aux.apply_async(self._read_range, (starts[0], min(starts[0] + piece, self.n_chunks)))
+                pending = [None] * len(bufs)
+                for k, b0 in enumerate(starts):
+                    b1 = min(b0 + piece, self.n_chunks)
+                    buf = nxt.get()
+                    nxt = aux.apply_async(self._read_range, (starts[k + 1], min(starts[k + 1] + piece, self.n_chunks))) if k + 1 < len(starts) else None
+                    slot = k % len(bufs)
+                    if pending[slot] is not None:
+                        pending[slot].get()                         # (the write that used this buffer two pieces ago)
+                    rows = self.chunk_bounds[b1] - self.chunk_bounds[b0]
+                    dst = bufs[slot][:rows]
+                    self._decode_into(b0, b1, dst, buf)
+                    pending[slot] = aux.apply_async(write_piece, (dst, self.chunk_bounds[b0] * row_bytes))
+                for p in pending:
+                    if p is not None:
+                        p.get()
+            return os.fstat(fd).st_size
+        finally:
+            os.close(fd)
 
     def close(self):
         """mtscomp.py:745-748."""
