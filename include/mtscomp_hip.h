@@ -131,6 +131,18 @@ int mts_cache_read_slices(long cache_id, int n_chunks, const long *chunk_keys, c
                           const long *c_offsets, const long *c_lengths, const long *n_rows, int n_channels,
                           int itemsize, int flags, int n_requests, const long *requests, void *out,
                           const long *out_offsets, long out_bytes, int *chunk_status);
+/* The same for requests that only touch the first n_leading channels of channel-major integer chunks (chunk_order 'F', the
+ * reference's default: the stream of a chunk is channel after channel, so the leading channels are a PREFIX of it): a chunk that
+ * is not resident is inflated only until that prefix is complete -- whole deflate blocks, no adler32 check, which needs the
+ * whole stream -- and kept as a (rows, n_leading) entry; c_lengths[i] may then be a prefix of the chunk's compressed bytes
+ * (about n_leading / n_channels of them plus a margin).  MTS_E_MISS: the bytes given do not reach the prefix, or a resident entry
+ * holds fewer channels than asked for -- call again with more bytes.  Column ranges of the requests must end at or before
+ * n_leading.  n_leading == n_channels is mts_cache_read_slices.  (The reference decodes whole chunks and drops columns on the
+ * host, mtscomp.py:835-842.) */
+int mts_cache_read_slices_leading(long cache_id, int n_chunks, const long *chunk_keys, const unsigned char *cdata,
+                                  const long *c_offsets, const long *c_lengths, const long *n_rows, int n_channels,
+                                  int itemsize, int flags, int n_leading, int n_requests, const long *requests,
+                                  void *out, const long *out_offsets, long out_bytes, int *chunk_status);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-resident variants (inputs and outputs already in HBM; used by bench.py and by callers that

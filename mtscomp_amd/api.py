@@ -229,6 +229,7 @@ class HipCodec:
 
     # -- decoded-chunk cache in HBM (Reader random access); lives on the first device
     device_cache = True
+    leading_channels = True      # cache_read_slices(..., n_leading=): chunks decoded up to the leading channels a request needs
 
     def cache_create(self, capacity_bytes):
         return hip.cache_create(capacity_bytes, device=self.devices[0])
@@ -739,29 +740,40 @@ class Reader:
             a = int(cum[where[sp[0]]]) + i0 - self.chunk_bounds[sp[0]] if sp else 0
             requests.append((a, a + (i1 - i0), rs, c0, c1, cs))
         present = self.codec.cache_query(self._dev_cache, keys)
+        # Requests that stay within the leading channels of channel-major chunks need only a prefix of every chunk's stream:
+        # the codec inflates a chunk that is not resident just that far, from a prefix of its compressed bytes (the channels
+        # compress about equally: the share of the bytes plus a margin; if that falls short the codec says so and the whole
+        # chunk is sent).  The reference inflates whole chunks and drops the columns on the host (mtscomp.py:835-842).
+        n_lead = max([r[4] for r, sp in zip(reqs, spans) if sp] or [self.n_channels])
+        leading = bool(getattr(self.codec, 'leading_channels', False)) and self.chunk_order == 'F' and self.dtype.kind in 'iu' and \
+            0 < 2 * n_lead <= self.n_channels
         for attempt in range(2):
             offs, lens, parts, at = [0] * len(keys), [0] * len(keys), [], 0
             need = [k for k, p in zip(keys, present) if not p]
             j = 0
             while j < len(need):                                # one read per run of neighbouring missing chunks
                 e = j
-                while e + 1 < len(need) and need[e + 1] == need[e] + 1:
+                while not (leading and attempt == 0) and e + 1 < len(need) and need[e + 1] == need[e] + 1:
                     e += 1
                 base = self.chunk_offsets[need[j]]
-                parts.append(self._pread(self.chunk_offsets[need[e] + 1] - base, base))
+                nbytes = self.chunk_offsets[need[e] + 1] - base
+                if leading and attempt == 0:                    # (one chunk: a prefix of its bytes)
+                    nbytes = min(nbytes, int(nbytes * n_lead / self.n_channels * 1.3) + 32768)
+                parts.append(self._pread(nbytes, base))
                 for k in need[j:e + 1]:
                     offs[where[k]] = at + self.chunk_offsets[k] - base
-                    lens[where[k]] = self.chunk_offsets[k + 1] - self.chunk_offsets[k]
+                    lens[where[k]] = min(self.chunk_offsets[k + 1] - self.chunk_offsets[k], nbytes)
                 at += len(parts[-1])
                 j = e + 1
             try:
+                extra = {'n_leading': n_lead} if leading else {}
                 status, arrays = self.codec.cache_read_slices(self._dev_cache, keys, b''.join(parts), offs, lens, rows,
-                                                              self.n_channels, self.dtype, self._flags(), requests)
+                                                              self.n_channels, self.dtype, self._flags(), requests, **extra)
                 break
             except hip.HipError as e:
                 if e.code != hip.E_MISS or attempt:
                     raise
-                present = [False] * len(keys)                  # dropped since the query: send everything
+                present = [False] * len(keys)                  # dropped since the query (or a prefix fell short): send everything
         for k, st in zip(keys, status):
             if st == hip.CHUNK_BADSIZE:
                 raise AssertionError("Chunk #%d does not have the expected size." % k)

@@ -596,19 +596,23 @@ static int dev_compress(Engine &E, hipStream_t st, const void *d_raw, int nc, in
 // ------------------------------------------------------------------------------------------------
 static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const long *c_off, const long *c_len,
                             const long *n_rows, int n_chunks, int nc, int sz, int flags, u8 *d_out, const long *out_off,
-                            int *status, bool accumulate_times, u8 *stream_copy_host /* debug: first chunk's stream */)
+                            int *status, bool accumulate_times, u8 *stream_copy_host /* debug: first chunk's stream */,
+                            int nc_full = 0 /* > nc: the chunks have nc_full channels and only the first nc are decoded */)
 {
+    if (nc_full <= nc) nc_full = 0;
     std::vector<InfChunk> ic(n_chunks);
     std::vector<u64> so(n_chunks), oo(n_chunks);
     std::vector<u32> nn(n_chunks), rows(n_chunks);
     u64 soff = 0, toff = 0;
     u32 max_n = 0, max_rows = 0;
-    const u64 row_bytes = (u64)nc * sz;
+    const u64 row_bytes = (u64)(nc_full ? nc_full : nc) * sz;
     for (int i = 0; i < n_chunks; i++) {
         const u64 n = (u64)n_rows[i] * row_bytes;
         if (n >= (1ull << 31)) { set_error("chunk %d is %llu bytes; chunks must be < 2 GiB", i, (unsigned long long)n); return MTS_E_ARG; }
         ic[i].c_off = (u64)c_off[i]; ic[i].c_len = (u64)c_len[i];
-        ic[i].stream_off = soff; ic[i].tok_off = toff; ic[i].n_expect = (u32)n; ic[i].pad = 0;
+        ic[i].stream_off = soff; ic[i].tok_off = toff; ic[i].n_expect = (u32)n;
+        ic[i].n_need = nc_full ? (u32)((u64)n_rows[i] * nc * sz) : 0u;
+        if (nc_full && ic[i].n_need == 0) ic[i].n_need = 1;      // (a chunk without rows: still a partial decode)
         so[i] = soff; oo[i] = (u64)out_off[i]; nn[i] = (u32)n; rows[i] = (u32)n_rows[i];
         if (n > max_n) max_n = (u32)n;
         if (n_rows[i] > (long)max_rows) max_rows = (u32)n_rows[i];
@@ -662,14 +666,14 @@ static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const 
 void inflate_mark(void *engine, hipStream_t st, const char *name) { ((Engine *)engine)->t_mark(st, name); }
 
 static int dev_decompress(Engine &E, hipStream_t st, const u8 *d_cdata, const long *c_off, const long *c_len, const long *n_rows,
-                          int n_chunks, int nc, int sz, int flags, u8 *d_out, const long *out_off, int *status)
+                          int n_chunks, int nc, int sz, int flags, u8 *d_out, const long *out_off, int *status, int nc_full = 0)
 {
     if (sz != 1 && sz != 2 && sz != 4 && sz != 8) { set_error("itemsize %d unsupported", sz); return MTS_E_ARG; }
     if ((flags & MTS_FLAG_FLOAT) && sz != 4 && sz != 8) { set_error("float items of %d bytes unsupported", sz); return MTS_E_ARG; }
     if (nc <= 0 || n_chunks < 0) return MTS_E_ARG;
     MTS_HIP(hipSetDevice(E.dev));
     const size_t budget = batch_budget_bytes() * 4;          // inflate needs ~5 bytes of workspace per byte
-    const u64 row_bytes = (u64)nc * sz;
+    const u64 row_bytes = (u64)(nc_full > nc ? nc_full : nc) * sz;
     int i = 0;
     bool first = true;
     while (i < n_chunks) {
@@ -681,7 +685,7 @@ static int dev_decompress(Engine &E, hipStream_t st, const u8 *d_cdata, const lo
             acc += n; j++;
         }
         int rc = decompress_batch(E, st, d_cdata, c_off + i, c_len + i, n_rows + i, j - i, nc, sz, flags, d_out, out_off + i,
-                                  status + i, !first, nullptr);
+                                  status + i, !first, nullptr, nc_full);
         if (rc) return rc;
         first = false;
         i = j;
@@ -724,7 +728,7 @@ long mts_compress_bound(long raw_len) { return compress_bound(raw_len); }
 
 // ---- decoded-chunk cache on the device (Reader random access) ------------------------------------
 namespace {
-struct CacheEntry { u8 *d = nullptr; u64 cap = 0, size = 0, stamp = 0; long rows = 0; };
+struct CacheEntry { u8 *d = nullptr; u64 cap = 0, size = 0, stamp = 0; long rows = 0; int cols = 0; };      // (rows, cols) C order; cols < n_channels: the leading channels only
 struct DevCache {
     int device = 0;
     u64 capacity = 0, used = 0, clock = 0;
@@ -1037,10 +1041,9 @@ int mts_cache_query(long cache_id, const long *chunk_keys, int n, int *present)
 // make every listed chunk resident (decode the missing ones in one batch) and pin them for this call by their stamp
 static int cache_ensure(DevCache *c, Engine *E, int n_chunks, const long *chunk_keys, const unsigned char *cdata, const long *c_offsets,
                         const long *c_lengths, const long *n_rows, int n_channels, int itemsize, int flags, int *chunk_status, u64 call_stamp,
-                        long *total_rows_out)
+                        long *total_rows_out, int n_cols /* leading channels wanted: n_channels = whole chunks */)
 {
     int rc;
-    const u64 row_bytes = (u64)n_channels * itemsize;
     std::vector<int> miss;
     long total_rows = 0;
     {   // every key once: a key listed twice would be decoded and accounted twice
@@ -1053,9 +1056,13 @@ static int cache_ensure(DevCache *c, Engine *E, int n_chunks, const long *chunk_
         total_rows += n_rows[i];
         chunk_status[i] = MTS_CHUNK_OK;
         auto it = c->map.find(chunk_keys[i]);
-        if (it != c->map.end() && it->second.rows == n_rows[i] && it->second.size == (u64)n_rows[i] * row_bytes) { it->second.stamp = call_stamp; continue; }
-        if (it != c->map.end()) c->drop(chunk_keys[i]);        // same key, other shape: stale
-        if (c_lengths[i] <= 0) { set_error("chunk key %ld is not resident and no compressed bytes were given", chunk_keys[i]); return MTS_E_MISS; }
+        if (it != c->map.end() && it->second.rows == n_rows[i] && it->second.cols >= n_cols && it->second.cols <= n_channels &&
+            it->second.size == (u64)n_rows[i] * it->second.cols * itemsize) { it->second.stamp = call_stamp; continue; }
+        if (c_lengths[i] <= 0) {
+            set_error("chunk key %ld is not resident%s and no compressed bytes were given", chunk_keys[i], it != c->map.end() ? " with the channels asked for" : "");
+            return MTS_E_MISS;
+        }
+        if (it != c->map.end()) c->drop(chunk_keys[i]);        // same key, other shape or fewer channels: decoded again
         miss.push_back(i);
     }
     *total_rows_out = total_rows;
@@ -1066,6 +1073,7 @@ static int cache_ensure(DevCache *c, Engine *E, int n_chunks, const long *chunk_
     };
     if (miss.empty()) return all_resident();
     const int m = (int)miss.size();
+    const u64 row_bytes = (u64)n_cols * itemsize;              // of what is decoded and kept
     std::vector<long> coff(m), clen(m), rows(m), ooff(m);
     std::vector<int> st(m);
     u64 ctot = 0, otot = 0;
@@ -1079,18 +1087,22 @@ static int cache_ensure(DevCache *c, Engine *E, int n_chunks, const long *chunk_
     if ((rc = E->h_out.ensure(otot + 256))) return rc;
     for (int k = 0; k < m; k++)
         MTS_HIP(hipMemcpyAsync(E->h_in.as<u8>() + coff[k], cdata + c_offsets[miss[k]], (size_t)clen[k], hipMemcpyHostToDevice, nullptr));
-    rc = dev_decompress(*E, nullptr, E->h_in.as<u8>(), coff.data(), clen.data(), rows.data(), m, n_channels, itemsize, flags,
-                        E->h_out.as<u8>(), ooff.data(), st.data());
+    rc = dev_decompress(*E, nullptr, E->h_in.as<u8>(), coff.data(), clen.data(), rows.data(), m, n_cols, itemsize, flags,
+                        E->h_out.as<u8>(), ooff.data(), st.data(), n_channels);
     if (rc) return rc;
     for (int k = 0; k < m; k++) {
         const int i = miss[k];
+        if (st[k] == MTS_CHUNK_NEEDMORE) {
+            set_error("chunk key %ld: the %ld compressed bytes given do not reach the %d leading channels asked for", chunk_keys[i], clen[k], n_cols);
+            return MTS_E_MISS;
+        }
         chunk_status[i] = st[k];
         if (st[k] != MTS_CHUNK_OK) continue;
         const u64 size = (u64)rows[k] * row_bytes;
         CacheEntry e;
         c->make_room(align_up(size ? size : 1, 4096), call_stamp);
         if ((rc = c->alloc(size, &e.d, &e.cap))) return rc;
-        e.size = size; e.rows = rows[k]; e.stamp = call_stamp;
+        e.size = size; e.rows = rows[k]; e.cols = n_cols; e.stamp = call_stamp;
         if (size) MTS_HIP(hipMemcpyAsync(e.d, E->h_out.as<u8>() + ooff[k], (size_t)size, hipMemcpyDeviceToDevice, nullptr));
         c->used += e.cap;
         c->map[chunk_keys[i]] = e;
@@ -1115,7 +1127,7 @@ int mts_cache_read_rows(long cache_id, int n_chunks, const long *chunk_keys, con
     const u64 row_bytes = (u64)n_channels * itemsize;
     const u64 call_stamp = ++c->clock;
     long total_rows = 0;
-    if ((rc = cache_ensure(c, E, n_chunks, chunk_keys, cdata, c_offsets, c_lengths, n_rows, n_channels, itemsize, flags, chunk_status, call_stamp, &total_rows))) return rc;
+    if ((rc = cache_ensure(c, E, n_chunks, chunk_keys, cdata, c_offsets, c_lengths, n_rows, n_channels, itemsize, flags, chunk_status, call_stamp, &total_rows, n_channels))) return rc;
     if (row_end > total_rows) return MTS_E_ARG;
     // rows [row_begin, row_end) of the concatenation, straight from the resident chunks
     long r0 = 0;
@@ -1134,10 +1146,15 @@ int mts_cache_read_rows(long cache_id, int n_chunks, const long *chunk_keys, con
     return MTS_OK;
 }
 
-int mts_cache_read_slices(long cache_id, int n_chunks, const long *chunk_keys, const unsigned char *cdata, const long *c_offsets,
-                          const long *c_lengths, const long *n_rows, int n_channels, int itemsize, int flags, int n_req,
-                          const long *req, void *out, const long *out_offsets, long out_bytes, int *chunk_status)
+int mts_cache_read_slices_leading(long cache_id, int n_chunks, const long *chunk_keys, const unsigned char *cdata, const long *c_offsets,
+                                  const long *c_lengths, const long *n_rows, int n_channels, int itemsize, int flags, int n_leading,
+                                  int n_req, const long *req, void *out, const long *out_offsets, long out_bytes, int *chunk_status)
 {
+    if (n_leading <= 0 || n_leading > n_channels) return MTS_E_ARG;
+    if (n_leading < n_channels && (!(flags & MTS_FLAG_ORDER_F) || (flags & MTS_FLAG_FLOAT))) {
+        set_error("leading channels alone can only be decoded from channel-major integer chunks");
+        return MTS_E_ARG;
+    }
     int dev = 0;
     DevCache *c = find_cache(cache_id, &dev);
     if (!c || n_chunks < 0 || n_channels <= 0 || n_req < 0 || out_bytes < 0) return MTS_E_ARG;
@@ -1158,7 +1175,7 @@ int mts_cache_read_slices(long cache_id, int n_chunks, const long *chunk_keys, c
     u64 max_items = 0;
     for (int k = 0; k < n_req; k++) {
         const long *q = req + 6 * k;
-        if (q[0] < 0 || q[1] < q[0] || q[1] > total_rows || q[2] < 1 || q[3] < 0 || q[4] < q[3] || q[4] > n_channels || q[5] < 1) return MTS_E_ARG;
+        if (q[0] < 0 || q[1] < q[0] || q[1] > total_rows || q[2] < 1 || q[3] < 0 || q[4] < q[3] || q[4] > n_leading || q[5] < 1) return MTS_E_ARG;
         GatherReq &g = gr[k];
         g.rb = q[0]; g.rs = q[2]; g.cb = q[3]; g.cs = q[5];
         g.nr = (q[1] - q[0] + q[2] - 1) / q[2]; g.ncol = (q[4] - q[3] + q[5] - 1) / q[5];
@@ -1171,13 +1188,14 @@ int mts_cache_read_slices(long cache_id, int n_chunks, const long *chunk_keys, c
     if ((rc = E->misc.ensure(desc + 256))) return rc;
     if ((rc = E->h_out.ensure((u64)out_bytes + 256))) return rc;
     long total_rows_seen = 0;
-    if ((rc = cache_ensure(c, E, n_chunks, chunk_keys, cdata, c_offsets, c_lengths, n_rows, n_channels, itemsize, flags, chunk_status, call_stamp, &total_rows_seen))) return rc;
+    if ((rc = cache_ensure(c, E, n_chunks, chunk_keys, cdata, c_offsets, c_lengths, n_rows, n_channels, itemsize, flags, chunk_status, call_stamp, &total_rows_seen, n_leading))) return rc;
     // (cache_ensure ends with the residency check and nothing below allocates: the base pointers stay valid)
     std::vector<GatherChunk> gc(n_chunks);
     long r0 = 0;
     for (int i = 0; i < n_chunks; i++) {
         gc[i].row0 = r0; r0 += n_rows[i];
-        gc[i].base = chunk_status[i] == MTS_CHUNK_OK ? c->map[chunk_keys[i]].d : nullptr;
+        if (chunk_status[i] == MTS_CHUNK_OK) { const CacheEntry &e = c->map[chunk_keys[i]]; gc[i].base = e.d; gc[i].pitch = e.cols; }
+        else { gc[i].base = nullptr; gc[i].pitch = n_channels; }
     }
     MTS_HIP(hipMemcpyAsync(E->misc.p, gc.data(), sizeof(GatherChunk) * n_chunks, hipMemcpyHostToDevice, nullptr));
     MTS_HIP(hipMemcpyAsync(E->misc.as<u8>() + o_req, gr.data(), sizeof(GatherReq) * n_req, hipMemcpyHostToDevice, nullptr));
@@ -1187,6 +1205,14 @@ int mts_cache_read_slices(long cache_id, int n_chunks, const long *chunk_keys, c
     MTS_HIP(hipStreamSynchronize(nullptr));
     c->make_room(0, ~0ull);
     return MTS_OK;
+}
+
+int mts_cache_read_slices(long cache_id, int n_chunks, const long *chunk_keys, const unsigned char *cdata, const long *c_offsets,
+                          const long *c_lengths, const long *n_rows, int n_channels, int itemsize, int flags, int n_req,
+                          const long *req, void *out, const long *out_offsets, long out_bytes, int *chunk_status)
+{
+    return mts_cache_read_slices_leading(cache_id, n_chunks, chunk_keys, cdata, c_offsets, c_lengths, n_rows, n_channels, itemsize, flags, n_channels,
+                                         n_req, req, out, out_offsets, out_bytes, chunk_status);
 }
 
 int mts_debug_inflate(int device, const unsigned char *zbytes, long zlen, unsigned char *out, long out_cap, long *out_len, int *status)

@@ -37,10 +37,13 @@ constexpr int STREAM_ALIGN = 256;
 // window-relative positions allow wins (match 31 -> 28.5 ms, sort 12.9 -> 11.4 from 96 Ki to 224 Ki).
 // The 32-bit sort keys hold the window-relative position (REL_BITS allow windows up to 2^18) and the 7 hash bits
 // the second radix pass still needs; the first pass takes its 8 bits straight from the bytes.
-constexpr int TILE = 229376;               // positions a match-stage workgroup owns
-constexpr int HALO = 32768;                // history it additionally needs (>= MAX_DIST)
-constexpr int WIN = TILE + HALO;           // 262144 = 2^REL_BITS
-constexpr int REL_BITS = 18;
+#ifndef MTS_REL_BITS
+#define MTS_REL_BITS 18
+#endif
+constexpr int REL_BITS = MTS_REL_BITS;     // 18 or 19 (a match entry word holds rel : 9 bits : the low bits of byte 7)
+constexpr int HALO = 32768;                // history a tile additionally needs (>= MAX_DIST)
+constexpr int WIN = 1 << REL_BITS;         // hashed window of a tile
+constexpr int TILE = WIN - HALO;           // positions a match-stage workgroup owns (229376 / 491520)
 constexpr u32 REL_MASK = (1u << REL_BITS) - 1;
 
 constexpr int SEG = 1024;                  // parse segment (positions per speculative walker); measured 512: 9.0, 1024: 8.5, 2048: 8.9, 4096: 9.3 ms (fixpoint + emit)
@@ -131,7 +134,7 @@ int launch_adler_stream(hipStream_t st, const u8 *d_stream, const u64 *d_stream_
                         const u32 *d_skip /* null, or per chunk (stride in words): >= 2 = already summed; the sums are then NOT zeroed here */, u32 skip_stride);
 
 // pieces of decoded chunks gathered on the device (mts_cache_read_slices)
-struct GatherChunk { long row0; const u8 *base; };                      // first row in the concatenation; null = the chunk failed
+struct GatherChunk { long row0; const u8 *base; long pitch; };          // first row in the concatenation; null = the chunk failed; items per row of the entry
 struct GatherReq { long rb, rs, cb, cs, nr, ncol, out_off; };           // rows rb + i * rs (i < nr), columns cb + j * cs (j < ncol) -> out_off
 int launch_gather_slices(hipStream_t st, const GatherChunk *d_chunks, int n_chunks, const GatherReq *d_req, int n_req, u64 max_items,
                          int n_channels, int itemsize, u8 *d_out);
@@ -189,9 +192,12 @@ struct InfChunk {
     u64 c_len;
     u64 stream_off;      // where the inflated stream goes (stream buffer)
     u64 tok_off;         // token buffer offset (capacity n + 2)
-    u32 n_expect;        // expected inflated size
-    u32 pad;
+    u32 n_expect;        // expected inflated size (the whole chunk)
+    u32 n_need;          // 0, or: only the first n_need bytes of the stream are wanted (the leading channels of a channel-major
+                         // chunk, for Reader[rows, columns]): the block chain stops once it has them, c_len may be a prefix of
+                         // the chunk's bytes, no adler32 check; MTS_CHUNK_NEEDMORE when the bytes given do not get that far
 };
+constexpr int MTS_CHUNK_NEEDMORE = 1;      // internal per-chunk status (never leaves the library: the cache answers MTS_E_MISS)
 struct InfResult {
     int status;          // MTS_CHUNK_*
     u32 n_out;

@@ -370,7 +370,7 @@ __device__ __forceinline__ u64 make_entry(u32 rel, u32 lo, u32 hi)       // lo =
 {
     const u32 b0 = lo & 0xff, b1 = (lo >> 8) & 0xff;
     const u32 d = ((b0 >> 5) << 6) | ((b0 & 7) << 3) | (b1 & 7);
-    const u32 w0 = rel | (d << REL_BITS) | (((hi >> 24) & 0x1f) << (REL_BITS + 9));
+    const u32 w0 = rel | (d << REL_BITS) | (((hi >> 24) & ((1u << (32 - REL_BITS - 9)) - 1)) << (REL_BITS + 9));
     const u32 w1 = (lo >> 24) | (hi << 8);
     return (u64)w0 | ((u64)w1 << 32);
 }
@@ -399,6 +399,9 @@ __device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
 // d-1).  With best length L the walk only pops candidates of M_(L+1) (M_7 from 6 on), so the number of
 // scored candidates is about the number of times the best length improves.
 // ------------------------------------------------------------------------------------------------
+#ifndef MTS_M5_NT_KEYS
+#define MTS_M5_NT_KEYS 0
+#endif
 constexpr int M5_WAVES = 8;
 constexpr int M5_SLICES = 64;                        // workgroups per tile (MTS_MATCH_SLICES overrides: experiments)
 constexpr int M5_RING = 256;
@@ -526,7 +529,11 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         const u32 b8 = alignbyte(w.w, w.z, r), b12 = alignbyte(0u, w.w, r) & 0xffu;
         x = (u64)(hi >> 24) | ((u64)b8 << 8) | ((u64)b12 << 40);                    // bytes 7..12
     };
+#if MTS_M5_NT_KEYS
+    auto slot_rel = [&](int idx) -> u32 { return __builtin_nontemporal_load(&sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1]) & REL_MASK; };      // (read once: keep them out of the way of the window and the table lines in L2)
+#else
     auto slot_rel = [&](int idx) -> u32 { return sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1] & REL_MASK; };
+#endif
     const int i_first = (int)g_begin * 64 + lane;
     {
         u32 kk[M5_LEVELS], nb;

@@ -1014,10 +1014,10 @@ __global__ __launch_bounds__(64) void k_inf_chain(const u8 *__restrict__ cdata, 
     u64 pos = br.pos;
     u32 ntok = 0, ntrue = 0;
     u64 nout = 0;
-    bool last = false, need_seq = cand_overflow;
+    bool last = false, need_seq = cand_overflow, enough = false;      // enough: a partial decode has the bytes it wants
     LaneLds L;
     L.bind(tabs, 1, 0);
-    while (!last && !need_seq) {
+    while (!last && !need_seq && !enough) {
         // find a candidate at exactly `pos` (wave-wide search forward)
         int found = -1;
         for (;;) {
@@ -1067,8 +1067,17 @@ __global__ __launch_bounds__(64) void k_inf_chain(const u8 *__restrict__ cdata, 
         ntrue++;
         ntok += b_ntok; nout += b_nout;
         pos = b_end;
+        if (ch.n_need && nout >= ch.n_need) enough = true;
     }
-    if (!need_seq) {
+    if (enough) {
+        // whole blocks up to the one that reaches the wanted prefix (the stream buffer has room for the whole chunk)
+        r.end_bit = pos; r.n_out = (u32)nout; r.ntok = ntok;
+    } else if (need_seq && ch.n_need) {
+        // the bytes given end before the wanted prefix does (or the fast path cannot follow them): the caller comes back with the whole chunk
+        r.status = MTS_CHUNK_NEEDMORE;
+        need_seq = false;
+        ntrue = 0;
+    } else if (!need_seq) {
         const u64 tb = (pos + 7) & ~7ull;
         if (tb + 32 > br.end) r.status = MTS_CHUNK_CORRUPT;                   // no room for the check value
         else {
@@ -2049,8 +2058,6 @@ __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restric
         }
     };
     // (every thread of the workgroup reaches finish() together: its shuffles and its barrier want whole waves)
-    for (u32 step = 0; step < TR_STEPS; step++) {
-    const u32 p = ((blockIdx.x * TR_STEPS + step) * 256 + threadIdx.x) * 16;
     const u16 *cells = sym + chunks[ci].stream_off;
     u8 *out = stream + chunks[ci].stream_off;
     const u8 *W = win + (size_t)ci * LZ_MAXSEG * LZ_WIN;
@@ -2059,9 +2066,20 @@ __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restric
         while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (q >= pl->b0[mid]) lo = mid; else hi = mid - 1; }
         return lo;
     };
+    // the cells of all steps are asked for together (the kernel waited for one pair of loads per step: 76 % of its wave cycles)
+    uint4 ca[TR_STEPS], cb[TR_STEPS];
+#pragma unroll
+    for (u32 step = 0; step < TR_STEPS; step++) {
+        const u32 p = ((blockIdx.x * TR_STEPS + step) * 256 + threadIdx.x) * 16;
+        if (p + 16 <= r.n_out) { ca[step] = *(const uint4 *)(cells + p); cb[step] = *(const uint4 *)(cells + p + 8); }
+        else { ca[step] = make_uint4(0, 0, 0, 0); cb[step] = ca[step]; }
+    }
+#pragma unroll
+    for (u32 step = 0; step < TR_STEPS; step++) {
+    const u32 p = ((blockIdx.x * TR_STEPS + step) * 256 + threadIdx.x) * 16;
     if (p >= r.n_out) {
     } else if (p + 16 <= r.n_out) {
-        const uint4 a = *(const uint4 *)(cells + p), b = *(const uint4 *)(cells + p + 8);
+        const uint4 a = ca[step], b = cb[step];
         const u32 cw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         const u32 k_lo = seg_of(p), k_hi = seg_of(p + 15);
         u32 ow[4] = {0, 0, 0, 0}, s1 = 0, s2 = 0;
@@ -2093,7 +2111,7 @@ __global__ __launch_bounds__(64) void k_inf_finish(const InfChunk *__restrict__ 
     const int ci = blockIdx.x * 64 + threadIdx.x;
     if (ci >= n_chunks) return;
     InfResult r = res[ci];
-    if (r.status == MTS_CHUNK_OK) {
+    if (r.status == MTS_CHUNK_OK && chunks[ci].n_need == 0) {                 // (a partial decode never reaches the check value)
         const u32 a = (u32)((1 + adler_acc[2 * ci]) % 65521u), b = (u32)((chunks[ci].n_expect + adler_acc[2 * ci + 1]) % 65521u);
         if (((b << 16) | a) != r.adler_stored) r.status = MTS_CHUNK_CORRUPT;
     }

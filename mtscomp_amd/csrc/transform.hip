@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) void k_gather_slices(const GatherChunk *__rest
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (chunks[mid].row0 <= row) lo = mid; else hi = mid - 1; }
         const GatherChunk c = chunks[lo];
         if (!c.base) continue;                                         // (a chunk that failed to decode: its rows are not written)
-        ((T *)(out + q.out_off))[e] = ((const T *)c.base)[(u64)(row - c.row0) * (u64)n_channels + (u64)col];
+        ((T *)(out + q.out_off))[e] = ((const T *)c.base)[(u64)(row - c.row0) * (u64)c.pitch + (u64)col];
     }
 }
 

@@ -83,6 +83,8 @@ def lib():
                                       vp, ip]
     L.mts_cache_read_slices.argtypes = [C.c_long, C.c_int, lp, vp, lp, lp, lp, C.c_int, C.c_int, C.c_int, C.c_int, lp, vp, lp,
                                         C.c_long, ip]
+    L.mts_cache_read_slices_leading.argtypes = [C.c_long, C.c_int, lp, vp, lp, lp, lp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, lp, vp, lp,
+                                                C.c_long, ip]
     L.mts_release.restype = None
     _lib = L
     return L
@@ -93,7 +95,7 @@ EXPORTS = ['mts_version', 'mts_device_count', 'mts_strerror', 'mts_last_error', 
            'mts_dev_compress_chunks', 'mts_dev_decompress_chunks', 'mts_dev_synth_int16',
            'mts_last_stage_times', 'mts_debug_match_tables', 'mts_debug_tokens', 'mts_debug_deflate',
            'mts_debug_inflate', 'mts_release', 'mts_cache_create', 'mts_cache_destroy', 'mts_cache_query',
-           'mts_cache_read_rows', 'mts_cache_read_slices']
+           'mts_cache_read_rows', 'mts_cache_read_slices', 'mts_cache_read_slices_leading']
 
 
 def _check(rc, what):
@@ -270,10 +272,11 @@ def cache_read_rows(cache_id, keys, cdata, offs, lens, n_rows, n_channels, dtype
     return [int(x) for x in status], out
 
 
-def cache_read_slices(cache_id, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, requests):
+def cache_read_slices(cache_id, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, requests, n_leading=None):
     """Several rectangles of the concatenation of the chunks `keys` in one call: requests = [(row_begin, row_end, row_step,
     col_begin, col_end, col_step), ...] (steps >= 1).  The pieces are gathered on the device and come back in one copy.
-    Returns (status list, list of 2-D arrays)."""
+    Returns (status list, list of 2-D arrays).  n_leading: the requests only touch channels below it, chunks that are not
+    resident are decoded up to there only and `lens` may be prefixes of their bytes (mts_cache_read_slices_leading)."""
     dtype = check_dtype(dtype)
     keys, offs, lens, rows = _longs(keys), _longs(offs), _longs(lens), _longs(n_rows)
     n = int(keys.size)
@@ -286,9 +289,10 @@ def cache_read_slices(cache_id, keys, cdata, offs, lens, n_rows, n_channels, dty
     out_offs = _longs(np.concatenate(([0], np.cumsum(sizes)))[:-1]) if shapes else _longs([])
     out = np.empty(int(sum(sizes)) + 8, dtype=np.uint8)
     status = np.zeros(max(n, 1), dtype=np.int32)
-    _check(lib().mts_cache_read_slices(int(cache_id), n, _lp(keys), _ptr(cdata), _lp(offs), _lp(lens), _lp(rows), n_channels,
-                                       dtype.itemsize, _dflags(flags, dtype), len(shapes), _lp(req), _ptr(out), _lp(out_offs),
-                                       int(sum(sizes)), status.ctypes.data_as(C.POINTER(C.c_int))), 'mts_cache_read_slices')
+    _check(lib().mts_cache_read_slices_leading(int(cache_id), n, _lp(keys), _ptr(cdata), _lp(offs), _lp(lens), _lp(rows), n_channels,
+                                               dtype.itemsize, _dflags(flags, dtype), int(n_leading or n_channels), len(shapes), _lp(req),
+                                               _ptr(out), _lp(out_offs), int(sum(sizes)), status.ctypes.data_as(C.POINTER(C.c_int))),
+           'mts_cache_read_slices')
     arrays = [out[int(o):int(o) + a * b * dtype.itemsize].view(dtype).reshape(a, b) for o, (a, b) in zip(out_offs, shapes)]
     return [int(x) for x in status[:n]], arrays
 

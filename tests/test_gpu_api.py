@@ -510,3 +510,50 @@ def test_read_slices_argument_checks_and_many_requests():
         assert np.array_equal(out[2:2 + 64].view(np.int16).reshape(4, 8), x[0:4])
     finally:
         hip.cache_destroy(cid)
+
+
+def test_leading_channels_are_decoded_from_a_prefix(tmp_cfg):
+    """Reader[rows, :k] of a cold file: the chunks are inflated only as far as the first k channels reach (channel-major streams:
+    a prefix), from a prefix of their compressed bytes; more channels or whole rows later decode the chunk again."""
+    arr = synth_int16(0, 3 * 30000, 385, 4)
+    raw = tmp_cfg / 'lead.bin'
+    arr.tofile(raw)
+    mtscomp_amd.compress(raw, tmp_cfg / 'lead.cbin', tmp_cfg / 'lead.ch', sample_rate=30000., n_channels=385, dtype=np.int16,
+                         check_after_compress=False)
+    r = mtscomp_amd.decompress(tmp_cfg / 'lead.cbin', tmp_cfg / 'lead.ch')
+    reads = []
+    orig = r._pread
+    r._pread = lambda length, start: (reads.append(length), orig(length, start))[1]
+    assert np.array_equal(r[100:45000, 0:32], arr[100:45000, 0:32])            # chunks 0 and 1, cold: prefixes only
+    full = [r.chunk_offsets[i + 1] - r.chunk_offsets[i] for i in range(3)]
+    assert len(reads) == 2 and all(n < f // 4 for n, f in zip(reads, full))
+    del reads[:]
+    assert np.array_equal(r[200:300, 5:30:5], arr[200:300, 5:30:5]) and reads == []      # resident (leading 32 channels)
+    assert np.array_equal(r[200:40000, 0:64], arr[200:40000, 0:64])            # more channels than the entries hold: decoded again
+    assert len(reads) >= 1                                                     # (one read of both chunks, whole)
+    assert np.array_equal(r[29990:30010], arr[29990:30010])                    # whole rows: whole chunks
+    assert np.array_equal(r[60000:60010, 380:385], arr[60000:60010, 380:385])  # trailing channels: whole chunk
+    got = r.read_slices([(slice(0, 90000, 1000), slice(0, 8)), (slice(45000, 45010), slice(2, 3))])
+    assert np.array_equal(got[0], arr[0:90000:1000, 0:8]) and np.array_equal(got[1], arr[45000:45010, 2:3])
+    r.close()
+    # C ABI: a prefix that is too short is a miss, not an error and not a wrong answer
+    z = hip.compress_chunks(arr[:30000], [0, 30000], hip.make_flags(), 6)[0]
+    cid = hip.cache_create(1 << 30)
+    try:
+        with pytest.raises(hip.HipError) as e:
+            hip.cache_read_slices(cid, [0], z[:200000], [0], [200000], [30000], 385, np.int16, hip.make_flags(), [(0, 10, 1, 0, 32, 1)], n_leading=32)
+        assert e.value.code == hip.E_MISS
+        st, got = hip.cache_read_slices(cid, [0], z[:len(z) // 8], [0], [len(z) // 8], [30000], 385, np.int16, hip.make_flags(),
+                                        [(10, 20, 1, 0, 32, 1)], n_leading=32)
+        assert st == [0] and np.array_equal(got[0], arr[10:20, 0:32])
+        with pytest.raises(hip.HipError):                                      # a request beyond the leading channels
+            hip.cache_read_slices(cid, [0], b'', [0], [0], [30000], 385, np.int16, hip.make_flags(), [(10, 20, 1, 0, 33, 1)], n_leading=32)
+        # damage in the part of the stream the prefix does not reach goes unnoticed by the partial read and is caught by a whole one
+        bad = bytearray(z)
+        bad[len(z) - 1000] ^= 0x40
+        st, got = hip.cache_read_slices(cid, [7], bytes(bad), [0], [len(bad)], [30000], 385, np.int16, hip.make_flags(), [(10, 20, 1, 0, 32, 1)], n_leading=32)
+        assert st == [0] and np.array_equal(got[0], arr[10:20, 0:32])
+        st, _ = hip.cache_read_slices(cid, [8], bytes(bad), [0], [len(bad)], [30000], 385, np.int16, hip.make_flags(), [(10, 20, 1, 0, 32, 1)])
+        assert st == [hip.CHUNK_CORRUPT]
+    finally:
+        hip.cache_destroy(cid)
