@@ -301,13 +301,6 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     }
     MTS_HIP(hipMemsetAsync(d_cout, 0, sizeof(ChunkOut) * n_chunks, st));
     MTS_HIP(hipMemsetAsync(pb.changed, 0, 8, st));           // + the match stage's flag word behind it
-    // zero the output slots (the packer ORs bits into them): exactly the compress_bound() bytes the header promises each
-    // slot has, never what lies between two slots (one launch, after the descriptors are on the device)
-    {
-        u32 max_n = 0;
-        for (int i = 0; i < n_chunks; i++) if (cd[i].n > max_n) max_n = cd[i].n;
-        if ((rc = launch_zero_slots(st, d_chunks, n_chunks, max_n, d_out))) return rc;
-    }
     // the host copies above must be complete before the std::vectors go away; they are pageable
     // copies, which hipMemcpyAsync finishes staging before returning.
 
@@ -420,6 +413,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     if ((rc = launch_block_trees(st, d_chunks, d_blk_chunk, (int)nblk, d_tokens, d_blk_in_start, d_cout, d_blocks,
                                  E.blkcodes.as<u32>(), E.blkhdr.as<u32>(), fast ? 1 : 0))) return rc;
     if ((rc = launch_block_layout(st, d_chunks, n_chunks, d_blocks, d_cout, d_adler))) return rc;
+    if ((rc = launch_zero_edges(st, d_chunks, d_blk_chunk, (int)nblk, d_blocks, d_cout, d_out))) return rc;      // (the words the packer ORs into)
     E.t_mark(st, "block_trees");
     if ((rc = launch_block_pack(st, d_stream, d_chunks, d_blk_chunk, (int)nblk, d_tokens, d_blocks, E.blkcodes.as<u32>(),
                                 E.blkhdr.as<u32>(), d_cout, d_out, level))) return rc;

@@ -182,7 +182,8 @@ int launch_block_pack(hipStream_t st, const u8 *d_stream, const ChunkDesc *d_chu
                       int total_blk_cap, const u32 *d_tokens, const BlockRec *d_blocks,
                       const u32 *d_blk_codes, const u32 *d_blk_hdr, const ChunkOut *d_cout, u8 *d_out,
                       int level);
-int launch_zero_slots(hipStream_t st, const ChunkDesc *d_chunks, int n_chunks, u32 max_n, u8 *d_out);
+int launch_zero_edges(hipStream_t st, const ChunkDesc *d_chunks, const u32 *d_blk_chunk, int total_blk_cap, const BlockRec *d_blocks,
+                      const ChunkOut *d_cout, u8 *d_out);      // the words of the output the packer ORs into
 constexpr int BLK_CODE_WORDS = 320;     // per block: 286 lit/len + 30 dist (code | len << 16), padded
 constexpr int BLK_HDR_WORDS = 96;       // per block: packed dynamic-tree header bits (<= 3072 bits)
 
