@@ -75,6 +75,18 @@ __device__ __forceinline__ u32 wave_excl_scan_u32(u32 v, u32 &total)
     return x - v;
 }
 
+// inclusive wave scan on the vector ALU alone (row shifts + row broadcasts: no LDS crossbar)
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 x)
+{
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);     // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);     // row_shr:8
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);     // row_bcast:15
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);     // row_bcast:31
+    return x;
+}
+
 __device__ __forceinline__ u32 __reduce_max_sync_u32(u32 v)
 {
 #pragma unroll
@@ -87,11 +99,16 @@ __device__ __forceinline__ u32 __reduce_max_sync_u32(u32 v)
 // ================================================================================================
 // The radix passes move 32-bit keys  (high 7 hash bits << 18) | window-relative position.  Everything else the
 // match stage wants about a position (its bytes, its chain length) it derives from the window bytes.
-constexpr int SORT_WAVES = 16;           // waves per sort workgroup (one tile)
-constexpr int SORT_KPL = 4;              // keys per lane and step: SORT_KPL * 64 keys are staged in destination order per wave
+#ifndef MTS_SORT_WAVES
+#define MTS_SORT_WAVES 16
+#endif
+#ifndef MTS_SORT_KPL
+#define MTS_SORT_KPL 4
+#endif
+constexpr int SORT_WAVES = MTS_SORT_WAVES; // waves per sort workgroup (one tile)
+constexpr int SORT_KPL = MTS_SORT_KPL;              // keys per lane and step: SORT_KPL * 64 keys are staged in destination order per wave
 constexpr int SORT_NT = SORT_WAVES * 64;
-constexpr int SORT_PASSES = 2;           // 2: 8 + 7 hash bits (12.4 ms), 3: 5 + 5 + 5 (runs of ~8 keys per store, but 17.8 ms: a pass costs ~6 ms whatever its stores look like)
-constexpr int SORT_B1 = SORT_PASSES == 2 ? 8 : 5;
+constexpr int SORT_B1 = 8;               // two passes: 8 + 7 hash bits
 // per-(wave, digit) counts -> where each wave's keys of each digit start (digit-major, wave-minor: stable)
 template <int NB>
 __device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
@@ -151,23 +168,28 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
         // put in destination order in LDS (keys of one digit sit together there: slot = destination - first destination
         // of the digit in this step + keys of smaller digits in this step) and then stored by consecutive lanes.
         constexpr int NBIN = 1 << NB;
+        static_assert(NBIN % 64 == 0 && NBIN <= 256, "a lane owns the counters of digits lane, lane + 64, ...");
         constexpr int KPL = SORT_KPL, BK = 64 * KPL;
         u32 *K = stg + wave * (2 * BK), *A = K + BK, *D = dlt + wave * 256;
         for (u32 base = beg; base < end; base += BK) {
             u32 key[KPL], at[KPL], bf[4];
 #pragma unroll
             for (int k = 0; k < KPL; k++) key[k] = fetch(base + 64 * k + lane);
+            // (a lane looks after the counters of digits lane, lane + 64, ...: neighbouring lanes on neighbouring words.  With
+            // digits 4 * lane + j, lanes 8 apart met in one LDS bank on each of these twelve accesses per step)
+            constexpr int NJ = NBIN / 64;
 #pragma unroll
-            for (int j = 0; j < 4; j++) bf[j] = 4 * lane + j < NBIN ? cnt[wave][4 * lane + j] : 0u;
+            for (int j = 0; j < NJ; j++) bf[j] = cnt[wave][lane + 64 * j];
 #pragma unroll
             for (int k = 0; k < KPL; k++) at[k] = base + 64 * k + lane < end ? atomicAdd(&cnt[wave][digit_of(key[k])], 1u) : 0u;
-            u32 lc[4], sum = 0;
+            u32 total = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) { lc[j] = 4 * lane + j < NBIN ? cnt[wave][4 * lane + j] - bf[j] : 0u; sum += lc[j]; }
-            u32 total;
-            u32 ex = wave_excl_scan_u32(sum, total);
-#pragma unroll
-            for (int j = 0; j < 4; j++) { if (4 * lane + j < NBIN) D[4 * lane + j] = ex - bf[j]; ex += lc[j]; }
+            for (int j = 0; j < NJ; j++) {
+                const u32 lcj = cnt[wave][lane + 64 * j] - bf[j];
+                const u32 inc = wave_incl_scan_dpp(lcj);
+                D[lane + 64 * j] = total + inc - lcj - bf[j];
+                total += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+            }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < KPL; k++) {
@@ -266,24 +288,13 @@ __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ st
         for (int i = threadIdx.x; i < SORT_WAVES * 128; i += SORT_NT) { cnt[i >> 7][i & 127] = cnt2[i >> 7][i & 127]; cnt2[i >> 7][i & 127] = 0; }
         __syncthreads();
     };
-    if (SORT_PASSES == 2) {
-        bin_offsets<8>(cnt, tot);
-        rank_pass<8, true, 0, 7>(s, nullptr, tmp_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);        // low 8 hash bits
-        next_counts();
-        bin_offsets<7>(cnt, tot);
-        rank_pass<7, false, 0, 0>(s, tmp_t, out_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);          // high 7 bits
-    } else {
-        // three passes of 5 bits: a wave step's 256 keys fall into 32 bins, so the stores of a step are runs of ~8 keys
-        // (whole sectors) instead of single keys; the sorted array goes tmp <- out <- tmp <- ... so that it ends in `sorted`
-        bin_offsets<5>(cnt, tot);
-        rank_pass<5, true, 0, 5>(s, nullptr, out_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);
-        next_counts();
-        bin_offsets<5>(cnt, tot);
-        rank_pass<5, false, 0, 5>(s, out_t, tmp_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);
-        next_counts();
-        bin_offsets<5>(cnt, tot);
-        rank_pass<5, false, 5, 0>(s, tmp_t, out_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);
-    }
+    bin_offsets<8>(cnt, tot);
+    rank_pass<8, true, 0, 7>(s, nullptr, tmp_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);        // low 8 hash bits
+    next_counts();
+    bin_offsets<7>(cnt, tot);
+    rank_pass<7, false, 0, 0>(s, tmp_t, out_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);          // high 7 bits
+    // (three passes of 5 bits -- runs of ~8 keys per store -- were measured at 17.8 ms against 12.4: a pass costs what it costs
+    // whatever its stores look like)
 }
 
 // 1 if this device's LDS retires same-address atomics of a wave instruction in lane order (probed once per device)
