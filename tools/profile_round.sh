@@ -6,7 +6,7 @@
 #   <tag>_traffic.json             HBM bytes per launch of the dominant kernel, read by bench.py
 #   <tag>_levels_kernel_stats.csv  rocprofv3 --kernel-trace --stats of tools/level_sweep.py (levels 1, 2, 3, 6, 7, 8, 9 on 240 chunks of 15.36 MB)
 #   <tag>_levels.json              its output line
-tag=${1:-r2}
+tag=${1:-r3}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/profile_$tag
 rm -rf $out; mkdir -p $out
@@ -37,13 +37,16 @@ with open(out + "/%s_bench_pmc_hbm_bytes.csv" % tag, "w") as w:
     w.write("kernel,launches,FETCH_SIZE_KB_total,WRITE_SIZE_KB_total\n")
     for k in sorted(agg, key=lambda k: -(agg[k]["FETCH_SIZE"] + agg[k]["WRITE_SIZE"])):
         w.write("%s,%d,%.3f,%.3f\n" % (k.replace(",", ";"), max(n[k].values()), agg[k]["FETCH_SIZE"], agg[k]["WRITE_SIZE"]))
-dom = [k for k in agg if "k_match5" in k]
-if dom:
-    k = dom[0]; L = max(n[k].values())
-    fe, wr = agg[k]["FETCH_SIZE"] / L, agg[k]["WRITE_SIZE"] / L
-    json.dump({"kernel": "k_match5", "fetch_size_kb": fe, "write_size_kb": wr, "traffic_bytes_per_launch": (fe + wr) * 1024,
-               "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py (60 x 23.1 MB chunks); FETCH not doubled: the kernel's window reads are 4-16 B per lane scattered, not wide coalesced",
-               "source": "profiles/%s_bench_pmc_hbm_bytes.csv" % tag}, open(out + "/%s_traffic.json" % tag, "w"), indent=1)
+per = {}
+for k in agg:
+    L = max(n[k].values())
+    short = k.split("::")[-1].split("<")[0]
+    per[short] = {"fetch_size_kb": agg[k]["FETCH_SIZE"] / L, "write_size_kb": agg[k]["WRITE_SIZE"] / L,
+                  "traffic_bytes_per_launch": (agg[k]["FETCH_SIZE"] + agg[k]["WRITE_SIZE"]) / L * 1024, "launches": L}
+json.dump({"kernels": {k: v["traffic_bytes_per_launch"] for k, v in per.items()}, "detail": per,
+           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 1 (60 x 23.1 MB chunks), bytes per launch = counter sum / launches x 1024; "
+                  "FETCH not doubled (the guide's x2 applies to wide coalesced streaming reads only; calibrate before reading absolutes)",
+           "source": "profiles/%s_bench_pmc_hbm_bytes.csv" % tag}, open(out + "/%s_traffic.json" % tag, "w"), indent=1)
 print(open(out + "/%s_bench_default.jsonl" % tag).read()[:600])
 PY
 ls -la $out | head -20
