@@ -2361,22 +2361,48 @@ __global__ __launch_bounds__(64) void k_block_trees(const ChunkDesc *__restrict_
 // ================================================================================================
 // L: block layout per chunk
 // ================================================================================================
+// One wave per chunk: the blocks 64 at a time, bit offsets by a wave scan of the block sizes (one lane walking a chunk's ~300
+// block records one dependent load after the other took 0.2 ms).  A stored block starts its bytes on a byte boundary, so its
+// size depends on where it starts: groups with a stored block are walked in order by lane 0.
 __global__ __launch_bounds__(64) void k_block_layout(const ChunkDesc *__restrict__ chunks, int n_chunks,
                                                      BlockRec *__restrict__ blocks, ChunkOut *__restrict__ cout,
                                                      const u64 *__restrict__ adler_acc)
 {
-    const int ci = blockIdx.x * 64 + threadIdx.x;
+    const int ci = blockIdx.x, lane = threadIdx.x;
     if (ci >= n_chunks) return;
     const ChunkDesc ch = chunks[ci];
     ChunkOut co = cout[ci];
     const u32 nblk = chunk_nblk(co.ntok, co.trailing);
     u64 bit = 16;
-    for (u32 bi = 0; bi < nblk; bi++) {
-        BlockRec &r = blocks[ch.blk0 + bi];
-        r.bit_start = bit;
-        if (r.btype == 0) { bit += 3; bit = (bit + 7) & ~7ull; bit += 32 + 8ull * r.in_len; }
-        else bit += r.nbits;
+    for (u32 b0 = 0; b0 < nblk; b0 += 64) {
+        const u32 bi = b0 + lane;
+        const bool have = bi < nblk;
+        BlockRec *r = blocks + ch.blk0 + (have ? bi : b0);
+        const u32 btype = have ? r->btype : 1u;
+        const u64 nbits = have ? (u64)r->nbits : 0ull;
+        if (__any(btype == 0)) {
+            if (lane == 0) {
+                for (u32 k = b0; k < min(b0 + 64u, nblk); k++) {
+                    BlockRec &q = blocks[ch.blk0 + k];
+                    q.bit_start = bit;
+                    if (q.btype == 0) { bit += 3; bit = (bit + 7) & ~7ull; bit += 32 + 8ull * q.in_len; }
+                    else bit += q.nbits;
+                }
+            }
+            bit = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)bit, 0)) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(bit >> 32), 0) << 32);
+            continue;
+        }
+        u64 x = nbits;                                          // inclusive scan (64-bit: a chunk's stream may pass 2^32 bits)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 lo = __shfl_up((u32)x, o, 64), hi = __shfl_up((u32)(x >> 32), o, 64);
+            if (lane >= o) x += ((u64)hi << 32) | lo;
+        }
+        if (have) r->bit_start = bit + x - nbits;
+        const u64 tot = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)x, 63)) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(x >> 32), 63) << 32);
+        bit += tot;
     }
+    if (lane != 0) return;
     bit = (bit + 7) & ~7ull;
     co.nblk = nblk;
     co.nbytes = bit / 8 + 4;
@@ -2597,7 +2623,7 @@ int launch_block_layout(hipStream_t st, const ChunkDesc *d_chunks, int n_chunks,
                         const u64 *d_adler_acc)
 {
     if (n_chunks == 0) return MTS_OK;
-    hipLaunchKernelGGL(k_block_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_chunks, n_chunks, d_blocks, d_cout, d_adler_acc);
+    hipLaunchKernelGGL(k_block_layout, dim3(n_chunks), dim3(64), 0, st, d_chunks, n_chunks, d_blocks, d_cout, d_adler_acc);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
