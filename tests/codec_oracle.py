@@ -139,3 +139,55 @@ class CachingOracleCodec(OracleCodec):
         while len(cache) > self.capacity_chunks:     # least recently inserted goes first
             cache.pop(next(iter(cache)))
         return status, out
+
+
+class LeadingOracleCodec(CachingOracleCodec):
+    """CachingOracleCodec + mts_cache_read_slices_leading restated (stdlib zlib's streaming inflate on a prefix of the bytes): lets
+    the CPU suite drive the Reader's prefix reads, its retry with whole chunks and the entries of leading channels."""
+    leading_channels = True
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.cols = {}                 # (cache id, key) -> channels the entry holds
+        self.bytes_given = []          # per call: compressed bytes handed over
+
+    def cache_read_slices(self, cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, requests, n_leading=None):
+        import zlib
+        from mtscomp_amd import hip
+        dtype = np.dtype(dtype)
+        n_lead = n_leading or n_channels
+        assert all(ce <= n_lead for _, _, _, _, ce, _ in requests)
+        cache = self.caches[cid]
+        self.calls.append(('cache_slices', sum(1 for n in lens if n)))
+        self.bytes_given.append(int(sum(lens)))
+        status = []
+        for k, o, n, nr in zip(keys, offs, lens, n_rows):
+            if k in cache and self.cols[(cid, k)] >= n_lead:
+                status.append(0)
+                continue
+            if not n:
+                raise hip.HipError(hip.E_MISS, 'mts_cache_read_slices', 'chunk key %d is not resident with the channels asked for' % k)
+            need = nr * n_lead * dtype.itemsize
+            if n_lead < n_channels:
+                assert flags & 4 and dtype.kind in 'iu'
+                d = zlib.decompressobj()
+                stream = d.decompress(bytes(cdata[o:o + n]), need)           # (a prefix of the stream from a prefix of the bytes)
+                if len(stream) < need:
+                    raise hip.HipError(hip.E_MISS, 'mts_cache_read_slices', 'the bytes given do not reach the leading channels')
+                arr = O.cumsum_transpose(np.frombuffer(stream[:need], dtype=np.uint8), nr, n_lead, dtype, flags)
+                st = 0
+            else:
+                sts, arrs = self.decompress([bytes(cdata[o:o + n])], [nr], n_channels, dtype, flags)
+                self.calls.pop()
+                st, arr = sts[0], arrs[0]
+            status.append(st)
+            if st == 0:
+                cache[k] = arr
+                self.cols[(cid, k)] = n_lead
+        whole = np.concatenate([cache[k][:, :n_lead] if st == 0 else np.zeros((nr, n_lead), dtype=dtype)
+                                for k, nr, st in zip(keys, n_rows, status)], axis=0)
+        arrays = [np.ascontiguousarray(whole[rb:re:rs, cb:ce:cs]) for rb, re, rs, cb, ce, cs in requests]
+        return status, arrays
+
+    def cache_query(self, cid, keys):
+        return np.array([k in self.caches[cid] for k in keys], dtype=bool)

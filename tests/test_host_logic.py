@@ -309,3 +309,31 @@ def test_trim_cache_copies_only_what_pins_a_big_buffer(tmp_cfg):
     (idx, kept), = r._cache.items()
     assert idx == 2 and kept.base is None and np.array_equal(kept, views[2])      # one quarter of the buffer left: copied
     r.close()
+
+
+def test_leading_channel_reads_send_prefixes_and_fall_back(tmp_cfg):
+    """Reader[rows, :k] with a codec that decodes leading channels from a prefix (mts_cache_read_slices_leading): the Reader reads
+    a share of every cold chunk's bytes, asks again with the whole chunks when an entry holds too few channels (or a prefix fell
+    short), and the rows come out as numpy's."""
+    from tests.codec_oracle import LeadingOracleCodec
+    rng = np.random.RandomState(8)
+    arr = np.cumsum(rng.randint(-40, 41, size=(6000, 200)), axis=0).astype(np.int16)
+    raw = tmp_cfg / 'lead.bin'
+    arr.tofile(raw)
+    codec = LeadingOracleCodec()
+    mtscomp_amd.compress(raw, tmp_cfg / 'lead.cbin', tmp_cfg / 'lead.ch', sample_rate=1000., n_channels=200, dtype=np.int16, codec=codec,
+                         check_after_compress=False)
+    r = mtscomp_amd.decompress(tmp_cfg / 'lead.cbin', tmp_cfg / 'lead.ch', codec=codec)
+    sizes = [r.chunk_offsets[i + 1] - r.chunk_offsets[i] for i in range(r.n_chunks)]
+    codec.bytes_given.clear()
+    assert np.array_equal(r[500:2500, 0:4], arr[500:2500, 0:4])                  # chunks 0..2, cold: prefixes
+    assert len(codec.bytes_given) >= 1 and codec.bytes_given[-1] <= sum(sizes[0:3])
+    first_call = codec.bytes_given[0]
+    assert first_call < sum(sizes[0:3])                                          # (a share of the bytes + the margin, not all of them)
+    assert np.array_equal(r[600:700, 1:4:2], arr[600:700, 1:4:2])                # resident
+    n_calls = len(codec.bytes_given)
+    assert np.array_equal(r[500:2500, 0:12], arr[500:2500, 0:12])                # more channels than the entries hold: miss, then whole chunks
+    assert len(codec.bytes_given) == n_calls + 2 and codec.bytes_given[-2] == 0 and codec.bytes_given[-1] == sum(sizes[0:3])
+    assert np.array_equal(r[0:6000:7, 199], arr[0:6000:7, 199])                  # the last channel: whole chunks
+    assert np.array_equal(r[100:200, 0:150], arr[100:200, 0:150])                # more than half of the channels: whole chunks
+    r.close()
