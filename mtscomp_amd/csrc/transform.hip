@@ -574,6 +574,9 @@ static int run_cumsum(hipStream_t st, const u8 *stream, u8 *out, const u64 *d_st
     return MTS_OK;
 }
 
+#ifndef MTS_K2_KU
+#define MTS_K2_KU 13     // (5: 1.06 ms, 9: 1.02, 13: 1.00, 25: 1.02 for the 60-chunk workload)
+#endif
 // K2, row-tile variant: (1) per (tile, channel) sums, (2) exclusive scan of the sums over the tiles of a chunk,
 // (3) scan inside the tile with the carry and write whole C-order rows.
 template <typename T>
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(256) void k_rows_sums(const u8 *__restrict__ stream
         // a lane reads IPL consecutive items (8 bytes) of one channel; the lanes of a channel are neighbours
         const int lpc = tt_rows / IPL, cpw = 64 / lpc;
         const int q = lane % lpc, cc = lane / lpc;
-        constexpr int KU = 5;                                     // wave steps whose loads are in flight together
+        constexpr int KU = MTS_K2_KU;                             // wave steps whose loads are in flight together
         for (int c00 = wave * cpw; c00 < nc; c00 += 4 * cpw * KU) {
             uint2 wq[KU];
 #pragma unroll
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(256) void k_cumsum_rows(const u8 *__restrict__ stre
     if (tt_rows % IPL == 0 && ((u64)nt * sizeof(T)) % 8 == 0 && (((u64)d) & 7) == 0 && ((u64)t0 * sizeof(T)) % 8 == 0 && t0 + tt_rows <= nt) {
         const int lpc = tt_rows / IPL, cpw = 64 / lpc;
         const int q = lane % lpc, cc = lane / lpc;
-        constexpr int KU = 5;                                     // wave steps whose loads are in flight together (see k_delta_rows)
+        constexpr int KU = MTS_K2_KU;                             // wave steps whose loads are in flight together (see k_delta_rows)
         for (int c00 = wave * cpw; c00 < nc; c00 += 4 * cpw * KU) {
             uint2 wq[KU];
             u32 cy[KU];
