@@ -122,6 +122,26 @@ __device__ __forceinline__ int chain_decode_mem(u32 v, const u32 *lc, u32 &len)
     return (int)(so + ((v - lo) >> (MAXL - l_)));
 }
 
+// the same for a prefix whose code is known to be longer than FROM bits (a lookup table indexed by FROM bits had no entry for
+// it): the first FROM steps of the chain are known to pass, and what they add up to -- the number of codes of up to FROM
+// bits -- is in lc[0] (build_chain puts it there)
+template <int MAXL, int FROM>
+__device__ __forceinline__ int chain_decode_mem_from(u32 v, const u32 *lc, u32 &len)
+{
+    u32 l_ = FROM + 1, lo = lc[FROM] & 0xffff, so = lc[0];
+#pragma unroll
+    for (int l = FROM + 1; l < MAXL; l++) {
+        const u32 w = lc[l], lim = w & 0xffff;
+        const bool ge = v >= lim;
+        l_ += ge;
+        lo = ge ? lim : lo;
+        so += ge ? (w >> 16) : 0;
+    }
+    len = l_;
+    if (v >= (lc[MAXL] & 0xffff)) return -1;
+    return (int)(so + ((v - lo) >> (MAXL - l_)));
+}
+
 // Huffman scratch in LDS.  Element k of a user sits at k*stride + lane: stride 64 = one private table set
 // per lane of a wave (64 independent streams), stride 1 / lane 0 = one table set shared by a wave.
 constexpr int INF_LENS = 320;        // u8 code lengths
@@ -146,6 +166,7 @@ struct LaneLds {
     __device__ __forceinline__ u16 &ds(int k) { return dsym[k * stride + lane]; }
 };
 
+constexpr int CHAIN_LUT_LBITS = 10, CHAIN_LUT_DBITS = 8;        // index bits of the lookup tables (= LUT_LBITS, LUT_DBITS below)
 // Build the compare chain + sorted symbol table for lens[first .. first+nsym).
 // returns 0 complete, 1 incomplete, -1 over-subscribed; maxlen = longest code
 template <int MAXL, bool DIST, class CHAIN>
@@ -154,8 +175,7 @@ __device__ int build_chain(LaneLds &L, int first, int nsym, CHAIN &&lc, int &max
     for (int l = 0; l < 16; l++) L.c(l) = 0;
     for (int s = 0; s < nsym; s++) L.c(L.len(first + s))++;
     int left = 1, ml = 0;
-    u32 off = 0, firstc = 0;
-    lc[0] = 0;
+    u32 off = 0, firstc = 0, short_codes = 0;
 #pragma unroll
     for (int l = 1; l <= MAXL; l++) {
         const u32 cn = L.c(l);
@@ -163,11 +183,13 @@ __device__ int build_chain(LaneLds &L, int first, int nsym, CHAIN &&lc, int &max
         if (cn) ml = l;
         L.c(16 + l) = (u16)off;
         off += cn;
+        if (l <= (DIST ? CHAIN_LUT_DBITS : CHAIN_LUT_LBITS)) short_codes += cn;
         // first code of length l = (first code of length l-1 + count[l-1]) << 1
         const u32 lim = (firstc + cn) << (MAXL - l);
         lc[l] = (lim & 0xffff) | (cn << 16);      // lim <= 2^MAXL <= 32768 unless over-subscribed (rejected below)
         firstc = (firstc + cn) << 1;
     }
+    lc[0] = short_codes;         // (slot 0 is no code length: chain_decode_mem_from starts from it)
     maxlen = ml;
     if (left < 0) return -1;
     for (int s = 0; s < nsym; s++) {
@@ -256,6 +278,26 @@ __device__ __forceinline__ void lz_emit_pieces(u32 *tk, u32 tok, u32 olen)
     if (!(tok >> 31) || olen <= LZ_PIECE) { tk[0] = tok; return; }
     const u32 dist = (tok & 0x7fff) + 1;
     u32 k = 0;
+    if (dist >= olen) {
+        // the copy does not overlap itself: every piece reads at the copy's own distance.  (Kept apart from the general
+        // case below because that one divides by the distance, and in a wave the set-up of the division ran for every
+        // token longer than a piece -- three quarters of all steps have one.)
+        const u32 base = 0x80000000u | (dist - 1);
+        if (olen <= 2 * LZ_PIECE) {
+            const u32 l0 = olen - LZ_PIECE < 3 ? olen - 3 : LZ_PIECE;
+            tk[0] = base | ((l0 - 3) << 16);
+            tk[1] = base | ((olen - l0 - 3) << 16);
+            return;
+        }
+        u32 left = olen;
+        while (left > 0) {
+            u32 l = left > LZ_PIECE ? LZ_PIECE : left;
+            if (left > LZ_PIECE && left - LZ_PIECE < 3) l = left - 3;
+            tk[k++] = base | ((l - 3) << 16);
+            left -= l;
+        }
+        return;
+    }
     // pieces of LZ_PIECE bytes; a short remainder (< 3 bytes is not encodable as len-3 >= 0) is merged
     // into the last piece by making the last two pieces share the remainder.
     // A copy that overlaps itself (dist < length) repeats a pattern of `dist` bytes, so byte o of it equals the byte any
@@ -317,7 +359,7 @@ __device__ __forceinline__ int decode_token(BitIn &br, LaneLds &L, const u32 (&L
 //   [5:4] 0 literal, 1 length / distance, 2 end of block, 3 invalid symbol
 //   [23:8] literal byte, or base length / base distance      [27:24] number of extra bits
 // The tables are filled by decoding every index with the compare chain once.
-constexpr int LUT_LBITS = 10, LUT_DBITS = 8;
+constexpr int LUT_LBITS = CHAIN_LUT_LBITS, LUT_DBITS = CHAIN_LUT_DBITS;
 constexpr int LUT_BYTES = 4 * ((1 << LUT_LBITS) + (1 << LUT_DBITS)) + 2 * 16 * 4;      // tables + the two compare chains
 __device__ __forceinline__ u32 lut_len_entry(u32 sym, u32 cl)
 {
@@ -366,7 +408,7 @@ __device__ __forceinline__ int decode_token_lut(READER &br, LaneLds &L, const u3
     u32 e = lutl[p & ((1u << LUT_LBITS) - 1)];
     if (!(e & 15)) {                                             // (rare) longer than the table index
         u32 cl;
-        const int si = chain_decode_mem<15>(__brev(p) >> 17, LC, cl);
+        const int si = chain_decode_mem_from<15, LUT_LBITS>(__brev(p) >> 17, LC, cl);
         if (si < 0) return INF_CORRUPT;
         e = lut_len_entry(L.ls(si), cl);
     }
@@ -379,7 +421,7 @@ __device__ __forceinline__ int decode_token_lut(READER &br, LaneLds &L, const u3
     u32 d = lutd[p & ((1u << LUT_DBITS) - 1)];
     if (is_match && !(d & 15)) {
         u32 dl;
-        const int si = chain_decode_mem<15>(__brev(p) >> 17, DC, dl);
+        const int si = chain_decode_mem_from<15, LUT_DBITS>(__brev(p) >> 17, DC, dl);
         if (si < 0) return INF_CORRUPT;
         d = lut_dist_entry(L.ds(si), dl);
     }
@@ -613,9 +655,18 @@ struct TrueBlk {
     u32 chunk;
 };
 constexpr int PASSA_STAGE_WORDS = 64 * 1024 / 32 + 16;   // a round of pass A: 64 sub-sequences + the reader's look-ahead and a token's overshoot
-constexpr int PASSB_STAGE_WORDS = 3072;   // LDS copy of the 64 sub-sequences a wave decodes in one step (~2048 words + slack)
+#ifndef MTS_PASSB_STAGE_WORDS
+#define MTS_PASSB_STAGE_WORDS 2304
+#endif
+constexpr int PASSB_STAGE_WORDS = MTS_PASSB_STAGE_WORDS;   // LDS copy of the 64 sub-sequences a wave decodes in one step: 64 x (1024 bits + a token's overshoot) <= 2144 words
+                                          // (a step that needs more reads the stream from memory); 3072 words left room for 8 waves per CU, 2304 for 10
 constexpr int SUBCAP = 512;      // sub-sequences recorded per candidate block
-constexpr u32 SUB_BITS = 1024;   // bits per sub-sequence (measured 1024 .. 3072: shorter is faster, the lanes' serial chains dominate)
+constexpr u32 SUB_BITS = 1024;   // bits per sub-sequence, at most (measured 1024 .. 3072: shorter is faster, the lanes' serial chains dominate)
+#ifndef MTS_SUB_TARGET
+#define MTS_SUB_TARGET 1024
+#endif
+constexpr u32 SUB_TARGET = MTS_SUB_TARGET;      // pass A cuts a block into rounds of 64 EQUAL sub-sequences of about this many bits (see k_inf_passA)
+constexpr u32 SUB_MIN = 256;
 
 constexpr int SCAN_L1_CAP = 14336;       // filter-1 survivors kept per workgroup (expected ~7200 of 32768)
 
@@ -898,7 +949,26 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     build_luts(L, lutl, lutd, lane);
     __builtin_amdgcn_wave_barrier();
     uint2 *sub = subs + (u64)slot * SUBCAP;
-    u64 base = br.pos;
+    // Sub-sequence length.  A block of B bits takes ceil(B / (64 * SUB_BITS)) rounds whatever is left for the last one (the
+    // ~26 KB blocks of zlib's level 6 on the recordings: 3.25 rounds' worth, i.e. a fourth round with 16 of 64 lanes busy).
+    // The candidates of a chunk are sorted and the next one is -- almost always -- where this block ends, so the length is
+    // known in advance and the rounds are made equal: the same number of rounds, each as short as the block allows.  A
+    // wrong guess (a validated header inside a block) can only make the sub-sequences shorter than they need be; if the
+    // block then has more of them than the records hold, it is done again with full-length ones.
+    u32 sub_bits = SUB_BITS;
+    {
+        const u32 ncand_c = min(cand_cnt[ci], f.cand_cap);
+        const u64 next_o = k + 1 < ncand_c ? cand_pos[slot + 1] : 8ull * ch.c_len;
+        const u64 est = next_o > br.pos ? next_o - br.pos : 0;
+        const u64 rounds = (est + 64ull * SUB_TARGET - 1) / (64ull * SUB_TARGET);
+        if (rounds >= 1 && rounds * 64 + 64 <= (u64)SUBCAP - 1) {
+            const u64 per = (est + 64 * rounds - 1) / (64 * rounds);
+            sub_bits = (u32)((per + 31) & ~31ull);
+            sub_bits = sub_bits < SUB_MIN ? SUB_MIN : sub_bits > SUB_BITS ? SUB_BITS : sub_bits;
+        }
+    }
+    const u64 base0 = br.pos;
+    u64 base = base0;
     u32 tot_tok = 0, tot_out = 0, nsub = 0;
     bool done = false, fail = false;
     // a round = 64 sub-sequences: that piece of the stream (+ slack for the reader's look-ahead and the last token's
@@ -910,12 +980,13 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
         const u64 wb0 = base >> 5;
         const u32 bofs = (u32)(base & 31);
         __builtin_amdgcn_wave_barrier();
-        for (u32 k2 = lane; k2 < (u32)PASSA_STAGE_WORDS; k2 += 64) stage[k2] = br.word(wb0 + k2);
+        const u32 stage_words = 64 * sub_bits / 32 + 16;
+        for (u32 k2 = lane; k2 < stage_words; k2 += 64) stage[k2] = br.word(wb0 + k2);
         __builtin_amdgcn_wave_barrier();
         const u64 end_rel64 = br.end - (wb0 << 5);
         const u32 end_rel = end_rel64 < 0x7fffffffull ? (u32)end_rel64 : 0x7fffffffu;
-        const u32 stop = bofs + (u32)(lane + 1) * SUB_BITS;
-        u32 start = bofs + (u32)lane * SUB_BITS, ex;
+        const u32 stop = bofs + (u32)(lane + 1) * sub_bits;
+        u32 start = bofs + (u32)lane * sub_bits, ex;
         u32 nt, no; int fl;
         // speculative pass: exits only
         bl.seek(start);
@@ -957,7 +1028,10 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
             if (lane >= off) { x += xx; y += yy; }
         }
         const int nvalid = fstop < 64 ? fstop + 1 : 64;
-        if (nsub + nvalid > SUBCAP - 1) { fail = true; break; }
+        if (nsub + nvalid > SUBCAP - 1) {
+            if (sub_bits < SUB_BITS) { sub_bits = SUB_BITS; base = base0; tot_tok = 0; tot_out = 0; nsub = 0; continue; }      // (the guess was too short)
+            fail = true; break;
+        }
         if (valid) sub[nsub + lane] = make_uint2((u32)((wb0 << 5) + start - o), tot_tok + x - nt);
         const u32 rt = __shfl(x, nvalid - 1, 64), ro = __shfl(y, nvalid - 1, 64);
         tot_tok += rt; tot_out += ro;
@@ -1101,7 +1175,12 @@ __global__ __launch_bounds__(64) void k_inf_chain(const u8 *__restrict__ cdata, 
 // ================================================================================================
 // Fast path, step 4: emit the tokens of every accepted block (one wave per block)
 // ================================================================================================
-__global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
+#ifndef MTS_PASSB_WAVES
+#define MTS_PASSB_WAVES 1
+#endif
+constexpr int PASSB_WAVES = MTS_PASSB_WAVES;      // waves that share a block's tables and take its steps in turn.  Measured: 1: 2.90 ms, 2: 2.98, 4: 3.76 (more waves
+                                                  // per CU, but they wait for the first one's tables and for each other's last, short step)
+__global__ __launch_bounds__(64 * PASSB_WAVES) void k_inf_passB(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
                                                   const InfFast *__restrict__ fast, const u32 *__restrict__ tslot_chunk,
                                                   const TrueBlk *__restrict__ tblk, const u32 *__restrict__ true_cnt,
                                                   const CandRes *__restrict__ cres, const uint2 *__restrict__ subs,
@@ -1116,12 +1195,13 @@ __global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, 
     __shared__ __attribute__((aligned(16))) u8 tabs[INF_SET_BYTES];
     LaneLds L;
     L.bind(tabs, 1, 0);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     BitIn br;
     br.init(cdata, ch.c_off, ch.c_len, 0);
     br.seek(tb.start_bit);
     u32 *tk = tokens + ch.tok_off + tb.tok_off;
     if (tb.cand == 0xffffffffu) {
+        if (wave) return;
         // a block the chain walk counted itself: stored bytes become literal tokens 64 at a time; a short Huffman block is
         // decoded by lane 0
         const u32 hdr0 = br.get(3);
@@ -1145,17 +1225,24 @@ __global__ __launch_bounds__(64) void k_inf_passB(const u8 *__restrict__ cdata, 
     __shared__ u32 lut_s[LUT_BYTES / 4];
     u32 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
     u32 *LC = lutd + (1 << LUT_DBITS), *DC = LC + 16;               // the compare chains live in LDS (wave-shared)
-    if (parse_tables(br, L, hdr >> 1, LC, DC) != INF_OK) { if (lane == 0) res[ci].status = MTS_CHUNK_CORRUPT; return; }
-    __builtin_amdgcn_wave_barrier();
-    build_luts(L, lutl, lutd, lane);
-    __builtin_amdgcn_wave_barrier();
+    // the first wave parses the header (every lane of it: identical control flow, identical LDS writes) and fills the tables
+    __shared__ int hdr_rc;
+    if (wave == 0) {
+        const int rc = parse_tables(br, L, hdr >> 1, LC, DC);
+        if (lane == 0) hdr_rc = rc;
+        __builtin_amdgcn_wave_barrier();
+        if (rc == INF_OK) build_luts(L, lutl, lutd, lane);
+    }
+    __syncthreads();
+    if (hdr_rc != INF_OK) { if (threadIdx.x == 0) res[ci].status = MTS_CHUNK_CORRUPT; return; }
     const u32 nsub = cres[tb.cand].nsub;
     const uint2 *sub = subs + (u64)tb.cand * SUBCAP;
     // every lane reads its own sub-sequence word by word: straight from memory that is one dependent, uncoalesced
     // load per ~3 tokens.  The 64 sub-sequences of a step are one contiguous piece of the stream (~16 KiB):
     // it is copied to LDS with coalesced loads first.
-    __shared__ u32 stage[PASSB_STAGE_WORDS];
-    for (u32 j0 = 0; j0 < nsub; j0 += 64) {
+    __shared__ u32 stage_s[PASSB_WAVES][PASSB_STAGE_WORDS];
+    u32 *stage = stage_s[wave];
+    for (u32 j0 = 64 * (u32)wave; j0 < nsub; j0 += 64 * PASSB_WAVES) {
         const u32 j = j0 + lane;
         const u32 jl = min(j0 + 64, nsub);
         // (the entry after the last sub-sequence is a terminator without a position: the round then ends where the block does)
@@ -2244,7 +2331,7 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
         hipLaunchKernelGGL(k_inf_chain, dim3(n_chunks), dim3(64), 0, st, d_cdata, d_chunks, d_fast, d_cand_pos, d_cand_cnt, d_cres,
                            d_tblk, d_true_cnt, d_res, d_seq);
         inflate_mark(engine, st, "inflate_chain");
-        hipLaunchKernelGGL(k_inf_passB, dim3(l.total_true), dim3(64), 0, st, d_cdata, d_chunks, d_fast, (const u32 *)(S + l.tslot_chunk),
+        hipLaunchKernelGGL(k_inf_passB, dim3(l.total_true), dim3(64 * PASSB_WAVES), 0, st, d_cdata, d_chunks, d_fast, (const u32 *)(S + l.tslot_chunk),
                            d_tblk, d_true_cnt, d_cres, d_subs, d_tokens, d_res);
         inflate_mark(engine, st, "inflate_passB");
     }
