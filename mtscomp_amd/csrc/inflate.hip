@@ -645,7 +645,7 @@ struct CandRes {                 // result of decoding one candidate block (pass
     u32 ntok, nout, nsub;
     u32 ok;                      // 1 = decoded to a clean end of block
     u32 bfinal;
-    u32 pad;
+    u32 rows;                    // 1 = pass A kept the block's tokens (rows of ROWCAP per sub-sequence): pass B only moves them
 };
 struct TrueBlk {
     u64 start_bit;
@@ -667,6 +667,16 @@ constexpr u32 SUB_BITS = 1024;   // bits per sub-sequence, at most (measured 102
 #endif
 constexpr u32 SUB_TARGET = MTS_SUB_TARGET;      // pass A cuts a block into rounds of 64 EQUAL sub-sequences of about this many bits (see k_inf_passA)
 constexpr u32 SUB_MIN = 256;
+// Pass A's counting decode keeps the tokens it sees: ROWCAP per sub-sequence (a row), 64 rows per round, taken from a pool
+// with one atomic per round.  A block whose rows all fit (a sub-sequence of <= 1024 bits holds ~100 tokens of ~10 bits on the
+// recordings) is not decoded a third time: pass B moves its rows to where the block's tokens belong.  Anything else -- a
+// row too short for its sub-sequence (runs: 33 pieces per 258-byte copy), the pool used up -- goes through pass B's decode.
+#ifndef MTS_INF_ROWCAP
+#define MTS_INF_ROWCAP 192
+#endif
+constexpr u32 ROWCAP = MTS_INF_ROWCAP;
+constexpr int ROUNDS_MAX = (SUBCAP + 63) / 64;          // rounds of a block (all but the last have 64 sub-sequences)
+static inline u64 rows_rounds_of(u64 c_len) { return c_len * 8 / (64 * 640) + 32; }      // pool share of a chunk, in rounds
 
 constexpr int SCAN_L1_CAP = 14336;       // filter-1 survivors kept per workgroup (expected ~7200 of 32768)
 
@@ -913,13 +923,33 @@ __device__ __forceinline__ void decode_span_fast(BitL &br, LaneLds &L, const u32
     }
 }
 
+// counting decode that also keeps the tokens while they fit into `cap` (pass A's rows)
+__device__ __forceinline__ void decode_span_rows(BitL &br, LaneLds &L, const u32 *lutl, const u32 *lutd, u32 stop, u32 end, u32 &ntok,
+                                                 u32 &nout, int &flag, u32 *row, u32 cap, bool &ovf)
+{
+    flag = SPAN_CONT;
+    ntok = 0; nout = 0; ovf = false;
+    for (;;) {
+        if (br.pos >= stop) break;
+        u32 tok, olen;
+        const int t = decode_token_lut(br, L, lutl, lutd, tok, olen);
+        if (t < 0 || br.pos > end) { flag = SPAN_ERR; break; }
+        if (t == 1) { flag = SPAN_EOB; break; }
+        const u32 np = lz_pieces(tok, olen);
+        if (ntok + np <= cap) lz_emit_pieces(row + ntok, tok, olen);
+        else ovf = true;
+        ntok += np; nout += olen;
+    }
+}
+
 // position of the first lane (>= 1 bit set) in a ballot, or 64
 __device__ __forceinline__ int first_lane(u64 m) { return m ? __ffsll((long long)m) - 1 : 64; }
 
 __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
                                                   const InfFast *__restrict__ fast, const u32 *__restrict__ slot_chunk,
                                                   const u64 *__restrict__ cand_pos, const u32 *__restrict__ cand_cnt,
-                                                  CandRes *__restrict__ cres, uint2 *__restrict__ subs)
+                                                  CandRes *__restrict__ cres, uint2 *__restrict__ subs, u32 *__restrict__ rows,
+                                                  u32 *__restrict__ row_ctr, u32 rounds_cap, u32 *__restrict__ round_row)
 {
     const u32 slot = blockIdx.x;
     const u32 ci = slot_chunk[slot];
@@ -936,7 +966,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     const u64 o = cand_pos[slot];
     br.seek(o);
     CandRes r;
-    r.end_bit = 0; r.ntok = 0; r.nout = 0; r.nsub = 0; r.ok = 0; r.bfinal = 0; r.pad = 0;
+    r.end_bit = 0; r.ntok = 0; r.nout = 0; r.nsub = 0; r.ok = 0; r.bfinal = 0; r.rows = 0;
     const u32 hdr = br.get(3);
     r.bfinal = hdr & 1;
     __shared__ u32 lut_s[LUT_BYTES / 4];
@@ -970,7 +1000,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     const u64 base0 = br.pos;
     u64 base = base0;
     u32 tot_tok = 0, tot_out = 0, nsub = 0;
-    bool done = false, fail = false;
+    bool done = false, fail = false, rows_ok = true;
     // a round = 64 sub-sequences: that piece of the stream (+ slack for the reader's look-ahead and the last token's
     // overshoot) is staged in LDS; positions inside a round are relative to its first staged word
     __shared__ u32 stage[PASSA_STAGE_WORDS];
@@ -988,6 +1018,13 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
         const u32 stop = bofs + (u32)(lane + 1) * sub_bits;
         u32 start = bofs + (u32)lane * sub_bits, ex;
         u32 nt, no; int fl;
+        // the round's rows
+        u32 rb = 0;
+        if (lane == 0) rb = atomicAdd(row_ctr, 1u);
+        rb = (u32)__builtin_amdgcn_readfirstlane((int)rb);
+        const bool have_rows = rb < rounds_cap;
+        u32 *row = rows + ((u64)(have_rows ? rb : 0) * 64 + lane) * ROWCAP;
+        bool ovf = false;
         // speculative pass: exits only
         bl.seek(start);
         decode_span_fast<0>(bl, L, lutl, lutd, stop, end_rel, nt, no, fl, nullptr, 0);
@@ -1007,7 +1044,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
             if (redo) {
                 start = want_start;
                 bl.seek(start);
-                decode_span_fast<1>(bl, L, lutl, lutd, stop, end_rel, nt, no, fl, nullptr, 0);
+                decode_span_rows(bl, L, lutl, lutd, stop, end_rel, nt, no, fl, row, have_rows ? ROWCAP : 0u, ovf);
                 ex = bl.pos;
                 counted = true;
             }
@@ -1029,9 +1066,11 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
         }
         const int nvalid = fstop < 64 ? fstop + 1 : 64;
         if (nsub + nvalid > SUBCAP - 1) {
-            if (sub_bits < SUB_BITS) { sub_bits = SUB_BITS; base = base0; tot_tok = 0; tot_out = 0; nsub = 0; continue; }      // (the guess was too short)
+            if (sub_bits < SUB_BITS) { sub_bits = SUB_BITS; base = base0; tot_tok = 0; tot_out = 0; nsub = 0; rows_ok = true; continue; }      // (the guess was too short)
             fail = true; break;
         }
+        if (!have_rows || __any(valid && ovf)) rows_ok = false;
+        if (lane == 0) round_row[(u64)slot * ROUNDS_MAX + (nsub >> 6)] = rb;       // (every round before this one had 64 sub-sequences)
         if (valid) sub[nsub + lane] = make_uint2((u32)((wb0 << 5) + start - o), tot_tok + x - nt);
         const u32 rt = __shfl(x, nvalid - 1, 64), ro = __shfl(y, nvalid - 1, 64);
         tot_tok += rt; tot_out += ro;
@@ -1046,7 +1085,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     if (lane == 0) {
         if (done && !fail) {
             sub[nsub] = make_uint2(0, tot_tok);
-            r.ok = 1; r.ntok = tot_tok; r.nout = tot_out; r.nsub = nsub;
+            r.ok = 1; r.ntok = tot_tok; r.nout = tot_out; r.nsub = nsub; r.rows = rows_ok ? 1u : 0u;
         }
         cres[slot] = r;
     }
@@ -1173,6 +1212,55 @@ __global__ __launch_bounds__(64) void k_inf_chain(const u8 *__restrict__ cdata, 
 }
 
 // ================================================================================================
+// Fast path, step 4a: the accepted blocks whose tokens pass A kept -- rows to their place in the chunk's token array
+// ================================================================================================
+// Row j holds the tokens of sub-sequence j, which belong at sub[j].y of the block.  A thread takes one token of the block at a
+// time, finds the row it is in (the row starts are ascending; the threads go through the block in order, so the search
+// starts at the row of the workgroup's first token of the step before) and moves it: reads run along rows, writes are
+// consecutive.
+constexpr int MOVE_THREADS = 256;
+__global__ __launch_bounds__(MOVE_THREADS) void k_inf_move_rows(const InfChunk *__restrict__ chunks, const InfFast *__restrict__ fast,
+                                                                const u32 *__restrict__ tslot_chunk, const TrueBlk *__restrict__ tblk,
+                                                                const u32 *__restrict__ true_cnt, const CandRes *__restrict__ cres,
+                                                                const uint2 *__restrict__ subs, const u32 *__restrict__ rows,
+                                                                const u32 *__restrict__ round_row, u32 *__restrict__ tokens)
+{
+    const u32 slot = blockIdx.x;
+    const u32 ci = tslot_chunk[slot];
+    const InfFast f = fast[ci];
+    if (slot - f.true_off >= true_cnt[ci]) return;
+    const TrueBlk tb = tblk[slot];
+    if (tb.cand == 0xffffffffu || !cres[tb.cand].rows) return;
+    __shared__ u32 ys[SUBCAP + 1], rid[SUBCAP];
+    const u32 nsub = cres[tb.cand].nsub, total = tb.ntok;
+    const uint2 *sub = subs + (u64)tb.cand * SUBCAP;
+    for (u32 j = threadIdx.x; j < nsub; j += MOVE_THREADS) {
+        ys[j] = sub[j].y;
+        rid[j] = round_row[(u64)tb.cand * ROUNDS_MAX + (j >> 6)] * 64 + (j & 63);
+    }
+    if (threadIdx.x == 0) ys[nsub] = 0xffffffffu;               // (ends every search)
+    __syncthreads();
+    u32 *tk = tokens + chunks[ci].tok_off + tb.tok_off;
+    constexpr u32 U = 4;
+    u32 jw = 0;                                                 // a row at or before the one of the workgroup's first token of this step
+    for (u32 t0 = 0; t0 < total; t0 += U * MOVE_THREADS) {
+        while (ys[jw + 1] <= t0) jw++;                          // (uniform)
+        u32 v[U], j = jw;
+#pragma unroll
+        for (u32 u = 0; u < U; u++) {
+            const u32 t = min(t0 + u * MOVE_THREADS + threadIdx.x, total - 1);
+            while (ys[j + 1] <= t) j++;
+            v[u] = rows[(u64)rid[j] * ROWCAP + (t - ys[j])];
+        }
+#pragma unroll
+        for (u32 u = 0; u < U; u++) {
+            const u32 t = t0 + u * MOVE_THREADS + threadIdx.x;
+            if (t < total) tk[t] = v[u];
+        }
+    }
+}
+
+// ================================================================================================
 // Fast path, step 4: emit the tokens of every accepted block (one wave per block)
 // ================================================================================================
 #ifndef MTS_PASSB_WAVES
@@ -1184,7 +1272,7 @@ __global__ __launch_bounds__(64 * PASSB_WAVES) void k_inf_passB(const u8 *__rest
                                                   const InfFast *__restrict__ fast, const u32 *__restrict__ tslot_chunk,
                                                   const TrueBlk *__restrict__ tblk, const u32 *__restrict__ true_cnt,
                                                   const CandRes *__restrict__ cres, const uint2 *__restrict__ subs,
-                                                  u32 *__restrict__ tokens, InfResult *__restrict__ res)
+                                                  u32 *__restrict__ tokens, InfResult *__restrict__ res, int use_rows)
 {
     const u32 slot = blockIdx.x;
     const u32 ci = tslot_chunk[slot];
@@ -1221,6 +1309,8 @@ __global__ __launch_bounds__(64 * PASSB_WAVES) void k_inf_passB(const u8 *__rest
         }
         return;
     }
+    __shared__ u32 stage_s[PASSB_WAVES][PASSB_STAGE_WORDS];
+    if (use_rows && cres[tb.cand].rows) return;                 // pass A kept this block's tokens: k_inf_move_rows puts them in place
     const u32 hdr = br.get(3);
     __shared__ u32 lut_s[LUT_BYTES / 4];
     u32 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
@@ -1240,7 +1330,6 @@ __global__ __launch_bounds__(64 * PASSB_WAVES) void k_inf_passB(const u8 *__rest
     // every lane reads its own sub-sequence word by word: straight from memory that is one dependent, uncoalesced
     // load per ~3 tokens.  The 64 sub-sequences of a step are one contiguous piece of the stream (~16 KiB):
     // it is copied to LDS with coalesced loads first.
-    __shared__ u32 stage_s[PASSB_WAVES][PASSB_STAGE_WORDS];
     u32 *stage = stage_s[wave];
     for (u32 j0 = 64 * (u32)wave; j0 < nsub; j0 += 64 * PASSB_WAVES) {
         const u32 j = j0 + lane;
@@ -2214,8 +2303,9 @@ static inline u32 cand_cap_of(u64 c_len) { return (u32)(c_len / 4096 + 64); }
 // scratch layout (all 256-B aligned): [so u64 n][nn u32 n][fast n][cand_cnt n][true_cnt n][seq_flag n]
 //   [slot_chunk total_cand][tslot_chunk total_true][cand_pos][cand_tmp][cres][tblk][subs]
 struct InfLayout {
-    size_t so, nn, fast, cand_cnt, true_cnt, seq_flag, slot_chunk, tslot_chunk, cand_pos, cand_tmp, cres, tblk, subs, gb_off, gbase, tb_off, tile_base, surv, surv_cnt, plan, win, sym, end;
-    u32 total_cand, total_true, surv_cap;
+    size_t so, nn, fast, cand_cnt, true_cnt, seq_flag, slot_chunk, tslot_chunk, cand_pos, cand_tmp, cres, tblk, subs, gb_off, gbase, tb_off, tile_base, surv, surv_cnt, plan, win, sym, rows,
+        round_row, row_ctr, end;
+    u32 total_cand, total_true, surv_cap, rounds_cap;
     int nseg;                // segments the resolver cuts every chunk into (1: none)
 };
 static InfLayout inf_layout(int n_chunks, const u64 *c_lens, const u32 *n_expect)
@@ -2252,7 +2342,17 @@ static InfLayout inf_layout(int n_chunks, const u64 *c_lens, const u32 *n_expect
     l.win = take(l.nseg > 1 ? (size_t)n_chunks * LZ_MAXSEG * LZ_WIN : 0);
     size_t cells = 0;
     for (int i = 0; i < n_chunks; i++) cells += align_up((u64)n_expect[i] + STREAM_PAD, STREAM_ALIGN);
-    l.sym = take(l.nseg > 1 ? 2 * cells + 4096 : 0);
+    // pass A's token rows are dead once pass B has run, the resolver's cells are written after that: one region for both
+    u64 rounds = 0;
+    for (int i = 0; i < n_chunks; i++) rounds += rows_rounds_of(c_lens[i]);
+    if (const char *e = getenv("MTS_INF_ROW_ROUNDS")) rounds = (u64)atoll(e);      // (tests: a pool that runs out)
+    if (rounds > 0x3ffffffull) rounds = 0x3ffffffull;                               // (row ids are 32 bits)
+    l.rounds_cap = (u32)rounds;
+    const size_t row_bytes = (size_t)rounds * 64 * ROWCAP * 4 + 256, sym_bytes = l.nseg > 1 ? 2 * cells + 4096 : 0;
+    l.sym = take(row_bytes > sym_bytes ? row_bytes : sym_bytes);
+    l.rows = l.sym;
+    l.round_row = take(4 * (size_t)ROUNDS_MAX * l.total_cand);
+    l.row_ctr = take(256);
     l.end = o;
     return l;
 }
@@ -2325,14 +2425,20 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
                            d_surv_cnt, l.surv_cap, d_cand_pos, d_cand_cnt);
         hipLaunchKernelGGL(k_inf_sortc, dim3(n_chunks), dim3(256), 0, st, d_fast, d_cand_pos, d_cand_tmp, d_cand_cnt);
         inflate_mark(engine, st, "inflate_scan");
+        const int use_rows = getenv("MTS_INF_NO_ROWS") ? 0 : 1;      // (A/B: pass B decodes every block again)
+        MTS_HIP(hipMemsetAsync(S + l.row_ctr, 0, 4, st));
         hipLaunchKernelGGL(k_inf_passA, dim3(l.total_cand), dim3(64), 0, st, d_cdata, d_chunks, d_fast, (const u32 *)(S + l.slot_chunk),
-                           d_cand_pos, d_cand_cnt, d_cres, d_subs);
+                           d_cand_pos, d_cand_cnt, d_cres, d_subs, (u32 *)(S + l.rows), (u32 *)(S + l.row_ctr), use_rows ? l.rounds_cap : 0u,
+                           (u32 *)(S + l.round_row));
         inflate_mark(engine, st, "inflate_passA");
         hipLaunchKernelGGL(k_inf_chain, dim3(n_chunks), dim3(64), 0, st, d_cdata, d_chunks, d_fast, d_cand_pos, d_cand_cnt, d_cres,
                            d_tblk, d_true_cnt, d_res, d_seq);
         inflate_mark(engine, st, "inflate_chain");
         hipLaunchKernelGGL(k_inf_passB, dim3(l.total_true), dim3(64 * PASSB_WAVES), 0, st, d_cdata, d_chunks, d_fast, (const u32 *)(S + l.tslot_chunk),
-                           d_tblk, d_true_cnt, d_cres, d_subs, d_tokens, d_res);
+                           d_tblk, d_true_cnt, d_cres, d_subs, d_tokens, d_res, use_rows);
+        if (use_rows)
+            hipLaunchKernelGGL(k_inf_move_rows, dim3(l.total_true), dim3(MOVE_THREADS), 0, st, d_chunks, d_fast, (const u32 *)(S + l.tslot_chunk), d_tblk,
+                               d_true_cnt, d_cres, d_subs, (const u32 *)(S + l.rows), (const u32 *)(S + l.round_row), d_tokens);
         inflate_mark(engine, st, "inflate_passB");
     }
     hipLaunchKernelGGL(k_inf_wave, dim3(n_chunks), dim3(WV_NT), 0, st, d_cdata, d_chunks, n_chunks, d_tokens, d_res, fast_path ? d_seq : nullptr);

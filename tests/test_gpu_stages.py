@@ -362,6 +362,30 @@ def test_lz_resolver_retry_pass(monkeypatch, segs):
     assert st != 0
 
 
+@pytest.mark.parametrize('env', [{}, {'MTS_INF_NO_ROWS': '1'}, {'MTS_INF_ROW_ROUNDS': '3'}, {'MTS_INF_ROW_ROUNDS': '0'}])
+def test_inflate_token_rows(monkeypatch, env):
+    """Pass A keeps the tokens of its counting decode in rows (192 per sub-sequence, from a pool); pass B only decodes
+    the blocks whose tokens did not fit.  Same bytes with the rows (default), without them, with a pool that runs out
+    after three rounds and with no pool at all; the inputs include rows that overflow (runs: 33 pieces per 258-byte
+    copy), blocks of every size, and streams of other encoders' block structure."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    big = inputs.repeats(700000, 11) + inputs.textlike(300000, 12) + inputs.farcopies(400000, 13) + bytes(300000) + inputs.skewlen(200000, 5)
+    for data in (CASES['repeats_200k'], CASES['text_100k'], CASES['zeros_999468'], big, inputs.ar1_stream(6000, 64)):
+        for level in (1, 6, 9):
+            st, out = hip.debug_inflate(zlib.compress(data, level), len(data))
+            assert st == 0 and out == data, (len(data), level, st, _first_diff(np.frombuffer(out, np.uint8), np.frombuffer(data, np.uint8)))
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 8)
+    data = inputs.ar1_stream(4000, 64)
+    z = b''.join(co.compress(data[i:i + 70000]) + co.flush(zlib.Z_FULL_FLUSH) for i in range(0, len(data), 70000)) + co.flush()
+    st, out = hip.debug_inflate(z, len(data))
+    assert st == 0 and out == data
+    bad = bytearray(zlib.compress(inputs.ar1_stream(3000, 64), 6))
+    bad[len(bad) // 2] ^= 0x10
+    st, _ = hip.debug_inflate(bytes(bad), 3000 * 64 * 2)
+    assert st != 0
+
+
 def _timed_inflate(z, n):
     hip.debug_inflate(z[:64] if len(z) > 64 else z, 1)          # (workspaces and code objects warm)
     t0 = time.perf_counter()
