@@ -166,7 +166,11 @@ struct LaneLds {
     __device__ __forceinline__ u16 &ds(int k) { return dsym[k * stride + lane]; }
 };
 
-constexpr int CHAIN_LUT_LBITS = 10, CHAIN_LUT_DBITS = 8;        // index bits of the lookup tables (= LUT_LBITS, LUT_DBITS below)
+#ifndef MTS_LUT_LBITS
+#define MTS_LUT_LBITS 8
+#endif
+constexpr int CHAIN_LUT_LBITS = MTS_LUT_LBITS, CHAIN_LUT_DBITS = 8;      // (lit/len index bits, pass A on the recordings: 11: 4.50 ms, 10: 3.80, 9: 3.46, 8: 3.22, 7: 3.45 --
+                                                                          //  the table's LDS sets how many waves a CU holds; longer codes walk the chain's tail)        // index bits of the lookup tables (= LUT_LBITS, LUT_DBITS below)
 // Build the compare chain + sorted symbol table for lens[first .. first+nsym).
 // returns 0 complete, 1 incomplete, -1 over-subscribed; maxlen = longest code
 template <int MAXL, bool DIST, class CHAIN>
