@@ -1007,6 +1007,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     bool done = false, fail = false, rows_ok = true;
     // a round = 64 sub-sequences: that piece of the stream (+ slack for the reader's look-ahead and the last token's
     // overshoot) is staged in LDS; positions inside a round are relative to its first staged word
+    // (reading the stream straight from memory instead -- no LDS copy, 20 waves per CU -- was measured at 6.55 ms against 3.22)
     __shared__ u32 stage[PASSA_STAGE_WORDS];
     BitL bl;
     bl.w = stage;
@@ -2011,7 +2012,8 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                                                            InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
                                                            const u64 *__restrict__ tb_off, const u32 *__restrict__ gbase,
                                                            const u32 *__restrict__ tile_base, const LzPlan *__restrict__ plan,
-                                                           u16 *__restrict__ sym, int n_workers, int pass)
+                                                           u16 *__restrict__ sym, int n_workers, int pass, u8 *__restrict__ stream,
+                                                           u8 *__restrict__ gflag, u64 *__restrict__ seg_adler)
 {
     const int ci = blockIdx.y, seg = blockIdx.x;
     const InfResult r = res[ci];
@@ -2073,8 +2075,15 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
     };
     if (wave >= LZ_WORKERS) {
         // ---- flushers: granule q belongs to flusher q % LZ_FLUSHERS; 8 cells (16 bytes) per lane and step ----
+        // A granule that lies inside the segment and holds no symbolic cell (two thirds of them on the recordings: what
+        // derives from the unknown window thins out quickly) leaves as BYTES, straight into the stream, with its part of
+        // the adler32 sums taken here; k_inf_translate only goes through the granules flagged in gflag.
         const u32 me = wave - LZ_WORKERS;
         u32 idle = 0;
+        u8 *bytes_out = stream + ch.stream_off;
+        u8 *gf = gflag + (ch.stream_off >> 12) + ci;
+        const u64 nn = ch.n_expect;
+        u64 sa = 0, sb = 0;
         for (u32 q = q0 + ((me - q0) & (LZ_FLUSHERS - 1));; q += LZ_FLUSHERS) {
             const u32 lo = q * LZ_FLUSH;
             if (lo >= Bend) break;
@@ -2084,12 +2093,40 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                 __builtin_amdgcn_s_sleep(2);
             }
             idle = 0;
-            for (u32 o = lo + lane * 8; o < lo + LZ_FLUSH; o += 512) {
-                if (o < hi && o + 8 > B) {
-                    u32x4 c;
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(c) : "v"(lds_data + 2 * (o & (LZ_RING - 1))) : "memory");
-                    if (o >= B && o + 8 <= hi) *(u32x4 *)(out + o) = c;
-                    else { const u32 cw[4] = {c.x, c.y, c.z, c.w}; for (u32 k = 0; k < 8; k++) if (o + k >= B && o + k < hi) out[o + k] = (u16)(cw[k >> 1] >> (16 * (k & 1))); }
+            const bool whole = lo >= B && hi == lo + LZ_FLUSH;
+            u32x4 c[LZ_FLUSH / 512];
+            u32 high = 0;
+#pragma unroll
+            for (u32 st = 0; st < LZ_FLUSH / 512; st++) {
+                const u32 o = lo + st * 512 + lane * 8;
+                c[st] = u32x4{0, 0, 0, 0};
+                if (o < hi && o + 8 > B) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(c[st]) : "v"(lds_data + 2 * (o & (LZ_RING - 1))) : "memory");
+                high |= c[st].x | c[st].y | c[st].z | c[st].w;
+            }
+            if (whole && !__any((high & 0xff00ff00u) != 0)) {
+#pragma unroll
+                for (u32 st = 0; st < LZ_FLUSH / 512; st++) {
+                    const u32 o = lo + st * 512 + lane * 8;
+                    const u32 cw[4] = {c[st].x, c[st].y, c[st].z, c[st].w};
+                    u32 d[2] = {0, 0}, s1 = 0, s2 = 0;
+#pragma unroll
+                    for (u32 k = 0; k < 8; k++) {
+                        const u32 v = (cw[k >> 1] >> (16 * (k & 1))) & 0xff;
+                        d[k >> 2] |= v << (8 * (k & 3));
+                        s1 += v; s2 += k * v;
+                    }
+                    *(uint2 *)(bytes_out + o) = make_uint2(d[0], d[1]);
+                    sa += s1; sb += (nn - o) * (u64)s1 - s2;
+                }
+            } else {
+                if (lane == 0) gf[q] = 1;
+#pragma unroll
+                for (u32 st = 0; st < LZ_FLUSH / 512; st++) {
+                    const u32 o = lo + st * 512 + lane * 8;
+                    if (o < hi && o + 8 > B) {
+                        if (o >= B && o + 8 <= hi) *(u32x4 *)(out + o) = c[st];
+                        else { const u32 cw[4] = {c[st].x, c[st].y, c[st].z, c[st].w}; for (u32 k = 0; k < 8; k++) if (o + k >= B && o + k < hi) out[o + k] = (u16)(cw[k >> 1] >> (16 * (k & 1))); }
+                    }
                 }
             }
             if (q >= LZ_ZLAG) {
@@ -2100,7 +2137,17 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
             }
             if (lane == 0) lds_st(lds_flnext + 4 * me, lo + LZ_FLUSHERS * LZ_FLUSH);
         }
-        if (lane == 0) lds_st(lds_flnext + 4 * me, 0xffffffffu);
+        // this flusher's share of the byte sums of the granules it wrote as bytes: a slot of its own, plainly stored, so that a
+        // second run of the segment (the retry pass runs every segment of its chunks again) replaces it
+        for (int d = 32; d; d >>= 1) {
+            sa += ((u64)(u32)__shfl_xor((u32)(sa >> 32), d) << 32) | (u32)__shfl_xor((u32)sa, d);
+            sb += ((u64)(u32)__shfl_xor((u32)(sb >> 32), d) << 32) | (u32)__shfl_xor((u32)sb, d);
+        }
+        if (lane == 0) {
+            u64 *slot = seg_adler + (((size_t)ci * LZ_MAXSEG + seg) * LZ_FLUSHERS + me) * 2;
+            slot[0] = sa % 65521u; slot[1] = sb % 65521u;
+            lds_st(lds_flnext + 4 * me, 0xffffffffu);
+        }
         return;
     }
     // ---- workers ----
@@ -2185,7 +2232,8 @@ __global__ __launch_bounds__(64) void k_inf_lz_settle(InfResult *__restrict__ re
 }
 
 __global__ __launch_bounds__(1024) void k_inf_windows(const InfChunk *__restrict__ chunks, const InfResult *__restrict__ res,
-                                                      const LzPlan *__restrict__ plan, const u16 *__restrict__ sym, u8 *__restrict__ win)
+                                                      const LzPlan *__restrict__ plan, const u16 *__restrict__ sym, u8 *__restrict__ win,
+                                                      const u8 *__restrict__ stream, const u8 *__restrict__ gflag)
 {
     const int ci = blockIdx.x;
     if (res[ci].status != MTS_CHUNK_OK) return;
@@ -2193,12 +2241,14 @@ __global__ __launch_bounds__(1024) void k_inf_windows(const InfChunk *__restrict
     const u32 nseg = pl->nseg;
     if (nseg < 2) return;
     const u16 *cells = sym + chunks[ci].stream_off;
+    const u8 *bytes = stream + chunks[ci].stream_off;                 // (granules without a flag left the resolver as bytes)
+    const u8 *gf = gflag + (chunks[ci].stream_off >> 12) + ci;
     u8 *W = win + (size_t)ci * LZ_MAXSEG * LZ_WIN;                  // W[k] = window of segment k
     for (u32 k = 1; k < nseg; k++) {
         const u32 p0 = pl->b0[k] - LZ_WIN;                           // >= b0[k - 1]: segments are at least a window long
         const u8 *prev = W + (size_t)(k - 1) * LZ_WIN;
         for (u32 i = threadIdx.x; i < LZ_WIN; i += 1024) {
-            const u32 c = cells[p0 + i];
+            const u32 c = gf[(p0 + i) / LZ_FLUSH] ? cells[p0 + i] : bytes[p0 + i];
             W[(size_t)k * LZ_WIN + i] = (u8)(c < 256 ? c : prev[(c - 256) & (LZ_WIN - 1)]);
         }
         __threadfence();
@@ -2211,7 +2261,8 @@ __global__ __launch_bounds__(1024) void k_inf_windows(const InfChunk *__restrict
 // registers: the separate pass over the finished stream is skipped for the chunks that come through here)
 __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restrict__ chunks, const InfResult *__restrict__ res,
                                                        const LzPlan *__restrict__ plan, const u16 *__restrict__ sym,
-                                                       const u8 *__restrict__ win, u8 *__restrict__ stream, u64 *__restrict__ adler_acc)
+                                                       const u8 *__restrict__ win, u8 *__restrict__ stream, u64 *__restrict__ adler_acc,
+                                                       const u8 *__restrict__ gflag)
 {
     const int ci = blockIdx.y;
     const InfResult r = res[ci];
@@ -2246,18 +2297,23 @@ __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restric
         while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (q >= pl->b0[mid]) lo = mid; else hi = mid - 1; }
         return lo;
     };
+    // a step is one granule of the resolver's flushers (256 threads x 16 cells = LZ_FLUSH): only the flagged ones are cells
+    static_assert(256 * 16 == LZ_FLUSH, "a translation step is a flush granule");
+    const u8 *gf = gflag + (chunks[ci].stream_off >> 12) + ci;
+    bool todo[TR_STEPS];
     // the cells of all steps are asked for together (the kernel waited for one pair of loads per step: 76 % of its wave cycles)
     uint4 ca[TR_STEPS], cb[TR_STEPS];
 #pragma unroll
     for (u32 step = 0; step < TR_STEPS; step++) {
         const u32 p = ((blockIdx.x * TR_STEPS + step) * 256 + threadIdx.x) * 16;
-        if (p + 16 <= r.n_out) { ca[step] = *(const uint4 *)(cells + p); cb[step] = *(const uint4 *)(cells + p + 8); }
+        todo[step] = (blockIdx.x * TR_STEPS + step) * (u32)LZ_FLUSH < r.n_out && gf[blockIdx.x * TR_STEPS + step] != 0;
+        if (todo[step] && p + 16 <= r.n_out) { ca[step] = *(const uint4 *)(cells + p); cb[step] = *(const uint4 *)(cells + p + 8); }
         else { ca[step] = make_uint4(0, 0, 0, 0); cb[step] = ca[step]; }
     }
 #pragma unroll
     for (u32 step = 0; step < TR_STEPS; step++) {
     const u32 p = ((blockIdx.x * TR_STEPS + step) * 256 + threadIdx.x) * 16;
-    if (p >= r.n_out) {
+    if (!todo[step] || p >= r.n_out) {
     } else if (p + 16 <= r.n_out) {
         const uint4 a = ca[step], b = cb[step];
         const u32 cw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -2286,13 +2342,16 @@ __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restric
 }
 
 __global__ __launch_bounds__(64) void k_inf_finish(const InfChunk *__restrict__ chunks, InfResult *__restrict__ res,
-                                                   const u64 *__restrict__ adler_acc, int n_chunks, int *__restrict__ status_out)
+                                                   const u64 *__restrict__ adler_acc, int n_chunks, int *__restrict__ status_out,
+                                                   const u64 *__restrict__ seg_adler)
 {
     const int ci = blockIdx.x * 64 + threadIdx.x;
     if (ci >= n_chunks) return;
     InfResult r = res[ci];
     if (r.status == MTS_CHUNK_OK && chunks[ci].n_need == 0) {                 // (a partial decode never reaches the check value)
-        const u32 a = (u32)((1 + adler_acc[2 * ci]) % 65521u), b = (u32)((chunks[ci].n_expect + adler_acc[2 * ci + 1]) % 65521u);
+        u64 fa = 0, fb = 0;                                                   // what the resolver's flushers wrote as bytes (zero for chunks that were not cut)
+        if (seg_adler) for (int k = 0; k < LZ_MAXSEG * LZ_FLUSHERS; k++) { fa += seg_adler[((size_t)ci * LZ_MAXSEG * LZ_FLUSHERS + k) * 2]; fb += seg_adler[((size_t)ci * LZ_MAXSEG * LZ_FLUSHERS + k) * 2 + 1]; }
+        const u32 a = (u32)((1 + adler_acc[2 * ci] + fa) % 65521u), b = (u32)((chunks[ci].n_expect + adler_acc[2 * ci + 1] + fb) % 65521u);
         if (((b << 16) | a) != r.adler_stored) r.status = MTS_CHUNK_CORRUPT;
     }
     res[ci].status = r.status;
@@ -2308,7 +2367,7 @@ static inline u32 cand_cap_of(u64 c_len) { return (u32)(c_len / 4096 + 64); }
 //   [slot_chunk total_cand][tslot_chunk total_true][cand_pos][cand_tmp][cres][tblk][subs]
 struct InfLayout {
     size_t so, nn, fast, cand_cnt, true_cnt, seq_flag, slot_chunk, tslot_chunk, cand_pos, cand_tmp, cres, tblk, subs, gb_off, gbase, tb_off, tile_base, surv, surv_cnt, plan, win, sym, rows,
-        round_row, row_ctr, end;
+        round_row, row_ctr, gflag, seg_adler, end;
     u32 total_cand, total_true, surv_cap, rounds_cap;
     int nseg;                // segments the resolver cuts every chunk into (1: none)
 };
@@ -2357,6 +2416,8 @@ static InfLayout inf_layout(int n_chunks, const u64 *c_lens, const u32 *n_expect
     l.rows = l.sym;
     l.round_row = take(4 * (size_t)ROUNDS_MAX * l.total_cand);
     l.row_ctr = take(256);
+    l.gflag = take(l.nseg > 1 ? cells / LZ_FLUSH + (size_t)n_chunks + 64 : 0);
+    l.seg_adler = take(l.nseg > 1 ? (size_t)n_chunks * LZ_MAXSEG * LZ_FLUSHERS * 16 : 0);
     l.end = o;
     return l;
 }
@@ -2468,18 +2529,21 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
                        (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base), d_stream, 1,
                        nullptr, (const LzPlan *)(S + l.plan), 1);                                  // (retry pass: returns at once unless a wait expired)
     if (l.nseg > 1 && max_n > 0) {
+        MTS_HIP(hipMemsetAsync(S + l.gflag, 0, l.seg_adler - l.gflag, st));
+        MTS_HIP(hipMemsetAsync(S + l.seg_adler, 0, (size_t)n_chunks * LZ_MAXSEG * LZ_FLUSHERS * 16, st));
         for (int pass = 0; pass < 2; pass++)
             hipLaunchKernelGGL(k_inf_lz_seg, dim3(l.nseg, n_chunks), dim3(LZ_THREADS), LZ2_LDS, st, d_tokens, d_chunks, d_res,
                                (const u64 *)(S + l.gb_off), (const u64 *)(S + l.tb_off), (const u32 *)(S + l.gbase), (const u32 *)(S + l.tile_base),
-                               (const LzPlan *)(S + l.plan), (u16 *)(S + l.sym), pass ? 1 : lz_workers, pass ? 1 : first_pass);
+                               (const LzPlan *)(S + l.plan), (u16 *)(S + l.sym), pass ? 1 : lz_workers, pass ? 1 : first_pass, d_stream,
+                               (u8 *)(S + l.gflag), (u64 *)(S + l.seg_adler));
     }
     hipLaunchKernelGGL(k_inf_lz_settle, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_res, n_chunks);
     MTS_HIP(hipMemsetAsync(d_adler_acc, 0, sizeof(u64) * 2 * n_chunks, st));      // (the translation of segmented chunks adds their byte sums)
     if (l.nseg > 1 && max_n > 0) {
         hipLaunchKernelGGL(k_inf_windows, dim3(n_chunks), dim3(1024), 0, st, d_chunks, d_res, (const LzPlan *)(S + l.plan),
-                           (const u16 *)(S + l.sym), (u8 *)(S + l.win));
+                           (const u16 *)(S + l.sym), (u8 *)(S + l.win), d_stream, (const u8 *)(S + l.gflag));
         hipLaunchKernelGGL(k_inf_translate, dim3((max_n + 16383) / 16384, n_chunks), dim3(256), 0, st, d_chunks, d_res,
-                           (const LzPlan *)(S + l.plan), (const u16 *)(S + l.sym), (const u8 *)(S + l.win), d_stream, d_adler_acc);
+                           (const LzPlan *)(S + l.plan), (const u16 *)(S + l.sym), (const u8 *)(S + l.win), d_stream, d_adler_acc, (const u8 *)(S + l.gflag));
     }
     MTS_HIP(hipGetLastError());
     if (d_prof) {
@@ -2498,7 +2562,7 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
                                  (const u32 *)(S + l.plan), (u32)(sizeof(LzPlan) / 4));
     if (rc) return rc;
     hipLaunchKernelGGL(k_inf_finish, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_chunks, d_res, d_adler_acc, n_chunks,
-                       d_status_out);
+                       d_status_out, l.nseg > 1 && max_n > 0 ? (const u64 *)(S + l.seg_adler) : nullptr);
     MTS_HIP(hipGetLastError());
     inflate_mark(engine, st, "adler32");
     return MTS_OK;
