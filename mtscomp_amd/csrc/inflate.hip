@@ -2292,9 +2292,13 @@ __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restric
     const u16 *cells = sym + chunks[ci].stream_off;
     u8 *out = stream + chunks[ci].stream_off;
     const u8 *W = win + (size_t)ci * LZ_MAXSEG * LZ_WIN;
+    // (the segment starts come to LDS once: looked up in memory, every step of the searches below was a round trip)
+    __shared__ u32 b0s[LZ_MAXSEG + 1];
+    if (threadIdx.x <= nseg) b0s[threadIdx.x] = pl->b0[threadIdx.x];
+    __syncthreads();
     auto seg_of = [&](u32 q) -> u32 {                               // last k with b0[k] <= q
         u32 lo = 0, hi = nseg - 1;
-        while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (q >= pl->b0[mid]) lo = mid; else hi = mid - 1; }
+        while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (q >= b0s[mid]) lo = mid; else hi = mid - 1; }
         return lo;
     };
     // a step is one granule of the resolver's flushers (256 threads x 16 cells = LZ_FLUSH): only the flagged ones are cells
@@ -2309,6 +2313,12 @@ __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restric
         todo[step] = (blockIdx.x * TR_STEPS + step) * (u32)LZ_FLUSH < r.n_out && gf[blockIdx.x * TR_STEPS + step] != 0;
         if (todo[step] && p + 16 <= r.n_out) { ca[step] = *(const uint4 *)(cells + p); cb[step] = *(const uint4 *)(cells + p + 8); }
         else { ca[step] = make_uint4(0, 0, 0, 0); cb[step] = ca[step]; }
+    }
+    {
+        bool any = false;
+#pragma unroll
+        for (u32 step = 0; step < TR_STEPS; step++) any |= todo[step];
+        if (!any) return;                                               // (the same for every thread of the workgroup)
     }
 #pragma unroll
     for (u32 step = 0; step < TR_STEPS; step++) {
