@@ -2486,13 +2486,16 @@ __device__ __forceinline__ u64 token_code(u32 t, const u32 *lc_tab, const u32 *d
 }
 
 // One workgroup per block.  The bits of the block are assembled in LDS and leave as whole words, coalesced:
-// a wave owns 4096 consecutive tokens and takes them 64 at a time (one coalesced load), a wave scan of
+// a wave owns 2048 consecutive tokens and takes them 64 at a time (one coalesced load), a wave scan of
 // the code lengths gives every token its bit position, and the code is OR-ed into the (zeroed) LDS image.
 // Only the first and the last word of the image can be shared with the neighbouring blocks: those two are
 // OR-ed into the (zeroed) output, the rest is stored.  A block too large for the image (it holds 16 bits
 // per token; zlib needs 9-10 on this kind of data) ORs the overhang straight into the output.
-constexpr int PACK_THREADS = 256;
-constexpr int PACK_WTOK = 4096;                 // token indices per wave (4 x 4096 >= 16383 tokens + end-of-block)
+#ifndef MTS_PACK_THREADS
+#define MTS_PACK_THREADS 512
+#endif
+constexpr int PACK_THREADS = MTS_PACK_THREADS;              // 256: 1.19 ms, 512: 1.01, 1024: 1.60 (the image's LDS lets four workgroups share a CU)
+constexpr int PACK_WTOK = 16384 / (PACK_THREADS / 64);      // token indices per wave (together >= 16383 tokens + end-of-block)
 constexpr int PACK_IMG_WORDS = 8192;
 
 __global__ __launch_bounds__(PACK_THREADS) void k_block_pack(const u8 *__restrict__ stream, const ChunkDesc *__restrict__ chunks,
@@ -2614,11 +2617,9 @@ __global__ __launch_bounds__(PACK_THREADS) void k_block_pack(const u8 *__restric
             const u32 i = i0 + 64 * a + lane;
             u32 nb = 0;
             const u64 v = i < i_end ? code_of(i, t[a], nb) : 0ull;
-            u32 x = nb;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+            const u32 x = wave_incl_scan_dpp(nb);                // (six shuffles through the LDS crossbar were the step's longest chain)
             or_bits(pos + x - nb, v, nb);
-            pos += __shfl(x, 63, 64);
+            pos += (u32)__builtin_amdgcn_readlane((int)x, 63);
         }
     }
     __syncthreads();
