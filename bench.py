@@ -488,6 +488,11 @@ def main(argv=None):
         sys.stderr.write('bench.py: rank %d has no device (%d visible)\n' % (local_rank, have))
         sys.exit(2)
     dev = local_rank % max(have, 1)
+    if args.oversubscribe and world > have and args.dist_backend == 'nccl':
+        # RCCL refuses two ranks on one device ("Duplicate GPU detected"); the shared-device smoke test runs over gloo
+        if rank == 0:
+            sys.stderr.write('bench.py: %d ranks share %d device(s): process group over gloo instead of nccl\n' % (world, have))
+        args.dist_backend = 'gloo'
     gloo = args.dist_backend == 'gloo'
     xdev = 'cpu' if gloo else 'cuda'                     # where the few numbers that cross ranks live
     if world > 1:
