@@ -537,6 +537,7 @@ __device__ __forceinline__ u32 wave_excl_scan(u32 v, u32 &total)
     return x - v;
 }
 
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 x);
 constexpr int SCAN_THREADS = 1024;
 constexpr int SCAN_SPAN_BITS = SCAN_THREADS * 32;
 constexpr int SCAN_SURV_CAP = 512;
@@ -682,6 +683,11 @@ constexpr u32 ROWCAP = MTS_INF_ROWCAP;
 constexpr int ROUNDS_MAX = (SUBCAP + 63) / 64;          // rounds of a block (all but the last have 64 sub-sequences)
 static inline u64 rows_rounds_of(u64 c_len) { return c_len * 8 / (64 * 640) + 32; }      // pool share of a chunk, in rounds
 
+#ifndef MTS_SCAN_SPANS
+#define MTS_SCAN_SPANS 1
+#endif
+constexpr int SCAN_SPANS = MTS_SCAN_SPANS;   // spans per workgroup (2, 4, 8: the stage takes 4.2 ms instead of 3.25 -- the Kraft table made once per
+                                             // workgroup does not pay for the fewer, longer workgroups)
 constexpr int SCAN_L1_CAP = 14336;       // filter-1 survivors kept per workgroup (expected ~7200 of 32768)
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
@@ -695,8 +701,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
     const u64 a = (u64)(cdata + ch.c_off);
     const u32 *w = (const u32 *)(a & ~(u64)3);
     const u64 bit0 = (a & 3) * 8, end = bit0 + 8 * ch.c_len, nwords = (end + 31) >> 5;
-    const u64 span0 = (u64)blockIdx.x * SCAN_SPAN_BITS;        // absolute bit of this workgroup's span
-    if (span0 >= end) return;
+    if ((u64)blockIdx.x * SCAN_SPANS * SCAN_SPAN_BITS >= end) return;
     __shared__ u32 sw[SCAN_THREADS + SCAN_TAIL];
     __shared__ u16 l1[SCAN_L1_CAP];
     __shared__ u32 surv[SCAN_SURV_CAP];
@@ -709,7 +714,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
         for (int f = 0; f < 4; f++) k += (0x80u >> ((i >> (3 * f)) & 7)) & 0x7f;
         ktab[i] = (u16)k;
     }
+    __shared__ u32 gbase_s;
+    // a workgroup takes SCAN_SPANS consecutive spans (the Kraft table above is made once for them)
+    for (int sp = 0; sp < SCAN_SPANS; sp++) {
+    const u64 span0 = ((u64)blockIdx.x * SCAN_SPANS + sp) * SCAN_SPAN_BITS;        // absolute bit of the span
+    if (span0 >= end) break;
     const u64 word0 = span0 >> 5;
+    __syncthreads();                                             // (everybody is done with the span before)
     for (int i = tid; i < SCAN_THREADS + SCAN_TAIL; i += SCAN_THREADS) sw[i] = word0 + i < nwords ? w[word0 + i] : 0;
     if (tid == 0) nsurv = 0;
     __syncthreads();
@@ -734,9 +745,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
     }
     // compact the survivors of the workgroup
     const u32 cntm = __popc(m);
-    u32 tot;
-    u32 ex = wave_excl_scan(cntm, tot);
-    if (lane == 63) wsum[wave] = tot;
+    const u32 incl = wave_incl_scan_dpp(cntm), ex = incl - cntm;
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     u32 base = 0, n1 = 0;
     for (int q = 0; q < 16; q++) { if (q < wave) base += wsum[q]; n1 += wsum[q]; }
@@ -776,17 +786,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
     // the survivors go to a global list; their full validation is a separate, fully occupied launch
     // (it is a long serial decode per survivor: latency bound, so it wants many waves in flight)
     const u32 ns = min(nsurv, (u32)SCAN_SURV_CAP);
-    __shared__ u32 gbase_s;
     if (tid == 0) gbase_s = ns ? atomicAdd(surv_cnt, ns) : 0;
     __syncthreads();
     if ((u32)tid < ns && gbase_s + tid < surv_cap) surv_list[gbase_s + tid] = ((u64)ci << 40) | (span0 + surv[tid]);
+    }
     (void)fast; (void)cand_pos; (void)cand_cnt;
 }
 
 constexpr int VAL_STAGE = 16;            // words of a candidate header staged in LDS
 constexpr int VAL_STEPS = 8;             // code-length symbols between two looks at the idle lanes
 constexpr u32 VAL_REFILL = 16;           // idle lanes that make a refill worth its setup (global loads + the code-length code)
-__global__ __launch_bounds__(256) void k_inf_validate(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
+#ifndef MTS_VAL_WAVES
+#define MTS_VAL_WAVES 4    // (5, 6, 8 waves per SIMD by spilling registers: 3.41, 3.91, 5.02 ms for the stage against 3.24)
+#endif
+__global__ __launch_bounds__(256, MTS_VAL_WAVES) void k_inf_validate(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
                                                       const InfFast *__restrict__ fast, const u64 *__restrict__ surv_list,
                                                       const u32 *__restrict__ surv_cnt, u32 surv_cap,
                                                       u64 *__restrict__ cand_pos, u32 *__restrict__ cand_cnt)
@@ -2490,7 +2503,7 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
     if (const char *e = getenv("MTS_LZ_WORKERS")) { lz_workers = atoi(e); if (lz_workers < 1) lz_workers = 1; if (lz_workers > LZ_WORKERS) lz_workers = LZ_WORKERS; }
     if (fast_path) {
         const u64 max_bits = 8 * max_clen + 32;
-        dim3 gscan((unsigned)((max_bits + SCAN_SPAN_BITS - 1) / SCAN_SPAN_BITS), n_chunks);
+        dim3 gscan((unsigned)((max_bits + (u64)SCAN_SPANS * SCAN_SPAN_BITS - 1) / ((u64)SCAN_SPANS * SCAN_SPAN_BITS)), n_chunks);
         u64 *d_surv = (u64 *)(S + l.surv);
         u32 *d_surv_cnt = (u32 *)(S + l.surv_cnt);
         MTS_HIP(hipMemsetAsync(d_surv_cnt, 0, 4, st));
