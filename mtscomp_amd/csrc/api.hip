@@ -241,7 +241,9 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     int rc;
     if (!raw_is_stream) { if ((rc = E.stream.ensure(stream_bytes))) return rc; }
     const size_t sort_n = align_up(sorted_off + 64, 64);          // 32-bit keys
-    if ((rc = E.sort_a.ensure(sort_n * 4))) return rc;
+    // (the first pass's keys are dead once the sort is done: the parse keeps its marks there)
+    const size_t marks_words = parse_marks_words((size_t)nseg + 64);
+    if ((rc = E.sort_a.ensure((sort_n > marks_words ? sort_n : marks_words) * 4))) return rc;
     if ((rc = E.sort_b.ensure(sort_n * 4))) return rc;
     // one word per position (levels 1..3: the inverse map) + for levels 4..9 the side table of the quarter-budget results, which is
     // written and read at a fraction of a percent of the positions only
@@ -270,6 +272,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     pb.seg_chunk = sg + 5 * SN; pb.seg_start = sg + 6 * SN;
     pb.cp = sg + 7 * SN;
     pb.changed = (int *)(E.adler.as<u8>() + sizeof(u64) * 2 * n_chunks);
+    pb.marks = E.sort_a.as<u32>();
     // block arrays
     BlockRec *d_blocks = E.blk.as<BlockRec>();
     u32 *d_blk_chunk = (u32 *)(d_blocks + nblk + 1);
@@ -330,6 +333,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     int force_ballot = getenv("MTS_SORT_INJECT_DISORDER") ? 2 : 0;      // (test hook: the first sort of the call is deliberately mis-ranked)
     const bool fast = level < 4;                              // deflate_fast: no candidate tables, the walk itself searches (deflate.hip, section F)
     u32 *d_inv = (u32 *)d_tables;                             // levels 1..3: the inverse map lives where the other levels keep the candidate tables
+    int fix_rounds = 0;                                       // parallel fix rounds of the parse that counted (they say where the exits are)
     for (;;) {
         if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, force_ballot))) return rc;
         E.t_mark(st, force_ballot == 1 ? "hash_sort_retry" : "hash_sort");
@@ -394,6 +398,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
             }
         }
         }
+        fix_rounds = round;
         if (!resort) break;
         // The lane-ordered LDS ranking of the sort (deflate.hip: rank_pass) did not hold: byte identity with zlib needs
         // position-ordered chains, so the stage is repeated with the ballot ranking, which relies on nothing.
@@ -407,7 +412,9 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         if ((rc = launch_parse_count(st, d_tables, d_chunks, pb, (int)nseg, n_chunks, cfg, d_cout))) return rc;
         u32 max_nseg = 0;
         for (int i = 0; i < n_chunks; i++) if (cd[i].nseg > max_nseg) max_nseg = cd[i].nseg;
-        if ((rc = launch_parse_emit(st, d_stream, d_tables, d_quarter, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start, d_cout, n_chunks, max_nseg))) return rc;
+        if (getenv("MTS_PARSE_EMIT_WALK")) {                     // (A/B: the tokens by a third walk instead of from the marks of the first two)
+            if ((rc = launch_parse_emit(st, d_stream, d_tables, d_quarter, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start, d_cout, n_chunks, max_nseg))) return rc;
+        } else if ((rc = launch_parse_emit_marks(st, d_stream, d_tables, d_quarter, d_chunks, pb, fix_rounds, d_tokens, d_blk_in_start, d_cout, n_chunks, max_nseg))) return rc;
     }
     E.t_mark(st, "parse_emit");
     if ((rc = launch_block_trees(st, d_chunks, d_blk_chunk, (int)nblk, d_tokens, d_blk_in_start, d_cout, d_blocks,

@@ -148,6 +148,7 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
 struct ParseBufs {
     u32 *entry, *exit_a, *exit_b, *cnt, *tokbase;   // per segment
     u32 *cp;                                        // per segment 16 words: 7 checkpoint positions, 7 token counts
+    u32 *marks;                                     // per segment MARK_WORDS words: what the walk did at every position (deflate.hip: MarkW)
     u32 *seg_chunk, *seg_start;                     // per segment: owning chunk / start position
     int *changed;                                   // device flag
 };
@@ -160,6 +161,9 @@ int launch_parse_fix_serial(hipStream_t st, const u32 *d_tables, const u32 *d_qu
                             LevelCfg cfg, int rounds_done);
 int launch_parse_count(hipStream_t st, const u32 *d_tables, const ChunkDesc *d_chunks, ParseBufs pb,
                        int n_segs, int n_chunks, LevelCfg cfg, ChunkOut *d_cout);
+int launch_parse_emit_marks(hipStream_t st, const u8 *d_stream, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks,
+                            ParseBufs pb, int rounds_done, u32 *d_tokens, u32 *d_blk_in_start, ChunkOut *d_cout, int n_chunks, u32 max_nseg);
+size_t parse_marks_words(size_t n_segs);
 int launch_parse_emit(hipStream_t st, const u8 *d_stream, const u32 *d_tables, const u32 *d_quarter,
                       const ChunkDesc *d_chunks, ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens,
                       u32 *d_blk_in_start, ChunkOut *d_cout, int n_chunks, u32 max_nseg);

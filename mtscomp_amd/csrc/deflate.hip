@@ -1052,9 +1052,11 @@ typedef const __attribute__((address_space(1))) u32x4_a4 *gptr_uint4_a4;
 // AHEAD: the entries of p0 + 1 .. p0 + 3 are read together with p0's (staged walkers: all four are in the LDS window, and
 // one LDS latency per step instead of one per position the lazy evaluation moves on matters when two waves share a SIMD)
 template <bool AHEAD, class RDU, class RD, class RDQ>
-__device__ __forceinline__ u32 lazy_step(RDU &&rdu /* p0 .. p0 + 3: no bounds check */, RD &&rd, RDQ &&rdq, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos, u32 &mlen, u32 &mdist)
+__device__ __forceinline__ u32 lazy_step(RDU &&rdu /* p0 .. p0 + 3: no bounds check */, RD &&rd, RDQ &&rdq, u32 p0, u32 n, const LevelCfg &cfg, u32 &mpos, u32 &mlen, u32 &mdist,
+                                         u32 &mside /* 1: (mlen, mdist) is the side table's entry of mpos, 0: the table's */)
 {
     u32 p = p0;
+    mside = 0;
     const u32 e0 = rdu(p);
     u32 e1 = 0, e2 = 0, e3 = 0;
     if (AHEAD) { e1 = rdu(p + 1); e2 = rdu(p + 2); e3 = rdu(p + 3); }
@@ -1067,12 +1069,13 @@ __device__ __forceinline__ u32 lazy_step(RDU &&rdu /* p0 .. p0 + 3: no bounds ch
             u32 d;
             if (AHEAD) { d = q == p0 + 1 ? e1 : q == p0 + 2 ? e2 : e3; if (q > p0 + 3) d = rd(q); }
             else d = rd(q);
+            u32 side = 0;
             if (len >= (u32)cfg.good) {                          // the quarter-budget result
                 if (d & TE_QNONE) d = 0;
-                else if (d & TE_QSIDE) d = rdq(q);
+                else if (d & TE_QSIDE) { d = rdq(q); side = 1; }
             }
             const u32 dl = te_len(d);
-            if (dl > len) { p = q; len = dl; dist = te_dist(d); continue; }
+            if (dl > len) { p = q; len = dl; dist = te_dist(d); mside = side; continue; }
         }
         break;
     }
@@ -1184,6 +1187,83 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int k)
 // has to run until it lands on a recorded checkpoint: from there on the two walks are the same walk.
 constexpr int PARSE_CP = SEG / 8;
 
+// The walks also leave MARKS: two bits per position of what the walk did there -- 0 nothing (inside a copy), 1 a literal, 2 a
+// copy taken from the table's entry of the position, 3 a copy taken from the side table's -- in MARK_WORDS words per segment
+// (16 positions a word, relative to the segment start; a walk's last token starts less than 256 positions past the segment:
+// every lazy step that moves on has found a longer copy).  With the entries and exits settled, the tokens are then written by
+// a kernel that does not walk: k_parse_emit_marks.  A re-walk that lands on a checkpoint keeps the marks from there on.
+constexpr int MARK_WORDS = (SEG + 288) / 16;
+// Word k of segment g lives at marks[((g / 64) * MARK_WORDS + k) * 64 + g % 64]: the 64 walkers of a wave are consecutive segments and write
+// the same word at about the same time -- one 256-byte piece instead of 64 lines with 4 bytes each (as many write transactions as
+// the speculative walk has reads; it was 0.7 ms slower for them)
+__device__ __forceinline__ u32 *mark_base(u32 *marks, u32 g) { return marks + ((size_t)(g >> 6) * MARK_WORDS) * 64 + (g & 63); }
+struct MarkW {
+    u32 *base;                  // the segment's words: word k at base[64 k] (see mark_base)
+    u32 a;                      // index of the lowest word held
+    u64 lo, hi;                 // the marks of words a .. a + 3: stores happen where the caller wants them (a store in the walk's
+                                // loop is waited for, with everything before it, by the next load that is waited for)
+    bool on;
+    __device__ __forceinline__ void start(u32 *b, u32 rel, bool on_) { base = b; a = rel >> 4; lo = 0; hi = 0; on = on_; }
+    // word i (>= a) becomes the lowest one held; what lies below it goes to memory
+    __device__ __forceinline__ void anchor(u32 i)
+    {
+        if (i <= a) return;
+        const u32 d = i - a;
+        if (on) {
+            base[(size_t)(a) * 64] = (u32)lo;
+            if (d > 1) base[(size_t)(a + 1) * 64] = (u32)(lo >> 32);
+            if (d > 2) base[(size_t)(a + 2) * 64] = (u32)hi;
+            if (d > 3) { base[(size_t)(a + 3) * 64] = (u32)(hi >> 32); for (u32 k = a + 4; k < i; k++) base[(size_t)(k) * 64] = 0; }
+        }
+        if (d == 1) { lo = (lo >> 32) | (hi << 32); hi >>= 32; }
+        else if (d == 2) { lo = hi; hi = 0; }
+        else if (d == 3) { lo = hi >> 32; hi = 0; }
+        else { lo = 0; hi = 0; }
+        a = i;
+    }
+    __device__ __forceinline__ void orbits(u64 pat, u32 sh)      // pat at bit sh of the 128 held (it fits: the callers see to that)
+    {
+        if (sh < 64) { lo |= pat << sh; if (sh) hi |= pat >> (64 - sh); }
+        else hi |= pat << (sh - 64);
+    }
+    // a step of the walk: nl literals at rel0 .. rel0 + nl - 1, then a token of `type` at rel0 + nl.  The caller keeps
+    // rel0 - 16 a below 48 (k_parse_spec anchors at its window; parse_rewalk when it gets there).
+    __device__ __forceinline__ void step(u32 rel0, u32 nl, u32 type)
+    {
+        if (nl <= 12) {
+            const u64 pat = (0x5555555555555555ull & ((1ull << (2 * nl)) - 1ull)) | ((u64)type << (2 * nl));
+            orbits(pat, 2 * (rel0 - 16 * a));
+        } else {                                                // (the lazy evaluation moved on more than 12 times: levels 8, 9)
+            for (u32 q = 0; q <= nl; q++) {
+                const u32 r = rel0 + q;
+                if (r - 16 * a >= 48) anchor(r >> 4);
+                orbits(q < nl ? 1u : type, 2 * (r - 16 * a));
+            }
+        }
+    }
+    // the walk ended at rel (its exit): no mark from there on
+    __device__ __forceinline__ void finish(u32 rel)
+    {
+        const u32 last = min(rel ? (rel - 1) >> 4 : 0u, (u32)MARK_WORDS - 1u);       // (a last copy may reach past what the words cover: no token starts there)
+        if (!on) return;
+        base[(size_t)(a) * 64] = (u32)lo;
+        if (last > a) base[(size_t)(a + 1) * 64] = (u32)(lo >> 32);
+        if (last > a + 1) base[(size_t)(a + 2) * 64] = (u32)hi;
+        if (last > a + 2) base[(size_t)(a + 3) * 64] = (u32)(hi >> 32);
+        for (u32 k = a + 4; k <= last; k++) base[(size_t)(k) * 64] = 0;
+    }
+    // the walk met the one whose marks are there at rel: below rel the marks are this walk's, from rel on they stay
+    __device__ __forceinline__ void merge(u32 rel)
+    {
+        const u32 i = rel >> 4;
+        anchor(i);
+        const u32 low = (1u << (2 * (rel & 15))) - 1u;
+        if (on) base[(size_t)(i) * 64] = ((u32)lo & low) | (base[(size_t)(i) * 64] & ~low);
+    }
+};
+// marks of the step that went from p0 to the token at mp (literals before it)
+#define MTS_MARK_STEP(mk, s, p0, mp, ml, mside) (mk).step((p0) - (s), (mp) - (p0), (ml) ? 2u + (mside) : 1u)
+
 __global__ __launch_bounds__(64) void k_parse_spec(const u32 *__restrict__ tables, const u32 *__restrict__ quarter, const ChunkDesc *__restrict__ chunks,
                                                    ParseBufs pb, int n_segs, LevelCfg cfg)
 {
@@ -1201,12 +1281,15 @@ __global__ __launch_bounds__(64) void k_parse_spec(const u32 *__restrict__ table
     ParseStage st{win, T + (size_t)k0seg * SEG, nlanes};
     const u32 *row = win + lane * PARSE_WIN_PITCH;
     u32 *cp = pb.cp + (u64)g * 16;
-    u32 pos = s, mp, ml, md, cnt = 0, k = 1;
+    u32 pos = s, mp, ml, md, ms, cnt = 0, k = 1;
+    MarkW mk;
+    mk.start(mark_base(pb.marks, (u32)g), 0, valid);
     st.request(0);
     for (int w = 0; w < PARSE_NWIN; w++) {
         __syncthreads();                                         // (everybody is done with the window before)
         st.land();
         __syncthreads();
+        mk.anchor(((u32)w * PARSE_WIN) >> 4);                    // (the marks below this window: stored before the next loads are asked for)
         if (w + 1 < PARSE_NWIN) st.request(w + 1);
         const u32 wb = s + (u32)w * PARSE_WIN;
         const u32 wend = min(wb + (u32)PARSE_WIN, segend);
@@ -1214,12 +1297,14 @@ __global__ __launch_bounds__(64) void k_parse_spec(const u32 *__restrict__ table
         while (pos < wend) {
             while (k < 8 && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++; }
             const u32 p0 = pos;
-            pos = lazy_step<true>(rdu, rd, rdq, pos, n, cfg, mp, ml, md);
+            pos = lazy_step<true>(rdu, rd, rdq, pos, n, cfg, mp, ml, md, ms);
             cnt += mp - p0 + 1;
+            MTS_MARK_STEP(mk, s, p0, mp, ml, ms);
         }
         if (!__any(pos < segend)) break;
     }
     if (!valid) return;
+    mk.finish(pos - s);
     for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }      // checkpoints past the exit
     pb.entry[g] = s;
     pb.exit_a[g] = pos;
@@ -1237,7 +1322,9 @@ __device__ __forceinline__ u32 parse_rewalk(const u32 *__restrict__ T, const u32
     MTS_PARSE_GLOBAL_READERS(T, TQ)
     u32 *cp = pb.cp + (u64)g * 16;
     const u32 old_cnt = pb.cnt[g];
-    u32 pos = ne, mp, ml, md, cnt = 0, k = 1;
+    u32 pos = ne, mp, ml, md, ms, cnt = 0, k = 1;
+    MarkW mk;
+    mk.start(mark_base(pb.marks, g), ne - s, true);
     while (pos < segend) {
         bool merged = false;
         while (k < 8 && pos >= s + k * PARSE_CP) {
@@ -1245,16 +1332,20 @@ __device__ __forceinline__ u32 parse_rewalk(const u32 *__restrict__ T, const u32
             cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++;               // this walk's own checkpoint
         }
         if (merged) {
-            // same walk from here on: keep the exit, shift the counts of the remaining checkpoints
+            // same walk from here on: keep the exit (and the marks), shift the counts of the remaining checkpoints
             const u32 at_old = cp[8 + k - 1];
             for (u32 q = k; q < 8; q++) cp[8 + q - 1] = cp[8 + q - 1] - at_old + cnt;
             pb.cnt[g] = cnt + (old_cnt - at_old);
+            mk.merge(pos - s);
             return old_exit;
         }
         const u32 p0 = pos;
-        pos = lazy_step<false>(rd, rd, rdq, pos, n, cfg, mp, ml, md);
+        pos = lazy_step<false>(rd, rd, rdq, pos, n, cfg, mp, ml, md, ms);
         cnt += mp - p0 + 1;
+        if (p0 - s - 16 * mk.a >= 48) mk.anchor((p0 - s) >> 4);
+        MTS_MARK_STEP(mk, s, p0, mp, ml, ms);
     }
+    mk.finish(pos - s);
     for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }
     pb.cnt[g] = cnt;
     return pos;
@@ -1433,7 +1524,8 @@ __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream
         for (;;) {
             while (pos < wend && (PTCAP == 0 || k - k0 < (u32)PTCAP)) {
                 const u32 p0 = pos;
-                pos = lazy_step<true>(rdu, rd, rdq, pos, n, cfg, mp, ml, md);
+                u32 ms;
+                pos = lazy_step<true>(rdu, rd, rdq, pos, n, cfg, mp, ml, md, ms);
                 if (pos >= n) cout[ci].trailing = (ml == 0) ? 1u : 0u;       // last token of the chunk
                 const u32 nlit = ml ? mp - p0 : 1;
                 for (u32 q = 0; q < nlit; q++) put(byte_at(p0 + q) << 16, p0 + q);
@@ -1446,6 +1538,90 @@ __global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream
         if (!__any(pos < segend)) break;
     }
     flush();
+}
+
+// The tokens from the marks (see MarkW): a wave per segment, a lane per word of 16 positions.  The segment's first token index
+// is known (k_seg_scan), a wave scan of the words' token counts gives every lane its own, and a token is the stream's byte or
+// the table's entry at the marked position: nothing is walked.  (The walking version above read the table a second time entry
+// by entry through LDS windows, 10 waves per CU: 3.5 ms.)
+__global__ __launch_bounds__(256) void k_parse_emit_marks(const u8 *__restrict__ stream, const u32 *__restrict__ tables, const u32 *__restrict__ quarter,
+                                                          const ChunkDesc *__restrict__ chunks, ParseBufs pb, const u32 *__restrict__ exits,
+                                                          u32 *__restrict__ tokens, u32 *__restrict__ blk_in_start, ChunkOut *__restrict__ cout)
+{
+    __shared__ u32 tokst[4][64 * 16];                           // a wave's tokens of one pass, in order: they leave by consecutive lanes
+    const u32 ci = blockIdx.y;                                  // grid: x = four segments of the chunk, y = chunk
+    const ChunkDesc ch = chunks[ci];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 seg = blockIdx.x * 4 + (u32)wave;
+    if (seg >= ch.nseg) return;
+    const u32 g = ch.seg0 + seg, s = seg * SEG;
+    const u32 entry = pb.entry[g], ex = exits[g], k0 = pb.tokbase[g], ntok = cout[ci].ntok;
+    const u32 *T = tables + ch.stream_off, *TQ = quarter + ch.stream_off;
+    const u8 *b = stream + ch.stream_off;
+    u32 *tk = tokens + ch.tok_off;
+    u32 *bis = blk_in_start + ch.blk0;
+    const u32 *mw = mark_base(pb.marks, g);
+    u32 *mine = tokst[wave];
+    const u32 bnd = (k0 + (u32)BLOCK_TOKENS - 1) / (u32)BLOCK_TOKENS * (u32)BLOCK_TOKENS;      // the block start at or after k0 (a segment meets one at most)
+    u32 kbase = k0;
+    for (u32 w0 = 0; w0 < (u32)MARK_WORDS; w0 += 64) {
+        if (s + 16 * w0 >= ex) break;
+        const u32 wi = w0 + lane, lo = s + 16 * wi;
+        u32 w = 0;
+        if (wi < (u32)MARK_WORDS && lo < ex && lo + 16 > entry) {
+            w = mw[(size_t)wi * 64];
+            if (entry > lo) w &= ~0u << (2 * (entry - lo));                 // only [entry, exit) is this segment's
+            if (ex < lo + 16) w &= (1u << (2 * (ex - lo))) - 1u;
+        }
+        // the word's 16 table entries and 16 stream bytes, asked for together (the tokens are made from registers below)
+        u32 e[16], bb[4];
+#pragma unroll
+        for (int q = 0; q < 16; q++) e[q] = 0;
+        bb[0] = bb[1] = bb[2] = bb[3] = 0;
+        if (w) {
+            const u32x4_v t0 = *(gptr_uint4)(u64)(T + lo), t1 = *(gptr_uint4)(u64)(T + lo + 4), t2 = *(gptr_uint4)(u64)(T + lo + 8),
+                          t3 = *(gptr_uint4)(u64)(T + lo + 12), sb = *(gptr_uint4)(u64)(b + lo);
+            e[0] = t0.x; e[1] = t0.y; e[2] = t0.z; e[3] = t0.w; e[4] = t1.x; e[5] = t1.y; e[6] = t1.z; e[7] = t1.w;
+            e[8] = t2.x; e[9] = t2.y; e[10] = t2.z; e[11] = t2.w; e[12] = t3.x; e[13] = t3.y; e[14] = t3.z; e[15] = t3.w;
+            bb[0] = sb.x; bb[1] = sb.y; bb[2] = sb.z; bb[3] = sb.w;
+        }
+        const u32 st = (w | (w >> 1)) & 0x55555555u;
+        const u32 c = (u32)__builtin_popcount(st);
+        const u32 incl = wave_incl_scan_dpp(c);
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        u32 idx = incl - c;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const u32 m = (w >> (2 * q)) & 3;
+            if (m) {
+                u32 v;
+                if (m == 1) v = ((bb[q >> 2] >> (8 * (q & 3))) & 0xffu) << 16;
+                else { const u32 en = m == 3 ? TQ[lo + q] : e[q]; v = (((en >> 15) & 0xffu) << 16) | (en & TE_DIST); }
+                mine[idx] = v;
+                const u32 kk = kbase + idx;
+                if (kk == bnd) bis[kk / (u32)BLOCK_TOKENS] = lo + q;            // first token of a block: where its input starts
+                if (kk + 1 == ntok) cout[ci].trailing = m == 1 ? 1u : 0u;       // last token of the chunk
+                idx++;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (u32 t = lane; t < total; t += 64) tk[kbase + t] = mine[t];
+        __builtin_amdgcn_wave_barrier();
+        kbase += total;
+    }
+}
+
+size_t parse_marks_words(size_t n_segs) { return (n_segs + 64) / 64 * 64 * MARK_WORDS; }
+
+int launch_parse_emit_marks(hipStream_t st, const u8 *d_stream, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks,
+                            ParseBufs pb, int rounds_done, u32 *d_tokens, u32 *d_blk_in_start, ChunkOut *d_cout, int n_chunks, u32 max_nseg)
+{
+    if (max_nseg == 0) return MTS_OK;
+    const u32 *exits = ((rounds_done - 1) & 1) ? pb.exit_a : pb.exit_b;      // where the last fix round left the exits
+    hipLaunchKernelGGL(k_parse_emit_marks, dim3((max_nseg + 3) / 4, n_chunks), dim3(256), 0, st, d_stream, d_tables, d_quarter, d_chunks, pb, exits,
+                       d_tokens, d_blk_in_start, d_cout);
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
 }
 
 int launch_parse_spec(hipStream_t st, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks, ParseBufs pb, int n_segs,

@@ -113,6 +113,20 @@ def test_deflate_bytes_ballot_sort(monkeypatch):
         assert hip.debug_deflate(data, 6) == zlib.compress(data, 6), name
 
 
+def test_deflate_bytes_emitting_walk(monkeypatch):
+    """The tokens are written from the marks the parse walks leave (k_parse_emit_marks); MTS_PARSE_EMIT_WALK=1 has them written by
+    a third walk instead (the version before, kept for A/B runs).  Both must give zlib's bytes, also where a re-walk meets the
+    first one (every segment), where it does not (zeros: the parse never re-synchronises) and at levels whose lazy evaluation
+    moves on more than twelve times in a step."""
+    big = inputs.repeats(300000, 21) + bytes(200000) + inputs.textlike(150000, 22) + inputs.skewlen(150000, 23)
+    for env in (None, '1'):
+        if env:
+            monkeypatch.setenv('MTS_PARSE_EMIT_WALK', env)
+        for level in (6, 9):
+            for data in (CASES['text_100k'], CASES['ar1_64ch_4k'], CASES['zeros_999468'], big):
+                assert hip.debug_deflate(data, level) == zlib.compress(data, level), (env, level, len(data))
+
+
 def test_deflate_block_boundaries():
     r = np.random.RandomState(7)
     base = r.randint(0, 256, size=16383 * 2 + 40).astype(np.uint8).tobytes()

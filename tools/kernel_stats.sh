@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/kstats
 rm -rf $out; mkdir -p $out
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --no-cpu-baseline > $out/stdout.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-extras > $out/stdout.txt 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$out/**/*kernel_stats.csv", recursive=True)
