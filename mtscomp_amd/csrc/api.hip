@@ -477,7 +477,9 @@ static void par_memcpy(void *dst, const void *src, size_t n)
     const int nt = n < ((size_t)4 << 20) ? 1 : host_threads();
     if (nt == 1) { memcpy(dst, src, n); return; }
     std::vector<std::thread> th;
-    const size_t per = (n / nt + 4095) & ~(size_t)4095;
+    // (the share is rounded UP before it is aligned: with n / nt an exact multiple of 4096 and n % nt != 0 the threads' shares
+    //  ended n % nt bytes short of n -- the last bytes of such a copy were never made; found by tools/fuzz_gpu.py, seed 301)
+    const size_t per = ((n + nt - 1) / nt + 4095) & ~(size_t)4095;
     for (int t = 1; t < nt; t++) {
         const size_t a = (size_t)t * per;
         if (a >= n) break;

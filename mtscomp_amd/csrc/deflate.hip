@@ -172,10 +172,12 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
     const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
     // first pass: the fetched word is the 15-bit hash (digit = its low 8 bits; what is stored and sorted on is
     // the key = high 7 hash bits : position); second pass: the key (digit = its 7 hash bits)
+    // (unconditional: a load under a branch is waited for where the branch ends, and the four loads of a step went out one after
+    //  the other, each behind the stores of the step before; a lane past the end reads the last key and drops it)
     auto fetch = [&](u32 i) -> u32 {
-        if (i >= end) return 0;
-        if (FIRST) return sort_hash(gld_u32_unaligned(s, i));
-        return src[i];
+        const u32 ic = i < end ? i : end - 1;
+        if (FIRST) return sort_hash(gld_u32_unaligned(s, ic));
+        return src[ic];
     };
     auto digit_of = [&](u32 f) -> u32 { return FIRST ? f & ((1u << NB) - 1) : (f >> (REL_BITS + SHIFT)) & ((1u << NB) - 1); };
     auto key_of = [&](u32 f, u32 i) -> u32 { return FIRST ? ((f >> NB) << REL_BITS) | i : f; };
@@ -190,10 +192,15 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
         static_assert(NBIN % 64 == 0 && NBIN <= 256, "a lane owns the counters of digits lane, lane + 64, ...");
         constexpr int KPL = SORT_KPL, BK = 64 * KPL;
         u32 *K = stg + wave * (2 * BK), *A = K + BK, *D = dlt + wave * 256;
+        // the keys of a step are asked for a step ahead, BEFORE the step's stores: what is waited for then is loads that went
+        // out a whole step earlier, with that step's stores (a fixed number: lanes without a key repeat lane 0's store) behind them
+        u32 key_n[KPL];
+#pragma unroll
+        for (int k = 0; k < KPL; k++) key_n[k] = fetch(beg + 64 * k + lane);
         for (u32 base = beg; base < end; base += BK) {
             u32 key[KPL], at[KPL], bf[4];
 #pragma unroll
-            for (int k = 0; k < KPL; k++) key[k] = fetch(base + 64 * k + lane);
+            for (int k = 0; k < KPL; k++) { key[k] = key_n[k]; key_n[k] = fetch(base + BK + 64 * k + lane); }
             // (a lane looks after the counters of digits lane, lane + 64, ...: neighbouring lanes on neighbouring words.  With
             // digits 4 * lane + j, lanes 8 apart met in one LDS bank on each of these twelve accesses per step)
             constexpr int NJ = NBIN / 64;
@@ -221,7 +228,7 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < KPL; k++) { const u32 j = 64 * k + lane; if (j < total) dst[A[j]] = K[j]; }
+            for (int k = 0; k < KPL; k++) { const u32 j = 64 * k + lane, jj = j < total ? j : 0u; dst[A[jj]] = K[jj]; }
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();

@@ -2447,6 +2447,17 @@ static InfLayout inf_layout(int n_chunks, const u64 *c_lens, const u32 *n_expect
 
 size_t inflate_scratch_bytes(int n_chunks, const u64 *c_lens, const u32 *n_expect) { return inf_layout(n_chunks, c_lens, n_expect).end + 256; }
 
+static void dbg_status(hipStream_t st, const InfResult *d_res, int n_chunks, const char *where)
+{
+    if (!getenv("MTS_DEBUG_STATUS")) return;
+    std::vector<InfResult> h(n_chunks);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), d_res, sizeof(InfResult) * n_chunks, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[status %s]", where);
+    for (int i = 0; i < n_chunks; i++) fprintf(stderr, " %d:(st %d nout %u ntok %u)", i, h[i].status, h[i].n_out, h[i].ntok);
+    fprintf(stderr, "\n");
+}
+
 int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, const InfChunk *h_chunks, int n_chunks,
                    u8 *d_stream, u32 *d_tokens, InfResult *d_res, u64 *d_adler_acc, u32 max_n, int *d_status_out,
                    void *d_scratch, void *engine)
@@ -2462,6 +2473,19 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
         if (lens[i] > max_clen) max_clen = lens[i];
     }
     const InfLayout l = inf_layout(n_chunks, lens.data(), nn.data());
+    if (getenv("MTS_DEBUG_STATUS"))
+        for (int i = 0; i < n_chunks; i++) {
+            std::vector<u8> hb(h_chunks[i].c_len);
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(hb.data(), d_cdata + h_chunks[i].c_off, hb.size(), hipMemcpyDeviceToHost);
+            u32 a = 1, b2 = 0;
+            for (u8 v : hb) { a = (a + v) % 65521u; b2 = (b2 + a) % 65521u; }
+            fprintf(stderr, "[chunk %d] device copy of the compressed bytes: adler32 %08x\n", i, (b2 << 16) | a);
+        }
+    if (getenv("MTS_DEBUG_STATUS"))
+        for (int i = 0; i < n_chunks; i++)
+            fprintf(stderr, "[chunk %d] c_off %llu c_len %llu n_expect %u n_need %u stream_off %llu tok_off %llu\n", i, (unsigned long long)h_chunks[i].c_off,
+                    (unsigned long long)h_chunks[i].c_len, h_chunks[i].n_expect, h_chunks[i].n_need, (unsigned long long)h_chunks[i].stream_off, (unsigned long long)h_chunks[i].tok_off);
     std::vector<u64> gboff(n_chunks), tboff(n_chunks);
     {
         u64 a = 0, b2 = 0;
@@ -2531,6 +2555,7 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
     }
     hipLaunchKernelGGL(k_inf_wave, dim3(n_chunks), dim3(WV_NT), 0, st, d_cdata, d_chunks, n_chunks, d_tokens, d_res, fast_path ? d_seq : nullptr);
     inflate_mark(engine, st, "inflate_wave_decoder");
+    dbg_status(st, d_res, n_chunks, "after decode");
     {
         u32 max_groups = 1;
         for (int i = 0; i < n_chunks; i++) { const u32 gmax = (u32)(((u64)nn[i] + 2 + 63) / 64); if (gmax > max_groups) max_groups = gmax; }
@@ -2580,6 +2605,7 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
                         (double)a[0] / nw, (double)a[1] / nw, (double)a[2] / nw, (double)a[3] / nw, (double)a[5] / nw, (double)a[4] / a[5], (double)a[0] / a[5], (double)a[6] / nw, (double)a[7] / nw);
     }
     inflate_mark(engine, st, "inflate_lz");
+    dbg_status(st, d_res, n_chunks, "after lz");
     // byte sums of the chunks that did not go through the translation (resolved as bytes by k_inf_lz)
     int rc = launch_adler_stream(st, d_stream, (const u64 *)(S + l.so), (const u32 *)(S + l.nn), n_chunks, max_n, d_adler_acc,
                                  (const u32 *)(S + l.plan), (u32)(sizeof(LzPlan) / 4));
@@ -2588,6 +2614,7 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
                        d_status_out, l.nseg > 1 && max_n > 0 ? (const u64 *)(S + l.seg_adler) : nullptr);
     MTS_HIP(hipGetLastError());
     inflate_mark(engine, st, "adler32");
+    dbg_status(st, d_res, n_chunks, "after adler");
     return MTS_OK;
 }
 

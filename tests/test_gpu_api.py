@@ -6,6 +6,7 @@ from pathlib import Path
 
 import numpy as np
 import pytest
+from zlib import compress as zlib_compress
 
 import mtscomp_amd
 from mtscomp_amd import api, hip
@@ -210,6 +211,35 @@ def test_wide_batch_with_tiny_chunks():
     assert all(z[i] == O.ref_compress_chunk(x[b[i]:b[i + 1]]) for i in range(4))
     st, arrs = hip.decompress_chunks(z, rows, 1024, 'int16', flags)
     assert st == [0] * 5 and all(np.array_equal(arrs[i], x[b[i]:b[i + 1]]) for i in range(5))
+
+
+def test_host_copies_whose_thread_shares_are_whole_pages():
+    """Copies of 8 MB and more cross the bus through pinned pieces filled (and emptied) by several host threads.  With a size
+    whose eighth is a whole number of 4 KiB pages plus a remainder, the shares once ended `size % 8` bytes short of the size: the
+    last bytes of the raw data, of the compressed range and of the decoded rows were never copied (found by tools/fuzz_gpu.py as a
+    last chunk that would not decode, once in ~4000 such calls)."""
+    n = 8 * 4096 * 300 + 6                                        # 9 830 406 bytes: floor(n / 8) is a multiple of 4096, n % 8 = 6
+    r = np.random.RandomState(5)
+    x = np.tile(r.randint(0, 256, size=4099).astype(np.uint8), n // 4099 + 1)[:n].reshape(-1, 1).copy()
+    x[-8:, 0] = np.arange(1, 9)                                   # a tail that says when it is missing
+    flags = hip.make_flags(False, False, 'C')
+    z = hip.compress_chunks(x, np.array([0, n]), flags, 6)        # raw bytes host -> device
+    assert z[0] == O.ref_compress_chunk(x, False, False, 'C', 6)
+    st, arrs = hip.decompress_chunks(z, [n], 1, 'uint8', flags)   # decoded bytes device -> host
+    assert st == [0] and np.array_equal(arrs[0], x)
+    # a compressed range of such a size host -> device: stored chunks (random bytes), the last one small
+    rnd = r.randint(0, 256, size=n + 70000).astype(np.uint8)
+    sizes = []
+    m = n
+    for k in range(40):                                           # the stored stream of k bytes is k + 5 per 65535 + 6: find the size that gives n
+        zs = [zlib_compress(rnd[:m].tobytes()), zlib_compress(rnd[m:m + 3000].tobytes())]
+        tot = len(zs[0]) + len(zs[1])
+        if tot == n:
+            break
+        m -= tot - n
+    assert tot == n, tot
+    st, arrs = hip.decompress_chunks(zs, [m, 3000], 1, 'uint8', flags)
+    assert st == [0, 0] and arrs[0].tobytes() == rnd[:m].tobytes() and arrs[1].tobytes() == rnd[m:m + 3000].tobytes()
 
 
 def test_more_chunks_than_a_grid_dimension():
