@@ -80,6 +80,24 @@ struct BitIn {
     }
 };
 
+// words [wb0, wb0 + count) of a stream into LDS (zero past the data), by `nthr` threads of which this is thread `t`.  The loads
+// are unconditional and eight per thread are in flight: written as  dst[k] = br.word(wb0 + k)  every load sat under the
+// bounds check's branch and was waited for where the branch ends -- a round trip per word and thread (a third of pass A's time
+// per round went there).
+__device__ __forceinline__ void stage_stream_words(u32 *dst, const BitIn &br, u64 wb0, u32 count, u32 t, u32 nthr)
+{
+    const __attribute__((address_space(1))) u32 *g = (const __attribute__((address_space(1))) u32 *)(u64)br.w;
+    const u64 nw = br.nwords;
+    if (nw == 0) { for (u32 k = t; k < count; k += nthr) dst[k] = 0; return; }
+    for (u32 k0 = 0; k0 < count; k0 += 8 * nthr) {
+        u32 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const u64 i = wb0 + k0 + (u32)j * nthr + t; v[j] = g[i < nw ? i : nw - 1]; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const u32 k = k0 + (u32)j * nthr + t; if (k < count) dst[k] = wb0 + k < nw ? v[j] : 0u; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // canonical Huffman decode by compare chain.
 //   lc[l] (l = 1..MAXL): low 16 bits = lim[l] = exclusive upper bound, left-aligned to MAXL bits, of
@@ -981,6 +999,11 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     BitIn br;
     br.init(cdata, ch.c_off, ch.c_len, 0);
     const u64 o = cand_pos[slot];
+    // the header (< 2560 bits) is parsed out of an LDS copy: read from memory it was a dependent load per 32 bits
+    __shared__ u32 stage[PASSA_STAGE_WORDS];
+    stage_stream_words(stage, br, o >> 5, SCAN_TAIL + 8, (u32)threadIdx.x, 64);
+    __builtin_amdgcn_wave_barrier();
+    br.lw = stage; br.lw0 = o >> 5; br.lwn = SCAN_TAIL + 8;
     br.seek(o);
     CandRes r;
     r.end_bit = 0; r.ntok = 0; r.nout = 0; r.nsub = 0; r.ok = 0; r.bfinal = 0; r.rows = 0;
@@ -1021,7 +1044,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     // a round = 64 sub-sequences: that piece of the stream (+ slack for the reader's look-ahead and the last token's
     // overshoot) is staged in LDS; positions inside a round are relative to its first staged word
     // (reading the stream straight from memory instead -- no LDS copy, 20 waves per CU -- was measured at 6.55 ms against 3.22)
-    __shared__ u32 stage[PASSA_STAGE_WORDS];
+    br.lw = nullptr; br.lwn = 0;                                     // (the header's copy makes way for the rounds')
     BitL bl;
     bl.w = stage;
     while (!done && !fail) {
@@ -1029,7 +1052,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
         const u32 bofs = (u32)(base & 31);
         __builtin_amdgcn_wave_barrier();
         const u32 stage_words = 64 * sub_bits / 32 + 16;
-        for (u32 k2 = lane; k2 < stage_words; k2 += 64) stage[k2] = br.word(wb0 + k2);
+        stage_stream_words(stage, br, wb0, stage_words, (u32)lane, 64);
         __builtin_amdgcn_wave_barrier();
         const u64 end_rel64 = br.end - (wb0 << 5);
         const u32 end_rel = end_rel64 < 0x7fffffffull ? (u32)end_rel64 : 0x7fffffffu;
@@ -1359,7 +1382,7 @@ __global__ __launch_bounds__(64 * PASSB_WAVES) void k_inf_passB(const u8 *__rest
         const bool staged = whi - wlo < (u64)PASSB_STAGE_WORDS;
         if (staged) {
             const u32 nw = (u32)(whi - wlo) + 1;
-            for (u32 k = lane; k < nw; k += 64) stage[k] = br.word(wlo + k);
+            stage_stream_words(stage, br, wlo, nw, (u32)lane, 64);
         }
         __builtin_amdgcn_wave_barrier();
         if (j < nsub) {
@@ -1495,7 +1518,7 @@ __global__ __launch_bounds__(WV_NT) void k_inf_wave(const u8 *__restrict__ cdata
             const u64 wb0 = base >> 5;
             const u32 bofs = (u32)(base & 31);
             __syncthreads();
-            for (u32 k2 = tid; k2 < (u32)WV_STAGE_WORDS; k2 += WV_NT) stage[k2] = br.word(wb0 + k2);
+            stage_stream_words(stage, br, wb0, (u32)WV_STAGE_WORDS, (u32)tid, (u32)WV_NT);
             __syncthreads();
             const u64 end_rel64 = br.end - (wb0 << 5);
             const u32 end_rel = end_rel64 < 0x7fffffffull ? (u32)end_rel64 : 0x7fffffffu;
