@@ -100,12 +100,14 @@ __device__ __forceinline__ u32 __reduce_max_sync_u32(u32 v)
 // The radix passes move 32-bit keys  (high 7 hash bits << 18) | window-relative position.  Everything else the
 // match stage wants about a position (its bytes, its chain length) it derives from the window bytes.
 #ifndef MTS_SORT_WAVES
-#define MTS_SORT_WAVES 16
+#define MTS_SORT_WAVES 8
 #endif
 #ifndef MTS_SORT_KPL
-#define MTS_SORT_KPL 4
+#define MTS_SORT_KPL 12
 #endif
-constexpr int SORT_WAVES = MTS_SORT_WAVES; // waves per sort workgroup (one tile)
+constexpr int SORT_WAVES = MTS_SORT_WAVES; // waves per sort workgroup (one tile).  With the key loads a step ahead of their use (rank_pass) the best tiling moved from
+                                           // 16 waves x 4 keys per lane and step (9.6 ms) to 8 x 12 (8.4): 8 x 4 10.1, 8 x 8 8.65, 8 x 10 8.6, 8 x 14 / 16 9.7, 4 x 8 8.9, 4 x 16 8.8,
+                                           // 6 x 8 9.3, 12 x 8 9.9, 16 x 8 9.4 -- longer runs per store against workgroups per CU (69 KB of LDS: two)
 constexpr int SORT_KPL = MTS_SORT_KPL;              // keys per lane and step: SORT_KPL * 64 keys are staged in destination order per wave
 constexpr int SORT_NT = SORT_WAVES * 64;
 constexpr int SORT_B1 = 8;               // two passes: 8 + 7 hash bits
