@@ -97,7 +97,7 @@ __device__ __forceinline__ u32 __reduce_max_sync_u32(u32 v)
 // ================================================================================================
 // S: hash sort
 // ================================================================================================
-// The radix passes move 32-bit keys  (high 7 hash bits << 18) | window-relative position.  Everything else the
+// The radix passes move 32-bit keys  (high 8 hash bits << 18) | window-relative position.  Everything else the
 // match stage wants about a position (its bytes, its chain length) it derives from the window bytes.
 #ifndef MTS_SORT_WAVES
 #define MTS_SORT_WAVES 8
@@ -110,7 +110,11 @@ constexpr int SORT_WAVES = MTS_SORT_WAVES; // waves per sort workgroup (one tile
                                            // 6 x 8 9.3, 12 x 8 9.9, 16 x 8 9.4 -- longer runs per store against workgroups per CU (69 KB of LDS: two)
 constexpr int SORT_KPL = MTS_SORT_KPL;              // keys per lane and step: SORT_KPL * 64 keys are staged in destination order per wave
 constexpr int SORT_NT = SORT_WAVES * 64;
-constexpr int SORT_B1 = 8;               // two passes: 8 + 7 hash bits
+#ifndef MTS_SORT_B1
+#define MTS_SORT_B1 7
+#endif
+constexpr int SORT_B1 = MTS_SORT_B1;     // two passes: SORT_B1 + (15 - SORT_B1) hash bits (7 + 8: 7.96 ms, 8 + 7: 8.28 -- fewer, longer runs in the first pass's stores)
+constexpr int SORT_B2 = 15 - SORT_B1;
 // The match stage only wants equal hashes next to each other in position order, whatever the order of the runs, so the
 // passes could sort on any bijective scramble of the hash.  zlib's hash of int16 deltas is lopsided (every other position
 // is (high, low, high) bytes: ~120 values that differ in a few bits) and the lanes of a wave instruction that meet in one
@@ -168,7 +172,7 @@ __device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
 // NNB > 0: count the next pass's digit (the NNB bits above this pass's) for the wave that will own the key there.
 template <int NB, bool FIRST, int SHIFT, int NNB>
 __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *__restrict__ src, u32 *__restrict__ dst, u32 wlen,
-                                          u32 per, u32 (*cnt)[256], u32 (*cnt2)[128], u32 per_magic, int lane_ordered, u32 *stg, u32 *dlt)
+                                          u32 per, u32 (*cnt)[256], u32 (*cnt2)[1 << SORT_B2], u32 per_magic, int lane_ordered, u32 *stg, u32 *dlt)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ st
 {
     const TileDesc td = tiles[blockIdx.x];
     __shared__ u32 cnt[SORT_WAVES][256];
-    __shared__ u32 cnt2[SORT_WAVES][128];
+    __shared__ u32 cnt2[SORT_WAVES][1 << SORT_B2];
     __shared__ u32 tot[256];
     __shared__ u32 stg[SORT_WAVES * 2 * 64 * SORT_KPL];      // per wave: the keys of a step + their destinations, in destination order
     __shared__ u32 dlt[SORT_WAVES * 256];                     // per wave and digit: slot of the digit's first key of the step - its destination
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ st
     // __umulhi(x >> 6, magic) == x / per (per is a multiple of 64; x >> 6 < 2^12); magic 0 stands for per == 64 (x / per = x >> 6)
     const u32 per_magic = per > 64 ? 0xffffffffu / (per >> 6) + 1 : 0;
     for (int i = threadIdx.x; i < SORT_WAVES * 256; i += SORT_NT) (&cnt[0][0])[i] = 0;
-    for (int i = threadIdx.x; i < SORT_WAVES * 128; i += SORT_NT) (&cnt2[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < SORT_WAVES * (1 << SORT_B2); i += SORT_NT) (&cnt2[0][0])[i] = 0;
     __syncthreads();
     {   // digits of the first pass: 4 positions per lane and step, so four loads are in flight
         const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
@@ -313,14 +317,14 @@ __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ st
     __syncthreads();
     u32 *tmp_t = tmp + td.sorted_off, *out_t = sorted + td.sorted_off;
     auto next_counts = [&]() {                       // the fused counts become the next pass's
-        for (int i = threadIdx.x; i < SORT_WAVES * 128; i += SORT_NT) { cnt[i >> 7][i & 127] = cnt2[i >> 7][i & 127]; cnt2[i >> 7][i & 127] = 0; }
+        for (int i = threadIdx.x; i < SORT_WAVES * (1 << SORT_B2); i += SORT_NT) { cnt[i >> SORT_B2][i & ((1 << SORT_B2) - 1)] = cnt2[i >> SORT_B2][i & ((1 << SORT_B2) - 1)]; cnt2[i >> SORT_B2][i & ((1 << SORT_B2) - 1)] = 0; }
         __syncthreads();
     };
-    bin_offsets<8>(cnt, tot);
-    rank_pass<8, true, 0, 7>(s, nullptr, tmp_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);        // low 8 hash bits
+    bin_offsets<SORT_B1>(cnt, tot);
+    rank_pass<SORT_B1, true, 0, SORT_B2>(s, nullptr, tmp_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);        // low hash bits
     next_counts();
-    bin_offsets<7>(cnt, tot);
-    rank_pass<7, false, 0, 0>(s, tmp_t, out_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);          // high 7 bits
+    bin_offsets<SORT_B2>(cnt, tot);
+    rank_pass<SORT_B2, false, 0, 0>(s, tmp_t, out_t, wlen, per, cnt, cnt2, per_magic, lane_ordered, stg, dlt);          // high bits
     // (three passes of 5 bits -- runs of ~8 keys per store -- were measured at 17.8 ms against 12.4: a pass costs what it costs
     // whatever its stores look like)
 }
