@@ -306,12 +306,18 @@ __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ st
     __syncthreads();
     {   // digits of the first pass: 4 positions per lane and step, so four loads are in flight
         const u32 beg = min((u32)wave * per, wlen), end = min(beg + per, wlen);
-        for (u32 i0 = beg + lane; i0 < end; i0 += 256) {
-            u32 v[4];
+        constexpr int CK = 8;                                    // loads in flight per lane; the next step's go out before this step's atomics
+        if (beg < end) {
+            u32 vn[CK];
 #pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = gld_u32_unaligned(s, min(i0 + 64 * k, end - 1));
+            for (int k = 0; k < CK; k++) vn[k] = gld_u32_unaligned(s, min(beg + lane + 64 * k, end - 1));
+            for (u32 i0 = beg + lane; i0 < end; i0 += 64 * CK) {
+                u32 v[CK];
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (i0 + 64 * k < end) atomicAdd(&cnt[wave][sort_hash(v[k]) & ((1u << SORT_B1) - 1)], 1u);
+                for (int k = 0; k < CK; k++) { v[k] = vn[k]; vn[k] = gld_u32_unaligned(s, min(i0 + 64 * CK + 64 * k, end - 1)); }
+#pragma unroll
+                for (int k = 0; k < CK; k++) if (i0 + 64 * k < end) atomicAdd(&cnt[wave][sort_hash(v[k]) & ((1u << SORT_B1) - 1)], 1u);
+            }
         }
     }
     __syncthreads();
