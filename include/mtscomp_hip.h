@@ -104,7 +104,8 @@ int mts_decompress_chunks(int device, const unsigned char *cdata, const long *c_
  * mtscomp.py:582-588, :602) -- the cache lives in HBM: decoded chunks stay on the device and a slice costs one
  * device-to-host copy of exactly the requested rows.
  *   mts_cache_create    capacity in bytes of decoded chunks (least recently used chunks are dropped beyond it)
- *   mts_cache_query     present[i] = 1 if the decoded chunk with key chunk_keys[i] is resident
+ *   mts_cache_query     present[i] = 0 if the decoded chunk with key chunk_keys[i] is not resident, else the number of channels
+ *                       the entry holds (n_channels, or the leading channels of mts_cache_read_slices_leading)
  *   mts_cache_read_slices  (below) any number of row/column rectangles per call, gathered on the device
  *   mts_cache_read_rows the chunks of one slice, in file order: resident ones may come with c_lengths[i] = 0, the others
  *                       with their compressed bytes (cdata + c_offsets[i], c_lengths[i]) and are decoded in one batch and

@@ -505,6 +505,10 @@ class Reader:
         self.cache_size = self.config.cache_size
         self.check_after_decompress = self.config.check_after_decompress
         self.batch_chunks = int(self.config.get('batch_chunks', None) or DEFAULT_BATCH_CHUNKS)
+        # partial_decode=True (off by default): Reader[rows, :k] may inflate only the prefix of a chunk's stream its leading
+        # channels need.  The reference inflates -- and adler32-checks -- the whole chunk on every read (mtscomp.py:618-621);
+        # a prefix decode cannot, so it is the caller's explicit choice.
+        self.partial_decode = bool(self.config.get('partial_decode', False))
         self._codec = codec
         self._cache = OrderedDict()
         self._dev_cache = None
@@ -654,7 +658,7 @@ class Reader:
                 self._dev_cache = self.codec.cache_create(self._dev_cache_bytes)
         keys = list(range(first, last + 1))
         a, b = i0 - self.chunk_bounds[first], i1 - self.chunk_bounds[first]
-        present = self.codec.cache_query(self._dev_cache, keys)
+        present = [int(p) >= self.n_channels for p in self.codec.cache_query(self._dev_cache, keys)]      # (entries of leading channels only do not count)
         for attempt in range(2):
             need = [k for k, p in zip(keys, present) if not p]
             offs, lens = [0] * n, [0] * n
@@ -739,14 +743,16 @@ class Reader:
         for (i0, i1, rs, c0, c1, cs, _), sp in zip(reqs, spans):
             a = int(cum[where[sp[0]]]) + i0 - self.chunk_bounds[sp[0]] if sp else 0
             requests.append((a, a + (i1 - i0), rs, c0, c1, cs))
-        present = self.codec.cache_query(self._dev_cache, keys)
+        held = self.codec.cache_query(self._dev_cache, keys)            # channels every resident entry holds (0: not resident)
         # Requests that stay within the leading channels of channel-major chunks need only a prefix of every chunk's stream:
         # the codec inflates a chunk that is not resident just that far, from a prefix of its compressed bytes (the channels
         # compress about equally: the share of the bytes plus a margin; if that falls short the codec says so and the whole
         # chunk is sent).  The reference inflates whole chunks and drops the columns on the host (mtscomp.py:835-842).
-        n_lead = max([r[4] for r, sp in zip(reqs, spans) if sp] or [self.n_channels])
-        leading = bool(getattr(self.codec, 'leading_channels', False)) and self.chunk_order == 'F' and self.dtype.kind in 'iu' and \
-            0 < 2 * n_lead <= self.n_channels
+        # Only with partial_decode=True: such a read cannot check the chunk's adler32 (the reference always does, mtscomp.py:618-621).
+        n_lead = max([r[4] for r in reqs] or [self.n_channels])     # (over ALL requests: the codec checks every one against it)
+        leading = self.partial_decode and bool(getattr(self.codec, 'leading_channels', False)) and self.chunk_order == 'F' and \
+            self.dtype.kind in 'iu' and 0 < 2 * n_lead <= self.n_channels
+        present = [int(h) >= (n_lead if leading else self.n_channels) for h in held]      # bytes are sent for entries that are too narrow only
         for attempt in range(2):
             offs, lens, parts, at = [0] * len(keys), [0] * len(keys), [], 0
             need = [k for k, p in zip(keys, present) if not p]
@@ -766,7 +772,9 @@ class Reader:
                 at += len(parts[-1])
                 j = e + 1
             try:
-                extra = {'n_leading': n_lead} if leading else {}
+                # the second attempt is a plain whole-chunk decode (every check runs: a chunk the prefix decoder cannot follow, or
+                # one damaged inside the prefix, gets the reference's verdict instead of a miss)
+                extra = {'n_leading': n_lead} if leading and attempt == 0 else {}
                 status, arrays = self.codec.cache_read_slices(self._dev_cache, keys, b''.join(parts), offs, lens, rows,
                                                               self.n_channels, self.dtype, self._flags(), requests, **extra)
                 break

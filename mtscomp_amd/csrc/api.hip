@@ -1037,7 +1037,10 @@ int mts_cache_query(long cache_id, const long *chunk_keys, int n, int *present)
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(E->mu);
     if (!cache_alive(cache_id, c)) return MTS_E_ARG;
-    for (int i = 0; i < n; i++) present[i] = c->map.count(chunk_keys[i]) ? 1 : 0;
+    for (int i = 0; i < n; i++) {           // 0: not resident, else the number of (leading) channels the entry holds
+        auto it = c->map.find(chunk_keys[i]);
+        present[i] = it == c->map.end() ? 0 : it->second.cols > 0 ? it->second.cols : 1;
+    }
     return MTS_OK;
 }
 
@@ -1054,18 +1057,23 @@ static int cache_ensure(DevCache *c, Engine *E, int n_chunks, const long *chunk_
         std::sort(keys.begin(), keys.end());
         if (std::adjacent_find(keys.begin(), keys.end()) != keys.end()) { set_error("a chunk key is listed twice"); return MTS_E_ARG; }
     }
-    for (int i = 0; i < n_chunks; i++) {
-        if (n_rows[i] < 0) return MTS_E_ARG;
-        total_rows += n_rows[i];
-        chunk_status[i] = MTS_CHUNK_OK;
+    auto usable = [&](int i) -> bool {
         auto it = c->map.find(chunk_keys[i]);
-        if (it != c->map.end() && it->second.rows == n_rows[i] && it->second.cols >= n_cols && it->second.cols <= n_channels &&
-            it->second.size == (u64)n_rows[i] * it->second.cols * itemsize) { it->second.stamp = call_stamp; continue; }
-        if (c_lengths[i] <= 0) {
-            set_error("chunk key %ld is not resident%s and no compressed bytes were given", chunk_keys[i], it != c->map.end() ? " with the channels asked for" : "");
+        return it != c->map.end() && it->second.rows == n_rows[i] && it->second.cols >= n_cols && it->second.cols <= n_channels &&
+               it->second.size == (u64)n_rows[i] * it->second.cols * itemsize;
+    };
+    for (int i = 0; i < n_chunks; i++) {          // every key is looked at before anything is dropped: a miss leaves the cache as it was
+        if (n_rows[i] < 0) return MTS_E_ARG;
+        if (!usable(i) && c_lengths[i] <= 0) {
+            set_error("chunk key %ld is not resident%s and no compressed bytes were given", chunk_keys[i], c->map.count(chunk_keys[i]) ? " with the channels asked for" : "");
             return MTS_E_MISS;
         }
-        if (it != c->map.end()) c->drop(chunk_keys[i]);        // same key, other shape or fewer channels: decoded again
+    }
+    for (int i = 0; i < n_chunks; i++) {
+        total_rows += n_rows[i];
+        chunk_status[i] = MTS_CHUNK_OK;
+        if (usable(i)) { c->map.find(chunk_keys[i])->second.stamp = call_stamp; continue; }
+        c->drop(chunk_keys[i]);                    // same key, other shape or fewer channels: decoded again
         miss.push_back(i);
     }
     *total_rows_out = total_rows;

@@ -5,15 +5,18 @@ the shared library has not been built (``python -c "import __graft_entry__ as g;
 ``make -C mtscomp_amd/csrc``) and every compute call raises ``HipError`` when no MI355X is visible.
 """
 import ctypes as C
+import os
+import warnings
 from pathlib import Path
 
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-import os
 
-# (MTSCOMP_HIP_LIB: another build of the same library, for A/B measurements -- tools/ab_stage_times.py)
+# (MTSCOMP_HIP_LIB: another build of the same library, for A/B measurements -- tools/ab_stage_times.py; said out loud when used)
 LIB_PATH = Path(os.environ.get('MTSCOMP_HIP_LIB') or _HERE / 'libmtscomp_hip.so')
+if os.environ.get('MTSCOMP_HIP_LIB'):
+    warnings.warn('mtscomp_amd: MTSCOMP_HIP_LIB replaces the in-tree library with %s' % LIB_PATH, RuntimeWarning, stacklevel=2)
 
 FLAG_TIME_DIFF = 1
 FLAG_SPATIAL_DIFF = 2
@@ -248,11 +251,12 @@ def cache_destroy(cache_id):
 
 
 def cache_query(cache_id, keys):
+    """Per key: 0 = not resident, else the number of channels the resident entry holds."""
     keys = _longs(keys)
     present = np.zeros(keys.size, dtype=np.int32)
     _check(lib().mts_cache_query(int(cache_id), _lp(keys), int(keys.size), present.ctypes.data_as(C.POINTER(C.c_int))),
            'mts_cache_query')
-    return present.astype(bool)
+    return present
 
 
 def cache_read_rows(cache_id, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, row_begin, row_end):
@@ -292,7 +296,7 @@ def cache_read_slices(cache_id, keys, cdata, offs, lens, n_rows, n_channels, dty
     _check(lib().mts_cache_read_slices_leading(int(cache_id), n, _lp(keys), _ptr(cdata), _lp(offs), _lp(lens), _lp(rows), n_channels,
                                                dtype.itemsize, _dflags(flags, dtype), int(n_leading or n_channels), len(shapes), _lp(req),
                                                _ptr(out), _lp(out_offs), int(sum(sizes)), status.ctypes.data_as(C.POINTER(C.c_int))),
-           'mts_cache_read_slices')
+           'mts_cache_read_slices_leading')
     arrays = [out[int(o):int(o) + a * b * dtype.itemsize].view(dtype).reshape(a, b) for o, (a, b) in zip(out_offs, shapes)]
     return [int(x) for x in status[:n]], arrays
 

@@ -77,7 +77,7 @@ class CachingOracleCodec(OracleCodec):
         self.caches.pop(cid, None)
 
     def cache_query(self, cid, keys):
-        return np.array([k in self.caches[cid] for k in keys], dtype=bool)
+        return np.array([self.caches[cid][k].shape[1] if k in self.caches[cid] else 0 for k in keys], dtype=np.int32)
 
     def _ensure(self, cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, what):
         from mtscomp_amd import hip
@@ -190,4 +190,4 @@ class LeadingOracleCodec(CachingOracleCodec):
         return status, arrays
 
     def cache_query(self, cid, keys):
-        return np.array([k in self.caches[cid] for k in keys], dtype=bool)
+        return np.array([self.cols[(cid, k)] if k in self.caches[cid] else 0 for k in keys], dtype=np.int32)

@@ -550,7 +550,7 @@ def test_leading_channels_are_decoded_from_a_prefix(tmp_cfg):
     arr.tofile(raw)
     mtscomp_amd.compress(raw, tmp_cfg / 'lead.cbin', tmp_cfg / 'lead.ch', sample_rate=30000., n_channels=385, dtype=np.int16,
                          check_after_compress=False)
-    r = mtscomp_amd.decompress(tmp_cfg / 'lead.cbin', tmp_cfg / 'lead.ch')
+    r = mtscomp_amd.decompress(tmp_cfg / 'lead.cbin', tmp_cfg / 'lead.ch', partial_decode=True)
     reads = []
     orig = r._pread
     r._pread = lambda length, start: (reads.append(length), orig(length, start))[1]
@@ -565,6 +565,8 @@ def test_leading_channels_are_decoded_from_a_prefix(tmp_cfg):
     assert np.array_equal(r[60000:60010, 380:385], arr[60000:60010, 380:385])  # trailing channels: whole chunk
     got = r.read_slices([(slice(0, 90000, 1000), slice(0, 8)), (slice(45000, 45010), slice(2, 3))])
     assert np.array_equal(got[0], arr[0:90000:1000, 0:8]) and np.array_equal(got[1], arr[45000:45010, 2:3])
+    got = r.read_slices([(slice(0, 100), slice(0, 4)), (slice(5, 5), slice(None))])      # an empty request with all columns
+    assert np.array_equal(got[0], arr[0:100, 0:4]) and got[1].shape == (0, 385)
     r.close()
     # C ABI: a prefix that is too short is a miss, not an error and not a wrong answer
     z = hip.compress_chunks(arr[:30000], [0, 30000], hip.make_flags(), 6)[0]
@@ -587,3 +589,49 @@ def test_leading_channels_are_decoded_from_a_prefix(tmp_cfg):
         assert st == [hip.CHUNK_CORRUPT]
     finally:
         hip.cache_destroy(cid)
+
+
+def test_partial_reads_check_the_whole_chunk_by_default(tmp_cfg):
+    """mtscomp.py:618-621: every read inflates -- and adler32-checks -- the whole chunk.  Default settings: damage BEHIND the prefix
+    the first 32 channels need makes r[a:b, :32] raise; with partial_decode=True (the caller's explicit choice) damage INSIDE the prefix
+    is refused too (the whole-chunk retry gives the reference's verdict), and a stream the prefix decoder cannot follow (Z_FIXED:
+    fixed Huffman blocks only) is read correctly through that retry."""
+    import zlib
+    arr = synth_int16(0, 2 * 30000, 385, 9)
+    raw = tmp_cfg / 'pc.bin'
+    arr.tofile(raw)
+    mtscomp_amd.compress(raw, tmp_cfg / 'pc.cbin', tmp_cfg / 'pc.ch', sample_rate=30000., n_channels=385, dtype=np.int16,
+                         check_after_compress=False)
+    hdr = json.loads((tmp_cfg / 'pc.ch').read_text())
+    offs = hdr['chunk_offsets']
+    data = bytearray((tmp_cfg / 'pc.cbin').read_bytes())
+    behind = bytearray(data)
+    behind[offs[1] - 1000] ^= 0x40                                  # the tail of chunk 0: far behind the first 32 channels
+    (tmp_cfg / 'behind.cbin').write_bytes(behind)
+    r = mtscomp_amd.decompress(tmp_cfg / 'behind.cbin', tmp_cfg / 'pc.ch')
+    with pytest.raises(IOError):
+        r[100:200, :32]
+    assert np.array_equal(r[30100:30200, :32], arr[30100:30200, :32])      # the other chunk stays readable
+    r.close()
+    inside = bytearray(data)
+    for k in range(2000, 2064):
+        inside[k] ^= 0xff                                           # inside the first channels' part of chunk 0
+    (tmp_cfg / 'inside.cbin').write_bytes(inside)
+    r = mtscomp_amd.decompress(tmp_cfg / 'inside.cbin', tmp_cfg / 'pc.ch', partial_decode=True)
+    with pytest.raises(IOError):
+        r[100:200, :32]
+    r.close()
+    # a chunk of fixed-Huffman blocks only (another encoder's output): the prefix decoder declines, the whole-chunk retry reads it
+    from oracle import oracle as O
+    flags = hip.make_flags()
+    zs = []
+    for i in range(2):
+        stream = O.delta_transpose(arr[i * 30000:(i + 1) * 30000], flags)
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        zs.append(c.compress(bytes(stream)) + c.flush())
+    (tmp_cfg / 'fixed.cbin').write_bytes(b''.join(zs))
+    hdr['chunk_offsets'] = [0, len(zs[0]), len(zs[0]) + len(zs[1])]
+    (tmp_cfg / 'fixed.ch').write_text(json.dumps(hdr))
+    r = mtscomp_amd.decompress(tmp_cfg / 'fixed.cbin', tmp_cfg / 'fixed.ch', partial_decode=True)
+    assert np.array_equal(r[100:200, :32], arr[100:200, :32])
+    r.close()
