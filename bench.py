@@ -10,11 +10,17 @@ N=1: BASELINE.json configs[1] (385 ch @ 30 kHz, 60 s, 1 s chunks, level 6).  Wit
 N x 60 s recording are sharded round-robin (chunk i -> rank i mod N, no data-path collective; only the
 compressed sizes are gathered), so per-GPU work is fixed: weak scaling.
 
-`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process -- before it has made any HIP / torch.cuda call --
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process -- before it has made any HIP call --
 starts the N ranks itself (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, the command the driver uses),
 relays rank 0's JSON line and exits with the child's status; fewer than N visible devices is an error, never a silent
-downgrade.  (`--dist-backend gloo --oversubscribe` lets the N ranks share the visible devices: a smoke test of the
-multi-rank path on a one-GPU box, not a measurement.)
+downgrade.  (`--oversubscribe` lets the N ranks share the visible devices: a smoke test of the multi-rank path on a one-GPU
+box, not a measurement.)
+
+The path has no data-path collective (chunks are independent zlib streams): the ranks' only exchange is the host-side gather of
+the compressed sizes, so the process group is gloo on CPU tensors by default and torch is used for torch.distributed alone --
+device memory, copies and waits go through libmtscomp_hip.so (mts_dev_alloc / mts_dev_copy / mts_dev_sync): ONE HIP runtime per
+process, whatever the import order.  `--dist-backend nccl` additionally brings up an RCCL group (init + one all-reduce outside
+the timed region, under a watchdog that exits non-zero if it hangs); the size exchange stays on the host group.
 
 The JSON line carries, next to the contract's keys:
   roofline             the dominant kernel (k_match5): algorithmic bytes (R + C of the batch) / its launch time
@@ -55,7 +61,9 @@ def parse_args(argv=None):
     p.add_argument('--cpu-chunks', type=int, default=0, help='chunks in the all-cores CPU sample (default: one per host cpu)')
     p.add_argument('--no-extras', action='store_true', help='skip the configs[2] / configs[4] measurements')
     p.add_argument('--extras-seconds', type=int, default=600, help='length of the random-read file (configs[2])')
-    p.add_argument('--dist-backend', default='nccl', choices=('nccl', 'gloo'), help='process group backend (nccl = RCCL)')
+    p.add_argument('--dist-backend', default='gloo', choices=('nccl', 'gloo'),
+                   help='gloo (default): the host-side size exchange is the path\'s only exchange; nccl: also bring up an RCCL group (init check)')
+    p.add_argument('--init-timeout', type=int, default=180, help='seconds the process group may take to come up before the rank exits non-zero')
     p.add_argument('--oversubscribe', action='store_true',
                    help='let ranks share devices (rank -> device rank mod visible): smoke test of the N > 1 path on fewer GPUs, not a measurement')
     p.add_argument('--master-port', type=int, default=0, help='rendezvous port of the self-launched ranks (default: a free one)')
@@ -70,17 +78,18 @@ def shard_ids(rank, world, n_total):
     return list(range(rank, n_total, world))
 
 
-def gather_chunk_offsets(local_sizes, rank, world, dist=None, device='cpu'):
+def gather_chunk_offsets(local_sizes, rank, world, dist=None, group=None):
     """The only cross-rank step of the path (mtscomp.py:474-483): every rank's compressed sizes -> chunk_offsets of the whole
-    recording (exclusive prefix sum in global chunk order i = rank + k * world).  All ranks own the same number of chunks."""
+    recording (exclusive prefix sum in global chunk order i = rank + k * world).  All ranks own the same number of chunks.
+    A host-side gather (CPU tensors over `group`, a gloo group): no device collective anywhere on the path."""
     local_sizes = np.asarray(local_sizes, dtype=np.int64)
     if world == 1:
         return np.concatenate(([0], np.cumsum(local_sizes)))
     import torch
-    t = torch.from_numpy(local_sizes).to(device)
+    t = torch.from_numpy(np.ascontiguousarray(local_sizes))
     out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
-    allsz = torch.stack(out, dim=1).reshape(-1).cpu().numpy()          # [k][rank] -> global order
+    dist.all_gather(out, t, group=group)
+    allsz = torch.stack(out, dim=1).reshape(-1).numpy()          # [k][rank] -> global order
     return np.concatenate(([0], np.cumsum(allsz)))
 
 
@@ -202,32 +211,29 @@ def lp(a):
     return a.ctypes.data_as(C.POINTER(C.c_long))
 
 
-def build_synth_file(torch, hip, L, dev, seconds, tmp, nc=385):
+def build_synth_file(hip, dev, seconds, tmp, nc=385):
     """A `seconds` s recording of the synthetic generator as data.cbin + data.ch under `tmp`, compressed on the device a minute
     at a time (the raw file is never materialised).  Returns (n_samples, compressed bytes)."""
     piece = 60
     cb = (hip.compress_bound(RATE * nc * 2) + 255) // 256 * 256
-    raw = torch.empty((piece * RATE, nc), dtype=torch.int16, device='cuda')
-    cbuf = torch.empty(piece * cb, dtype=torch.uint8, device='cuda')
+    raw = hip.DevBuffer(piece * RATE * nc * 2, dev)
+    cbuf = hip.DevBuffer(piece * cb, dev)
     flags = hip.make_flags(True, False, 'F')
     offsets = [0]
     with open(tmp / 'data.cbin', 'wb') as f:
         for p0 in range(0, seconds, piece):
             n = min(piece, seconds - p0)
-            for k in range(n):
-                rc = L.mts_dev_synth_int16(dev, None, C.c_void_p(raw[k * RATE:].data_ptr()), (p0 + k) * RATE, (p0 + k + 1) * RATE, nc, 0)
-                assert rc == 0
+            hip.dev_synth_int16(raw, 0, p0 * RATE, (p0 + n) * RATE, nc, 0)
             bounds = np.arange(n + 1, dtype=np.int64) * RATE
             slots = np.arange(n, dtype=np.int64) * cb
             sizes = np.zeros(n, dtype=np.int64)
-            rc = L.mts_dev_compress_chunks(dev, None, C.c_void_p(raw.data_ptr()), nc, 2, lp(bounds), n, flags, 6, C.c_void_p(cbuf.data_ptr()),
-                                           lp(slots), lp(sizes))
-            assert rc == 0, L.mts_last_error()
-            host = cbuf[:n * cb].cpu().numpy()
+            hip.dev_compress_chunks(raw, nc, 2, bounds, flags, 6, cbuf, slots, sizes)
+            host = cbuf.download(0, n * cb)
             for k in range(n):
                 f.write(host[k * cb:k * cb + int(sizes[k])].tobytes())
                 offsets.append(offsets[-1] + int(sizes[k]))
-    del raw, cbuf
+    raw.free()
+    cbuf.free()
     n_samples = seconds * RATE
     header = {'version': '1.0', 'algorithm': 'zlib', 'comp_level': -1, 'do_time_diff': True, 'do_spatial_diff': False, 'dtype': 'int16',
               'n_channels': nc, 'sample_rate': float(RATE), 'chunk_bounds': list(range(0, n_samples + 1, RATE)), 'chunk_offsets': offsets,
@@ -236,12 +242,21 @@ def build_synth_file(torch, hip, L, dev, seconds, tmp, nc=385):
     return n_samples, offsets[-1]
 
 
+def synth_host(hip, dev, t0, t1, nc):
+    """Rows [t0, t1) of the synthetic recording as a host array (generated on the device)."""
+    buf = hip.DevBuffer((t1 - t0) * nc * 2, dev)
+    hip.dev_synth_int16(buf, 0, t0, t1, nc, 0)
+    out = buf.download(dtype=np.int16).reshape(t1 - t0, nc)
+    buf.free()
+    return out
+
+
 def window_starts(n_samples, n_windows):
     """BASELINE configs[2]'s windows: start = splitmix64(i) mod (n_samples - 30000)  (SURVEY 8d)."""
     return [int(splitmix(i) % (n_samples - RATE)) for i in range(n_windows)]
 
 
-def extra_random_read(torch, hip, L, dev, seconds, n_windows=1000):
+def extra_random_read(hip, dev, seconds, n_windows=1000, partial_decode=False):
     """BASELINE configs[2]: a `seconds` s 385-channel file (compressed on the device, written to tmpfs with its header), then
     Reader[s:s+30000] at s = splitmix(i) mod (n_samples - 30000): first pass (chunks decoded on first touch, then resident in
     the decoded-chunk cache in HBM) and second pass (every chunk resident); windows checked against the generator."""
@@ -251,7 +266,7 @@ def extra_random_read(torch, hip, L, dev, seconds, n_windows=1000):
     tmp = Path(tempfile.mkdtemp(prefix='mtsbench_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None))
     os.environ.setdefault('HOME', str(tmp))
     t_gen = time.perf_counter()
-    n_samples, cbytes = build_synth_file(torch, hip, L, dev, seconds, tmp, nc)
+    n_samples, cbytes = build_synth_file(hip, dev, seconds, tmp, nc)
     offsets = [0, cbytes]
     t_gen = time.perf_counter() - t_gen
     r = mtscomp_amd.decompress(tmp / 'data.cbin', tmp / 'data.ch')
@@ -265,27 +280,25 @@ def extra_random_read(torch, hip, L, dev, seconds, n_windows=1000):
         passes.append((time.perf_counter() - t0, nb))
     # a few windows against the generator, and a column subset through the device gather
     ok = True
-    chk = torch.empty((RATE, nc), dtype=torch.int16, device='cuda')
-    assert L.mts_dev_synth_int16(dev, None, C.c_void_p(chk.data_ptr()), starts[99], starts[99] + RATE, nc, 0) == 0
-    r_last = chk.cpu().numpy()
+    r_last = synth_host(hip, dev, starts[99], starts[99] + RATE, nc)
     for s in starts[:3]:
-        assert L.mts_dev_synth_int16(dev, None, C.c_void_p(chk.data_ptr()), s, s + RATE, nc, 0) == 0
-        want = chk.cpu().numpy()
+        want = synth_host(hip, dev, s, s + RATE, nc)
         ok = ok and np.array_equal(r[s:s + RATE], want) and np.array_equal(r[s:s + RATE, 10:40], want[:, 10:40])
     t0 = time.perf_counter()
     got = r.read_slices([(slice(s, s + RATE), slice(0, 32)) for s in starts[:256]])
     t_cols = time.perf_counter() - t0
     r.close()
-    # the same column windows one at a time from a Reader that has nothing resident: the chunks are inflated only as far as the
-    # leading 32 channels reach, from a prefix of their bytes (mts_cache_read_slices_leading), against whole chunks for all columns
+    # the same column windows one at a time from a Reader that has nothing resident.  Default settings inflate and check whole chunks
+    # like the reference; with partial_decode=True (the caller's explicit choice) the chunks are inflated only as far as
+    # the leading 32 channels reach, from a prefix of their bytes (mts_cache_read_slices_leading)
     cold = {}
-    for cols in (32, nc):
-        rc_ = mtscomp_amd.decompress(tmp / 'data.cbin', tmp / 'data.ch')
+    for cols, key, kw in ((32, 'cols32', {}), (32, 'cols32_partial', {'partial_decode': True}), (nc, 'all', {})):
+        rc_ = mtscomp_amd.decompress(tmp / 'data.cbin', tmp / 'data.ch', **kw)
         t0 = time.perf_counter()
         for s in starts[:100]:
             w = rc_[s:s + RATE, 0:cols]
-        cold[cols] = (time.perf_counter() - t0) / 100 * 1e3
-        ok = ok and np.array_equal(w, r_last[:, 0:cols]) if cols == nc else ok
+        cold[key] = (time.perf_counter() - t0) / 100 * 1e3
+        ok = ok and np.array_equal(w, r_last[:, 0:cols])
         rc_.close()
     for p in (tmp / 'data.cbin', tmp / 'data.ch'):
         p.unlink()
@@ -299,24 +312,24 @@ def extra_random_read(torch, hip, L, dev, seconds, n_windows=1000):
             'first_pass_ms_per_window': passes[0][0] / n_windows * 1e3, 'first_pass_gbps': passes[0][1] / passes[0][0] / 1e9,
             'resident_ms_per_window': passes[1][0] / n_windows * 1e3, 'resident_gbps': passes[1][1] / passes[1][0] / 1e9,
             'columns_0_32_of_256_windows_one_call_ms': t_cols * 1e3, 'columns_bytes_returned': int(sum(g.nbytes for g in got)),
-            'cold_ms_per_window_columns_0_32': cold[32], 'cold_ms_per_window_all_columns': cold[nc],
+            'cold_ms_per_window_columns_0_32': cold['cols32'], 'cold_ms_per_window_columns_0_32_partial_decode': cold['cols32_partial'],
+            'cold_ms_per_window_all_columns': cold['all'],
             'verified': bool(ok), 'build_file_s': t_gen,
             'reader': 'Reader[a:b] through the decoded-chunk cache in HBM (MTSCOMP_DEVICE_CACHE_GB, default 32); pread + H2D + decode on first touch, one D2H of the rows after'}
 
 
-def extra_level_sweep(torch, hip, L, dev, seconds=60, levels=(1, 2, 3, 6, 9)):
+def extra_level_sweep(hip, dev, seconds=60, levels=(1, 2, 3, 6, 9)):
     """BASELINE configs[4] shape: 1024 ch @ 30 kHz, chunk = 0.25 s (7500 rows); `seconds` s of it, compressed on the device at
     levels 1, 2, 3 (deflate_fast), 6 and 9; chunk 0 of every level checked against stdlib zlib."""
     import zlib
     from oracle import oracle as O
     nc, rows = 1024, 7500
     n = seconds * 4
-    raw = torch.empty((n * rows, nc), dtype=torch.int16, device='cuda')
-    for k in range(n):
-        assert L.mts_dev_synth_int16(dev, None, C.c_void_p(raw[k * rows:].data_ptr()), k * rows, (k + 1) * rows, nc, 0) == 0
+    raw = hip.DevBuffer(n * rows * nc * 2, dev)
+    hip.dev_synth_int16(raw, 0, 0, n * rows, nc, 0)
     cb = (hip.compress_bound(rows * nc * 2) + 255) // 256 * 256
-    cbuf = torch.empty(n * cb, dtype=torch.uint8, device='cuda')
-    back = torch.empty_like(raw)
+    cbuf = hip.DevBuffer(n * cb, dev)
+    back = hip.DevBuffer(raw.nbytes, dev)
     bounds = np.arange(n + 1, dtype=np.int64) * rows
     slots = np.arange(n, dtype=np.int64) * cb
     sizes = np.zeros(n, dtype=np.int64)
@@ -324,32 +337,31 @@ def extra_level_sweep(torch, hip, L, dev, seconds=60, levels=(1, 2, 3, 6, 9)):
     ooffs = np.arange(n, dtype=np.int64) * rows * nc * 2
     status = np.zeros(n, dtype=np.int32)
     flags = hip.make_flags(True, False, 'F')
-    stream0 = O.delta_transpose(raw[:rows].cpu().numpy(), flags).tobytes()
+    stream0 = O.delta_transpose(raw.download(0, rows * nc * 2, np.int16).reshape(rows, nc), flags).tobytes()
     out = {}
     for level in levels:
         best = None
         for rep in range(2):                                  # (the first call at a level also allocates its workspace)
-            torch.cuda.synchronize()
+            hip.dev_sync(dev)
             t0 = time.perf_counter()
-            rc = L.mts_dev_compress_chunks(dev, None, C.c_void_p(raw.data_ptr()), nc, 2, lp(bounds), n, flags, level, C.c_void_p(cbuf.data_ptr()),
-                                           lp(slots), lp(sizes))
-            torch.cuda.synchronize()
+            hip.dev_compress_chunks(raw, nc, 2, bounds, flags, level, cbuf, slots, sizes)
+            hip.dev_sync(dev)
             dt = time.perf_counter() - t0
-            assert rc == 0, L.mts_last_error()
             best = dt if best is None else min(best, dt)
         dt_d = None
         for rep in range(2):                                  # (the first call at a new shape also allocates the inflate workspace)
             t0 = time.perf_counter()
-            rc = L.mts_dev_decompress_chunks(dev, None, C.c_void_p(cbuf.data_ptr()), lp(slots), lp(sizes), lp(nrows), n, nc, 2, flags,
-                                             C.c_void_p(back.data_ptr()), lp(ooffs), status.ctypes.data_as(C.POINTER(C.c_int)))
-            torch.cuda.synchronize()
+            hip.dev_decompress_chunks(cbuf, slots, sizes, nrows, nc, 2, flags, back, ooffs, status)
+            hip.dev_sync(dev)
             dt = time.perf_counter() - t0
-            assert rc == 0 and not status.any()
+            assert not status.any()
             dt_d = dt if dt_d is None else min(dt_d, dt)
-        ident = cbuf[:int(sizes[0])].cpu().numpy().tobytes() == zlib.compress(stream0, level)
+        ident = cbuf.download(0, int(sizes[0])).tobytes() == zlib.compress(stream0, level)
         out[str(level)] = {'ratio': float(sizes.sum()) / (n * rows * nc * 2), 'compress_gbps': n * rows * nc * 2 / best / 1e9,
-                           'decompress_gbps': n * rows * nc * 2 / dt_d / 1e9, 'round_trip_ok': bool(torch.equal(back, raw)),
+                           'decompress_gbps': n * rows * nc * 2 / dt_d / 1e9, 'round_trip_ok': back.diff(raw)[0] == 0,
                            'byte_identical_chunk0': bool(ident)}
+    for b in (raw, cbuf, back):
+        b.free()
     out['workload'] = '1024 ch @ 30 kHz, %d s, chunk = 0.25 s (%d chunks of 15.36 MB), device resident' % (seconds, n)
     return out
 
@@ -467,46 +479,75 @@ def extra_in_process_multi_gpu(hip, x, nc, n_dev):
             'path': 'HipCodec(devices=range(N)): host arrays in, bytes out, one host thread per GPU (rank 0 of the bench, the other ranks idle)'}
 
 
+def init_ranks(args, rank, world, dev):
+    """The process groups of a multi-rank run, under a watchdog: a rendezvous or RCCL bring-up that does not finish within
+    --init-timeout seconds ends this rank with a message and a non-zero status instead of hanging the node.
+    Returns (dist, host_group): host_group is a gloo group -- every exchange of the run goes over it."""
+    import datetime
+    import threading
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(args.init_timeout):
+            sys.stderr.write('bench.py: rank %d: the %s process group did not come up within %d s; giving up\n' % (rank, args.dist_backend, args.init_timeout))
+            sys.stderr.flush()
+            os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
+    timeout = datetime.timedelta(seconds=args.init_timeout)
+    try:
+        if args.dist_backend == 'gloo':
+            dist.init_process_group('gloo', timeout=timeout)
+            host_group = dist.group.WORLD
+        else:
+            import torch
+            torch.cuda.set_device(dev)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev), timeout=timeout)
+            host_group = dist.new_group(backend='gloo', timeout=timeout)
+            t = torch.ones(1, device='cuda')
+            dist.all_reduce(t)                              # RCCL up and counting: outside the timed region, never on the data path
+            torch.cuda.synchronize()
+            assert int(t.item()) == world, 'RCCL all-reduce over %d ranks gave %r' % (world, t.item())
+        dist.barrier(group=host_group)
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write('bench.py: rank %d: process group (%s) failed: %r\n' % (rank, args.dist_backend, e))
+        sys.stderr.flush()
+        os._exit(3)
+    done.set()
+    return dist, host_group
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # not under torch.distributed yet: start the ranks (nothing in this process has touched the GPU)
         sys.exit(self_launch(args, argv))
-    import torch
-    import torch.distributed as dist
-    from mtscomp_amd import hip
-
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != max(args.gpus, 1):
         sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
         sys.exit(2)
-    have = visible_gpus()
+    if world > 1:
+        import torch  # noqa: F401  (torch.distributed only; imported before the library so that, if torch's HIP runtime is ever
+        #                            initialised -- --dist-backend nccl --, the library resolves to that same runtime)
+    from mtscomp_amd import hip
+    have = hip.device_count()
     if local_rank >= have and not args.oversubscribe:
         sys.stderr.write('bench.py: rank %d has no device (%d visible)\n' % (local_rank, have))
         sys.exit(2)
+    hip.require_device()
     dev = local_rank % max(have, 1)
     if args.oversubscribe and world > have and args.dist_backend == 'nccl':
         # RCCL refuses two ranks on one device ("Duplicate GPU detected"); the shared-device smoke test runs over gloo
         if rank == 0:
             sys.stderr.write('bench.py: %d ranks share %d device(s): process group over gloo instead of nccl\n' % (world, have))
         args.dist_backend = 'gloo'
-    gloo = args.dist_backend == 'gloo'
-    xdev = 'cpu' if gloo else 'cuda'                     # where the few numbers that cross ranks live
+    dist = host_group = None
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(dev)
-        if gloo:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
-        # (a host-side group for the last wait: an RCCL barrier would park a spinning kernel on every other GPU while rank 0
-        # runs its after-the-measurement extras)
-        host_group = dist.new_group(backend='gloo')
-    torch.cuda.set_device(dev)
-    hip.require_device()
+        dist, host_group = init_ranks(args, rank, world, dev)
     L = hip.lib()
 
     nc, rate = args.channels, RATE
@@ -514,20 +555,18 @@ def main(argv=None):
     row = nc * 2
     chunk_bytes = rate * row
     raw_bytes = n_chunks * chunk_bytes
-    stream = torch.cuda.current_stream()
-    sh = C.c_void_p(stream.cuda_stream)
+    sh = None                                   # the library's default stream on `dev`
 
     # synthetic recording, generated on device: this rank owns global chunks rank, rank + world, ... of a world x 60 s recording
     mine = shard_ids(rank, world, n_chunks * world)
-    raw = torch.empty((n_chunks * rate, nc), dtype=torch.int16, device='cuda')
+    raw = hip.DevBuffer(raw_bytes, dev)
     for k, g in enumerate(mine):
-        rc = L.mts_dev_synth_int16(dev, sh, C.c_void_p(raw[k * rate:].data_ptr()), g * rate, (g + 1) * rate, nc, 0)
-        assert rc == 0, hip.lib().mts_last_error()
-    torch.cuda.synchronize()
+        hip.dev_synth_int16(raw, k * chunk_bytes, g * rate, (g + 1) * rate, nc, 0)
+    hip.dev_sync(dev)
 
     bound = (hip.compress_bound(chunk_bytes) + 255) // 256 * 256
-    cbuf = torch.empty(n_chunks * bound, dtype=torch.uint8, device='cuda')
-    back = torch.empty_like(raw)
+    cbuf = hip.DevBuffer(n_chunks * bound, dev)
+    back = hip.DevBuffer(raw_bytes, dev)
     bounds = np.arange(n_chunks + 1, dtype=np.int64) * rate
     slots = np.arange(n_chunks, dtype=np.int64) * bound
     sizes = np.zeros(n_chunks, dtype=np.int64)
@@ -537,19 +576,17 @@ def main(argv=None):
     flags = hip.make_flags(True, False, 'F')
 
     def compress():
-        rc = L.mts_dev_compress_chunks(dev, sh, C.c_void_p(raw.data_ptr()), nc, 2, lp(bounds), n_chunks, flags, 6,
-                                       C.c_void_p(cbuf.data_ptr()), lp(slots), lp(sizes))
+        rc = L.mts_dev_compress_chunks(dev, sh, raw.at(), nc, 2, lp(bounds), n_chunks, flags, 6, cbuf.at(), lp(slots), lp(sizes))
         assert rc == 0, L.mts_last_error()
 
     def decompress():
-        rc = L.mts_dev_decompress_chunks(dev, sh, C.c_void_p(cbuf.data_ptr()), lp(slots), lp(sizes), lp(rows), n_chunks,
-                                         nc, 2, flags, C.c_void_p(back.data_ptr()), lp(ooffs),
+        rc = L.mts_dev_decompress_chunks(dev, sh, cbuf.at(), lp(slots), lp(sizes), lp(rows), n_chunks, nc, 2, flags, back.at(), lp(ooffs),
                                          status.ctypes.data_as(C.POINTER(C.c_int)))
         assert rc == 0, L.mts_last_error()
         assert not status.any(), status
 
     def gather_sizes():
-        return gather_chunk_offsets(sizes, rank, world, dist, xdev)
+        return gather_chunk_offsets(sizes, rank, world, dist, host_group)
 
     stage = {}
 
@@ -557,10 +594,11 @@ def main(argv=None):
         for name, ms in hip.last_stage_times(dev):
             stage.setdefault(name, []).append(ms)
 
-    def barrier():
+    def barrier():                                  # every rank's device idle, then every rank here (the contract's barrier + synchronize)
+        hip.dev_sync(dev)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.barrier(group=host_group)
+        hip.dev_sync(dev)
 
     for _ in range(args.warmup):
         compress(); decompress(); gather_sizes()
@@ -582,19 +620,21 @@ def main(argv=None):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed, t_c, t_d], dtype=torch.float64, device=xdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        import torch
+        t = torch.tensor([elapsed, t_c, t_d], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=host_group)
         elapsed, t_c, t_d = t.tolist()
 
     # correctness of what was timed (outside the timed region): device round trip on every rank + oracle spot check
-    assert torch.equal(back, raw), 'round trip mismatch'
+    n_diff, first_diff = back.diff(raw)
+    assert n_diff == 0, 'round trip mismatch: %d bytes differ, the first at %d' % (n_diff, first_diff)
     csize_local = int(sizes.sum())
     csize = int(offsets[-1]) if args.steps else csize_local
     ok_oracle = None
     if rank == 0:
         from oracle import oracle as O
-        first = raw[:rate].cpu().numpy()
-        z0 = cbuf[:int(sizes[0])].cpu().numpy().tobytes()
+        first = raw.download(0, chunk_bytes, np.int16).reshape(rate, nc)
+        z0 = cbuf.download(0, int(sizes[0])).tobytes()
         ok_oracle = z0 == O.ref_compress_chunk(first)
         assert ok_oracle, 'chunk 0 is not byte-identical to zlib level 6'
 
@@ -633,7 +673,7 @@ def main(argv=None):
                                    '(BASELINE configs[1])' % (nc, args.seconds),
                        'n_channels': nc, 'chunks_per_gpu': n_chunks, 'chunk_bytes': chunk_bytes,
                        'sharding': 'chunk i -> rank i mod N (round robin), no collective on the data path; the compressed sizes are '
-                                   'all-gathered (%s) and prefix-summed into chunk_offsets' % args.dist_backend,
+                                   'gathered on the host (gloo, CPU tensors) and prefix-summed into chunk_offsets; process group: %s' % args.dist_backend,
                        'rank_chunks': {str(r): shard_ids(r, world, n_chunks * world) for r in range(world)} if world > 1 else None,
                        'oversubscribed': bool(args.oversubscribe and world > have)},
             'compress_gbps': raw_bytes * world * args.steps / t_c / 1e9,
@@ -651,7 +691,7 @@ def main(argv=None):
         x_host = None
         cpu_chunks = None
         if (not args.no_cpu_baseline or not args.no_extras) and world == 1:
-            x_host = raw.cpu().numpy()
+            x_host = raw.download(dtype=np.int16).reshape(n_chunks * rate, nc)
         if not args.no_cpu_baseline and world == 1:             # (the CPU comparison is taken once, at N = 1)
             try:
                 res['cpu_baseline'], cpu_chunks = cpu_baseline(x_host, nc, n_chunks, args.cpu_chunks)
@@ -660,7 +700,7 @@ def main(argv=None):
         if cpu_chunks is not None:
             # the whole recording, not chunk 0 alone: every chunk the timed region produced against the CPU path's bytes
             import hashlib
-            host = cbuf.cpu().numpy()
+            host = cbuf.download()
             mine_c = [host[int(slots[k]):int(slots[k]) + int(sizes[k])].tobytes() for k in range(n_chunks)]
             same = [a == b for a, b in zip(mine_c, cpu_chunks)]
             res['byte_identical_chunks'] = '%d/%d' % (sum(same), n_chunks)
@@ -669,12 +709,12 @@ def main(argv=None):
             del host, mine_c
             assert all(same), 'chunks %s differ from zlib level 6' % [i for i, ok in enumerate(same) if not ok][:8]
         if not args.no_extras and world == 1:
-            back = cbuf = raw = None                # (room for the extras' buffers)
-            torch.cuda.empty_cache()
+            for b in (back, cbuf, raw):             # (room for the extras' buffers)
+                b.free()
             extras = {}
             for name, fn in (('file_to_file', lambda: extra_file_to_file(x_host, nc, not args.no_cpu_baseline)),
-                             ('random_read', lambda: extra_random_read(torch, hip, L, dev, args.extras_seconds)),
-                             ('level_sweep', lambda: extra_level_sweep(torch, hip, L, dev))):
+                             ('random_read', lambda: extra_random_read(hip, dev, args.extras_seconds)),
+                             ('level_sweep', lambda: extra_level_sweep(hip, dev))):
                 t1 = time.perf_counter()
                 try:
                     extras[name] = fn()
@@ -685,7 +725,7 @@ def main(argv=None):
         if not args.no_extras and world > 1 and not args.oversubscribe:
             t1 = time.perf_counter()
             try:
-                res['extras'] = {'in_process_multi_gpu': extra_in_process_multi_gpu(hip, raw.cpu().numpy(), nc, world)}
+                res['extras'] = {'in_process_multi_gpu': extra_in_process_multi_gpu(hip, raw.download(dtype=np.int16).reshape(n_chunks * rate, nc), nc, world)}
             except Exception as e:  # noqa: BLE001
                 res['extras'] = {'in_process_multi_gpu': {'error': repr(e)}}
             res['extras']['in_process_multi_gpu']['wall_s'] = time.perf_counter() - t1

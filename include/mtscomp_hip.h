@@ -162,6 +162,17 @@ int mts_dev_decompress_chunks(int device, void *stream, const unsigned char *d_c
 int mts_dev_synth_int16(int device, void *stream, void *d_out, long t0, long t1, int n_channels,
                         long seed);
 
+/* Device memory for callers of the dev_* entry points (bench.py, the tests at BASELINE's sizes): allocate, copy and wait through
+ * THIS library, so that a process holds its recordings with the HIP runtime the kernels are launched with and needs no other
+ * (torch ships its own runtime libraries).  kind: 0 host -> device, 1 device -> host, 2 device -> device; mts_dev_copy returns
+ * when the copy is done.  mts_dev_compare: bytes that differ between two device buffers (16-byte aligned) and the first such offset
+ * (-1: none) -- the round-trip check of a recording that stays in HBM. */
+int mts_dev_alloc(int device, long nbytes, void **d_ptr);
+int mts_dev_free(int device, void *d_ptr);
+int mts_dev_copy(int device, void *stream, void *dst, const void *src, long nbytes, int kind);
+int mts_dev_sync(int device);               /* hipDeviceSynchronize on `device` */
+int mts_dev_compare(int device, void *stream, const void *d_a, const void *d_b, long nbytes, long *n_diff, long *first_diff);
+
 /* Kernel-stage timings (ms, HIP events on the launch stream) of the last dev_* call on `device`:
  * fills up to `cap` entries of (name, ms); returns the number of stages.  For bench.py / profiling. */
 int mts_last_stage_times(int device, const char **names, float *ms, int cap);

@@ -923,6 +923,97 @@ int mts_dev_synth_int16(int device, void *stream, void *d_out, long t0, long t1,
     return launch_synth_int16((hipStream_t)stream, (int16_t *)d_out, t0, t1, n_channels, seed);
 }
 
+// ------------------------------------------------------------------------------------------------
+// device memory for callers of the dev_* entry points: a process that keeps its recordings in HBM allocates, copies and waits
+// through THIS library -- one HIP runtime per process, the one these kernels are launched with (no second runtime's handles)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_count_diff(const u8 *__restrict__ a, const u8 *__restrict__ b, u64 n, unsigned long long *__restrict__ out /* count, first */)
+{
+    const u64 n16 = n / 16, stride = (u64)gridDim.x * blockDim.x;
+    u32 cnt = 0;
+    u64 first = ~0ull;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const uint4 x = ((const uint4 *)a)[i], y = ((const uint4 *)b)[i];
+        if (x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w) {
+            for (int k = 0; k < 16; k++) if (a[i * 16 + k] != b[i * 16 + k]) { cnt++; if (first == ~0ull) first = i * 16 + k; }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (u32)(n & 15)) { const u64 j = n16 * 16 + threadIdx.x; if (a[j] != b[j]) { cnt++; first = first < j ? first : j; } }
+    if (cnt) { atomicAdd(&out[0], (unsigned long long)cnt); atomicMin(&out[1], (unsigned long long)first); }
+}
+
+int mts_dev_alloc(int device, long nbytes, void **d_ptr)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    if (nbytes < 0 || !d_ptr) return MTS_E_ARG;
+    MTS_HIP(hipSetDevice(E->dev));
+    void *p = nullptr;
+    if (hipMalloc(&p, nbytes > 0 ? (size_t)nbytes : 1) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc of %ld bytes failed", nbytes); return MTS_E_NOMEM; }
+    *d_ptr = p;
+    return MTS_OK;
+}
+
+int mts_dev_free(int device, void *d_ptr)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    MTS_HIP(hipSetDevice(E->dev));
+    if (d_ptr) MTS_HIP(hipFree(d_ptr));
+    return MTS_OK;
+}
+
+int mts_dev_copy(int device, void *stream, void *dst, const void *src, long nbytes, int kind)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    if (nbytes < 0 || kind < 0 || kind > 2) return MTS_E_ARG;
+    MTS_HIP(hipSetDevice(E->dev));
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (nbytes) MTS_HIP(hipMemcpyAsync(dst, src, (size_t)nbytes, k, (hipStream_t)stream));
+    MTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return MTS_OK;
+}
+
+int mts_dev_sync(int device)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    MTS_HIP(hipSetDevice(E->dev));
+    MTS_HIP(hipDeviceSynchronize());
+    return MTS_OK;
+}
+
+int mts_dev_compare(int device, void *stream, const void *d_a, const void *d_b, long nbytes, long *n_diff, long *first_diff)
+{
+    Engine *E;
+    int rc = get_engine(device, &E);
+    if (rc) return rc;
+    if (nbytes < 0 || !n_diff) return MTS_E_ARG;
+    if (((uintptr_t)d_a | (uintptr_t)d_b) & 15) { set_error("mts_dev_compare: buffers must be 16-byte aligned"); return MTS_E_ARG; }
+    std::lock_guard<std::mutex> lk(E->mu);
+    MTS_HIP(hipSetDevice(E->dev));
+    unsigned long long *d_out = nullptr, h[2] = {0, ~0ull};
+    MTS_HIP(hipMalloc(&d_out, 16));
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(d_out, h, 16, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && nbytes) {
+        hipLaunchKernelGGL(k_count_diff, dim3(2048), dim3(256), 0, st, (const u8 *)d_a, (const u8 *)d_b, (u64)nbytes, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_out);
+    MTS_HIP(e);
+    *n_diff = (long)h[0];
+    if (first_diff) *first_diff = h[0] ? (long)h[1] : -1;
+    return MTS_OK;
+}
+
 int mts_last_stage_times(int device, const char **names, float *ms, int cap)
 {
     Engine *E;

@@ -73,6 +73,11 @@ def lib():
     L.mts_dev_compress_chunks.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, lp, C.c_int, C.c_int, C.c_int, vp, lp, lp]
     L.mts_dev_decompress_chunks.argtypes = [C.c_int, vp, vp, lp, lp, lp, C.c_int, C.c_int, C.c_int, C.c_int, vp, lp, ip]
     L.mts_dev_synth_int16.argtypes = [C.c_int, vp, vp, C.c_long, C.c_long, C.c_int, C.c_long]
+    L.mts_dev_alloc.argtypes = [C.c_int, C.c_long, C.POINTER(vp)]
+    L.mts_dev_free.argtypes = [C.c_int, vp]
+    L.mts_dev_copy.argtypes = [C.c_int, vp, vp, vp, C.c_long, C.c_int]
+    L.mts_dev_sync.argtypes = [C.c_int]
+    L.mts_dev_compare.argtypes = [C.c_int, vp, vp, vp, C.c_long, lp, lp]
     L.mts_last_stage_times.restype = C.c_int
     L.mts_last_stage_times.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     L.mts_debug_match_tables.argtypes = [C.c_int, vp, C.c_long, C.c_int, vp, vp]
@@ -96,6 +101,7 @@ def lib():
 EXPORTS = ['mts_version', 'mts_device_count', 'mts_strerror', 'mts_last_error', 'mts_compress_bound',
            'mts_delta_transpose', 'mts_cumsum_transpose', 'mts_compress_chunks', 'mts_decompress_chunks',
            'mts_dev_compress_chunks', 'mts_dev_decompress_chunks', 'mts_dev_synth_int16',
+           'mts_dev_alloc', 'mts_dev_free', 'mts_dev_copy', 'mts_dev_sync', 'mts_dev_compare',
            'mts_last_stage_times', 'mts_debug_match_tables', 'mts_debug_tokens', 'mts_debug_deflate',
            'mts_debug_inflate', 'mts_release', 'mts_cache_create', 'mts_cache_destroy', 'mts_cache_query',
            'mts_cache_read_rows', 'mts_cache_read_slices', 'mts_cache_read_slices_leading']
@@ -299,6 +305,74 @@ def cache_read_slices(cache_id, keys, cdata, offs, lens, n_rows, n_channels, dty
            'mts_cache_read_slices_leading')
     arrays = [out[int(o):int(o) + a * b * dtype.itemsize].view(dtype).reshape(a, b) for o, (a, b) in zip(out_offs, shapes)]
     return [int(x) for x in status[:n]], arrays
+
+
+# ------------------------------------------------------------------------------------------------
+# device-resident recordings (bench.py, the tests at BASELINE's sizes): memory held through the library -- no second HIP runtime
+# ------------------------------------------------------------------------------------------------
+class DevBuffer:
+    """`nbytes` of HBM on `device`, allocated, copied and freed by libmtscomp_hip.so (mts_dev_alloc / mts_dev_copy / mts_dev_free)."""
+
+    def __init__(self, nbytes, device=0):
+        self.device, self.nbytes = int(device), int(nbytes)
+        p = C.c_void_p()
+        _check(lib().mts_dev_alloc(self.device, self.nbytes, C.byref(p)), 'mts_dev_alloc')
+        self.ptr = p.value or 0
+
+    def at(self, offset=0):
+        assert 0 <= offset <= self.nbytes
+        return C.c_void_p(self.ptr + int(offset))
+
+    def upload(self, arr, offset=0):
+        a = np.ascontiguousarray(arr)
+        assert offset + a.nbytes <= self.nbytes
+        _check(lib().mts_dev_copy(self.device, None, self.at(offset), _ptr(a), a.nbytes, 0), 'mts_dev_copy')
+
+    def download(self, offset=0, nbytes=None, dtype=np.uint8):
+        nbytes = self.nbytes - offset if nbytes is None else int(nbytes)
+        assert offset + nbytes <= self.nbytes
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _check(lib().mts_dev_copy(self.device, None, _ptr(out), self.at(offset), out.nbytes, 1), 'mts_dev_copy')
+        return out
+
+    def diff(self, other, nbytes=None):
+        """(bytes that differ, first such offset or -1) between this buffer and `other` (compared on the device)."""
+        n, first = C.c_long(0), C.c_long(-1)
+        nbytes = min(self.nbytes, other.nbytes) if nbytes is None else int(nbytes)
+        _check(lib().mts_dev_compare(self.device, None, self.at(), other.at(), nbytes, C.byref(n), C.byref(first)), 'mts_dev_compare')
+        return int(n.value), int(first.value)
+
+    def free(self):
+        if self.ptr:
+            ptr, self.ptr = self.ptr, 0
+            _check(lib().mts_dev_free(self.device, C.c_void_p(ptr)), 'mts_dev_free')
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def dev_sync(device=0):
+    _check(lib().mts_dev_sync(int(device)), 'mts_dev_sync')
+
+
+def dev_synth_int16(buf, offset, t0, t1, n_channels, seed=0):
+    """Rows [t0, t1) of the synthetic recording written at `offset` of a DevBuffer."""
+    assert offset + (t1 - t0) * n_channels * 2 <= buf.nbytes
+    _check(lib().mts_dev_synth_int16(buf.device, None, buf.at(offset), int(t0), int(t1), int(n_channels), int(seed)), 'mts_dev_synth_int16')
+
+
+def dev_compress_chunks(raw, n_channels, itemsize, bounds, flags, level, out, slots, sizes):
+    """mts_dev_compress_chunks on DevBuffers: `bounds` rows (int64 array, n + 1), `slots` byte offsets into `out`, `sizes` filled."""
+    _check(lib().mts_dev_compress_chunks(raw.device, None, raw.at(), n_channels, itemsize, _lp(bounds), len(bounds) - 1, int(flags), int(level),
+                                         out.at(), _lp(slots), _lp(sizes)), 'mts_dev_compress_chunks')
+
+
+def dev_decompress_chunks(cbuf, offs, lens, rows, n_channels, itemsize, flags, out, out_offs, status):
+    _check(lib().mts_dev_decompress_chunks(cbuf.device, None, cbuf.at(), _lp(offs), _lp(lens), _lp(rows), len(rows), n_channels, itemsize, int(flags),
+                                           out.at(), _lp(out_offs), status.ctypes.data_as(C.POINTER(C.c_int))), 'mts_dev_decompress_chunks')
 
 
 def last_stage_times(device=0):

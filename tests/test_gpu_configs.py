@@ -5,7 +5,13 @@
               (reference contract: mtscomp.py:474-495, tests.py:403-410)
   configs[2]  600 s file, 1000 windows Reader[s:s+30000] at splitmix starts, EVERY window against the generator
               (mtscomp.py:798-856; LRU of decoded chunks :582-588 -- here the device cache, default and a small one)
+  configs[3]  385 ch x 3600 s sharded over 8 GPUs: ONE rank's shard at its size -- chunks 0, 8, 16, ... = 450 chunks, 10.4 GB raw --
+              through the device-resident entry points, full round trip, every 25th chunk against zlib.compress
+              (mtscomp.py:399-423, :474-483; the other seven shards are the same code on other chunk ids)
   configs[4]  1024 ch, 0.25 s chunks, 240 chunks, levels 1 / 6 / 9: EVERY chunk against zlib.compress(stream, level)
+
+The recordings live in HBM through the library's own allocator (hip.DevBuffer -> mts_dev_alloc / mts_dev_copy): this process
+initialises one HIP runtime, whatever else it imports and in whatever order (test_import_order_* pins both orders with torch).
 """
 import ctypes as C
 import hashlib
@@ -28,14 +34,6 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 RATE = 30000
 
-# These tests hold their recordings in torch tensors.  torch brings its own HIP / HSA runtime libraries: they must be the first
-# ones this process initialises (a second runtime opening the device after libmtscomp_hip.so's finds no GPU), so the device is
-# initialised here, at collection time, before any test has called into the library.
-if os.path.exists('/dev/kfd'):
-    import torch
-    torch.cuda.init()
-
-
 @pytest.fixture
 def shm(monkeypatch):
     tmp = Path(tempfile.mkdtemp(prefix='mtstest_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None))
@@ -49,16 +47,13 @@ def _lp(a):
     return a.ctypes.data_as(C.POINTER(C.c_long))
 
 
-def _synth_host(torch, t0, t1, nc):
-    buf = torch.empty((t1 - t0, nc), dtype=torch.int16, device='cuda')
-    assert hip.lib().mts_dev_synth_int16(0, None, C.c_void_p(buf.data_ptr()), t0, t1, nc, 0) == 0
-    torch.cuda.synchronize()
-    return buf.cpu().numpy()
+def _synth_host(t0, t1, nc):
+    return bench.synth_host(hip, 0, t0, t1, nc)
 
 
 def test_config1_whole_recording_byte_identical(shm):
     nc, seconds = 385, 60
-    x = np.concatenate([_synth_host(torch, s * RATE, (s + 1) * RATE, nc) for s in range(seconds)])
+    x = _synth_host(0, seconds * RATE, nc)
     raw, out, outmeta, back = shm / 'data.bin', shm / 'data.cbin', shm / 'data.ch', shm / 'back.bin'
     x.tofile(raw)
     ratio = mtscomp_amd.compress(raw, out, outmeta, sample_rate=float(RATE), n_channels=nc, dtype=np.int16)      # (check_after_compress on, like the default)
@@ -89,34 +84,69 @@ def test_config2_random_windows_600s(shm, monkeypatch, cache_gb):
     n_windows = 1000 if cache_gb is None else 150
     if cache_gb is not None:
         monkeypatch.setenv('MTSCOMP_DEVICE_CACHE_GB', cache_gb)
-    L = hip.lib()
-    n_samples, _ = bench.build_synth_file(torch, hip, L, 0, seconds, shm, nc)
+    n_samples, _ = bench.build_synth_file(hip, 0, seconds, shm, nc)
     r = mtscomp_amd.decompress(shm / 'data.cbin', shm / 'data.ch')
     assert r.shape == (n_samples, nc)
-    chk = torch.empty((RATE, nc), dtype=torch.int16, device='cuda')
+    chk, got_d = hip.DevBuffer(RATE * nc * 2), hip.DevBuffer(RATE * nc * 2)
     bad = []
     for k, s in enumerate(bench.window_starts(n_samples, n_windows)):
         got = r[s:s + RATE]
-        assert L.mts_dev_synth_int16(0, None, C.c_void_p(chk.data_ptr()), s, s + RATE, nc, 0) == 0
-        if got.shape != (RATE, nc) or not torch.equal(torch.from_numpy(got).cuda(), chk):
+        hip.dev_synth_int16(chk, 0, s, s + RATE, nc, 0)
+        if got.shape != (RATE, nc):
+            bad.append((k, s))
+            continue
+        got_d.upload(got)
+        if got_d.diff(chk)[0]:
             bad.append((k, s))
     assert bad == []
     # the same windows again from what is resident, a few by sha1 against the first read's generator
     for s in bench.window_starts(n_samples, 8):
-        assert L.mts_dev_synth_int16(0, None, C.c_void_p(chk.data_ptr()), s, s + RATE, nc, 0) == 0
-        assert hashlib.sha1(r[s:s + RATE]).hexdigest() == hashlib.sha1(chk.cpu().numpy()).hexdigest()
+        assert hashlib.sha1(r[s:s + RATE]).hexdigest() == hashlib.sha1(_synth_host(s, s + RATE, nc)).hexdigest()
     r.close()
+
+
+def test_config3_one_rank_shard_of_the_3600s_recording():
+    """configs[3]: rank 0's shard of the 8-GPU run at its real size: chunks 0, 8, 16, ... of the 3600 s recording."""
+    nc, world, seconds = 385, 8, 3600
+    ids = bench.shard_ids(0, world, seconds)
+    n = len(ids)
+    assert n == 450
+    chunk_bytes = RATE * nc * 2
+    raw = hip.DevBuffer(n * chunk_bytes)
+    for k, g in enumerate(ids):
+        hip.dev_synth_int16(raw, k * chunk_bytes, g * RATE, (g + 1) * RATE, nc, 0)
+    cb = (hip.compress_bound(chunk_bytes) + 255) // 256 * 256
+    cbuf, back = hip.DevBuffer(n * cb), hip.DevBuffer(n * chunk_bytes)
+    bounds = np.arange(n + 1, dtype=np.int64) * RATE
+    slots = np.arange(n, dtype=np.int64) * cb
+    sizes = np.zeros(n, dtype=np.int64)
+    nrows = np.full(n, RATE, dtype=np.int64)
+    ooffs = np.arange(n, dtype=np.int64) * chunk_bytes
+    status = np.zeros(n, dtype=np.int32)
+    flags = hip.make_flags(True, False, 'F')
+    hip.dev_compress_chunks(raw, nc, 2, bounds, flags, 6, cbuf, slots, sizes)
+    assert (sizes > 0).all() and 0.30 < sizes.sum() / (n * chunk_bytes) < 0.42
+    hip.dev_decompress_chunks(cbuf, slots, sizes, nrows, nc, 2, flags, back, ooffs, status)
+    assert not status.any()
+    assert back.diff(raw) == (0, -1)
+    picks = list(range(0, n, 25))
+    with ThreadPool(min(32, os.cpu_count() or 1)) as pool:
+        want = pool.map(lambda k: O.ref_compress_chunk(raw.download(k * chunk_bytes, chunk_bytes, np.int16).reshape(RATE, nc)), picks)
+    diff = [ids[k] for k, w in zip(picks, want) if cbuf.download(int(slots[k]), int(sizes[k])).tobytes() != w]
+    assert diff == []
+    # the host-side gather of the sizes (the path's only exchange) puts this shard's chunks where the file has them
+    offsets = np.concatenate(([0], np.cumsum(sizes)))
+    assert offsets[-1] == sizes.sum() and list(bench.gather_chunk_offsets(sizes, 0, 1)) == list(offsets)
+    for b in (raw, cbuf, back):
+        b.free()
 
 
 def test_config4_stress_shape_every_chunk_levels_1_6_9():
     nc, rows, n = 1024, 7500, 240
-    L = hip.lib()
-    raw = torch.empty((n * rows, nc), dtype=torch.int16, device='cuda')
-    for k in range(n):
-        assert L.mts_dev_synth_int16(0, None, C.c_void_p(raw[k * rows:].data_ptr()), k * rows, (k + 1) * rows, nc, 0) == 0
+    raw = hip.DevBuffer(n * rows * nc * 2)
+    hip.dev_synth_int16(raw, 0, 0, n * rows, nc, 0)
     cb = (hip.compress_bound(rows * nc * 2) + 255) // 256 * 256
-    cbuf = torch.empty(n * cb, dtype=torch.uint8, device='cuda')
-    back = torch.empty_like(raw)
+    cbuf, back = hip.DevBuffer(n * cb), hip.DevBuffer(raw.nbytes)
     bounds = np.arange(n + 1, dtype=np.int64) * rows
     slots = np.arange(n, dtype=np.int64) * cb
     sizes = np.zeros(n, dtype=np.int64)
@@ -124,19 +154,50 @@ def test_config4_stress_shape_every_chunk_levels_1_6_9():
     ooffs = np.arange(n, dtype=np.int64) * rows * nc * 2
     status = np.zeros(n, dtype=np.int32)
     flags = hip.make_flags(True, False, 'F')
-    x = raw.cpu().numpy()
+    x = raw.download(dtype=np.int16).reshape(n * rows, nc)
+    zeros = np.zeros(1 << 24, dtype=np.uint8)
     with ThreadPool(min(64, os.cpu_count() or 1)) as pool:
         streams = pool.map(lambda k: O.delta_transpose(x[k * rows:(k + 1) * rows], flags).tobytes(), range(n))
         for level in (1, 6, 9):
-            rc = L.mts_dev_compress_chunks(0, None, C.c_void_p(raw.data_ptr()), nc, 2, _lp(bounds), n, flags, level, C.c_void_p(cbuf.data_ptr()),
-                                           _lp(slots), _lp(sizes))
-            assert rc == 0, L.mts_last_error()
-            host = cbuf.cpu().numpy()
+            hip.dev_compress_chunks(raw, nc, 2, bounds, flags, level, cbuf, slots, sizes)
+            host = cbuf.download()
             want = pool.map(lambda k: zlib.compress(streams[k], level), range(n))
             diff = [k for k in range(n) if host[k * cb:k * cb + int(sizes[k])].tobytes() != want[k]]
             assert diff == [], (level, diff[:8])
-            back.zero_()
-            rc = L.mts_dev_decompress_chunks(0, None, C.c_void_p(cbuf.data_ptr()), _lp(slots), _lp(sizes), _lp(nrows), n, nc, 2, flags,
-                                             C.c_void_p(back.data_ptr()), _lp(ooffs), status.ctypes.data_as(C.POINTER(C.c_int)))
-            assert rc == 0 and not status.any()
-            assert torch.equal(back, raw), level
+            for o in range(0, back.nbytes, zeros.nbytes):                       # (what a decode that wrote nothing would leave)
+                back.upload(zeros[:min(zeros.nbytes, back.nbytes - o)], o)
+            hip.dev_decompress_chunks(cbuf, slots, sizes, nrows, nc, 2, flags, back, ooffs, status)
+            assert not status.any()
+            assert back.diff(raw) == (0, -1), level
+
+
+_ORDER_CHILD = r'''
+import sys
+sys.path.insert(0, %r)
+%s
+import numpy as np
+from mtscomp_amd.synth import synth_int16
+x = synth_int16(0, 900, 64, 0)
+got = hip.compress_chunks(x, [0, 900], hip.make_flags(), 6, device=0)
+st, arrs = hip.decompress_chunks(got, [900], 64, 'int16', hip.make_flags(), device=0)
+assert st == [0] and np.array_equal(arrs[0], x)
+b = hip.DevBuffer(x.nbytes); b.upload(x); assert np.array_equal(b.download(dtype=np.int16).reshape(x.shape), x)
+maps = open('/proc/self/maps').read()
+print('RUNTIMES', len({l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l}))
+print('OK')
+'''
+
+
+@pytest.mark.parametrize('order', ['torch_first', 'library_first'])
+def test_import_order_with_torch(order):
+    """`import mtscomp_amd` before or after `import torch`: the codec works either way.  torch ships its own HIP runtime libraries;
+    the package never asks torch for device memory or streams, so whichever runtime torch loaded is not the one that opens the device
+    for these kernels -- unless torch came first, in which case the loader gives both the same one."""
+    import subprocess
+    import sys
+    first = 'import torch\nfrom mtscomp_amd import hip\nhip.lib()' if order == 'torch_first' else 'from mtscomp_amd import hip\nhip.lib()\nimport torch'
+    first += '\nimport torch.distributed  # what bench.py uses torch for'
+    r = subprocess.run([sys.executable, '-c', _ORDER_CHILD % (str(Path(__file__).resolve().parent.parent), first)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-400:], r.stderr[-800:])
+    if order == 'torch_first':
+        assert 'RUNTIMES 1' in r.stdout

@@ -14,35 +14,31 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 
 CHILD = r'''
-import ctypes as C, hashlib, json, sys
-import numpy as np, torch
+import hashlib, json, sys
+import numpy as np
 sys.path.insert(0, %r)
 from mtscomp_amd import hip
 level, n = int(sys.argv[1]), int(sys.argv[2])
-L = hip.lib(); nc = 385; rate = 30000
-raw = torch.empty((n * rate, nc), dtype=torch.int16, device="cuda")
-for k in range(n):
-    L.mts_dev_synth_int16(0, None, C.c_void_p(raw[k * rate:].data_ptr()), k * rate, (k + 1) * rate, nc, 0)
-bound = (hip.compress_bound(rate * nc * 2) + 255) // 256 * 256
-cbuf = torch.empty(n * bound, dtype=torch.uint8, device="cuda")
-back = torch.empty_like(raw)
+nc = 385; rate = 30000; cb = rate * nc * 2
+raw = hip.DevBuffer(n * cb)
+hip.dev_synth_int16(raw, 0, 0, n * rate, nc, 0)
+bound = (hip.compress_bound(cb) + 255) // 256 * 256
+cbuf, back = hip.DevBuffer(n * bound), hip.DevBuffer(n * cb)
 b = np.arange(n + 1, dtype=np.int64) * rate; sl = np.arange(n, dtype=np.int64) * bound; sz = np.zeros(n, dtype=np.int64)
-rows = np.full(n, rate, dtype=np.int64); oo = np.arange(n, dtype=np.int64) * rate * nc * 2; st = np.zeros(n, dtype=np.int32)
-lp = lambda a: a.ctypes.data_as(C.POINTER(C.c_long))
+rows = np.full(n, rate, dtype=np.int64); oo = np.arange(n, dtype=np.int64) * cb; st = np.zeros(n, dtype=np.int32)
 acc = {}
 for i in range(4):
-    rc = L.mts_dev_compress_chunks(0, None, C.c_void_p(raw.data_ptr()), nc, 2, lp(b), n, 5, level, C.c_void_p(cbuf.data_ptr()), lp(sl), lp(sz))
-    assert rc == 0, L.mts_last_error()
+    hip.dev_compress_chunks(raw, nc, 2, b, 5, level, cbuf, sl, sz)
     if i:
         for k, v in hip.last_stage_times(): acc.setdefault(k, []).append(v)
-    rc = L.mts_dev_decompress_chunks(0, None, C.c_void_p(cbuf.data_ptr()), lp(sl), lp(sz), lp(rows), n, nc, 2, 5, C.c_void_p(back.data_ptr()), lp(oo), st.ctypes.data_as(C.POINTER(C.c_int)))
-    assert rc == 0 and not st.any()
+    hip.dev_decompress_chunks(cbuf, sl, sz, rows, nc, 2, 5, back, oo, st)
+    assert not st.any()
     if i:
         for k, v in hip.last_stage_times(): acc.setdefault(k, []).append(v)
-host = cbuf.cpu().numpy()
+host = cbuf.download()
 h = hashlib.sha1()
 for k in range(n): h.update(host[int(sl[k]):int(sl[k]) + int(sz[k])].tobytes())
-print(json.dumps({"sha1": h.hexdigest(), "ok": bool(torch.equal(back, raw)), "ms": {k: round(min(v), 3) for k, v in acc.items()}}))
+print(json.dumps({"sha1": h.hexdigest(), "ok": back.diff(raw)[0] == 0, "ms": {k: round(min(v), 3) for k, v in acc.items()}}))
 '''
 
 

@@ -32,19 +32,12 @@ def main():
     os.environ.setdefault('HOME', str(tmp))
     raw = tmp / 'data.bin'
     with open(raw, 'wb') as f:
-        try:                                    # the same integer-exact generator, on the device (the host one is slow)
-            import ctypes as C
-            import torch
-            from mtscomp_amd import hip
-            buf = torch.empty((rate, nc), dtype=torch.int16, device='cuda')
-            for s in range(a.seconds):
-                rc = hip.lib().mts_dev_synth_int16(0, None, C.c_void_p(buf.data_ptr()), s * rate, (s + 1) * rate, nc, 0)
-                assert rc == 0
-                torch.cuda.synchronize()
-                buf.cpu().numpy().tofile(f)
-        except ImportError:
-            for s in range(a.seconds):
-                synth_int16(s * rate, (s + 1) * rate, nc, 0).tofile(f)
+        from mtscomp_amd import hip              # the same integer-exact generator, on the device (the host one is slow)
+        buf = hip.DevBuffer(rate * nc * 2)
+        for s in range(a.seconds):
+            hip.dev_synth_int16(buf, 0, s * rate, (s + 1) * rate, nc, 0)
+            buf.download().tofile(f)
+        buf.free()
     nbytes = raw.stat().st_size
     out, outmeta = tmp / 'data.cbin', tmp / 'data.ch'
     t = time.perf_counter()
