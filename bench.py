@@ -106,16 +106,19 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def launch_ranks(n, script, script_args, port=0, env=None, timeout=None):
+def launch_ranks(n, script, script_args, port=0, env=None, timeout=None, capture=False):
     """Start `n` ranks of `script` on this node the way the driver does (one process per GPU, torch.distributed.run,
     rendezvous on 127.0.0.1) from a process that has NOT touched the GPU; relays the children's output and returns their
-    exit status."""
+    exit status (capture=True: returns (status, stdout, stderr) instead)."""
     import subprocess
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
            '--master-port', str(port or free_port()), str(script)] + list(script_args)
     e = dict(os.environ if env is None else env)
     e.setdefault('MASTER_ADDR', '127.0.0.1')
     e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if capture:
+        r = subprocess.run(cmd, env=e, timeout=timeout, capture_output=True, text=True)
+        return r.returncode, r.stdout, r.stderr
     return subprocess.run(cmd, env=e, timeout=timeout).returncode
 
 

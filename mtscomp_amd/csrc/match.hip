@@ -1,0 +1,671 @@
+// M: per-position best matches of the bit-exact zlib-1.2.11 DEFLATE (levels 4..9) on gfx950 -- k_match5 / k_match6.
+// A translation unit of its own: the candidate loops run under wave-uniform branches, and the structurizer's copies of the loop
+// state at every join go away with  -mllvm -structurizecfg-skip-uniform-regions  (Makefile: this file only; the same flag
+// miscompiles the level 1..3 kernels of deflate.hip).  Replaces the longest_match() calls inside `zlib.compress`
+// (/root/reference/mtscomp.py:394); orc_match_tables() of oracle/mtsc_oracle.c is the oracle.
+#include <stdlib.h>
+
+#include "deflate_dev.h"
+
+namespace mts {
+
+// ================================================================================================
+// M: per-position best matches (t_full, t_quarter) -- orc_match_tables() is the oracle
+// ================================================================================================
+// The kernel scores a candidate from a 64-bit "entry" built (from the LDS window) for every staged slot:
+//   w0 [17:0]  rel   window-relative position
+//      [26:18] d     9 bits that, TOGETHER WITH AN EQUAL 15-BIT HASH, prove bytes 0..2 equal:
+//                    h = (b0<<10 ^ b1<<5 ^ b2) & 0x7fff exposes b0[4:3], b1[4:3], b2[4:0] directly and
+//                    b0[2:0]^b1[7:5], b1[2:0]^b2[7:5]; b0[7:5] not at all.  d = b0[7:5] : b0[2:0] : b1[2:0].
+//      [31:27] low 5 bits of byte 7
+//   w1         bytes 3..6
+// so the common prefix of two same-hash positions is known exactly up to 7 bytes from the entries alone;
+// only longer matches go back to the window bytes.
+// A table entry is ONE word per position:  [14:0] dist (0: no match), [22:15] len - 3  = the full-budget result, and two flags
+// for the quarter-budget result (what the walk looks at when it already holds a match of >= good_match bytes):
+//   neither   the same as the full-budget result
+//   TE_QNONE  another one that cannot matter: it is not longer than good_match, and the walk only takes what is LONGER than the
+//             match it holds
+//   TE_QSIDE  another one that can: it is in the side table quarter[p] (same packing), which is written for these positions
+//             only (0.4 % of them on the synthetic recordings; the debug tap of the tests has it written everywhere)
+// (Rounds 1-2 kept both results and the position's byte in 8 bytes per position: twice the table traffic in the match store
+// and in both parse walks, and half as many walkers per CU, whose windows of the table live in LDS.)
+__device__ __forceinline__ u64 make_entry(u32 rel, u32 lo, u32 hi)       // lo = bytes 0..3, hi = bytes 4..7
+{
+    const u32 b0 = lo & 0xff, b1 = (lo >> 8) & 0xff;
+    const u32 d = ((b0 >> 5) << 6) | ((b0 & 7) << 3) | (b1 & 7);
+    const u32 w0 = rel | (d << REL_BITS) | (((hi >> 24) & ((1u << (32 - REL_BITS - 9)) - 1)) << (REL_BITS + 9));
+    const u32 w1 = (lo >> 24) | (hi << 8);
+    return (u64)w0 | ((u64)w1 << 32);
+}
+__device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
+{
+    const u32 a = addr >> 2;
+    return alignbyte(win[a + 1], win[a], addr & 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The walk is filtered: it produces exactly what the plain newest-first walk produces, scoring far fewer candidates:
+// a candidate can only replace the current best if it can be LONGER than it, so once the best length is L only candidates
+// whose first L + 1 bytes may equal the position's own are looked at; all others are skipped -- which changes nothing,
+// because zlib's walk would have compared and rejected them (they still count against the chain budget: budgets are
+// positions in the run, not candidates scored).
+// ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// k_match5 (chain budget <= 128): the filter masks are looked up.  Every wave keeps, next to its 256-slot ring of
+// entries, four tables of 32 rows x 256 bits (the first one 64 rows): row k of table d (d = 4..7) has bit r set iff the slot at
+// ring position r has key_d = k, where key_d is a 5-bit hash of bytes 3 .. d-1 of the slot's string (6 bits of byte 3 for the
+// first table, which the walk consults most: with 32 rows a lane met ~4 candidates per group that only shared the row).  A
+// slot entering the ring clears the bits of the slot it replaces and sets its own (8 LDS atomics per 64
+// slots).  A lane reads the rows of its OWN keys and funnel-shifts out the 128 bits of the slots before
+// it: M_d = candidates whose first d bytes may equal its own (hash + bytes 3..d-1; a superset, which is
+// all the filter needs: a candidate that passes is scored exactly, one that fails cannot be longer than
+// d-1).  With best length L the walk only pops candidates of M_(L+1) (M_7 from 6 on), so the number of
+// scored candidates is about the number of times the best length improves.
+// ------------------------------------------------------------------------------------------------
+#ifndef MTS_M5_NT_KEYS
+#define MTS_M5_NT_KEYS 0
+#endif
+constexpr int M5_WAVES = 8;
+constexpr int M5_SLICES = 64;                        // workgroups per tile (MTS_MATCH_SLICES overrides: experiments)
+constexpr int M5_RING = 256;
+constexpr int M5_ROWS = 32;
+constexpr int M5_LEVELS = 4;                         // tables for prefix lengths 4, 5, 6, 7
+constexpr int M5_ROW_WORDS = M5_RING / 32 + 1;       // a row is 8 words of bits + 1 of padding, so that rows start in different LDS banks
+constexpr int M5_TABLE = M5_ROWS * M5_ROW_WORDS * 4; // bytes per table
+constexpr int M5_SLOTS = M5_LEVELS + 1;                // the first table has 64 rows (a 6-bit key of byte 3): two table slots
+constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_SLOTS * M5_TABLE;      // 9856: entries, bytes 7..12, tables
+__device__ __forceinline__ constexpr int m5_slot(int d) { return d ? d + 1 : 0; }
+// requested LDS is padded so that TWO workgroups share a CU, not three (16 waves per CU keep the vector units busy)
+constexpr int MATCH5_LDS = M5_WAVES * M5_WAVE_LDS > 56 * 1024 ? M5_WAVES * M5_WAVE_LDS : 56 * 1024;
+
+// 5-bit keys of the prefixes (b3), (b3,b4), (b3..b5), (b3..b6) of e1 = bytes 3..6
+__device__ __forceinline__ u32 m5_hash24(u32 x) { return (__umul24(x, 0x9E3779u) >> 19) & 31; }
+__device__ __forceinline__ void m5_keys(u32 e1, u32 (&k)[M5_LEVELS])
+{
+    k[0] = (__umul24(e1 & 0xff, 0x9E3779u) >> 18) & 63;
+    k[1] = m5_hash24(e1 & 0xffff);
+    k[2] = m5_hash24(e1 & 0xffffff);
+    k[3] = m5_hash24((e1 ^ (e1 >> 11)) & 0xffffff);
+}
+
+// Workgroups share tiles: `nsl` consecutive workgroups OF ONE XCD (block b runs on XCD b % 8) take the `nsl` slices of one
+// tile's sorted order, so an XCD has 64 / nsl tiles in flight and their windows (read at random) and table regions (written
+// at random) stay in its L2 until they are complete (L2 hit rate 12 % -> 92 %, 10x fewer misses: tools/pmc_cache.sh).
+// flags[0] |= 1 when the sorted order is found NOT to be position-ordered inside a hash run (the sort's ranking relies on
+// a hardware property, see rank_pass): the caller then sorts again with the ballot ranking and repeats the stage.
+__global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, int nsl,
+                                                          const u32 *__restrict__ sorted, u32 *__restrict__ tables, u32 *__restrict__ quarter, LevelCfg cfg,
+                                                          u32 *__restrict__ flags, int all_quarters)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const u32 xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const u32 tile_id = (jb / (u32)nsl) * 8 + xcd, slice = jb % (u32)nsl;
+    if (tile_id >= (u32)n_tiles) return;
+    const TileDesc td = tiles[tile_id];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u8 *wbase = smem + wave * M5_WAVE_LDS;
+    const u8 *gwin = stream + td.stream_off + td.w;
+    auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
+    u64 *SE = (u64 *)wbase;
+    u64 *SX = SE + M5_RING;                                        // bytes 7..12 of every slot: matches up to 13 never leave the LDS
+    u32 *TB = (u32 *)(wbase + 2 * M5_RING * 8);                    // [level][row][8 words + 1]
+    u32 *T = tables + td.stream_off, *TQ = quarter + td.stream_off;
+    if (threadIdx.x < 2 && slice == 0) {
+        const u32 hashed_end = td.w + td.wlen;
+        const u32 p = hashed_end + threadIdx.x;
+        if (p >= td.a && p < td.own_end) { T[p] = 0; if (all_quarters) TQ[p] = 0; }
+    }
+    if (td.wlen == 0) return;
+    const u32 *sk = sorted + td.sorted_off;
+    const u32 wlen = td.wlen, n = td.n;
+    const u32 ngroups = (wlen + 63) / 64;
+    const u32 halo = td.a - td.w;
+    const u32 chain = (u32)cfg.chain, qchain = (u32)cfg.chain >> 2;
+    const u32 nwv = (u32)nsl * M5_WAVES;
+    const u32 gpw = (ngroups + nwv - 1) / nwv;
+    const u32 g_begin = (slice * M5_WAVES + wave) * gpw, g_end = min(ngroups, g_begin + gpw);
+    if (g_begin >= g_end) return;
+    // the tables start empty (the entry ring may hold anything: it is only read where table bits point)
+    for (int k = lane; k < M5_SLOTS * M5_TABLE / 16; k += 64) ((uint4 *)TB)[k] = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+    u32 h_carry = 0xffffffffu;                                     // hash of the slot before the one lane 0 commits next
+    u32 rc_carry = 0;                                              // its position
+    u32 run_carry = 0;                                             // slots between the newest run start and lane 0 of the group being committed (capped)
+    const u32 le_lo = lane >= 31 ? 0xffffffffu : (2u << lane) - 1, le_hi = lane < 32 ? 0u : lane == 63 ? 0xffffffffu : (2u << (lane - 32)) - 1;      // lanes <= this one
+    u32 inv[6];                                                    // lane r builds row r of the first table: bit j of r clear -> all ones
+#pragma unroll
+    for (int j = 0; j < 6; j++) inv[j] = ((lane >> j) & 1) ? 0u : 0xffffffffu;
+    // slot idx -> position -> its 13 bytes -> entry; enters the ring at idx & 255, replacing slot idx - 256.  The ring
+    // positions of a 64-slot group are two whole words of every table row: they are cleared and set again (the first table,
+    // whose keys repeat most -- 32 lanes adding the same bit to the same word would be serialised by the LDS -- is rebuilt
+    // from five ballots by the lane that owns the row; the others take one atomic OR per slot).  `nbv` = the chain behind
+    // the slot = the slots back to the start of its hash run (at most 128 matter), from the ballot of the run starts.
+    auto commit = [&](int idx, u32 rc, u32 lo, u32 hi, u64 x, u32 (&key)[M5_LEVELS], u32 &nbv) -> u64 {
+        const u32 rp = (u32)idx & (M5_RING - 1), word = rp >> 5, bit = 1u << (rp & 31);
+        const bool valid = idx >= 0 && (u32)idx < wlen;
+        const u64 ce = valid ? make_entry(rc, lo, hi) : ~0ull;
+        // a slot starts a run when its hash differs from its predecessor's (slots are committed in order)
+        const u32 h = valid ? hash_of(lo) : 0xfffffffeu;
+        const u32 hp = __shfl_up(h, 1, 64), rcp = __shfl_up(rc, 1, 64);
+        const bool starts_run = h != (lane == 0 ? h_carry : hp);
+        const bool disorder = valid && !starts_run && rc <= (lane == 0 ? rc_carry : rcp);      // positions must increase inside a run
+        if (__any(disorder)) { if (lane == 0) atomicOr(flags, 1u); }
+        h_carry = (u32)__builtin_amdgcn_readlane((int)h, 63);
+        rc_carry = (u32)__builtin_amdgcn_readlane((int)rc, 63);
+        const u64 sr = __ballot(starts_run);
+        const u32 mlo = (u32)sr & le_lo, mhi = (u32)(sr >> 32) & le_hi;
+        const u32 top = mhi ? 63u - (u32)__builtin_clz(mhi) : 31u - (u32)__builtin_clz(mlo | 1u);
+        nbv = (mlo | mhi) ? (u32)lane - top : (u32)lane + run_carry;
+        nbv = nbv < 128u ? nbv : 128u;
+        run_carry = sr ? (u32)__builtin_clzll(sr) + 1u : (run_carry + 64u < 128u ? run_carry + 64u : 128u);
+        m5_keys((u32)(ce >> 32), key);
+        const u32 wp = word & ~1u;                                 // the group's word pair
+        {
+            u32 *t1 = TB + 2 * (M5_TABLE / 4) + lane * M5_ROW_WORDS + wp;   // rows of tables 1..3 are contiguous: 96 rows
+            t1[0] = 0; t1[1] = 0;
+            if (lane < 32) { t1[64 * M5_ROW_WORDS] = 0; t1[64 * M5_ROW_WORDS + 1] = 0; }
+            const u64 vm = __ballot(valid);
+            u32 m0 = (u32)vm, m1 = (u32)(vm >> 32);
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const u64 B = __ballot((key[0] >> j) & 1);
+                m0 &= (u32)B ^ inv[j]; m1 &= (u32)(B >> 32) ^ inv[j];
+            }
+            { u32 *t0 = TB + lane * M5_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int d = 1; d < M5_LEVELS; d++)
+            if (valid) atomicOr(&TB[m5_slot(d) * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS + word], bit);
+        SE[rp] = ce;
+        SX[rp] = x;
+        return ce;
+    };
+    // bytes 0..12 of the string at window offset r with ONE 16-byte load (the four dwords around it): the lanes are each
+    // somewhere else in the window, and the address unit charges by the instruction
+    typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    auto load16 = [&](u32 r, u32 &lo, u32 &hi, u64 &x) {
+        const u8 *q = gwin + (r & ~3u);
+        const u32x4_a4 w = *(const u32x4_a4 *)q;
+        lo = alignbyte(w.y, w.x, r);
+        hi = alignbyte(w.z, w.y, r);
+        const u32 b8 = alignbyte(w.w, w.z, r), b12 = alignbyte(0u, w.w, r) & 0xffu;
+        x = (u64)(hi >> 24) | ((u64)b8 << 8) | ((u64)b12 << 40);                    // bytes 7..12
+    };
+#if MTS_M5_NT_KEYS
+    auto slot_rel = [&](int idx) -> u32 { return __builtin_nontemporal_load(&sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1]) & REL_MASK; };      // (read once: keep them out of the way of the window and the table lines in L2)
+#else
+    auto slot_rel = [&](int idx) -> u32 { return sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1] & REL_MASK; };
+#endif
+    const int i_first = (int)g_begin * 64 + lane;
+    {
+        u32 kk[M5_LEVELS], nb;
+        const u32 ra = slot_rel(i_first - 128), rb = slot_rel(i_first - 64);
+        u32 la, ha, lb, hb;
+        u64 xa, xb;
+        load16(ra, la, ha, xa);
+        load16(rb, lb, hb, xb);
+        commit(i_first - 128, ra, la, ha, xa, kk, nb);
+        __builtin_amdgcn_wave_barrier();
+        commit(i_first - 64, rb, lb, hb, xb, kk, nb);
+    }
+    // pipeline: (rc, lo, hi) of the group about to be walked, rc of the one after
+    u32 rc_c = slot_rel(i_first), rc_n = slot_rel(i_first + 64);
+    u32 lo_c, hi_c;
+    u64 x_c;
+    load16(rc_c, lo_c, hi_c, x_c);
+    for (u32 g = g_begin; g < g_end; g++) {
+        const u32 i0 = g * 64, i = i0 + lane;
+        u32 key[M5_LEVELS], nbv;
+        __builtin_amdgcn_wave_barrier();
+        const u64 e = commit((int)i, rc_c, lo_c, hi_c, x_c, key, nbv);
+        const u64 ex = x_c;
+        __builtin_amdgcn_wave_barrier();
+        // next group's words, and the position of the one after
+        rc_c = rc_n;
+        load16(rc_c, lo_c, hi_c, x_c);
+        rc_n = slot_rel((int)i + 128);
+        const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
+        const u32 rel_p = e0 & REL_MASK;
+        const bool own = i < wlen && rel_p >= halo;
+        if (!__any(own)) continue;
+        const u32 p_abs = td.w + rel_p;
+        const u32 look = n - p_abs;
+        const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
+        const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
+        const int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
+        const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
+        // the 128 slots before this lane's own are ring positions lo .. lo + 127 (mod 256); candidate j
+        // (1 = newest) is bit 128 - j of the masks.  V = the candidates inside this lane's chain budget.
+        const u32 lo = (i + 128) & (M5_RING - 1), w0 = lo >> 5, sh = lo & 31;
+        nbv = own ? (nbv < chain ? nbv : chain) : 0;
+        u32 V[4], A4[4], A5[4], A6[4], A7[4];                     // V = inside the budget; A_d = V & "first d bytes may match"
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int s = 32 * k + (int)nbv - 96;               // candidates of word k: bits >= 32 - s
+            V[k] = s <= 0 ? 0u : s >= 32 ? 0xffffffffu : 0xffffffffu << (32 - s);
+        }
+        auto rowmask = [&](const int d, const u32 (&in)[4], u32 (&out)[4]) __attribute__((always_inline)) {
+            const u32 *row = TB + m5_slot(d) * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS;
+            const u32 W0 = row[w0 & 7], W1 = row[(w0 + 1) & 7], W2 = row[(w0 + 2) & 7], W3 = row[(w0 + 3) & 7], W4 = row[(w0 + 4) & 7];
+            out[0] = in[0] & __builtin_amdgcn_alignbit(W1, W0, sh);
+            out[1] = in[1] & __builtin_amdgcn_alignbit(W2, W1, sh);
+            out[2] = in[2] & __builtin_amdgcn_alignbit(W3, W2, sh);
+            out[3] = in[3] & __builtin_amdgcn_alignbit(W4, W3, sh);
+        };
+        rowmask(0, V, A4);
+        rowmask(1, A4, A5);
+        rowmask(2, A5, A6);
+        rowmask(3, A6, A7);
+        u32 best = 2, bdist = 0;
+        bool stop = false;
+        // candidates of word w restricted to `part`, newest first
+        auto walk = [&](const u32 tb, const u32 m0, const u32 m1, const u32 m2, const u32 m3, const u32 m4, const u32 part) __attribute__((always_inline)) {
+            // (the empty asm statements keep the compiler from turning the select chain into a table in scratch memory)
+            auto pick = [&]() -> u32 {
+                u32 r = best >= 3 ? m1 : m0;
+                asm volatile("" : "+v"(r));
+                r = best >= 4 ? m2 : r;
+                asm volatile("" : "+v"(r));
+                r = best >= 5 ? m3 : r;
+                asm volatile("" : "+v"(r));
+                return best >= 6 ? m4 : r;
+            };
+            u32 el = stop ? 0 : pick() & part;
+            while (__any(el != 0)) {
+                if (el) {
+                    const u32 b = 31 - __builtin_clz(el);
+                    el &= ~(1u << b);
+                    const u32 t = tb + b;
+                    const u32 slot = (lo + t) & (M5_RING - 1);
+                    const u64 c = SE[slot];
+                    const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
+                    const u32 rel_c = c0 & REL_MASK;
+                    if ((int)rel_c > (t == 127 ? lim1 : limn)) {
+                        const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
+                        if ((x0 & 0x1ff) == 0) {
+                            u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
+                            if (x1 == 0 && (x0 >> 9) == 0) {
+                                const u64 y = SX[slot] ^ ex;
+                                if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
+                                else {
+                                    len = 13;
+                                    while (len < maxlen) {
+                                        const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
+                                        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+                                        len += 4;
+                                    }
+                                }
+                            }
+                            len = len < maxlen ? len : maxlen;
+                            if (len > best) {
+                                best = len; bdist = rel_p - rel_c;
+                                if (len >= nice) stop = true;
+                                el &= pick();                       // fewer candidates can still win now
+                            }
+                        }
+                    } else stop = true;                 // out of range: so is everything older
+                    if (stop) el = 0;
+                }
+            }
+        };
+        // candidates 1 .. qchain first: what the walk holds then is the quarter-budget result
+        const u32 qpart = qchain >= 32 ? 0xffffffffu : ~(0xffffffffu >> qchain);        // qchain <= 32 (chain <= 128)
+#define MTS_WALK(w, part) walk(32 * (w), V[w], A4[w], A5[w], A6[w], A7[w], part)
+        MTS_WALK(3, qpart);
+        const u32 qbest = best, qdist = bdist;
+        if (qpart != 0xffffffffu) MTS_WALK(3, ~qpart);
+#undef MTS_WALK
+        {
+            // The other 96 candidates in ONE loop (a lane takes its own next candidate, whichever of the three words it is in):
+            // word by word the wave ran as many rounds as the busiest lane of EACH word needed -- 4.4 rounds per group at 10 % lane
+            // use; together it is the busiest lane over all three.
+            auto pickw = [&](const int w) __attribute__((always_inline)) -> u32 {
+                u32 r = best >= 3 ? A4[w] : V[w];
+                asm volatile("" : "+v"(r));
+                r = best >= 4 ? A5[w] : r;
+                asm volatile("" : "+v"(r));
+                r = best >= 5 ? A6[w] : r;
+                asm volatile("" : "+v"(r));
+                return best >= 6 ? A7[w] : r;
+            };
+            u32 f2 = stop ? 0u : pickw(2), f1 = stop ? 0u : pickw(1), f0 = stop ? 0u : pickw(0);
+            while (__any((f2 | f1 | f0) != 0)) {
+                if (f2 | f1 | f0) {
+                    const bool t2 = f2 != 0, t1 = f1 != 0;
+                    const u32 cur = t2 ? f2 : t1 ? f1 : f0;
+                    const u32 tb = t2 ? 64u : t1 ? 32u : 0u;
+                    const u32 b = 31 - __builtin_clz(cur);
+                    const u32 clr = ~(1u << b);
+                    f2 = t2 ? f2 & clr : f2;
+                    f1 = (!t2 && t1) ? f1 & clr : f1;
+                    f0 = (!t2 && !t1) ? f0 & clr : f0;
+                    const u32 slot = (lo + tb + b) & (M5_RING - 1);
+                    const u64 c = SE[slot];
+                    const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
+                    const u32 rel_c = c0 & REL_MASK;
+                    if ((int)rel_c > limn) {
+                        const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
+                        if ((x0 & 0x1ff) == 0) {
+                            u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
+                            if (x1 == 0 && (x0 >> 9) == 0) {
+                                const u64 y = SX[slot] ^ ex;
+                                if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
+                                else {
+                                    len = 13;
+                                    while (len < maxlen) {
+                                        const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
+                                        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+                                        len += 4;
+                                    }
+                                }
+                            }
+                            len = len < maxlen ? len : maxlen;
+                            if (len > best) {
+                                best = len; bdist = rel_p - rel_c;
+                                if (len >= nice) stop = true;
+                                f2 &= pickw(2); f1 &= pickw(1); f0 &= pickw(0);      // fewer candidates can still win now
+                            }
+                        }
+                    } else stop = true;                 // out of range: so is everything older
+                    if (stop) { f2 = 0; f1 = 0; f0 = 0; }
+                }
+            }
+        }
+        if (own) te_store(T, TQ, p_abs, best, bdist, qbest, qdist, (u32)cfg.good, all_quarters);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_match6 (chain budget > 128: levels 7..9): k_match5's looked-up filter masks and walk, block after block of 128
+// candidates.  The eight waves of a workgroup take eight consecutive groups
+// of 64 slots and go through the blocks together: what their lanes' candidates of block b lie in is 640 consecutive slots of
+// the sorted order, 128 slots older with every block -- ONE ring of 1024 slots per workgroup (entries, bytes 7..12, the bits
+// of the four key tables) into which two waves enter the 128 new slots of the next block while the current block is walked;
+// nothing is ever staged twice.  (Round 1's kernel for these levels restaged 192 slots per wave and block and compared two byte
+// keys per candidate with SWAR arithmetic: ~840 instructions per block before the first candidate was looked at.)
+// The quarter-budget result is what the walk holds when it has seen chain/4 candidates: at a block boundary for chain
+// 1024 and 4096, between the two halves of the first block for chain 256.
+// ------------------------------------------------------------------------------------------------
+constexpr int M6_RING = 1024;
+constexpr int M6_ROW_WORDS = M6_RING / 32 + 1;
+constexpr int M6_TABLE = M5_ROWS * M6_ROW_WORDS * 4;
+constexpr int MATCH6_LDS = 2 * M6_RING * 8 + M5_SLOTS * M6_TABLE;       // 37504 per workgroup
+
+__global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, int nsl,
+                                                          const u32 *__restrict__ sorted, u32 *__restrict__ tables, u32 *__restrict__ quarter, LevelCfg cfg,
+                                                          u32 *__restrict__ flags, int all_quarters)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    __shared__ u32 wg_h[M5_WAVES], wg_rc[M5_WAVES], wg_tail[M5_WAVES], wg_min;      // per group of the set: hash and position of its last slot, slots since its last run start (0: none starts in it)
+    const u32 xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const u32 tile_id = (jb / (u32)nsl) * 8 + xcd, slice = jb % (u32)nsl;
+    if (tile_id >= (u32)n_tiles) return;
+    const TileDesc td = tiles[tile_id];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u8 *gwin = stream + td.stream_off + td.w;
+    auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
+    u64 *SE = (u64 *)smem;
+    u64 *SX = SE + M6_RING;
+    u32 *TB = (u32 *)(smem + 2 * M6_RING * 8);                     // [level][row][32 words + 1]
+    u32 *T = tables + td.stream_off, *TQ = quarter + td.stream_off;
+    if (threadIdx.x < 2 && slice == 0) {
+        const u32 hashed_end = td.w + td.wlen;
+        const u32 p = hashed_end + threadIdx.x;
+        if (p >= td.a && p < td.own_end) { T[p] = 0; if (all_quarters) TQ[p] = 0; }
+    }
+    if (td.wlen == 0) return;
+    const u32 *sk = sorted + td.sorted_off;
+    const u32 wlen = td.wlen, n = td.n;
+    const u32 ngroups = (wlen + 63) / 64;
+    const u32 halo = td.a - td.w;
+    const u32 chain = (u32)cfg.chain, qchain = (u32)cfg.chain >> 2;
+    const u32 gpb = ((ngroups + (u32)nsl - 1) / (u32)nsl + M5_WAVES - 1) / M5_WAVES * M5_WAVES;      // groups per workgroup: whole sets of eight
+    const u32 gb_begin = slice * gpb, gb_end = min(ngroups, gb_begin + gpb);
+    if (gb_begin >= gb_end) return;                                // (the whole workgroup)
+    for (int k = threadIdx.x; k < M5_SLOTS * M6_TABLE / 4; k += M5_WAVES * 64) TB[k] = 0;
+    u32 inv[6];                                                    // lane r builds row r of the first table: bit j of r clear -> all ones
+#pragma unroll
+    for (int j = 0; j < 6; j++) inv[j] = ((lane >> j) & 1) ? 0u : 0xffffffffu;
+    typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    auto load16 = [&](u32 r, u32 &lo, u32 &hi, u64 &x) {
+        const u8 *q = gwin + (r & ~3u);
+        const u32x4_a4 w = *(const u32x4_a4 *)q;
+        lo = alignbyte(w.y, w.x, r);
+        hi = alignbyte(w.z, w.y, r);
+        const u32 b8 = alignbyte(w.w, w.z, r), b12 = alignbyte(0u, w.w, r) & 0xffu;
+        x = (u64)(hi >> 24) | ((u64)b8 << 8) | ((u64)b12 << 40);                    // bytes 7..12
+    };
+    // a batch = 64 consecutive slots from idx0 (a multiple of 64, possibly negative or beyond the window: no bits then)
+    struct Batch { bool valid; u32 rc, lo, hi; u64 x; };
+    auto fetch = [&](int idx0, Batch &bt) {
+        const int idx = idx0 + lane;
+        bt.valid = idx >= 0 && (u32)idx < wlen;
+        bt.rc = bt.valid ? sk[idx] & REL_MASK : 0;
+        load16(bt.rc, bt.lo, bt.hi, bt.x);
+    };
+    // it takes word pair (idx0 / 32) mod 32 of every table row: cleared and set again (first table from five ballots by the
+    // lane that owns the row, the others by atomic OR, as in k_match5)
+    auto commit = [&](int idx0, const Batch &bt) {
+        const u32 rp = (u32)(idx0 + lane) & (M6_RING - 1), word = rp >> 5, bit = 1u << (rp & 31);
+        const u64 ce = bt.valid ? make_entry(bt.rc, bt.lo, bt.hi) : ~0ull;
+        u32 key[M5_LEVELS];
+        m5_keys((u32)(ce >> 32), key);
+        const u32 wp = word & ~1u;
+        u32 *t1 = TB + 2 * (M6_TABLE / 4) + lane * M6_ROW_WORDS + wp;       // rows of tables 1..3 are contiguous: 96 rows
+        t1[0] = 0; t1[1] = 0;
+        if (lane < 32) { t1[64 * M6_ROW_WORDS] = 0; t1[64 * M6_ROW_WORDS + 1] = 0; }
+        const u64 vm = __ballot(bt.valid);
+        u32 m0 = (u32)vm, m1 = (u32)(vm >> 32);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const u64 B = __ballot((key[0] >> j) & 1);
+            m0 &= (u32)B ^ inv[j]; m1 &= (u32)(B >> 32) ^ inv[j];
+        }
+        { u32 *t0 = TB + lane * M6_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int d = 1; d < M5_LEVELS; d++)
+            if (bt.valid) atomicOr(&TB[m5_slot(d) * (M6_TABLE / 4) + key[d] * M6_ROW_WORDS + word], bit);
+        SE[rp] = ce;
+        SX[rp] = bt.x;
+    };
+    // The chain behind a slot = the slots back to the start of its hash run (the sorted order lists a run's positions in a row):
+    // inside a group from the ballot of the run starts, across groups carried along -- c_tail = slots since the last run start
+    // before the set's first group (capped), c_h / c_rc = hash and position of the slot before it; the same in every wave.
+    // Before the workgroup's first group the whole workgroup looks back for the start of that run.
+    u32 c_h = 0xfffffffdu, c_rc = 0, c_tail = 0;
+    if (gb_begin > 0) {
+        const u32 i1 = gb_begin * 64 - 1;
+        c_rc = sk[i1] & REL_MASK;
+        c_h = hash_of(wread(c_rc));
+        if (threadIdx.x == 0) wg_min = 0xffffffffu;
+        __syncthreads();
+        for (u32 r = 0; r * (M5_WAVES * 64) < chain; r++) {
+            const u32 t = 1 + threadIdx.x + r * (M5_WAVES * 64);            // is slot i1 - t still in the run of slot i1?
+            const bool mism = t > i1 || hash_of(wread(sk[i1 - (t > i1 ? 0 : t)] & REL_MASK)) != c_h;
+            if (mism) atomicMin(&wg_min, t);
+            __syncthreads();
+            if (wg_min != 0xffffffffu) break;
+        }
+        c_tail = wg_min < chain ? wg_min : chain;
+        __syncthreads();
+    }
+    for (u32 gs = gb_begin; gs < gb_end; gs += M5_WAVES) {
+        const int G0 = (int)gs * 64;
+        const u32 g = gs + (u32)wave;
+        const bool active = g < gb_end;
+        const u32 i = g * 64 + lane;
+        const u32 rp0 = (active && i < wlen) ? sk[i] & REL_MASK : 0;
+        u32 own_lo, own_hi;
+        u64 ex;
+        load16(rp0, own_lo, own_hi, ex);
+        // block 0 needs slots G0 - 128 .. G0 + 511: ten batches, wave v enters batches v and v + 8
+        Batch ba, bb;
+        fetch(G0 - 128 + 64 * wave, ba);
+        if (wave < 2) fetch(G0 - 128 + 64 * (wave + 8), bb);
+        const u64 e = make_entry(rp0, own_lo, own_hi);
+        const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
+        const u32 rel_p = e0 & REL_MASK;
+        const bool own = active && i < wlen && rel_p >= halo;
+        u32 key[M5_LEVELS];
+        m5_keys(e1, key);
+        const u32 p_abs = td.w + rel_p;
+        const u32 look = n - p_abs;
+        const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
+        const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
+        const int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
+        const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
+        u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
+        bool stop = false, qtaken = false;
+        const bool have = active && i < wlen;
+        const u32 h_own = have ? hash_of(own_lo) : 0xfffffffeu;
+        if (lane == 63) { wg_h[wave] = h_own; wg_rc[wave] = rel_p; }
+        __syncthreads();                                           // the ring is free (first set: the tables are zero)
+        commit(G0 - 128 + 64 * wave, ba);
+        if (wave < 2) commit(G0 - 128 + 64 * (wave + 8), bb);
+        u32 nbv;
+        {
+            u32 hp = __shfl_up(h_own, 1, 64), rcp = __shfl_up(rel_p, 1, 64);
+            if (lane == 0) { hp = wave ? wg_h[wave - 1] : c_h; rcp = wave ? wg_rc[wave - 1] : c_rc; }
+            const bool starts_run = h_own != hp;
+            if (__any(have && !starts_run && rel_p <= rcp)) { if (lane == 0) atomicOr(flags, 1u); }      // positions must increase inside a run (see k_match5)
+            const u64 sr = __ballot(starts_run);
+            if (lane == 0) wg_tail[wave] = sr ? (u32)__builtin_clzll(sr) + 1u : 0u;
+            __syncthreads();
+            u32 t = c_tail;                                         // slots since the last run start before this wave's group
+            for (int w = 0; w < wave; w++) { const u32 x = wg_tail[w]; t = x ? x : (t + 64u < chain ? t + 64u : chain); }
+            const u32 le_lo = lane >= 31 ? 0xffffffffu : (2u << lane) - 1, le_hi = lane < 32 ? 0u : lane == 63 ? 0xffffffffu : (2u << (lane - 32)) - 1;
+            const u32 mlo = (u32)sr & le_lo, mhi = (u32)(sr >> 32) & le_hi;
+            const u32 top = mhi ? 63u - (u32)__builtin_clz(mhi) : 31u - (u32)__builtin_clz(mlo | 1u);
+            nbv = (mlo | mhi) ? (u32)lane - top : (u32)lane + t;
+            nbv = own ? (nbv < chain ? nbv : chain) : 0;
+            // what the next set starts from (every wave works it out for itself)
+            u32 tt = c_tail;
+            for (int w = 0; w < M5_WAVES; w++) { const u32 x = wg_tail[w]; tt = x ? x : (tt + 64u < chain ? tt + 64u : chain); }
+            c_tail = tt; c_h = wg_h[M5_WAVES - 1]; c_rc = wg_rc[M5_WAVES - 1];
+        }
+        // The 128 slots block b + 1 adds lie just below what block b reads (other ring positions, other table words, and what
+        // they replace in the ring is 1024 slots newer: beyond anything still read), so they are entered DURING block b, by the
+        // wave pair (b mod 4), which fetched them during block b - 1: one barrier per block, and entering overlaps walking.
+        if (wave < 2) fetch(G0 - 256 + 64 * wave, ba);
+        for (u32 jbase = 0, blk = 0;; jbase += 128, blk++) {
+            if ((u32)(wave >> 1) == (blk & 3)) commit(G0 - (int)jbase - 256 + 64 * (wave & 1), ba);
+            if ((u32)(wave >> 1) == ((blk + 1) & 3)) fetch(G0 - (int)jbase - 384 + 64 * (wave & 1), ba);
+            if (jbase == qchain && !qtaken) { qbest = best; qdist = bdist; qtaken = true; }      // (chain / 4 a multiple of 128)
+            const u32 nbl = nbv > jbase ? (nbv - jbase < 128 ? nbv - jbase : 128) : 0;          // candidates of this lane in the block
+            if (__any(nbl != 0 && !stop)) {
+                // candidate jj (1 = newest) of this lane is slot i - jbase - jj: bit 128 - jj of the 128 ring positions from lo
+                const u32 lo = (u32)((int)i - (int)jbase - 128) & (M6_RING - 1), w0 = lo >> 5, sh = lo & 31;
+                u32 V[4], A4[4], A5[4], A6[4], A7[4];                 // V = inside the budget; A_d = V & "first d bytes may match"
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int s = 32 * k + (int)nbl - 96;           // candidates of word k: bits >= 32 - s
+                    V[k] = s <= 0 ? 0u : s >= 32 ? 0xffffffffu : 0xffffffffu << (32 - s);
+                }
+                auto rowmask = [&](const int d, const u32 (&in)[4], u32 (&out)[4]) __attribute__((always_inline)) {
+                    const u32 *row = TB + m5_slot(d) * (M6_TABLE / 4) + key[d] * M6_ROW_WORDS;
+                    const u32 W0 = row[w0], W1 = row[(w0 + 1) & 31], W2 = row[(w0 + 2) & 31], W3 = row[(w0 + 3) & 31], W4 = row[(w0 + 4) & 31];
+                    out[0] = in[0] & __builtin_amdgcn_alignbit(W1, W0, sh);
+                    out[1] = in[1] & __builtin_amdgcn_alignbit(W2, W1, sh);
+                    out[2] = in[2] & __builtin_amdgcn_alignbit(W3, W2, sh);
+                    out[3] = in[3] & __builtin_amdgcn_alignbit(W4, W3, sh);
+                };
+                rowmask(0, V, A4);
+                rowmask(1, A4, A5);
+                rowmask(2, A5, A6);
+                rowmask(3, A6, A7);
+                auto pickw = [&](const int w) __attribute__((always_inline)) -> u32 {
+                    u32 r = best >= 3 ? A4[w] : V[w];
+                    asm volatile("" : "+v"(r));
+                    r = best >= 4 ? A5[w] : r;
+                    asm volatile("" : "+v"(r));
+                    r = best >= 5 ? A6[w] : r;
+                    asm volatile("" : "+v"(r));
+                    return best >= 6 ? A7[w] : r;
+                };
+                const bool first = jbase == 0;
+                // a lane takes its own next candidate, newest first, whichever of the enabled words it is in
+                auto walk = [&](const bool u3, const bool u2, const bool u1, const bool u0) __attribute__((always_inline)) {
+                    u32 f3 = (stop || !u3) ? 0u : pickw(3), f2 = (stop || !u2) ? 0u : pickw(2);
+                    u32 f1 = (stop || !u1) ? 0u : pickw(1), f0 = (stop || !u0) ? 0u : pickw(0);
+                    while (__any((f3 | f2 | f1 | f0) != 0)) {
+                        if (f3 | f2 | f1 | f0) {
+                            const bool t3 = f3 != 0, t2 = f2 != 0, t1 = f1 != 0;
+                            const u32 cur = t3 ? f3 : t2 ? f2 : t1 ? f1 : f0;
+                            const u32 tb = t3 ? 96u : t2 ? 64u : t1 ? 32u : 0u;
+                            const u32 b = 31 - __builtin_clz(cur);
+                            const u32 clr = ~(1u << b);
+                            f3 = t3 ? f3 & clr : f3;
+                            f2 = (!t3 && t2) ? f2 & clr : f2;
+                            f1 = (!t3 && !t2 && t1) ? f1 & clr : f1;
+                            f0 = (!t3 && !t2 && !t1) ? f0 & clr : f0;
+                            const u32 t = tb + b;
+                            const u32 slot = (lo + t) & (M6_RING - 1);
+                            const u64 c = SE[slot];
+                            const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
+                            const u32 rel_c = c0 & REL_MASK;
+                            if ((int)rel_c > ((first && t == 127) ? lim1 : limn)) {
+                                const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
+                                if ((x0 & 0x1ff) == 0) {
+                                    u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
+                                    if (x1 == 0 && (x0 >> 9) == 0) {
+                                        const u64 y = SX[slot] ^ ex;
+                                        if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
+                                        else {
+                                            len = 13;
+                                            while (len < maxlen) {
+                                                const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
+                                                if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+                                                len += 4;
+                                            }
+                                        }
+                                    }
+                                    len = len < maxlen ? len : maxlen;
+                                    if (len > best) {
+                                        best = len; bdist = rel_p - rel_c;
+                                        if (len >= nice) stop = true;
+                                        f3 &= pickw(3); f2 &= pickw(2); f1 &= pickw(1); f0 &= pickw(0);      // fewer candidates can still win now
+                                    }
+                                }
+                            } else stop = true;                 // out of range: so is everything older
+                            if (stop) { f3 = 0; f2 = 0; f1 = 0; f0 = 0; }
+                        }
+                    }
+                };
+                if (first && qchain == 64) {
+                    walk(true, true, false, false);
+                    qbest = best; qdist = bdist; qtaken = true;
+                    walk(false, false, true, true);
+                } else walk(true, true, true, true);
+            } else if (jbase == 0 && qchain == 64) { qbest = best; qdist = bdist; qtaken = true; }
+            // another block while any lane of the workgroup has candidates left (this is also where everybody is done reading)
+            if (!__syncthreads_or(!stop && nbv > jbase + 128)) break;
+        }
+        if (!qtaken) { qbest = best; qdist = bdist; }
+        if (own) te_store(T, TQ, p_abs, best, bdist, qbest, qdist, (u32)cfg.good, all_quarters);
+    }
+}
+
+int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, u32 *d_tables, u32 *d_quarter,
+                 LevelCfg cfg, u32 *d_flags, int all_quarters)
+{
+    if (n_tiles == 0) return MTS_OK;
+    if (cfg.chain <= 128) {
+        if (MATCH5_LDS > 65536) MTS_LDS_ATTR(k_match5, MATCH5_LDS);
+        int nsl = M5_SLICES;
+        if (const char *e = getenv("MTS_MATCH_SLICES")) nsl = atoi(e) > 0 ? atoi(e) : nsl;
+        const int grid = (n_tiles + 7) / 8 * 8 * nsl;
+        hipLaunchKernelGGL(k_match5, dim3(grid), dim3(M5_WAVES * 64), MATCH5_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, d_quarter, cfg, d_flags, all_quarters);
+    } else {
+        if (cfg.chain != 256 && (cfg.chain >> 2) % 128 != 0) { set_error("match: chain budget %d unsupported", cfg.chain); return MTS_E_INTERNAL; }
+        const int nsl = M5_SLICES;
+        const int grid = (n_tiles + 7) / 8 * 8 * nsl;
+        hipLaunchKernelGGL(k_match6, dim3(grid), dim3(M5_WAVES * 64), MATCH6_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, d_quarter, cfg, d_flags, all_quarters);
+    }
+    MTS_HIP(hipGetLastError());
+    return MTS_OK;
+}
+
+}  // namespace mts

@@ -303,9 +303,9 @@ def test_slices_through_device_cache(cache_gb, tmp_cfg, monkeypatch):
     if float(cache_gb) > 0:
         assert r._dev_cache is not None
         if cache_gb == '8':
-            assert hip.cache_query(r._dev_cache, list(range(30))).sum() >= 25     # what was touched stays resident
+            assert (hip.cache_query(r._dev_cache, list(range(30))) > 0).sum() >= 25     # what was touched stays resident
         else:
-            assert 1 <= hip.cache_query(r._dev_cache, list(range(30))).sum() <= 3
+            assert 1 <= (hip.cache_query(r._dev_cache, list(range(30))) > 0).sum() <= 3
     else:
         assert r._dev_cache is None
     r.close()
@@ -343,12 +343,12 @@ def test_cache_c_abi_miss_and_eviction():
         lens = [len(c) for c in z]
         st, rows = hip.cache_read_rows(cid, [0, 1, 2], buf, offs[:3], lens[:3], [1000] * 3, 8, np.int16, flags, 500, 2500)
         assert st == [0, 0, 0] and np.array_equal(rows, x[500:2500])
-        assert list(hip.cache_query(cid, [0, 1, 2, 3])) == [True, True, True, False]
+        assert list(hip.cache_query(cid, [0, 1, 2, 3]) > 0) == [True, True, True, False]
         st, rows = hip.cache_read_rows(cid, [1, 2], b'', [0, 0], [0, 0], [1000] * 2, 8, np.int16, flags, 0, 2000)   # from HBM only
         assert np.array_equal(rows, x[1000:3000])
         st, rows = hip.cache_read_rows(cid, [3], buf, [offs[3]], [lens[3]], [1000], 8, np.int16, flags, 0, 1000)
         assert np.array_equal(rows, x[3000:4000])
-        assert list(hip.cache_query(cid, [0, 1, 2, 3])) == [False, True, True, True]                                # LRU: chunk 0 went
+        assert list(hip.cache_query(cid, [0, 1, 2, 3]) > 0) == [False, True, True, True]                                # LRU: chunk 0 went
         st, rows = hip.cache_read_rows(cid, [0], buf, [offs[0]], [lens[0]], [999], 8, np.int16, flags, 0, 999)     # wrong row count
         assert st == [hip.CHUNK_BADSIZE]
     finally:

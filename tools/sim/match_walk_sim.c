@@ -1,0 +1,204 @@
+// Walk simulator for the match stage (development tool, CPU only; not part of the library or the oracle).
+//
+// Replays, on a real stream window, what k_match5 does per 64-slot group of the hash-sorted order -- the filter masks of
+// every lane (V, A4..A7 from the same 6/5-bit keys), the newest-first walk with its refinement -- and counts scorings and
+// rounds (a round = one trip of the wave through the candidate loop: as many as the busiest lane needs), so that other
+// schedules of the same work can be costed before any of them is built:
+//   current      rounds of the newest 32 + rounds of the other 96, per group
+//   pooled       the other 96 (optionally: whatever is left after R rounds in place) taken over by work items that are
+//                refilled as lanes finish; items live G groups at most (the ring)
+//   more filters extra key levels (bytes 7, 8, ...)
+// and the demand side: which positions the exact parse visits (tables from the same walk).
+//
+//   gcc -O2 -o /tmp/match_walk_sim tools/sim/match_walk_sim.c && /tmp/match_walk_sim stream.bin [window_offset] [window_len]
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+enum { MAX_DIST = 32506, MAX_MATCH = 258, CHAIN = 128, QCHAIN = 32, NICE = 128, GOOD = 8, LAZY = 16, TOO_FAR = 4096 };
+
+static u32 hash_of(const u8 *b) { return ((b[0] << 10) ^ (b[1] << 5) ^ b[2]) & 0x7fff; }
+static u32 umul24(u32 a, u32 b) { return (a & 0xffffff) * (b & 0xffffff); }
+static u32 h24(u32 x) { return (umul24(x, 0x9E3779u) >> 19) & 31; }
+static void keys(const u8 *b, u32 k[6])
+{
+    const u32 e1 = b[3] | (b[4] << 8) | (b[5] << 16) | ((u32)b[6] << 24);
+    k[0] = (umul24(e1 & 0xff, 0x9E3779u) >> 18) & 63;
+    k[1] = h24(e1 & 0xffff);
+    k[2] = h24(e1 & 0xffffff);
+    k[3] = h24((e1 ^ (e1 >> 11)) & 0xffffff);
+    k[4] = b[7] & 31;                                    // extra levels (what-if): byte 7 (5 bits, exact within them), byte 8
+    k[5] = (b[8] ^ (b[8] >> 3)) & 31;
+}
+static u32 lcp(const u8 *a, const u8 *b, u32 maxlen)
+{
+    u32 l = 0;
+    while (l < maxlen && a[l] == b[l]) l++;
+    return l;
+}
+
+typedef struct { u32 n1, n2; u32 best, bdist, qbest, qdist; } LaneRes;
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: %s stream.bin [offset] [len] [levels=4]\n", argv[0]); return 2; }
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) { perror("open"); return 2; }
+    fseek(f, 0, SEEK_END);
+    long fsz = ftell(f);
+    long off = argc > 2 ? atol(argv[2]) : 0, W = argc > 3 ? atol(argv[3]) : (1 << 18);
+    const int NLEV = argc > 4 ? atoi(argv[4]) : 4;       // key levels in use: 4 (as built) .. 6
+    if (off + W > fsz) W = fsz - off;
+    u8 *s = malloc(W + 512);
+    memset(s, 0, W + 512);
+    fseek(f, off, SEEK_SET);
+    if (fread(s, 1, W, f) != (size_t)W) { perror("read"); return 2; }
+    fclose(f);
+    const u32 n = (u32)W, wlen = n - 2;
+    // sorted order: stable by (hash, position)
+    u32 *cnt = calloc(32769, 4), *sorted = malloc(4 * wlen), *slot_of = malloc(4 * wlen);
+    for (u32 p = 0; p < wlen; p++) cnt[hash_of(s + p) + 1]++;
+    for (int h = 0; h < 32768; h++) cnt[h + 1] += cnt[h];
+    for (u32 p = 0; p < wlen; p++) sorted[cnt[hash_of(s + p)]++] = p;
+    for (u32 i = 0; i < wlen; i++) slot_of[sorted[i]] = i;
+    u32 *tf = calloc(n + 4, 4), *tq = calloc(n + 4, 4);          // (len << 16 | dist)
+    const u32 ngroups = (wlen + 63) / 64;
+    u64 tot1 = 0, tot2 = 0, rounds1 = 0, rounds2 = 0, lanes = 0, hist1[64] = {0}, hist2[64] = {0}, wasted = 0;
+    u64 act1[40] = {0}, act2[40] = {0};
+    // pooled what-ifs: in-place rounds R for the newest word, everything else as items
+    enum { NR = 4 };
+    u64 inplace_rounds[NR] = {0}, items[NR] = {0}, item_scorings[NR] = {0}, item_max[NR] = {0};
+    LaneRes *res = malloc(sizeof(LaneRes) * 64);
+    u32 (*seq)[160] = malloc(64 * 160 * 4);                 // per lane: scorings in walk order (candidate index j), for the what-ifs
+    for (u32 g = 0; g < ngroups; g++) {
+        u32 gmax1 = 0, gmax2 = 0;
+        u32 nseq[64];
+        for (int lane = 0; lane < 64; lane++) {
+            const u32 i = g * 64 + lane;
+            nseq[lane] = 0;
+            res[lane].n1 = res[lane].n2 = 0;
+            if (i >= wlen) continue;
+            const u32 p = sorted[i];
+            const u8 *me = s + p;
+            const u32 h = hash_of(me);
+            u32 nbv = 0;
+            while (nbv < CHAIN && i > nbv && hash_of(s + sorted[i - nbv - 1]) == h) nbv++;
+            const u32 look = n - p, maxlen = look < MAX_MATCH ? look : MAX_MATCH, nice = NICE < look ? NICE : look;
+            u32 mk[6];
+            keys(me, mk);
+            // level of every candidate: how many key levels agree in a row (0..NLEV)
+            u8 lev[CHAIN + 1];
+            for (u32 j = 1; j <= nbv; j++) {
+                u32 ck[6];
+                keys(s + sorted[i - j], ck);
+                int l = 0;
+                while (l < NLEV && ck[l] == mk[l]) l++;
+                lev[j] = (u8)l;
+            }
+            u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
+            int stop = 0, qset = 0;
+            lanes++;
+            for (u32 j = 1; j <= nbv && !stop; j++) {
+                if (j == QCHAIN + 1) { qbest = best; qdist = bdist; qset = 1; }
+                // is candidate j let through at the current best?  level needed: best>=3 -> A4 (lev>=1), >=4 -> A5, ... capped at NLEV
+                u32 need = best >= 3 ? best - 2 : 0;
+                if (need > (u32)NLEV) need = NLEV;
+                if (lev[j] < need) continue;
+                // scored
+                if (j <= QCHAIN) res[lane].n1++; else res[lane].n2++;
+                seq[lane][nseq[lane]++] = j;
+                const u32 c = sorted[i - j];
+                // zlib: the head of the chain may be MAX_DIST away, the others must be nearer; position 0 is NIL
+                const u32 lim = j == 1 ? (p > MAX_DIST + 1 ? p - MAX_DIST - 1 : 0) : (p > MAX_DIST ? p - MAX_DIST : 0);
+                if (!(c > lim)) { stop = 1; break; }
+                if (memcmp(s + c, me, 3)) { wasted++; continue; }                       // same hash, other bytes
+                const u32 len = lcp(s + c, me, maxlen);
+                if (len > best) { best = len; bdist = p - c; if (len >= nice) stop = 1; }
+                else wasted++;
+            }
+            if (!qset) { qbest = best; qdist = bdist; }             // the walk ended inside the newest QCHAIN candidates
+            res[lane].best = best; res[lane].bdist = bdist; res[lane].qbest = qbest; res[lane].qdist = qdist;
+            tf[p] = best >= 3 ? (best << 16) | bdist : 0;
+            tq[p] = qbest >= 3 ? (qbest << 16) | qdist : 0;
+            tot1 += res[lane].n1; tot2 += res[lane].n2;
+            hist1[res[lane].n1 < 63 ? res[lane].n1 : 63]++;
+            hist2[res[lane].n2 < 63 ? res[lane].n2 : 63]++;
+            if (res[lane].n1 > gmax1) gmax1 = res[lane].n1;
+            if (res[lane].n2 > gmax2) gmax2 = res[lane].n2;
+        }
+        rounds1 += gmax1; rounds2 += gmax2;
+        for (u32 r = 0; r < gmax1 && r < 40; r++) for (int l = 0; l < 64; l++) if (res[l].n1 > r) act1[r]++;
+        for (u32 r = 0; r < gmax2 && r < 40; r++) for (int l = 0; l < 64; l++) if (res[l].n2 > r) act2[r]++;
+        // what-if: R rounds of the newest word in place, then every lane with anything left becomes an item
+        for (int R = 0; R < NR; R++) {
+            u32 rr = gmax1 < (u32)R ? gmax1 : (u32)R;
+            inplace_rounds[R] += rr;
+            for (int l = 0; l < 64; l++) {
+                const u32 left = (res[l].n1 > (u32)R ? res[l].n1 - R : 0) + res[l].n2;
+                if (left) { items[R]++; item_scorings[R] += left; if (left > item_max[R]) item_max[R] = left; }
+            }
+        }
+    }
+    printf("window %ld bytes at %ld: %u groups, %llu lanes\n", W, off, ngroups, (unsigned long long)lanes);
+    printf("scorings per position: newest32 %.3f  other96 %.3f  (wasted %.3f)\n", (double)tot1 / lanes, (double)tot2 / lanes, (double)wasted / lanes);
+    printf("rounds per group:      newest32 %.2f  other96 %.2f   lane use %.1f%% / %.1f%%\n", (double)rounds1 / ngroups, (double)rounds2 / ngroups,
+           100.0 * tot1 / (rounds1 * 64.0), 100.0 * tot2 / (rounds2 * 64.0));
+    printf("lanes by scorings (newest32): ");
+    for (int k = 0; k < 12; k++) printf("%d:%.1f%% ", k, 100.0 * hist1[k] / lanes);
+    printf("\nlanes by scorings (other96):  ");
+    for (int k = 0; k < 12; k++) printf("%d:%.1f%% ", k, 100.0 * hist2[k] / lanes);
+    printf("\nactive lanes per round (newest32): ");
+    for (int r = 0; r < 10; r++) printf("%.1f ", (double)act1[r] / ngroups);
+    printf("\nactive lanes per round (other96):  ");
+    for (int r = 0; r < 10; r++) printf("%.1f ", (double)act2[r] / ngroups);
+    printf("\n");
+    for (int R = 0; R < NR; R++)
+        printf("pool after %d in-place rounds: in-place %.2f rounds/group, items %.1f/group with %.2f scorings each (max %llu) = %.2f full rounds/group\n", R,
+               (double)inplace_rounds[R] / ngroups, (double)items[R] / ngroups, (double)item_scorings[R] / (items[R] ? items[R] : 1),
+               (unsigned long long)item_max[R], (double)item_scorings[R] / ngroups / 64.0);
+    // demand side: which positions does the exact level-6 parse visit (SURVEY A.2 with the tables above)?
+    {
+        u64 visited = 0, vis_full = 0, vis_quarter = 0, vis_none = 0;
+        u8 *vis = calloc(n + 1, 1);
+        u32 p = 0, ml = 2, ms = 0, avail = 0;
+        (void)ms;
+        while (p < n) {
+            u32 pl = ml, cand_len = 0;
+            ml = 2;
+            if (n - p >= 3) {
+                if (pl < LAZY) {
+                    const u32 e = pl >= GOOD ? tq[p] : tf[p];
+                    visited++; vis[p] = 1;
+                    if (pl >= GOOD) vis_quarter++; else vis_full++;
+                    cand_len = e >> 16;
+                    const u32 cd = e & 0xffff;
+                    if (cand_len > pl) { ml = cand_len; if (ml == 3 && cd > TOO_FAR) ml = 2; }
+                } else vis_none++;
+            }
+            if (pl >= 3 && ml <= pl) { p += pl - 1; avail = 0; ml = 2; }
+            else if (avail) { p++; }
+            else { avail = 1; p++; }
+        }
+        printf("demand: the exact parse looks up %.1f%% of the positions (full budget %.1f%%, quarter %.1f%%; %.1f%% visited without a lookup)\n",
+               100.0 * visited / n, 100.0 * vis_full / n, 100.0 * vis_quarter / n, 100.0 * vis_none / n);
+        // per 64-slot group of the sorted order: how many lanes are in demand
+        u64 dl = 0, dgroups = 0, d_r1 = 0, d_r2 = 0;
+        u64 dh[65] = {0};
+        (void)d_r1; (void)d_r2;
+        for (u32 g = 0; g < ngroups; g++) {
+            u32 c = 0;
+            for (int l = 0; l < 64; l++) { const u32 i = g * 64 + l; if (i < wlen && vis[sorted[i]]) c++; }
+            dl += c; dgroups++; dh[c]++;
+        }
+        printf("demand per sorted group: %.1f lanes of 64 on average; groups by demanded lanes: ", (double)dl / dgroups);
+        for (int c = 0; c <= 64; c += 8) { u64 a = 0; for (int k = c; k < c + 8 && k <= 64; k++) a += dh[k]; printf("%d+:%.1f%% ", c, 100.0 * a / dgroups); }
+        printf("\n");
+        free(vis);
+    }
+    return 0;
+}
