@@ -52,17 +52,19 @@ def main():
     a = ap.parse_args()
     stages = a.stages.split(',')
     for rep in range(a.reps):
-        for lib in a.libs:
-            env = dict(os.environ, MTSCOMP_HIP_LIB=str(Path(lib).resolve()))
+        for spec in a.libs:                                  # path[@ENV=VALUE[@ENV=VALUE...]]: a library build, plus environment switches for that run
+            lib, *sets = spec.split('@')
+            env = dict(os.environ, MTSCOMP_HIP_LIB=str(Path(lib).resolve()), PYTHONWARNINGS='ignore')
+            env.update(dict(kv.split('=', 1) for kv in sets))
             r = subprocess.run([sys.executable, '-c', CHILD % str(ROOT), str(a.level), str(a.chunks)], env=env, capture_output=True, text=True, timeout=900)
             line = r.stdout.strip().split('\n')[-1] if r.stdout.strip() else ''
             try:
                 d = json.loads(line)
                 ms = d['ms']
                 comp = sum(v for k, v in ms.items() if not k.startswith('inflate') and k not in ('adler32', 'cumsum_transpose'))
-                print('%-28s %s ok=%s  compress %.2f  ' % (Path(lib).name, d['sha1'][:10], d['ok'], comp) + ' '.join('%s %.2f' % (k.replace('inflate_', 'i_')[:10], ms[k]) for k in stages if k in ms), flush=True)
+                print('%-28s %s ok=%s  compress %.2f  ' % (Path(lib).name + ''.join('@' + x for x in sets), d['sha1'][:10], d['ok'], comp) + ' '.join('%s %.2f' % (k.replace('inflate_', 'i_')[:10], ms[k]) for k in stages if k in ms), flush=True)
             except Exception:  # noqa: BLE001
-                print('%-28s FAILED rc=%d %s' % (Path(lib).name, r.returncode, (r.stderr or r.stdout)[-400:]), flush=True)
+                print('%-28s FAILED rc=%d %s' % (spec, r.returncode, (r.stderr or r.stdout)[-400:]), flush=True)
 
 
 if __name__ == '__main__':
