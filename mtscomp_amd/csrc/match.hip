@@ -76,7 +76,8 @@ __device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
 __device__ unsigned long long g_m5_stats[8];          // groups walked, rounds of the newest word, rounds of the other 96, scorings of each
 #endif
 constexpr int M5_WAVES = 8;
-constexpr int M5_SLICES = 64;                        // workgroups per tile (MTS_MATCH_SLICES overrides: experiments)
+constexpr int M5_SLICES = 32;                        // workgroups per tile (MTS_MATCH_SLICES overrides: experiments): 16 groups per wave; 64: +0.25 ms, 48: +0.15 (round 4, two alternating runs each)
+constexpr int M6_SLICES = 64;
 constexpr int M5_RING = 256;
 constexpr int M5_ROWS = 32;
 constexpr int M5_LEVELS = 4;                         // tables for prefix lengths 4, 5, 6, 7
@@ -680,396 +681,21 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_match7 (chain budget 128: level 6, the reference's level): k_match5's filter masks and scoring, k_match6's ring -- ONE ring of
-// 1024 slots per workgroup, into which the eight waves enter eight consecutive 64-slot groups per step, every slot once (the entry
-// a lane scores against is the entry it entered) -- and a POOLED walk.  In k_match5 a wave stays in its candidate loop for as long
-// as its busiest lane needs: on the recordings the third and later rounds of the newest 32 candidates run with 5 lanes of 64, the
-// rounds of the other 96 with 23, 4, 1 (tools/sim/match_walk_sim.c).  Here a lane scores at most two candidates of the newest 32 in
-// place (64 and 48 lanes busy); whatever a lane has left then -- the rest of its newest word, its candidates among the other 96 --
-// becomes a work item in LDS (what it holds, its remaining candidates, the masks a longer match narrows them with: 80 bytes), and
-// after a barrier the workgroup's waves work the items off with every lane busy: a lane whose item is finished takes the next one
-// from the queue (refilled 16 lanes at a time, so the fetch code runs every few rounds, not every round).  Ring, tables and queue
-// are 77 KB: two workgroups per CU as before.
+// Built, measured and taken out again in round 4: k_match7, a POOLED walk (the commit before this one has it).  One ring per
+// workgroup like k_match6's, every slot entered once; a lane scored two candidates of its newest word in place (64 and 48 lanes of
+// 64 busy; the later rounds run with 5, the rounds of the other 96 candidates with 23, 4, 1 -- tools/sim/match_walk_sim.c,
+// confirmed by the instrumented kernel, tools/m5_stats.py) and left the rest as an 80-byte work item in LDS (what it holds, its
+// remaining candidates, the masks a longer match narrows them with), which the workgroup's waves worked off after a barrier,
+// refilling lanes from the queue.  Bit-exact on the first run, and slower: 8 waves per workgroup 42.4 ms (every wave takes 64
+// items and finds the queue empty: no refills, SQ_INSTS_VALU -5 %) / 55 ms (one wave works the queue off: -18 % instructions, seven
+// waves wait), 4 waves 38-42 ms, 2 waves 34.4 ms (-12 % instructions) against k_match5's 25.2 -- three barriers per step leave
+// the vector units idle, and parking, fetching and the barriers' bookkeeping (SALU x2.3) eat most of what the idle lanes cost.
 // ------------------------------------------------------------------------------------------------
-constexpr int M7_ITEM_WORDS = 20;                    // header (2 words), 2 spare, then per mask word (remaining, A5, A6, A7)
-constexpr int M7_INPLACE = 2;                        // rounds of the newest word scored in place
-#ifndef MTS_M7_PER_CONSUMER
-#define MTS_M7_PER_CONSUMER 160
-#endif
-constexpr int M7_PER_CONSUMER = MTS_M7_PER_CONSUMER;   // items per wave that works the queue off
-constexpr int M7_REFILL = 16;                        // idle lanes that make a wave go back to the queue
-template <int WAVES, int RING> constexpr int match7_lds() { return 2 * RING * 8 + M5_SLOTS * (M5_ROWS * (RING / 32 + 1) * 4) + WAVES * 64 * M7_ITEM_WORDS * 4; }      // <8, 1024>: 78464
-
-// WAVES waves per workgroup enter WAVES groups per step into a ring of RING >= 128 + 64 * WAVES slots
-template <int WAVES, int RING>
-__global__ __launch_bounds__(WAVES * 64) void k_match7(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, int nsl,
-                                                          const u32 *__restrict__ sorted, u32 *__restrict__ tables, u32 *__restrict__ quarter, LevelCfg cfg,
-                                                          u32 *__restrict__ flags, int all_quarters)
-{
-    constexpr int M7_RING = RING, M7_ROW_WORDS = RING / 32 + 1, M7_TABLE = M5_ROWS * M7_ROW_WORDS * 4, M7_QCAP = WAVES * 64;
-    static_assert(RING >= 128 + 64 * WAVES && (RING & (RING - 1)) == 0, "the ring holds a step's groups and the 128 slots before them");
-    (void)M7_QCAP;
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    __shared__ u32 wg_h[WAVES], wg_rc[WAVES], wg_tail[WAVES], wg_min, q_tail, q_head;
-    const u32 xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const u32 tile_id = (jb / (u32)nsl) * 8 + xcd, slice = jb % (u32)nsl;
-    if (tile_id >= (u32)n_tiles) return;
-    const TileDesc td = tiles[tile_id];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u8 *gwin = stream + td.stream_off + td.w;
-    auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
-    u64 *SE = (u64 *)smem;
-    u64 *SX = SE + M7_RING;
-    u32 *TB = (u32 *)(smem + 2 * M7_RING * 8);                     // [level][row][32 words + 1]
-    u32 *Q = (u32 *)(smem + 2 * M7_RING * 8 + M5_SLOTS * M7_TABLE);
-    u32 *T = tables + td.stream_off, *TQ = quarter + td.stream_off;
-    if (threadIdx.x < 2 && slice == 0) {
-        const u32 hashed_end = td.w + td.wlen;
-        const u32 p = hashed_end + threadIdx.x;
-        if (p >= td.a && p < td.own_end) { T[p] = 0; if (all_quarters) TQ[p] = 0; }
-    }
-    if (td.wlen == 0) return;
-    const u32 *sk = sorted + td.sorted_off;
-    const u32 wlen = td.wlen, n = td.n;
-    const u32 ngroups = (wlen + 63) / 64;
-    const u32 halo = td.a - td.w;
-    const u32 chain = (u32)cfg.chain;                              // 128
-    const u32 gpb = ((ngroups + (u32)nsl - 1) / (u32)nsl + WAVES - 1) / WAVES * WAVES;      // groups per workgroup: whole sets of eight
-    const u32 gb_begin = slice * gpb, gb_end = min(ngroups, gb_begin + gpb);
-    if (gb_begin >= gb_end) return;                                // (the whole workgroup)
-    for (int k = threadIdx.x; k < M5_SLOTS * M7_TABLE / 4; k += WAVES * 64) TB[k] = 0;
-    u32 inv[6];                                                    // lane r builds row r of the first table: bit j of r clear -> all ones
-#pragma unroll
-    for (int j = 0; j < 6; j++) inv[j] = ((lane >> j) & 1) ? 0u : 0xffffffffu;
-    typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-    auto load16 = [&](u32 r, u32 &lo, u32 &hi, u64 &x) {
-        const u8 *q = gwin + (r & ~3u);
-        const u32x4_a4 w = *(const u32x4_a4 *)q;
-        lo = alignbyte(w.y, w.x, r);
-        hi = alignbyte(w.z, w.y, r);
-        const u32 b8 = alignbyte(w.w, w.z, r), b12 = alignbyte(0u, w.w, r) & 0xffu;
-        x = (u64)(hi >> 24) | ((u64)b8 << 8) | ((u64)b12 << 40);                    // bytes 7..12
-    };
-    auto slot_rel = [&](long idx) -> u32 { return sk[idx < 0 ? 0 : (u64)idx < wlen ? (u32)idx : wlen - 1] & REL_MASK; };
-    // 64 consecutive slots from idx0 (a multiple of 64) take word pair (idx0 / 32) mod 32 of every table row: cleared and set again
-    // (first table from six ballots by the lane that owns the row, the others by atomic OR, as in k_match5)
-    auto commit = [&](long idx0, u32 rc, u32 lo, u32 hi, u64 x, u32 (&key)[M5_LEVELS]) -> u64 {
-        const long idx = idx0 + lane;
-        const bool valid = idx >= 0 && (u64)idx < wlen;
-        const u32 rp = (u32)idx & (M7_RING - 1), word = rp >> 5, bit = 1u << (rp & 31);
-        const u64 ce = valid ? make_entry(rc, lo, hi) : ~0ull;
-        m5_keys((u32)(ce >> 32), key);
-        const u32 wp = word & ~1u;
-        u32 *t1 = TB + 2 * (M7_TABLE / 4) + lane * M7_ROW_WORDS + wp;       // rows of tables 1..3 are contiguous: 96 rows
-        t1[0] = 0; t1[1] = 0;
-        if (lane < 32) { t1[64 * M7_ROW_WORDS] = 0; t1[64 * M7_ROW_WORDS + 1] = 0; }
-        const u64 vm = __ballot(valid);
-        u32 m0 = (u32)vm, m1 = (u32)(vm >> 32);
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const u64 B = __ballot((key[0] >> j) & 1);
-            m0 &= (u32)B ^ inv[j]; m1 &= (u32)(B >> 32) ^ inv[j];
-        }
-        { u32 *t0 = TB + lane * M7_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int d = 1; d < M5_LEVELS; d++)
-            if (valid) atomicOr(&TB[m5_slot(d) * (M7_TABLE / 4) + key[d] * M7_ROW_WORDS + word], bit);
-        SE[rp] = ce;
-        SX[rp] = x;
-        return ce;
-    };
-    // The chain behind a slot = the slots back to the start of its hash run: inside a group from the ballot of the run starts,
-    // across groups carried along (as in k_match6: c_tail = slots since the last run start before the set's first group (capped),
-    // c_h / c_rc = hash and position of the slot before it; the same in every wave).  Before the workgroup's first group the whole
-    // workgroup looks back for the start of that run.
-    u32 c_h = 0xfffffffdu, c_rc = 0, c_tail = 0;
-    if (gb_begin > 0) {
-        const u32 i1 = gb_begin * 64 - 1;
-        c_rc = sk[i1] & REL_MASK;
-        c_h = hash_of(wread(c_rc));
-        if (threadIdx.x == 0) wg_min = 0xffffffffu;
-        __syncthreads();
-        for (u32 r = 0; r * (WAVES * 64) < chain; r++) {
-            const u32 t = 1 + threadIdx.x + r * (WAVES * 64);            // is slot i1 - t still in the run of slot i1?
-            const bool mism = t > i1 || hash_of(wread(sk[i1 - (t > i1 ? 0 : t)] & REL_MASK)) != c_h;
-            if (mism) atomicMin(&wg_min, t);
-            __syncthreads();
-            if (wg_min != 0xffffffffu) break;
-        }
-        c_tail = wg_min < chain ? wg_min : chain;
-        __syncthreads();
-    }
-    // one candidate of the position with entry (e0, e1), bytes 7..12 ex: its match length (0: other bytes behind an equal hash)
-    auto score = [&](u32 slot, u32 c0, u32 c1, u32 e0, u32 e1, u64 ex, u32 maxlen) __attribute__((always_inline)) -> u32 {
-        const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
-        if ((x0 & 0x1ff) != 0) return 0u;
-        u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
-        if (x1 == 0 && (x0 >> 9) == 0) {
-            const u64 y = SX[slot] ^ ex;
-            if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
-            else {
-                const u32 rel_c = c0 & REL_MASK, rel_p = e0 & REL_MASK;
-                len = 13;
-                while (len < maxlen) {
-                    const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
-                    if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
-                    len += 4;
-                }
-            }
-        }
-        return len < maxlen ? len : maxlen;
-    };
-    const bool first_set_has_history = gb_begin > 0;
-    // pipeline: position and bytes of this wave's slot of the current set, position of the next set's
-    long i_c = (long)(gb_begin + (u32)wave) * 64 + lane;
-    u32 rc_c = slot_rel(i_c), rc_n = slot_rel(i_c + WAVES * 64);
-    u32 lo_c, hi_c;
-    u64 x_c;
-    load16(rc_c, lo_c, hi_c, x_c);
-    for (u32 gs = gb_begin; gs < gb_end; gs += WAVES) {
-        const long G0 = (long)gs * 64;
-        const u32 g = gs + (u32)wave;
-        const bool active = g < gb_end;
-        const u32 i = g * 64 + lane;
-        const bool have = active && i < wlen;
-        // the 128 slots before the workgroup's first group are its first lanes' candidates: entered once, by waves 0 and 1
-        u32 h_rc = 0, h_lo = 0, h_hi = 0;
-        u64 h_x = 0;
-        const bool hist = gs == gb_begin && first_set_has_history && wave < 2;
-        if (hist) { h_rc = slot_rel(G0 - 128 + 64 * wave + lane); load16(h_rc, h_lo, h_hi, h_x); }
-        const u32 h_own = have ? hash_of(lo_c) : 0xfffffffeu;
-        if (lane == 63) { wg_h[wave] = h_own; wg_rc[wave] = rc_c; }
-        __syncthreads();                                           // A: nobody reads the ring or the queue of the step before any more
-        if (threadIdx.x == 0) { q_tail = 0; q_head = 0; }
-        u32 key[M5_LEVELS], hk[M5_LEVELS];
-        if (hist) commit(G0 - 128 + 64 * wave, h_rc, h_lo, h_hi, h_x, hk);
-        u64 e = ~0ull;
-#pragma unroll
-        for (int d = 0; d < M5_LEVELS; d++) key[d] = 0;
-        if (active) e = commit((long)g * 64, rc_c, lo_c, hi_c, x_c, key);
-        const u64 ex = x_c;
-        const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
-        const u32 rel_p = e0 & REL_MASK;
-        const bool own = have && rel_p >= halo;
-        u64 sr;
-        {
-            u32 hp = __shfl_up(h_own, 1, 64), rcp = __shfl_up(rc_c, 1, 64);
-            if (lane == 0) { hp = wave ? wg_h[wave - 1] : c_h; rcp = wave ? wg_rc[wave - 1] : c_rc; }
-            const bool starts_run = h_own != hp;
-            if (__any(have && !starts_run && rc_c <= rcp)) { if (lane == 0) atomicOr(flags, 1u); }      // positions must increase inside a run (see k_match5)
-            sr = __ballot(starts_run);
-            if (lane == 0) wg_tail[wave] = sr ? (u32)__builtin_clzll(sr) + 1u : 0u;
-        }
-        // next set's words, and the position of the one after
-        rc_c = rc_n;
-        load16(rc_c, lo_c, hi_c, x_c);
-        rc_n = slot_rel((long)i + 2 * WAVES * 64);
-        __syncthreads();                                           // B: the set is in the ring
-        u32 nbv;
-        {
-            u32 t = c_tail;                                         // slots since the last run start before this wave's group
-            for (int w = 0; w < wave; w++) { const u32 x = wg_tail[w]; t = x ? x : (t + 64u < chain ? t + 64u : chain); }
-            const u32 le_lo = lane >= 31 ? 0xffffffffu : (2u << lane) - 1, le_hi = lane < 32 ? 0u : lane == 63 ? 0xffffffffu : (2u << (lane - 32)) - 1;
-            const u32 mlo = (u32)sr & le_lo, mhi = (u32)(sr >> 32) & le_hi;
-            const u32 top = mhi ? 63u - (u32)__builtin_clz(mhi) : 31u - (u32)__builtin_clz(mlo | 1u);
-            nbv = (mlo | mhi) ? (u32)lane - top : (u32)lane + t;
-            nbv = own ? (nbv < chain ? nbv : chain) : 0;
-            u32 tt = c_tail;                                        // what the next set starts from (every wave works it out for itself)
-            for (int w = 0; w < WAVES; w++) { const u32 x = wg_tail[w]; tt = x ? x : (tt + 64u < chain ? tt + 64u : chain); }
-            c_tail = tt; c_h = wg_h[WAVES - 1]; c_rc = wg_rc[WAVES - 1];
-        }
-        if (__any(own)) {
-            const u32 p_abs = td.w + rel_p;
-            const u32 look = n - p_abs;
-            const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
-            const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
-            const int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
-            const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
-            // candidate j (1 = newest) of this lane is slot i - j: bit 128 - j of the 128 ring positions from lo
-            const u32 lo = (i - 128u) & (M7_RING - 1), w0 = lo >> 5, sh = lo & 31;
-            u32 V[4], A4[4], A5[4], A6[4], A7[4];                 // V = inside the budget; A_d = V & "first d bytes may match"
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int s = 32 * k + (int)nbv - 96;               // candidates of word k: bits >= 32 - s
-                V[k] = s <= 0 ? 0u : s >= 32 ? 0xffffffffu : 0xffffffffu << (32 - s);
-            }
-            auto rowmask = [&](const int d, const u32 (&in)[4], u32 (&out)[4]) __attribute__((always_inline)) {
-                const u32 *row = TB + m5_slot(d) * (M7_TABLE / 4) + key[d] * M7_ROW_WORDS;
-                const u32 W0 = row[w0], W1 = row[(w0 + 1) & (M7_RING / 32 - 1)], W2 = row[(w0 + 2) & (M7_RING / 32 - 1)], W3 = row[(w0 + 3) & (M7_RING / 32 - 1)], W4 = row[(w0 + 4) & (M7_RING / 32 - 1)];
-                out[0] = in[0] & __builtin_amdgcn_alignbit(W1, W0, sh);
-                out[1] = in[1] & __builtin_amdgcn_alignbit(W2, W1, sh);
-                out[2] = in[2] & __builtin_amdgcn_alignbit(W3, W2, sh);
-                out[3] = in[3] & __builtin_amdgcn_alignbit(W4, W3, sh);
-            };
-            rowmask(0, V, A4);
-            rowmask(1, A4, A5);
-            rowmask(2, A5, A6);
-            rowmask(3, A6, A7);
-            u32 best = 2, bdist = 0;
-            bool stop = false;
-            auto pickw = [&](const int w) __attribute__((always_inline)) -> u32 {
-                u32 r = best >= 3 ? A4[w] : V[w];
-                asm volatile("" : "+v"(r));
-                r = best >= 4 ? A5[w] : r;
-                asm volatile("" : "+v"(r));
-                r = best >= 5 ? A6[w] : r;
-                asm volatile("" : "+v"(r));
-                return best >= 6 ? A7[w] : r;
-            };
-            // the newest word in place: two rounds (a lane that has found nothing yet -- other bytes behind an equal hash -- goes on:
-            // an item keeps the masks of prefixes of five and more bytes only)
-            u32 el = pickw(3);
-            for (int r = 0; __any(el != 0 && (r < M7_INPLACE || best < 3)); r++) {
-                if (el != 0 && (r < M7_INPLACE || best < 3)) {
-                    const u32 b = 31 - __builtin_clz(el);
-                    el &= ~(1u << b);
-                    const u32 slot = (lo + 96 + b) & (M7_RING - 1);
-                    const u64 c = SE[slot];
-                    const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
-                    const u32 rel_c = c0 & REL_MASK;
-                    if ((int)rel_c > (b == 31 ? lim1 : limn)) {
-                        const u32 len = score(slot, c0, c1, e0, e1, ex, maxlen);
-                        if (len > best) {
-                            best = len; bdist = rel_p - rel_c;
-                            if (len >= nice) stop = true;
-                            el &= pickw(3);                         // fewer candidates can still win now
-                        }
-                    } else stop = true;                             // out of range: so is everything older
-                    if (stop) el = 0;
-                }
-            }
-            // what is left becomes an item; a lane with nothing left has its result
-            const u32 f2 = stop ? 0u : pickw(2), f1 = stop ? 0u : pickw(1), f0 = stop ? 0u : pickw(0);
-            const bool park = own && (el | f2 | f1 | f0) != 0;
-            const u64 pm = __ballot(park);
-            if (pm) {
-                u32 base = 0;
-                if (lane == 0) base = atomicAdd(&q_tail, (u32)__popcll(pm));
-                base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-                if (park) {
-                    const u32 idx = base + __builtin_amdgcn_mbcnt_hi((u32)(pm >> 32), __builtin_amdgcn_mbcnt_lo((u32)pm, 0u));
-                    u32 *it = Q + idx * M7_ITEM_WORDS;
-                    const u32 qtaken = el == 0 ? 1u : 0u;             // the newest 32 are done: what is held is the quarter-budget result
-                    *(uint2 *)it = make_uint2((i & (M7_RING - 1)) | (best << 10) | (best << 19) | (qtaken << 28), bdist | (bdist << 16));
-                    ((uint4 *)it)[1] = make_uint4(f0, A5[0], A6[0], A7[0]);
-                    ((uint4 *)it)[2] = make_uint4(f1, A5[1], A6[1], A7[1]);
-                    ((uint4 *)it)[3] = make_uint4(f2, A5[2], A6[2], A7[2]);
-                    ((uint4 *)it)[4] = make_uint4(el, A5[3], A6[3], A7[3]);
-                }
-            }
-            if (own && !park) te_store(T, TQ, p_abs, best, bdist, best, bdist, (u32)cfg.good, all_quarters);
-        }
-        __syncthreads();                                           // C: the queue is complete
-        {
-            const u32 qn = q_tail;
-            bool has = false, pending = false, drained = false;
-            u32 F0 = 0, F1 = 0, F2 = 0, F3 = 0, B5[4], B6[4], B7[4];
-            u32 ie0 = 0, ie1 = 0, ibest = 2, ibdist = 0, iqbest = 2, iqdist = 0, imaxlen = 0, inice = 0, ilo = 0, ipabs = 0;
-            int ilimn = 0;
-            u64 iex = 0;
-            bool iqtaken = false;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { B5[k] = 0; B6[k] = 0; B7[k] = 0; }
-            // few waves, each with work for several refills: a wave that takes its 64 items and finds the queue empty runs as many
-            // rounds as its busiest item needs, mostly idle
-            const u32 n_cons = qn / (u32)M7_PER_CONSUMER < 1u ? 1u : qn / (u32)M7_PER_CONSUMER;
-            if (qn != 0 && (u32)wave < n_cons) for (;;) {
-                const u64 idle = __ballot(!has);
-                if (!drained && (u32)__popcll(idle) >= (u32)M7_REFILL) {
-                    if (pending) { te_store(T, TQ, ipabs, ibest, ibdist, iqbest, iqdist, (u32)cfg.good, all_quarters); pending = false; }
-                    u32 base = 0;
-                    const int leader = __builtin_ffsll((long long)idle) - 1;
-                    if (lane == leader) base = atomicAdd(&q_head, (u32)__popcll(idle));
-                    base = (u32)__builtin_amdgcn_readlane((int)base, leader);
-                    drained = base + (u32)__popcll(idle) >= qn;
-                    const u32 k = base + __builtin_amdgcn_mbcnt_hi((u32)(idle >> 32), __builtin_amdgcn_mbcnt_lo((u32)idle, 0u));
-                    if (!has && k < qn) {
-                        const u32 *it = Q + k * M7_ITEM_WORDS;
-                        const uint2 hd = *(const uint2 *)it;
-                        const uint4 m0 = ((const uint4 *)it)[1], m1 = ((const uint4 *)it)[2], m2 = ((const uint4 *)it)[3], m3 = ((const uint4 *)it)[4];
-                        F0 = m0.x; B5[0] = m0.y; B6[0] = m0.z; B7[0] = m0.w;
-                        F1 = m1.x; B5[1] = m1.y; B6[1] = m1.z; B7[1] = m1.w;
-                        F2 = m2.x; B5[2] = m2.y; B6[2] = m2.z; B7[2] = m2.w;
-                        F3 = m3.x; B5[3] = m3.y; B6[3] = m3.z; B7[3] = m3.w;
-                        const u32 rp = hd.x & (M7_RING - 1);
-                        ibest = (hd.x >> 10) & 0x1ff; iqbest = (hd.x >> 19) & 0x1ff; iqtaken = (hd.x >> 28) & 1;
-                        ibdist = hd.y & 0xffff; iqdist = hd.y >> 16;
-                        const u64 oe = SE[rp];
-                        iex = SX[rp];
-                        ie0 = (u32)oe; ie1 = (u32)(oe >> 32);
-                        ilo = (rp - 128u) & (M7_RING - 1);
-                        ipabs = td.w + (ie0 & REL_MASK);
-                        const u32 look = n - ipabs;
-                        imaxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
-                        inice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
-                        ilimn = (int)(ipabs > (u32)MAX_DIST ? ipabs - MAX_DIST : 0) - (int)td.w;
-                        has = true;
-                    }
-                }
-                if (!__any(has)) break;
-                if (has) {
-                    if (!iqtaken && F3 == 0) { iqbest = ibest; iqdist = ibdist; iqtaken = true; }
-                    const bool t3 = F3 != 0, t2 = F2 != 0, t1 = F1 != 0;
-                    const u32 cur = t3 ? F3 : t2 ? F2 : t1 ? F1 : F0;
-                    const u32 tb = t3 ? 96u : t2 ? 64u : t1 ? 32u : 0u;
-                    const u32 b = 31 - __builtin_clz(cur);
-                    const u32 clr = ~(1u << b);
-                    F3 = t3 ? F3 & clr : F3;
-                    F2 = (!t3 && t2) ? F2 & clr : F2;
-                    F1 = (!t3 && !t2 && t1) ? F1 & clr : F1;
-                    F0 = (!t3 && !t2 && !t1) ? F0 & clr : F0;
-                    const u32 t = tb + b;
-                    const u32 slot = (ilo + t) & (M7_RING - 1);
-                    const u64 c = SE[slot];
-                    const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
-                    const u32 rel_c = c0 & REL_MASK;
-                    bool stop = false;
-                    // (the head of the chain, which alone may be MAX_DIST away, was scored in place: it is every lane's first candidate)
-                    if ((int)rel_c > ilimn) {
-                        const u32 len = score(slot, c0, c1, ie0, ie1, iex, imaxlen);
-                        if (len > ibest) {
-                            ibest = len; ibdist = (ie0 & REL_MASK) - rel_c;
-                            if (len >= inice) stop = true;
-                            // fewer candidates can still win now (the masks of prefixes of 5, 6, 7 bytes; a superset is all a filter has to be)
-                            const bool l7 = len >= 6, l6 = len == 5, l5 = len == 4;
-                            F0 &= l7 ? B7[0] : l6 ? B6[0] : l5 ? B5[0] : 0xffffffffu;
-                            F1 &= l7 ? B7[1] : l6 ? B6[1] : l5 ? B5[1] : 0xffffffffu;
-                            F2 &= l7 ? B7[2] : l6 ? B6[2] : l5 ? B5[2] : 0xffffffffu;
-                            F3 &= l7 ? B7[3] : l6 ? B6[3] : l5 ? B5[3] : 0xffffffffu;
-                        }
-                    } else stop = true;                             // out of range: so is everything older
-                    if (stop) { F0 = 0; F1 = 0; F2 = 0; F3 = 0; }
-                    if ((F0 | F1 | F2 | F3) == 0) {
-                        if (!iqtaken) { iqbest = ibest; iqdist = ibdist; }
-                        has = false; pending = true;                // stored when the lane goes for its next item
-                    }
-                }
-            }
-            if (pending) te_store(T, TQ, ipabs, ibest, ibdist, iqbest, iqdist, (u32)cfg.good, all_quarters);
-        }
-    }
-}
-
 int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, u32 *d_tables, u32 *d_quarter,
                  LevelCfg cfg, u32 *d_flags, int all_quarters)
 {
     if (n_tiles == 0) return MTS_OK;
-    static const int use7 = getenv("MTS_MATCH7") ? atoi(getenv("MTS_MATCH7")) : 0;      // the pooled walk (k_match7)
-    if (cfg.chain == 128 && use7 == 8) {
-        MTS_LDS_ATTR((k_match7<8, 1024>), (match7_lds<8, 1024>()));
-        const int nsl = M5_SLICES;
-        const int grid = (n_tiles + 7) / 8 * 8 * nsl;
-        hipLaunchKernelGGL((k_match7<8, 1024>), dim3(grid), dim3(8 * 64), (match7_lds<8, 1024>()), st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, d_quarter, cfg, d_flags, all_quarters);
-    } else if (cfg.chain == 128 && use7 == 4) {
-        const int nsl = M5_SLICES * 2;
-        const int grid = (n_tiles + 7) / 8 * 8 * nsl;
-        hipLaunchKernelGGL((k_match7<4, 512>), dim3(grid), dim3(4 * 64), (match7_lds<4, 512>()), st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, d_quarter, cfg, d_flags, all_quarters);
-    } else if (cfg.chain == 128 && use7 == 2) {
-        const int nsl = M5_SLICES * 4;
-        const int grid = (n_tiles + 7) / 8 * 8 * nsl;
-        hipLaunchKernelGGL((k_match7<2, 256>), dim3(grid), dim3(2 * 64), (match7_lds<2, 256>()), st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, d_quarter, cfg, d_flags, all_quarters);
-    } else if (cfg.chain <= 128) {
+    if (cfg.chain <= 128) {
         if (MATCH5_LDS > 65536) MTS_LDS_ATTR(k_match5, MATCH5_LDS);
         int nsl = M5_SLICES;
         if (const char *e = getenv("MTS_MATCH_SLICES")) nsl = atoi(e) > 0 ? atoi(e) : nsl;
@@ -1077,7 +703,7 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
         hipLaunchKernelGGL(k_match5, dim3(grid), dim3(M5_WAVES * 64), MATCH5_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, d_quarter, cfg, d_flags, all_quarters);
     } else {
         if (cfg.chain != 256 && (cfg.chain >> 2) % 128 != 0) { set_error("match: chain budget %d unsupported", cfg.chain); return MTS_E_INTERNAL; }
-        const int nsl = M5_SLICES;
+        const int nsl = M6_SLICES;
         const int grid = (n_tiles + 7) / 8 * 8 * nsl;
         hipLaunchKernelGGL(k_match6, dim3(grid), dim3(M5_WAVES * 64), MATCH6_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, d_quarter, cfg, d_flags, all_quarters);
     }
