@@ -625,9 +625,10 @@ static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const 
     int rc;
     if ((rc = E.stream.ensure(soff + STREAM_PAD))) return rc;
     if ((rc = E.tokens.ensure((toff + 64) * 4))) return rc;
-    const size_t o_ic = 0, o_res = align_up(sizeof(InfChunk) * n_chunks, 256), o_so = o_res + align_up(sizeof(InfResult) * n_chunks, 256),
-                 o_nn = o_so + align_up(8 * (size_t)n_chunks, 256), o_oo = o_nn + align_up(4 * (size_t)n_chunks, 256),
-                 o_rows = o_oo + align_up(8 * (size_t)n_chunks, 256), o_status = o_rows + align_up(4 * (size_t)n_chunks, 256),
+    // (what the host fills lies in a row: one copy)
+    const size_t o_ic = 0, o_so = align_up(sizeof(InfChunk) * n_chunks, 256), o_nn = o_so + align_up(8 * (size_t)n_chunks, 256),
+                 o_oo = o_nn + align_up(4 * (size_t)n_chunks, 256), o_rows = o_oo + align_up(8 * (size_t)n_chunks, 256),
+                 o_res = o_rows + align_up(4 * (size_t)n_chunks, 256), o_status = o_res + align_up(sizeof(InfResult) * n_chunks, 256),
                  o_end = o_status + align_up(4 * (size_t)n_chunks, 256);
     if ((rc = E.inf_desc.ensure(o_end + 256))) return rc;
     if ((rc = E.adler.ensure(sizeof(u64) * 2 * n_chunks + 256))) return rc;
@@ -637,7 +638,6 @@ static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const 
     InfChunk *d_ic = (InfChunk *)(dp + o_ic);
     InfResult *d_res = (InfResult *)(dp + o_res);
     u64 *d_so = (u64 *)(dp + o_so);
-    u32 *d_nn = (u32 *)(dp + o_nn);
     u64 *d_oo = (u64 *)(dp + o_oo);
     u32 *d_rows = (u32 *)(dp + o_rows);
     int *d_status = (int *)(dp + o_status);
@@ -646,11 +646,15 @@ static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const 
         for (int i = 0; i < n_chunks; i++) clens[i] = ic[i].c_len;
         if ((rc = E.inf_scratch.ensure(inflate_scratch_bytes(n_chunks, clens.data(), nn.data())))) return rc;
     }
-    MTS_HIP(hipMemcpyAsync(d_ic, ic.data(), sizeof(InfChunk) * n_chunks, hipMemcpyHostToDevice, st));
-    MTS_HIP(hipMemcpyAsync(d_so, so.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
-    MTS_HIP(hipMemcpyAsync(d_nn, nn.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
-    MTS_HIP(hipMemcpyAsync(d_oo, oo.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
-    MTS_HIP(hipMemcpyAsync(d_rows, rows.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    {
+        std::vector<u8> hst(o_res, 0);
+        memcpy(hst.data() + o_ic, ic.data(), sizeof(InfChunk) * n_chunks);
+        memcpy(hst.data() + o_so, so.data(), 8 * (size_t)n_chunks);
+        memcpy(hst.data() + o_nn, nn.data(), 4 * (size_t)n_chunks);
+        memcpy(hst.data() + o_oo, oo.data(), 8 * (size_t)n_chunks);
+        memcpy(hst.data() + o_rows, rows.data(), 4 * (size_t)n_chunks);
+        MTS_HIP(hipMemcpyAsync(dp, hst.data(), o_res, hipMemcpyHostToDevice, st));      // (pageable: staged before the call returns)
+    }
     E.t_begin(st);
     if ((rc = launch_inflate(st, d_cdata, d_ic, ic.data(), n_chunks, E.stream.as<u8>(), E.tokens.as<u32>(), d_res, E.adler.as<u64>(),
                              max_n, d_status, E.inf_scratch.p, &E))) return rc;

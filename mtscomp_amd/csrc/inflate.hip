@@ -2407,6 +2407,14 @@ __global__ __launch_bounds__(64) void k_inf_finish(const InfChunk *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // host side of the inflate pipeline
 // ------------------------------------------------------------------------------------------------
+// which chunk a candidate slot / a true-block slot belongs to
+__global__ __launch_bounds__(256) void k_inf_fill_slots(const InfFast *__restrict__ fast, u32 *__restrict__ slot_chunk, u32 *__restrict__ tslot_chunk)
+{
+    const InfFast f = fast[blockIdx.x];
+    for (u32 k = threadIdx.x; k < f.cand_cap; k += 256) slot_chunk[f.cand_off + k] = blockIdx.x;
+    for (u32 k = threadIdx.x; k < f.true_cap; k += 256) tslot_chunk[f.true_off + k] = blockIdx.x;
+}
+
 static inline u32 cand_cap_of(u64 c_len) { return (u32)(c_len / 4096 + 64); }
 
 // scratch layout (all 256-B aligned): [so u64 n][nn u32 n][fast n][cand_cnt n][true_cnt n][seq_flag n]
@@ -2426,17 +2434,17 @@ static InfLayout inf_layout(int n_chunks, const u64 *c_lens, const u32 *n_expect
     l.total_true = (u32)(2 * tc);
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t r = o; o += align_up(bytes, 256); return r; };
+    // (what the host fills -- so, nn, fast, gb_off, tb_off -- lies in a row: one copy)
     l.so = take(8 * (size_t)n_chunks); l.nn = take(4 * (size_t)n_chunks); l.fast = take(sizeof(InfFast) * (size_t)n_chunks);
+    l.gb_off = take(8 * (size_t)n_chunks); l.tb_off = take(8 * (size_t)n_chunks);
     l.cand_cnt = take(4 * (size_t)n_chunks); l.true_cnt = take(4 * (size_t)n_chunks); l.seq_flag = take(4 * (size_t)n_chunks);
     l.slot_chunk = take(4 * (size_t)l.total_cand); l.tslot_chunk = take(4 * (size_t)l.total_true);
     l.cand_pos = take(8 * (size_t)l.total_cand); l.cand_tmp = take(8 * (size_t)l.total_cand);
     l.cres = take(sizeof(CandRes) * (size_t)l.total_cand); l.tblk = take(sizeof(TrueBlk) * (size_t)l.total_true);
     l.subs = take(sizeof(uint2) * (size_t)SUBCAP * l.total_cand);
-    l.gb_off = take(8 * (size_t)n_chunks);
     size_t ng = 0;
     for (int i = 0; i < n_chunks; i++) ng += ((size_t)n_expect[i] + 2 + 63) / 64 + 2;       // tokens <= bytes + 1
     l.gbase = take(4 * ng);
-    l.tb_off = take(8 * (size_t)n_chunks);
     l.tile_base = take(4 * (ng / GS_TILE + 2 * (size_t)n_chunks + 16));
     u64 cbits = 0;
     for (int i = 0; i < n_chunks; i++) cbits += 8 * c_lens[i];
@@ -2509,35 +2517,30 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
         for (int i = 0; i < n_chunks; i++)
             fprintf(stderr, "[chunk %d] c_off %llu c_len %llu n_expect %u n_need %u stream_off %llu tok_off %llu\n", i, (unsigned long long)h_chunks[i].c_off,
                     (unsigned long long)h_chunks[i].c_len, h_chunks[i].n_expect, h_chunks[i].n_need, (unsigned long long)h_chunks[i].stream_off, (unsigned long long)h_chunks[i].tok_off);
-    std::vector<u64> gboff(n_chunks), tboff(n_chunks);
+    // the per-chunk index arrays go to the device in ONE copy (they lie in a row in the scratch area, see inf_layout); which chunk a
+    // candidate / true-block slot belongs to -- ~6000 words per chunk -- is filled in on the device (the 60-chunk batch spent
+    // 0.9 ms of host time and a 1.5 MB pageable copy on it before its first kernel)
+    u8 *S = (u8 *)d_scratch;
+    std::vector<u8> hst(l.cand_cnt - l.so, 0);
+    u64 *h_so = (u64 *)(hst.data() + (l.so - l.so)), *h_gb = (u64 *)(hst.data() + (l.gb_off - l.so)), *h_tb = (u64 *)(hst.data() + (l.tb_off - l.so));
+    u32 *h_nn = (u32 *)(hst.data() + (l.nn - l.so));
+    InfFast *h_fast = (InfFast *)(hst.data() + (l.fast - l.so));
     {
-        u64 a = 0, b2 = 0;
+        u64 a = 0, b2 = 0, co = 0;
+        u32 to = 0;
         for (int i = 0; i < n_chunks; i++) {
             const u64 ng1 = ((u64)nn[i] + 2 + 63) / 64 + 2;
-            gboff[i] = a; a += ng1;
-            tboff[i] = b2; b2 += ng1 / GS_TILE + 2;
+            h_gb[i] = a; a += ng1;
+            h_tb[i] = b2; b2 += ng1 / GS_TILE + 2;
+            h_so[i] = so[i]; h_nn[i] = nn[i];
+            h_fast[i].cand_off = co; h_fast[i].cand_cap = cand_cap_of(lens[i]);
+            h_fast[i].true_off = to; h_fast[i].true_cap = 2 * h_fast[i].cand_cap; h_fast[i].pad = 0;
+            co += h_fast[i].cand_cap; to += h_fast[i].true_cap;
         }
     }
-    u8 *S = (u8 *)d_scratch;
-    std::vector<InfFast> fast(n_chunks);
-    std::vector<u32> slot_chunk(l.total_cand), tslot_chunk(l.total_true);
-    u64 co = 0; u32 to = 0;
-    for (int i = 0; i < n_chunks; i++) {
-        fast[i].cand_off = co; fast[i].cand_cap = cand_cap_of(lens[i]);
-        fast[i].true_off = to; fast[i].true_cap = 2 * fast[i].cand_cap; fast[i].pad = 0;
-        for (u32 k = 0; k < fast[i].cand_cap; k++) slot_chunk[co + k] = (u32)i;
-        for (u32 k = 0; k < fast[i].true_cap; k++) tslot_chunk[to + k] = (u32)i;
-        co += fast[i].cand_cap; to += fast[i].true_cap;
-    }
-    MTS_HIP(hipMemcpyAsync(S + l.so, so.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
-    MTS_HIP(hipMemcpyAsync(S + l.nn, nn.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
-    MTS_HIP(hipMemcpyAsync(S + l.fast, fast.data(), sizeof(InfFast) * (size_t)n_chunks, hipMemcpyHostToDevice, st));
-    MTS_HIP(hipMemcpyAsync(S + l.slot_chunk, slot_chunk.data(), 4 * (size_t)l.total_cand, hipMemcpyHostToDevice, st));
-    MTS_HIP(hipMemcpyAsync(S + l.tslot_chunk, tslot_chunk.data(), 4 * (size_t)l.total_true, hipMemcpyHostToDevice, st));
-    MTS_HIP(hipMemcpyAsync(S + l.gb_off, gboff.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
-    MTS_HIP(hipMemcpyAsync(S + l.tb_off, tboff.data(), 8 * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+    MTS_HIP(hipMemcpyAsync(S + l.so, hst.data(), hst.size(), hipMemcpyHostToDevice, st));      // (pageable: staged before the call returns)
     MTS_HIP(hipMemsetAsync(S + l.cand_cnt, 0, 4 * (size_t)n_chunks, st));
-    MTS_HIP(hipStreamSynchronize(st));      // the staging vectors above are locals
+    hipLaunchKernelGGL(k_inf_fill_slots, dim3(n_chunks), dim3(256), 0, st, (const InfFast *)(S + l.fast), (u32 *)(S + l.slot_chunk), (u32 *)(S + l.tslot_chunk));
     const InfFast *d_fast = (const InfFast *)(S + l.fast);
     u64 *d_cand_pos = (u64 *)(S + l.cand_pos), *d_cand_tmp = (u64 *)(S + l.cand_tmp);
     u32 *d_cand_cnt = (u32 *)(S + l.cand_cnt), *d_true_cnt = (u32 *)(S + l.true_cnt);
