@@ -30,6 +30,8 @@ namespace mts {
 //             only (0.4 % of them on the synthetic recordings; the debug tap of the tests has it written everywhere)
 // (Rounds 1-2 kept both results and the position's byte in 8 bytes per position: twice the table traffic in the match store
 // and in both parse walks, and half as many walkers per CU, whose windows of the table live in LDS.)
+// a & (b ^ c) in one instruction (v_bitop3_b32; truth table index = a << 2 | b << 1 | c)
+__device__ __forceinline__ u32 and_xor(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x60); }
 __device__ __forceinline__ u64 make_entry(u32 rel, u32 lo, u32 hi)       // lo = bytes 0..3, hi = bytes 4..7
 {
     const u32 b0 = lo & 0xff, b1 = (lo >> 8) & 0xff;
@@ -65,9 +67,6 @@ __device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
 // ------------------------------------------------------------------------------------------------
 #ifndef MTS_M5_NT_KEYS
 #define MTS_M5_NT_KEYS 0
-#endif
-#ifndef MTS_M5_T0_ATOMIC
-#define MTS_M5_T0_ATOMIC 0
 #endif
 #ifndef MTS_M5_STATS
 #define MTS_M5_STATS 0
@@ -178,23 +177,19 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
             u32 *t1 = TB + 2 * (M5_TABLE / 4) + lane * M5_ROW_WORDS + wp;   // rows of tables 1..3 are contiguous: 96 rows
             t1[0] = 0; t1[1] = 0;
             if (lane < 32) { t1[64 * M5_ROW_WORDS] = 0; t1[64 * M5_ROW_WORDS + 1] = 0; }
-#if MTS_M5_T0_ATOMIC
-            { u32 *t0 = TB + lane * M5_ROW_WORDS + wp; t0[0] = 0; t0[1] = 0; }
-#else
+            // (atomic ORs for this table as well take 42 vector instructions off a group -- 8 % of the kernel's -- and give them back
+            //  as LDS waits: byte 3 of an even position is the high byte of a small delta, two values, 32 lanes per word;
+            //  SQ_WAIT_INST_LDS x5, the same 25.2 ms)
             const u64 vm = __ballot(valid);
             u32 m0 = (u32)vm, m1 = (u32)(vm >> 32);
 #pragma unroll
             for (int j = 0; j < 6; j++) {
                 const u64 B = __ballot((key[0] >> j) & 1);
-                m0 &= (u32)B ^ inv[j]; m1 &= (u32)(B >> 32) ^ inv[j];
+                m0 = and_xor(m0, (u32)B, inv[j]); m1 = and_xor(m1, (u32)(B >> 32), inv[j]);
             }
             { u32 *t0 = TB + lane * M5_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
-#endif
         }
         __builtin_amdgcn_wave_barrier();
-#if MTS_M5_T0_ATOMIC
-        if (valid) atomicOr(&TB[key[0] * M5_ROW_WORDS + word], bit);
-#endif
 #pragma unroll
         for (int d = 1; d < M5_LEVELS; d++)
             if (valid) atomicOr(&TB[m5_slot(d) * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS + word], bit);
@@ -493,7 +488,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             const u64 B = __ballot((key[0] >> j) & 1);
-            m0 &= (u32)B ^ inv[j]; m1 &= (u32)(B >> 32) ^ inv[j];
+            m0 = and_xor(m0, (u32)B, inv[j]); m1 = and_xor(m1, (u32)(B >> 32), inv[j]);
         }
         { u32 *t0 = TB + lane * M6_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
         __builtin_amdgcn_wave_barrier();
