@@ -190,7 +190,7 @@ def measured_traffic(kernel, n_chunks, nc):
     process).  Only valid for the profiled workload (60 chunks x 385 ch) and for a kernel the profile lists; null otherwise."""
     if n_chunks != 60 or nc != 385:
         return None, None
-    for name in ('r3_traffic.json', 'r2_traffic.json', 'r1_traffic.json'):
+    for name in ('r4_traffic.json', 'r3_traffic.json', 'r2_traffic.json', 'r1_traffic.json'):
         p = ROOT / 'profiles' / name
         if not p.exists():
             continue

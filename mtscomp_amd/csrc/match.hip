@@ -5,6 +5,8 @@
 // (/root/reference/mtscomp.py:394); orc_match_tables() of oracle/mtsc_oracle.c is the oracle.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "deflate_dev.h"
 
 namespace mts {
@@ -88,6 +90,14 @@ __device__ __forceinline__ constexpr int m5_slot(int d) { return d ? d + 1 : 0; 
 // requested LDS is padded so that TWO workgroups share a CU, not three (16 waves per CU keep the vector units busy)
 constexpr int MATCH5_LDS = M5_WAVES * M5_WAVE_LDS > 56 * 1024 ? M5_WAVES * M5_WAVE_LDS : 56 * 1024;
 
+// 3 + the equal bytes among bytes 3..6 (x1 = their xor): v_ffbl_b32 gives -1 for 0, and 3 + (0xffffffff >> 3) is still more than 7
+__device__ __forceinline__ u32 m5_len37(u32 x1)
+{
+    u32 f;
+    asm("v_ffbl_b32 %0, %1" : "=v"(f) : "v"(x1));
+    const u32 l = 3 + (f >> 3);
+    return l < 7 ? l : 7;
+}
 // 5-bit keys of the prefixes (b3), (b3,b4), (b3..b5), (b3..b6) of e1 = bytes 3..6
 __device__ __forceinline__ u32 m5_hash24(u32 x) { return (__umul24(x, 0x9E3779u) >> 19) & 31; }
 __device__ __forceinline__ void m5_keys(u32 e1, u32 (&k)[M5_LEVELS])
@@ -273,10 +283,42 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         rowmask(1, A4, A5);
         rowmask(2, A5, A6);
         rowmask(3, A6, A7);
-        u32 best = 2, bdist = 0;
+        // The walks.  NEAR_END = some lane of the group is within 258 bytes of the end of its chunk (one group in a thousand of a
+        // chunk's last tile): match lengths are capped by what is left and nice_match shrinks with it.  Everywhere else both are
+        // constants, the cap never binds below the long compare, and nice_match (>= 16 at every level) can only be reached there:
+        // the common path of a round carries neither the cap nor the test.
+        u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
+        auto walks = [&](auto near_end) __attribute__((always_inline)) {
+        constexpr bool NEAR_END = decltype(near_end)::value;
         bool stop = false;
+        // one candidate: its match length against this lane's string (0: other bytes behind an equal hash); `kill` = 0 when the
+        // walk ends with it (nice_match reached), all ones otherwise
+        auto score = [&](const u32 slot, const u32 c0, const u32 c1, const u32 rel_c, u32 &kill) __attribute__((always_inline)) -> u32 {
+            const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
+            kill = 0xffffffffu;
+            if ((x0 & 0x1ff) != 0) return 0u;
+            u32 len = m5_len37(x1);
+            if (len == 7 && (x0 >> 9) == 0) {
+                const u64 y = SX[slot] ^ ex;
+                if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
+                else {
+                    const u32 cap = NEAR_END ? maxlen : (u32)MAX_MATCH;
+                    len = 13;
+                    while (len < cap) {
+                        const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
+                        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+                        len += 4;
+                    }
+                    len = len < cap ? len : cap;
+                    // (a candidate that reaches nice_match is an improvement: a match that long already held would have ended the walk)
+                    if (!NEAR_END && len >= (u32)cfg.nice) { kill = 0; stop = true; }
+                }
+            }
+            if (NEAR_END) { len = len < maxlen ? len : maxlen; if (len >= nice) kill = 0; }
+            return len;
+        };
         // candidates of word w restricted to `part`, newest first
-        auto walk = [&](const u32 tb, const u32 m0, const u32 m1, const u32 m2, const u32 m3, const u32 m4, const u32 part) __attribute__((always_inline)) {
+        auto walk = [&](const u32 tb, const u32 m0, const u32 m1, const u32 m2, const u32 m3, const u32 m4, const u32 part, const bool head) __attribute__((always_inline)) {
             // (the empty asm statements keep the compiler from turning the select chain into a table in scratch memory)
             auto pick = [&]() -> u32 {
                 u32 r = best >= 3 ? m1 : m0;
@@ -288,6 +330,30 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                 return best >= 6 ? m4 : r;
             };
             u32 el = stop ? 0 : pick() & part;
+            if (head) {
+                // The head of the chain (the slot before this lane's own: bit 31 of the newest word) is every lane's first candidate,
+                // and the only one that may be MAX_DIST away (zlib checks the head against MAX_DIST, the others against the limit
+                // one nearer): scored here, by all lanes at once, so that the rounds below know one limit and one kind of candidate.
+#if MTS_M5_STATS
+                st_r1++; st_s1 += (u32)__popcll(__ballot(el != 0));
+#endif
+                const u32 slot = (lo + 127) & (M5_RING - 1);
+                const u64 c = SE[slot];
+                if ((int)el < 0) {                                  // (bit 31: the lane has a chain)
+                    el &= 0x7fffffffu;
+                    const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
+                    const u32 rel_c = c0 & REL_MASK;
+                    if ((int)rel_c > lim1) {
+                        u32 kill;
+                        const u32 len = score(slot, c0, c1, rel_c, kill);
+                        if (len > best) {
+                            best = len; bdist = rel_p - rel_c;
+                            el &= pick() & kill;
+                            if (NEAR_END && kill == 0) stop = true;
+                        }
+                    } else { stop = true; el = 0; }
+                }
+            }
             while (__any(el != 0)) {
 #if MTS_M5_STATS
                 st_r1++; st_s1 += (u32)__popcll(__ballot(el != 0));
@@ -300,45 +366,31 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                     const u64 c = SE[slot];
                     const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                     const u32 rel_c = c0 & REL_MASK;
-                    if ((int)rel_c > (t == 127 ? lim1 : limn)) {
-                        const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
-                        if ((x0 & 0x1ff) == 0) {
-                            u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
-                            if (x1 == 0 && (x0 >> 9) == 0) {
-                                const u64 y = SX[slot] ^ ex;
-                                if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
-                                else {
-                                    len = 13;
-                                    while (len < maxlen) {
-                                        const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
-                                        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
-                                        len += 4;
-                                    }
-                                }
-                            }
-                            len = len < maxlen ? len : maxlen;
-                            if (len > best) {
-                                best = len; bdist = rel_p - rel_c;
-                                if (len >= nice) stop = true;
-                                el &= pick();                       // fewer candidates can still win now
-                            }
+                    // (what ends a lane's walk -- a candidate out of range, a match of nice_match bytes -- is rare: the lane's mask is
+                    //  cleared where it happens, not looked at in every round)
+                    if ((int)rel_c > ((!head && t == 127) ? lim1 : limn)) {
+                        u32 kill;
+                        const u32 len = score(slot, c0, c1, rel_c, kill);
+                        if (len > best) {
+                            best = len; bdist = rel_p - rel_c;
+                            el &= pick() & kill;                    // fewer candidates can still win now
+                            if (NEAR_END && kill == 0) stop = true;
                         }
-                    } else stop = true;                 // out of range: so is everything older
-                    if (stop) el = 0;
+                    } else { stop = true; el = 0; }     // out of range: so is everything older
                 }
             }
         };
         // candidates 1 .. qchain first: what the walk holds then is the quarter-budget result
         const u32 qpart = qchain >= 32 ? 0xffffffffu : ~(0xffffffffu >> qchain);        // qchain <= 32 (chain <= 128)
-#define MTS_WALK(w, part) walk(32 * (w), V[w], A4[w], A5[w], A6[w], A7[w], part)
-        MTS_WALK(3, qpart);
-        const u32 qbest = best, qdist = bdist;
-        if (qpart != 0xffffffffu) MTS_WALK(3, ~qpart);
+#define MTS_WALK(w, part, head) walk(32 * (w), V[w], A4[w], A5[w], A6[w], A7[w], part, head)
+        MTS_WALK(3, qpart, true);
+        qbest = best; qdist = bdist;
+        if (qpart != 0xffffffffu) MTS_WALK(3, ~qpart, false);
 #undef MTS_WALK
         {
             // The other 96 candidates in ONE loop (a lane takes its own next candidate, whichever of the three words it is in):
-            // word by word the wave ran as many rounds as the busiest lane of EACH word needed -- 4.4 rounds per group at 10 % lane
-            // use; together it is the busiest lane over all three.
+            // word by word the wave ran as many rounds as the busiest lane of EACH word needed; together it is the busiest lane
+            // over all three.
             auto pickw = [&](const int w) __attribute__((always_inline)) -> u32 {
                 u32 r = best >= 3 ? A4[w] : V[w];
                 asm volatile("" : "+v"(r));
@@ -367,33 +419,18 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                     const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                     const u32 rel_c = c0 & REL_MASK;
                     if ((int)rel_c > limn) {
-                        const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
-                        if ((x0 & 0x1ff) == 0) {
-                            u32 len = x1 ? 3 + ((u32)__builtin_ctz(x1) >> 3) : 7;
-                            if (x1 == 0 && (x0 >> 9) == 0) {
-                                const u64 y = SX[slot] ^ ex;
-                                if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
-                                else {
-                                    len = 13;
-                                    while (len < maxlen) {
-                                        const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
-                                        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
-                                        len += 4;
-                                    }
-                                }
-                            }
-                            len = len < maxlen ? len : maxlen;
-                            if (len > best) {
-                                best = len; bdist = rel_p - rel_c;
-                                if (len >= nice) stop = true;
-                                f2 &= pickw(2); f1 &= pickw(1); f0 &= pickw(0);      // fewer candidates can still win now
-                            }
+                        u32 kill;
+                        const u32 len = score(slot, c0, c1, rel_c, kill);
+                        if (len > best) {
+                            best = len; bdist = rel_p - rel_c;
+                            f2 &= pickw(2) & kill; f1 &= pickw(1) & kill; f0 &= pickw(0) & kill;      // fewer candidates can still win now
                         }
-                    } else stop = true;                 // out of range: so is everything older
-                    if (stop) { f2 = 0; f1 = 0; f0 = 0; }
+                    } else { f2 = 0; f1 = 0; f0 = 0; }  // out of range: so is everything older
                 }
             }
         }
+        };
+        if (__any(own && look < (u32)MAX_MATCH)) walks(std::true_type{}); else walks(std::false_type{});
         if (own) te_store(T, TQ, p_abs, best, bdist, qbest, qdist, (u32)cfg.good, all_quarters);
 #if MTS_M5_STATS
         st_groups++;

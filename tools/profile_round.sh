@@ -6,7 +6,7 @@
 #   <tag>_traffic.json             HBM bytes per launch of the dominant kernel, read by bench.py
 #   <tag>_levels_kernel_stats.csv  rocprofv3 --kernel-trace --stats of tools/level_sweep.py (levels 1, 2, 3, 6, 7, 8, 9 on 240 chunks of 15.36 MB)
 #   <tag>_levels.json              its output line
-tag=${1:-r3}
+tag=${1:-r4}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/profile_$tag
 rm -rf $out; mkdir -p $out
@@ -41,11 +41,15 @@ per = {}
 for k in agg:
     L = max(n[k].values())
     short = k.split("::")[-1].split("<")[0]
+    # calibrated on known byte counts (tools/mb_calib.sh, round 4): FETCH_SIZE is HALF the bytes of the 128-B lines fetched, for streams
+    # and for 16-byte gathers alike; WRITE_SIZE is exact, in 32-byte sectors
     per[short] = {"fetch_size_kb": agg[k]["FETCH_SIZE"] / L, "write_size_kb": agg[k]["WRITE_SIZE"] / L,
-                  "traffic_bytes_per_launch": (agg[k]["FETCH_SIZE"] + agg[k]["WRITE_SIZE"]) / L * 1024, "launches": L}
+                  "traffic_bytes_per_launch": (2 * agg[k]["FETCH_SIZE"] + agg[k]["WRITE_SIZE"]) / L * 1024, "launches": L}
 json.dump({"kernels": {k: v["traffic_bytes_per_launch"] for k, v in per.items()}, "detail": per,
            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 1 (60 x 23.1 MB chunks), bytes per launch = counter sum / launches x 1024; "
-                  "FETCH not doubled (the guide's x2 applies to wide coalesced streaming reads only; calibrate before reading absolutes)",
+                  "traffic = 2 x FETCH_SIZE + WRITE_SIZE: calibrated on this box with tools/microbench/hbm_counter_calibration.hip (tools/mb_calib.sh) -- FETCH_SIZE = 0.500 x the bytes of the "
+                  "128-B lines fetched for 16-B streams, 4-B streams and 16-B gathers (one per line) alike; WRITE_SIZE = 1.000 x for coalesced 16-B and 4-B stores, 32 B per isolated 4-B store (sectors)",
+           "calibration": {"fetch_factor": 2.0, "write_factor": 1.0, "write_granule_bytes": 32, "read_granule_bytes": 128},
            "source": "profiles/%s_bench_pmc_hbm_bytes.csv" % tag}, open(out + "/%s_traffic.json" % tag, "w"), indent=1)
 print(open(out + "/%s_bench_default.jsonl" % tag).read()[:600])
 PY
