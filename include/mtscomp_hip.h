@@ -167,6 +167,10 @@ int mts_dev_synth_int16(int device, void *stream, void *d_out, long t0, long t1,
  * (torch ships its own runtime libraries).  kind: 0 host -> device, 1 device -> host, 2 device -> device; mts_dev_copy returns
  * when the copy is done.  mts_dev_compare: bytes that differ between two device buffers (16-byte aligned) and the first such offset
  * (-1: none) -- the round-trip check of a recording that stays in HBM. */
+/* Page-locked host memory (hipHostMalloc): the host entry points copy to / from such a buffer by DMA directly, without the pinned
+ * pieces and host copies that pageable memory needs (Reader.tofile decodes into two of these and writes the file from them). */
+int mts_host_alloc(long nbytes, void **h_ptr);
+int mts_host_free(void *h_ptr);
 int mts_dev_alloc(int device, long nbytes, void **d_ptr);
 int mts_dev_free(int device, void *d_ptr);
 int mts_dev_copy(int device, void *stream, void *dst, const void *src, long nbytes, int kind);

@@ -55,6 +55,7 @@ CHECK_ATOL = 1e-16              # mtscomp.py:59
 CRITICAL_ERROR_URL = "https://github.com/int-brain-lab/mtscomp/issues/new?title=Critical+error"
 DEFAULT_BATCH_CHUNKS = 64       # chunks handed to one device call
 TOFILE_PIECE_CHUNKS = 8         # chunks per piece of Reader.tofile (decode of one piece under the file writes of the one before)
+TOFILE_WRITERS = 8              # threads writing a piece
 DEFAULT_DEVICE_CACHE_GB = 32    # decoded chunks a Reader may keep in HBM for slicing (allocated as touched; env MTSCOMP_DEVICE_CACHE_GB, 0 = off)
 DEVICE_CACHE_MAX_CHUNKS = 8     # longer slices are streamed through the host path instead of the cache
 
@@ -233,6 +234,8 @@ class HipCodec:
 
     def cache_create(self, capacity_bytes):
         return hip.cache_create(capacity_bytes, device=self.devices[0])
+
+    host_buffer = staticmethod(hip.HostBuffer)            # page-locked host memory for Reader.tofile's pieces
 
     cache_destroy = staticmethod(hip.cache_destroy)
     cache_query = staticmethod(hip.cache_query)
@@ -904,8 +907,18 @@ class Reader:
         starts = list(range(0, self.n_chunks, piece))
         row_bytes = self.n_channels * self.dtype.itemsize
         max_rows = max(self.chunk_bounds[min(b0 + piece, self.n_chunks)] - self.chunk_bounds[b0] for b0 in starts)
-        bufs = [np.empty((max_rows, self.n_channels), dtype=self.dtype) for _ in range(min(2, len(starts)))]
-        n_writers = 8
+        # page-locked buffers when the codec has them: the decoded rows arrive by DMA, without a copy out of a staging piece
+        pinned = []
+        if hasattr(self.codec, 'host_buffer'):
+            try:
+                pinned = [self.codec.host_buffer(max_rows * row_bytes) for _ in range(min(2, len(starts)))]
+            except Exception:  # noqa: BLE001  (no page-locked memory to be had: pageable buffers do)
+                pinned = []
+        if pinned:
+            bufs = [h.array.view(self.dtype).reshape(max_rows, self.n_channels) for h in pinned]
+        else:
+            bufs = [np.empty((max_rows, self.n_channels), dtype=self.dtype) for _ in range(min(2, len(starts)))]
+        n_writers = max(1, int(TOFILE_WRITERS))
         fd = os.open(str(out), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
 
         def write_piece(arr, offset):
@@ -944,6 +957,9 @@ class Reader:
             return os.fstat(fd).st_size
         finally:
             os.close(fd)
+            del bufs
+            for h in pinned:
+                h.free()
 
     def close(self):
         """mtscomp.py:745-748."""

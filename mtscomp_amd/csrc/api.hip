@@ -505,10 +505,28 @@ static int pin_init(Engine &E)
 // device -> user memory, any number of pieces (dst, src, bytes).  The device data must be complete (the caller synchronised the
 // stream that produced it).  The DMA of the next piece runs while the host threads copy the one before out of its pinned buffer.
 struct CopyItem { void *dst; const void *src; size_t n; };
+static bool host_ptr_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
 static int staged_d2h_multi(Engine &E, const std::vector<CopyItem> &segs)
 {
     size_t total = 0;
     for (auto &s : segs) total += s.n;
+    // a destination that is pinned already (mts_host_alloc) takes the DMA itself: no pinned piece in between, no host copy
+    if (total >= ((size_t)1 << 20) && !segs.empty()) {
+        bool all_pinned = true;
+        for (auto &s : segs) if (s.n && !host_ptr_pinned(s.dst)) { all_pinned = false; break; }
+        if (all_pinned) {
+            hipStream_t cs = pin_init(E) == MTS_OK ? E.copy_st : nullptr;
+            for (auto &s : segs) if (s.n) MTS_HIP(hipMemcpyAsync(s.dst, s.src, s.n, hipMemcpyDeviceToHost, cs));
+            MTS_HIP(hipStreamSynchronize(cs));
+            return MTS_OK;
+        }
+    }
     if (total < ((size_t)8 << 20) || pin_init(E) != MTS_OK) {
         for (auto &s : segs) if (s.n) MTS_HIP(hipMemcpy(s.dst, s.src, s.n, hipMemcpyDeviceToHost));
         return MTS_OK;
@@ -535,6 +553,11 @@ static int staged_d2h(Engine &E, void *dst, const void *d_src, size_t n) { retur
 // user memory -> device; complete on return
 static int staged_h2d(Engine &E, void *d_dst, const void *src, size_t n)
 {
+    if (n >= ((size_t)1 << 20) && host_ptr_pinned(src)) {            // (a pinned source: the DMA reads it directly)
+        MTS_HIP(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, nullptr));
+        MTS_HIP(hipStreamSynchronize(nullptr));
+        return MTS_OK;
+    }
     if (n < ((size_t)8 << 20) || pin_init(E) != MTS_OK) { MTS_HIP(hipMemcpy(d_dst, src, n, hipMemcpyHostToDevice)); return MTS_OK; }
     const size_t np = (n + PIN_PIECE - 1) / PIN_PIECE;
     auto len = [&](size_t k) { return k + 1 < np ? PIN_PIECE : n - k * PIN_PIECE; };
@@ -944,6 +967,22 @@ __global__ void k_count_diff(const u8 *__restrict__ a, const u8 *__restrict__ b,
     }
     if (blockIdx.x == 0 && threadIdx.x < (u32)(n & 15)) { const u64 j = n16 * 16 + threadIdx.x; if (a[j] != b[j]) { cnt++; first = first < j ? first : j; } }
     if (cnt) { atomicAdd(&out[0], (unsigned long long)cnt); atomicMin(&out[1], (unsigned long long)first); }
+}
+
+int mts_host_alloc(long nbytes, void **h_ptr)
+{
+    if (nbytes < 0 || !h_ptr) return MTS_E_ARG;
+    if (device_count() <= 0) { set_error("no gfx950 device visible (libmtscomp_hip has no CPU path)"); return MTS_E_NODEV; }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, nbytes > 0 ? (size_t)nbytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); set_error("hipHostMalloc of %ld bytes failed", nbytes); return MTS_E_NOMEM; }
+    *h_ptr = p;
+    return MTS_OK;
+}
+
+int mts_host_free(void *h_ptr)
+{
+    if (h_ptr) MTS_HIP(hipHostFree(h_ptr));
+    return MTS_OK;
 }
 
 int mts_dev_alloc(int device, long nbytes, void **d_ptr)

@@ -68,7 +68,7 @@ __device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
 // scored candidates is about the number of times the best length improves.
 // ------------------------------------------------------------------------------------------------
 #ifndef MTS_M5_NT_KEYS
-#define MTS_M5_NT_KEYS 0
+#define MTS_M5_NT_KEYS 1     // the sorted keys are read once: non-temporal loads keep them from pushing table lines out of L2 (same time, 17.0 -> 13.4 GB written)
 #endif
 #ifndef MTS_M5_STATS
 #define MTS_M5_STATS 0
@@ -77,7 +77,10 @@ __device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
 __device__ unsigned long long g_m5_stats[8];          // groups walked, rounds of the newest word, rounds of the other 96, scorings of each
 #endif
 constexpr int M5_WAVES = 8;
-constexpr int M5_SLICES = 32;                        // workgroups per tile (MTS_MATCH_SLICES overrides: experiments): 16 groups per wave; 64: +0.25 ms, 48: +0.15 (round 4, two alternating runs each)
+constexpr int M5_SLICES = 64;                        // workgroups per tile (MTS_MATCH_SLICES overrides: experiments) = the workgroups an XCD holds: ONE tile per XCD at a
+                                                     // time.  Round 4, time / bytes written per launch (60 chunks; the table is 5.5 GB): 32 slices 24.7 ms / 38-44 GB (two tiles
+                                                     // share an L2: lines leave half filled again and again), 64: 24.9 ms / 13.4 GB, 96: 26.2 ms / 9.7 GB, 128: 7.8 GB (a tile is
+                                                     // finished sooner, but a wave's two history groups and empty tables are spread over fewer groups)
 constexpr int M6_SLICES = 64;
 constexpr int M5_RING = 256;
 constexpr int M5_ROWS = 32;

@@ -73,6 +73,8 @@ def lib():
     L.mts_dev_compress_chunks.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, lp, C.c_int, C.c_int, C.c_int, vp, lp, lp]
     L.mts_dev_decompress_chunks.argtypes = [C.c_int, vp, vp, lp, lp, lp, C.c_int, C.c_int, C.c_int, C.c_int, vp, lp, ip]
     L.mts_dev_synth_int16.argtypes = [C.c_int, vp, vp, C.c_long, C.c_long, C.c_int, C.c_long]
+    L.mts_host_alloc.argtypes = [C.c_long, C.POINTER(vp)]
+    L.mts_host_free.argtypes = [vp]
     L.mts_dev_alloc.argtypes = [C.c_int, C.c_long, C.POINTER(vp)]
     L.mts_dev_free.argtypes = [C.c_int, vp]
     L.mts_dev_copy.argtypes = [C.c_int, vp, vp, vp, C.c_long, C.c_int]
@@ -101,7 +103,7 @@ def lib():
 EXPORTS = ['mts_version', 'mts_device_count', 'mts_strerror', 'mts_last_error', 'mts_compress_bound',
            'mts_delta_transpose', 'mts_cumsum_transpose', 'mts_compress_chunks', 'mts_decompress_chunks',
            'mts_dev_compress_chunks', 'mts_dev_decompress_chunks', 'mts_dev_synth_int16',
-           'mts_dev_alloc', 'mts_dev_free', 'mts_dev_copy', 'mts_dev_sync', 'mts_dev_compare',
+           'mts_host_alloc', 'mts_host_free', 'mts_dev_alloc', 'mts_dev_free', 'mts_dev_copy', 'mts_dev_sync', 'mts_dev_compare',
            'mts_last_stage_times', 'mts_debug_match_tables', 'mts_debug_tokens', 'mts_debug_deflate',
            'mts_debug_inflate', 'mts_release', 'mts_cache_create', 'mts_cache_destroy', 'mts_cache_query',
            'mts_cache_read_rows', 'mts_cache_read_slices', 'mts_cache_read_slices_leading']
@@ -310,6 +312,30 @@ def cache_read_slices(cache_id, keys, cdata, offs, lens, n_rows, n_channels, dty
 # ------------------------------------------------------------------------------------------------
 # device-resident recordings (bench.py, the tests at BASELINE's sizes): memory held through the library -- no second HIP runtime
 # ------------------------------------------------------------------------------------------------
+class HostBuffer:
+    """Page-locked host memory (mts_host_alloc) as a numpy array: `.array` (uint8, nbytes).  Copies between it and the device are
+    DMA transfers without a staging copy.  Keep the object alive while the array (or views of it) is in use."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _check(lib().mts_host_alloc(self.nbytes, C.byref(p)), 'mts_host_alloc')
+        self.ptr = p.value or 0
+        self.array = np.ctypeslib.as_array((C.c_ubyte * max(self.nbytes, 1)).from_address(self.ptr))[:self.nbytes]
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            ptr, self.ptr = self.ptr, 0
+            _check(lib().mts_host_free(C.c_void_p(ptr)), 'mts_host_free')
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class DevBuffer:
     """`nbytes` of HBM on `device`, allocated, copied and freed by libmtscomp_hip.so (mts_dev_alloc / mts_dev_copy / mts_dev_free)."""
 
