@@ -32,6 +32,19 @@ namespace mts {
 //             only (0.4 % of them on the synthetic recordings; the debug tap of the tests has it written everywhere)
 // (Rounds 1-2 kept both results and the position's byte in 8 bytes per position: twice the table traffic in the match store
 // and in both parse walks, and half as many walkers per CU, whose windows of the table live in LDS.)
+// wave-wide predicates straight from the condition's lane mask (HIP's __ballot / __any take an int: the mask is first turned into a
+// value per lane and compared again)
+__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+// the value of the lane before (wave_shr:1); lane 0 gets `first`
+__device__ __forceinline__ u32 prev_lane(u32 v, u32 first) { return (u32)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false); }
+// lane-wise select by a lane mask held in scalar registers: mask bit set -> a, else b
+__device__ __forceinline__ u32 sel64(u64 mask, u32 a, u32 b)
+{
+    u32 r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
 // a & (b ^ c) in one instruction (v_bitop3_b32; truth table index = a << 2 | b << 1 | c)
 __device__ __forceinline__ u32 and_xor(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x60); }
 __device__ __forceinline__ u64 make_entry(u32 rel, u32 lo, u32 hi)       // lo = bytes 0..3, hi = bytes 4..7
@@ -91,7 +104,11 @@ constexpr int M5_SLOTS = M5_LEVELS + 1;                // the first table has 64
 constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_SLOTS * M5_TABLE;      // 9856: entries, bytes 7..12, tables
 __device__ __forceinline__ constexpr int m5_slot(int d) { return d ? d + 1 : 0; }
 // requested LDS is padded so that TWO workgroups share a CU, not three (16 waves per CU keep the vector units busy)
-constexpr int MATCH5_LDS = M5_WAVES * M5_WAVE_LDS > 56 * 1024 ? M5_WAVES * M5_WAVE_LDS : 56 * 1024;
+#ifndef MTS_M5_LDS_PAD
+#define MTS_M5_LDS_PAD 0
+#endif
+constexpr int M5_VLUT = 129 * 16;                    // the budget masks (one table per workgroup, behind the waves' areas)
+constexpr int MATCH5_LDS = MTS_M5_LDS_PAD ? MTS_M5_LDS_PAD : (M5_WAVES * M5_WAVE_LDS + M5_VLUT > 56 * 1024 ? M5_WAVES * M5_WAVE_LDS + M5_VLUT : 56 * 1024);      // (MTS_M5_LDS_PAD: occupancy experiments)
 
 // 3 + the equal bytes among bytes 3..6 (x1 = their xor): v_ffbl_b32 gives -1 for 0, and 3 + (0xffffffff >> 3) is still more than 7
 __device__ __forceinline__ u32 m5_len37(u32 x1)
@@ -126,12 +143,20 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     if (tile_id >= (u32)n_tiles) return;
     const TileDesc td = tiles[tile_id];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    u8 *wbase = smem + wave * M5_WAVE_LDS;
+    // LDS: the waves' entry rings (2 KB each, 2 KB aligned: a slot's address is (offset & 2040) | base), their rings of bytes 7..12
+    // (the same offset + 16 KB), their tables, the table of budget masks
     const u8 *gwin = stream + td.stream_off + td.w;
     auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
-    u64 *SE = (u64 *)wbase;
-    u64 *SX = SE + M5_RING;                                        // bytes 7..12 of every slot: matches up to 13 never leave the LDS
-    u32 *TB = (u32 *)(wbase + 2 * M5_RING * 8);                    // [level][row][8 words + 1]
+    u64 *SE = (u64 *)(smem + wave * (M5_RING * 8));
+    u64 *SX = (u64 *)(smem + M5_WAVES * M5_RING * 8 + wave * (M5_RING * 8));      // bytes 7..12 of every slot: matches up to 13 never leave the LDS
+    u32 *TB = (u32 *)(smem + 2 * M5_WAVES * M5_RING * 8 + wave * (M5_SLOTS * M5_TABLE));      // [level][row][8 words + 1]
+    const uint4 *VLUT = (const uint4 *)(smem + M5_WAVES * M5_WAVE_LDS);      // [0 .. 128]: the newest n of 128 bits (one table per workgroup)
+    typedef __attribute__((address_space(3))) const u64 *lds_u64p;
+    const u32 se_base = (u32)(size_t)(__attribute__((address_space(3))) u8 *)(u8 *)SE;      // (byte address in LDS)
+    if (se_base & (M5_RING * 8 - 1)) __builtin_trap();            // (the kernel has no static LDS: the dynamic area starts at 0)
+    // entry / bytes 7..12 of the ring slot at byte offset o8 (any multiple of 8; only its low 11 bits count)
+    auto ring_e = [&](u32 o8) -> u64 { return *(lds_u64p)(size_t)((o8 & (M5_RING * 8 - 8)) | se_base); };
+    auto ring_x = [&](u32 o8) -> u64 { return *(lds_u64p)(size_t)(((o8 & (M5_RING * 8 - 8)) | se_base) + M5_WAVES * M5_RING * 8); };
     u32 *T = tables + td.stream_off, *TQ = quarter + td.stream_off;
     if (threadIdx.x < 2 && slice == 0) {
         const u32 hashed_end = td.w + td.wlen;
@@ -147,6 +172,15 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     const u32 nwv = (u32)nsl * M5_WAVES;
     const u32 gpw = (ngroups + nwv - 1) / nwv;
     const u32 g_begin = (slice * M5_WAVES + wave) * gpw, g_end = min(ngroups, g_begin + gpw);
+    for (int k = threadIdx.x; k <= 128; k += M5_WAVES * 64) {
+        uint4 v;
+        v.w = k >= 32 ? 0xffffffffu : k ? 0xffffffffu << (32 - k) : 0u;
+        v.z = k >= 64 ? 0xffffffffu : k > 32 ? 0xffffffffu << (64 - k) : 0u;
+        v.y = k >= 96 ? 0xffffffffu : k > 64 ? 0xffffffffu << (96 - k) : 0u;
+        v.x = k >= 128 ? 0xffffffffu : k > 96 ? 0xffffffffu << (128 - k) : 0u;
+        ((uint4 *)(smem + M5_WAVES * M5_WAVE_LDS))[k] = v;
+    }
+    __syncthreads();                                               // (the only barrier: every wave is still here)
     if (g_begin >= g_end) return;
     // the tables start empty (the entry ring may hold anything: it is only read where table bits point)
     for (int k = lane; k < M5_SLOTS * M5_TABLE / 16; k += 64) ((uint4 *)TB)[k] = make_uint4(0, 0, 0, 0);
@@ -172,16 +206,24 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         const u64 ce = valid ? make_entry(rc, lo, hi) : ~0ull;
         // a slot starts a run when its hash differs from its predecessor's (slots are committed in order)
         const u32 h = valid ? hash_of(lo) : 0xfffffffeu;
-        const u32 hp = __shfl_up(h, 1, 64), rcp = __shfl_up(rc, 1, 64);
-        const bool starts_run = h != (lane == 0 ? h_carry : hp);
-        const bool disorder = valid && !starts_run && rc <= (lane == 0 ? rc_carry : rcp);      // positions must increase inside a run
-        if (__any(disorder)) { if (lane == 0) atomicOr(flags, 1u); }
+        const u32 hp = prev_lane(h, h_carry), rcp = prev_lane(rc, rc_carry);
+        const bool starts_run = h != hp;
+        const bool disorder = valid && !starts_run && rc <= rcp;      // positions must increase inside a run
+        if (any64(disorder)) { if (lane == 0) atomicOr(flags, 1u); }
         h_carry = (u32)__builtin_amdgcn_readlane((int)h, 63);
         rc_carry = (u32)__builtin_amdgcn_readlane((int)rc, 63);
-        const u64 sr = __ballot(starts_run);
-        const u32 mlo = (u32)sr & le_lo, mhi = (u32)(sr >> 32) & le_hi;
-        const u32 top = mhi ? 63u - (u32)__builtin_clz(mhi) : 31u - (u32)__builtin_clz(mlo | 1u);
-        nbv = (mlo | mhi) ? (u32)lane - top : (u32)lane + run_carry;
+        const u64 sr = ballot64(starts_run);
+        // slots back to the start of the lane's run: lane + what the groups before carried, or lane - (the last run start at or
+        // before the lane).  Runs are long (a few hundred slots on the recordings): the starts of a group are few, and each is two
+        // instructions (lanes before a start wrap around to huge values and keep what they have)
+        if (__builtin_popcountll(sr) <= 6) {
+            nbv = (u32)lane + run_carry;
+            for (u64 m = sr; m; m &= m - 1) { const u32 d = (u32)lane - (u32)__builtin_ctzll(m); nbv = d < nbv ? d : nbv; }
+        } else {
+            const u32 mlo = (u32)sr & le_lo, mhi = (u32)(sr >> 32) & le_hi;
+            const u32 top = mhi ? 63u - (u32)__builtin_clz(mhi) : 31u - (u32)__builtin_clz(mlo | 1u);
+            nbv = (mlo | mhi) ? (u32)lane - top : (u32)lane + run_carry;
+        }
         nbv = nbv < 128u ? nbv : 128u;
         run_carry = sr ? (u32)__builtin_clzll(sr) + 1u : (run_carry + 64u < 128u ? run_carry + 64u : 128u);
         m5_keys((u32)(ce >> 32), key);
@@ -193,11 +235,11 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
             // (atomic ORs for this table as well take 42 vector instructions off a group -- 8 % of the kernel's -- and give them back
             //  as LDS waits: byte 3 of an even position is the high byte of a small delta, two values, 32 lanes per word;
             //  SQ_WAIT_INST_LDS x5, the same 25.2 ms)
-            const u64 vm = __ballot(valid);
+            const u64 vm = ballot64(valid);
             u32 m0 = (u32)vm, m1 = (u32)(vm >> 32);
 #pragma unroll
             for (int j = 0; j < 6; j++) {
-                const u64 B = __ballot((key[0] >> j) & 1);
+                const u64 B = ballot64((key[0] >> j) & 1);
                 m0 = and_xor(m0, (u32)B, inv[j]); m1 = and_xor(m1, (u32)(B >> 32), inv[j]);
             }
             { u32 *t0 = TB + lane * M5_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
@@ -257,7 +299,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
         const u32 rel_p = e0 & REL_MASK;
         const bool own = i < wlen && rel_p >= halo;
-        if (!__any(own)) continue;
+        if (!any64(own)) continue;
         const u32 p_abs = td.w + rel_p;
         const u32 look = n - p_abs;
         const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
@@ -266,13 +308,12 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
         // the 128 slots before this lane's own are ring positions lo .. lo + 127 (mod 256); candidate j
         // (1 = newest) is bit 128 - j of the masks.  V = the candidates inside this lane's chain budget.
-        const u32 lo = (i + 128) & (M5_RING - 1), w0 = lo >> 5, sh = lo & 31;
+        const u32 lo = (i + 128) & (M5_RING - 1), w0 = lo >> 5, sh = lo & 31, lo8 = lo << 3;
         nbv = own ? (nbv < chain ? nbv : chain) : 0;
         u32 V[4], A4[4], A5[4], A6[4], A7[4];                     // V = inside the budget; A_d = V & "first d bytes may match"
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int s = 32 * k + (int)nbv - 96;               // candidates of word k: bits >= 32 - s
-            V[k] = s <= 0 ? 0u : s >= 32 ? 0xffffffffu : 0xffffffffu << (32 - s);
+        {   // the newest nbv of the 128 bits: one 16-byte read of a table of the 129 masks (24 instructions of shifts and selects otherwise)
+            const uint4 v = VLUT[nbv];
+            V[0] = v.x; V[1] = v.y; V[2] = v.z; V[3] = v.w;
         }
         auto rowmask = [&](const int d, const u32 (&in)[4], u32 (&out)[4]) __attribute__((always_inline)) {
             const u32 *row = TB + m5_slot(d) * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS;
@@ -296,13 +337,13 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         bool stop = false;
         // one candidate: its match length against this lane's string (0: other bytes behind an equal hash); `kill` = 0 when the
         // walk ends with it (nice_match reached), all ones otherwise
-        auto score = [&](const u32 slot, const u32 c0, const u32 c1, const u32 rel_c, u32 &kill) __attribute__((always_inline)) -> u32 {
+        auto score = [&](const u32 o8 /* byte offset of the candidate's ring slot */, const u32 c0, const u32 c1, const u32 rel_c, u32 &kill) __attribute__((always_inline)) -> u32 {
             const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
             kill = 0xffffffffu;
             if ((x0 & 0x1ff) != 0) return 0u;
             u32 len = m5_len37(x1);
             if (len == 7 && (x0 >> 9) == 0) {
-                const u64 y = SX[slot] ^ ex;
+                const u64 y = ring_x(o8) ^ ex;
                 if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
                 else {
                     const u32 cap = NEAR_END ? maxlen : (u32)MAX_MATCH;
@@ -340,15 +381,15 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
 #if MTS_M5_STATS
                 st_r1++; st_s1 += (u32)__popcll(__ballot(el != 0));
 #endif
-                const u32 slot = (lo + 127) & (M5_RING - 1);
-                const u64 c = SE[slot];
+                const u32 o8 = lo8 + 127 * 8;
+                const u64 c = ring_e(o8);
                 if ((int)el < 0) {                                  // (bit 31: the lane has a chain)
                     el &= 0x7fffffffu;
                     const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                     const u32 rel_c = c0 & REL_MASK;
                     if ((int)rel_c > lim1) {
                         u32 kill;
-                        const u32 len = score(slot, c0, c1, rel_c, kill);
+                        const u32 len = score(o8, c0, c1, rel_c, kill);
                         if (len > best) {
                             best = len; bdist = rel_p - rel_c;
                             el &= pick() & kill;
@@ -357,7 +398,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                     } else { stop = true; el = 0; }
                 }
             }
-            while (__any(el != 0)) {
+            while (any64(el != 0)) {
 #if MTS_M5_STATS
                 st_r1++; st_s1 += (u32)__popcll(__ballot(el != 0));
 #endif
@@ -365,15 +406,15 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                     const u32 b = 31 - __builtin_clz(el);
                     el &= ~(1u << b);
                     const u32 t = tb + b;
-                    const u32 slot = (lo + t) & (M5_RING - 1);
-                    const u64 c = SE[slot];
+                    const u32 o8 = lo8 + (t << 3);
+                    const u64 c = ring_e(o8);
                     const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                     const u32 rel_c = c0 & REL_MASK;
                     // (what ends a lane's walk -- a candidate out of range, a match of nice_match bytes -- is rare: the lane's mask is
                     //  cleared where it happens, not looked at in every round)
                     if ((int)rel_c > ((!head && t == 127) ? lim1 : limn)) {
                         u32 kill;
-                        const u32 len = score(slot, c0, c1, rel_c, kill);
+                        const u32 len = score(o8, c0, c1, rel_c, kill);
                         if (len > best) {
                             best = len; bdist = rel_p - rel_c;
                             el &= pick() & kill;                    // fewer candidates can still win now
@@ -403,8 +444,16 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                 asm volatile("" : "+v"(r));
                 return best >= 6 ? A7[w] : r;
             };
-            u32 f2 = stop ? 0u : pickw(2), f1 = stop ? 0u : pickw(1), f0 = stop ? 0u : pickw(0);
-            while (__any((f2 | f1 | f0) != 0)) {
+            // (the three words' first picks share their four comparisons: the lane masks are kept and the selects take them as they are)
+            const u64 c3 = ballot64(best >= 3), c4 = ballot64(best >= 4), c5 = ballot64(best >= 5), c6 = ballot64(best >= 6 || stop);
+            auto pick0 = [&](const int w) __attribute__((always_inline)) -> u32 {
+                u32 r = sel64(c3, A4[w], V[w]);
+                r = sel64(c4, A5[w], r);
+                r = sel64(c5, A6[w], r);
+                return sel64(c6, stop ? 0u : A7[w], r);
+            };
+            u32 f2 = pick0(2), f1 = pick0(1), f0 = pick0(0);
+            while (any64((f2 | f1 | f0) != 0)) {
 #if MTS_M5_STATS
                 st_r2++; st_s2 += (u32)__popcll(__ballot((f2 | f1 | f0) != 0));
 #endif
@@ -417,13 +466,13 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                     f2 = t2 ? f2 & clr : f2;
                     f1 = (!t2 && t1) ? f1 & clr : f1;
                     f0 = (!t2 && !t1) ? f0 & clr : f0;
-                    const u32 slot = (lo + tb + b) & (M5_RING - 1);
-                    const u64 c = SE[slot];
+                    const u32 o8 = lo8 + ((tb + b) << 3);
+                    const u64 c = ring_e(o8);
                     const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                     const u32 rel_c = c0 & REL_MASK;
                     if ((int)rel_c > limn) {
                         u32 kill;
-                        const u32 len = score(slot, c0, c1, rel_c, kill);
+                        const u32 len = score(o8, c0, c1, rel_c, kill);
                         if (len > best) {
                             best = len; bdist = rel_p - rel_c;
                             f2 &= pickw(2) & kill; f1 &= pickw(1) & kill; f0 &= pickw(0) & kill;      // fewer candidates can still win now
@@ -433,7 +482,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
             }
         }
         };
-        if (__any(own && look < (u32)MAX_MATCH)) walks(std::true_type{}); else walks(std::false_type{});
+        if (any64(own && look < (u32)MAX_MATCH)) walks(std::true_type{}); else walks(std::false_type{});
         if (own) te_store(T, TQ, p_abs, best, bdist, qbest, qdist, (u32)cfg.good, all_quarters);
 #if MTS_M5_STATS
         st_groups++;
