@@ -42,6 +42,9 @@ static u32 lcp(const u8 *a, const u8 *b, u32 maxlen)
     return l;
 }
 
+// the masks are ANDed level after level: a candidate passes level `need` when every EXISTING table up to it has its key equal
+static int levok(u8 bits, u32 need, int levmask) { for (u32 l = 0; l < need; l++) if (((levmask >> l) & 1) && !((bits >> l) & 1)) return 0; return 1; }
+
 typedef struct { u32 n1, n2; u32 best, bdist, qbest, qdist; } LaneRes;
 
 int main(int argc, char **argv)
@@ -52,7 +55,8 @@ int main(int argc, char **argv)
     fseek(f, 0, SEEK_END);
     long fsz = ftell(f);
     long off = argc > 2 ? atol(argv[2]) : 0, W = argc > 3 ? atol(argv[3]) : (1 << 18);
-    const int NLEV = argc > 4 ? atoi(argv[4]) : 4;       // key levels in use: 4 (as built) .. 6
+    const int NLEV = argc > 5 ? atoi(argv[5]) : 4;       // key levels considered (5, 6: what-if tables for bytes 7 and 8)
+    const int LEVMASK = argc > 4 ? atoi(argv[4]) : 15;    // which of the four key tables exist: bit d = the table of prefix length 4 + d (15 = as built)
     if (off + W > fsz) W = fsz - off;
     u8 *s = malloc(W + 512);
     memset(s, 0, W + 512);
@@ -92,23 +96,25 @@ int main(int argc, char **argv)
             u32 mk[6];
             keys(me, mk);
             // level of every candidate: how many key levels agree in a row (0..NLEV)
-            u8 lev[CHAIN + 1];
+            u8 lev_bits[CHAIN + 1];                              // bit d: key d equal
             for (u32 j = 1; j <= nbv; j++) {
                 u32 ck[6];
                 keys(s + sorted[i - j], ck);
-                int l = 0;
-                while (l < NLEV && ck[l] == mk[l]) l++;
-                lev[j] = (u8)l;
+                u8 b = 0;
+                for (int l = 0; l < NLEV; l++) if (ck[l] == mk[l]) b |= 1 << l;
+                lev_bits[j] = b;
             }
             u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
             int stop = 0, qset = 0;
             lanes++;
             for (u32 j = 1; j <= nbv && !stop; j++) {
                 if (j == QCHAIN + 1) { qbest = best; qdist = bdist; qset = 1; }
-                // is candidate j let through at the current best?  level needed: best>=3 -> A4 (lev>=1), >=4 -> A5, ... capped at NLEV
+                // is candidate j let through at the current best?  level wanted: best>=3 -> A4 (lev>=1), >=4 -> A5, ... capped at NLEV;
+                // a table that does not exist is replaced by the deepest existing one below it
                 u32 need = best >= 3 ? best - 2 : 0;
                 if (need > (u32)NLEV) need = NLEV;
-                if (lev[j] < need) continue;
+                while (need && !((LEVMASK >> (need - 1)) & 1)) need--;
+                if (need && !levok(lev_bits[j], need, LEVMASK)) continue;
                 // scored
                 if (j <= QCHAIN) res[lane].n1++; else res[lane].n2++;
                 seq[lane][nseq[lane]++] = j;
