@@ -99,7 +99,8 @@ constexpr int M5_RING = 256;
 constexpr int M5_ROWS = 32;
 constexpr int M5_LEVELS = 4;                         // tables for prefix lengths 4, 5, 6, 7
 constexpr int M5_ROW_WORDS = M5_RING / 32 + 1;       // a row is 8 words of bits + 1 of padding, so that rows start in different LDS banks (32-byte rows whose word
-                                                     // addresses are (offset & 28) | row save ten instructions per group and cost 1.8 ms in bank conflicts: round 4)
+                                                     // addresses are (offset & 28) | row save ten instructions per group and cost 1.8 ms in bank conflicts; whole rows read
+                                                     // from one address -- four ds_read2_b32 -- and the five words picked in registers save fourteen and cost 0.5 ms: round 4)
 constexpr int M5_TABLE = M5_ROWS * M5_ROW_WORDS * 4; // bytes per table
 constexpr int M5_SLOTS = M5_LEVELS + 1;                // the first table has 64 rows (a 6-bit key of byte 3): two table slots
 constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_SLOTS * M5_TABLE;      // 9856: entries, bytes 7..12, tables
