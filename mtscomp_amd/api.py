@@ -518,6 +518,9 @@ class Reader:
         self._dev_cache_lock = threading.Lock()
         self._cache_lock = threading.RLock()                      # the host LRU is shared by the threads that slice (mtscomp.py:648)
         self._dev_cache_bytes = int(float(os.environ.get('MTSCOMP_DEVICE_CACHE_GB', DEFAULT_DEVICE_CACHE_GB)) * 2 ** 30)
+        self._pin = None                                          # page-locked buffer the compressed bytes of slices are read into
+        self._pin_lock = threading.Lock()
+        self._io_pool = None
 
     @property
     def codec(self):
@@ -583,6 +586,43 @@ class Reader:
                 buf = self.cdata.read(length)
         assert len(buf) == length
         return buf
+
+    def _pread_pinned(self, length, start):
+        """`length` bytes at `start` of the compressed file as a uint8 view of a page-locked buffer (the codec's: the bytes go to
+        the device by DMA from where the file system put them -- no fresh pages to fault in for every read, no staging copy);
+        reads of a few MB and more are split over four threads.  The caller holds self._pin_lock while the view is in use.
+        None when the codec has no such buffers (the caller reads into a bytes object then)."""
+        alloc = getattr(self.codec, 'host_buffer', None)
+        if alloc is None or not hasattr(os, 'preadv'):
+            return None
+        if self._pin is None or self._pin.nbytes < length + 64:
+            try:
+                new = alloc(max(int((length + 64) * 1.5), 16 << 20))
+            except Exception:  # noqa: BLE001
+                return None
+            if self._pin is not None:
+                self._pin.free()
+            self._pin = new
+        mv = memoryview(self._pin.array)
+        fd = self.cdata.fileno()
+
+        def part(a, b):
+            while a < b:
+                got = os.preadv(fd, [mv[a:b]], start + a)
+                if got <= 0:
+                    break
+                a += got
+            return a
+        if length >= (4 << 20):
+            if self._io_pool is None:
+                self._io_pool = ThreadPool(4)
+            per = (length + 3) // 4
+            ends = self._io_pool.starmap(part, [(k * per, min((k + 1) * per, length)) for k in range(4) if k * per < length])
+            assert all(e == min((k + 1) * per, length) for k, e in enumerate(ends))
+        else:
+            assert part(0, length) == length
+        self._pin.array[length:length + 16] = 0                  # (the kernels may read a few bytes past a stream)
+        return self._pin.array[:length + 16]
 
     def _flags(self):
         return _int_flags(self.cmeta.do_time_diff, self.cmeta.do_spatial_diff, self.chunk_order)
@@ -665,10 +705,17 @@ class Reader:
         for attempt in range(2):
             need = [k for k, p in zip(keys, present) if not p]
             offs, lens = [0] * n, [0] * n
-            buf = b''
+            buf, locked = b'', False
             if need:
                 base = self.chunk_offsets[need[0]]                 # one read from the first to the last missing chunk
-                buf = self._pread(self.chunk_offsets[need[-1] + 1] - base, base)
+                nbytes = self.chunk_offsets[need[-1] + 1] - base
+                self._pin_lock.acquire()
+                locked = True
+                buf = self._pread_pinned(nbytes, base)
+                if buf is None:
+                    self._pin_lock.release()
+                    locked = False
+                    buf = self._pread(nbytes, base)
                 for k in need:
                     offs[k - first] = self.chunk_offsets[k] - base
                     lens[k - first] = self.chunk_offsets[k + 1] - self.chunk_offsets[k]
@@ -680,6 +727,9 @@ class Reader:
                 if e.code != hip.E_MISS or attempt:
                     raise
                 present = [False] * n                          # dropped since the query: send everything
+            finally:
+                if locked:
+                    self._pin_lock.release()
         for k, st in zip(keys, status):
             if st == hip.CHUNK_BADSIZE:
                 raise AssertionError("Chunk #%d does not have the expected size." % k)
@@ -969,6 +1019,12 @@ class Reader:
                 self.codec.cache_destroy(cache)
             except Exception:  # pragma: no cover
                 pass
+        if self._io_pool is not None:
+            self._io_pool.close()
+            self._io_pool = None
+        if self._pin is not None:
+            self._pin.free()
+            self._pin = None
         if self.cdata:
             self.cdata.close()
 

@@ -1654,7 +1654,10 @@ constexpr u32 LZ_SPIN_MAX = 1u << 20;                     // bound on every wait
 // so it works on 16-bit cells: 0..255 = a byte, 256 + i = "byte i of my unknown window".  The cells leave
 // as they are; k_inf_windows then makes the real windows one after the other (window k = the last 32 KiB
 // of segment k-1, translated with window k-1) and k_inf_translate turns every cell into a byte.
-constexpr int LZ_MAXSEG = 32;
+#ifndef MTS_LZ_MAXSEG
+#define MTS_LZ_MAXSEG 32
+#endif
+constexpr int LZ_MAXSEG = MTS_LZ_MAXSEG;
 constexpr int LZ_STATUS_RETRY = 1000;                    // internal chunk status: a resolver wait expired, run the chunk again with one worker wave
 constexpr u32 LZ_WIN = 32768;
 struct LzPlan {
