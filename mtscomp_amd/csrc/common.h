@@ -98,6 +98,11 @@ struct ChunkOut {
 
 inline __host__ __device__ u64 align_up(u64 x, u64 a) { return (x + a - 1) / a * a; }
 
+// wave-wide predicates straight from the condition's lane mask (HIP's __ballot / __any take an int: the mask is first turned into a
+// value per lane -- v_cndmask -- and compared again -- v_cmp: two vector instructions per use in kernels that are bound by them)
+__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+
 // ---- error plumbing -------------------------------------------------------------------------------
 void set_error(const char *fmt, ...);
 #define MTS_HIP(call)                                                                       \

@@ -32,10 +32,6 @@ namespace mts {
 //             only (0.4 % of them on the synthetic recordings; the debug tap of the tests has it written everywhere)
 // (Rounds 1-2 kept both results and the position's byte in 8 bytes per position: twice the table traffic in the match store
 // and in both parse walks, and half as many walkers per CU, whose windows of the table live in LDS.)
-// wave-wide predicates straight from the condition's lane mask (HIP's __ballot / __any take an int: the mask is first turned into a
-// value per lane and compared again)
-__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-__device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 // the value of the lane before (wave_shr:1); lane 0 gets `first`
 __device__ __forceinline__ u32 prev_lane(u32 v, u32 first) { return (u32)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false); }
 // lane-wise select by a lane mask held in scalar registers: mask bit set -> a, else b
@@ -381,7 +377,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                 // and the only one that may be MAX_DIST away (zlib checks the head against MAX_DIST, the others against the limit
                 // one nearer): scored here, by all lanes at once, so that the rounds below know one limit and one kind of candidate.
 #if MTS_M5_STATS
-                st_r1++; st_s1 += (u32)__popcll(__ballot(el != 0));
+                st_r1++; st_s1 += (u32)__popcll(ballot64(el != 0));
 #endif
                 const u32 o8 = lo8 + 127 * 8;
                 const u64 c = ring_e(o8);
@@ -402,7 +398,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
             }
             while (any64(el != 0)) {
 #if MTS_M5_STATS
-                st_r1++; st_s1 += (u32)__popcll(__ballot(el != 0));
+                st_r1++; st_s1 += (u32)__popcll(ballot64(el != 0));
 #endif
                 if (el) {
                     const u32 b = 31 - __builtin_clz(el);
@@ -457,7 +453,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
             u32 f2 = pick0(2), f1 = pick0(1), f0 = pick0(0);
             while (any64((f2 | f1 | f0) != 0)) {
 #if MTS_M5_STATS
-                st_r2++; st_s2 += (u32)__popcll(__ballot((f2 | f1 | f0) != 0));
+                st_r2++; st_s2 += (u32)__popcll(ballot64((f2 | f1 | f0) != 0));
 #endif
                 if (f2 | f1 | f0) {
                     const bool t2 = f2 != 0, t1 = f1 != 0;
@@ -574,11 +570,11 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
         u32 *t1 = TB + 2 * (M6_TABLE / 4) + lane * M6_ROW_WORDS + wp;       // rows of tables 1..3 are contiguous: 96 rows
         t1[0] = 0; t1[1] = 0;
         if (lane < 32) { t1[64 * M6_ROW_WORDS] = 0; t1[64 * M6_ROW_WORDS + 1] = 0; }
-        const u64 vm = __ballot(bt.valid);
+        const u64 vm = ballot64(bt.valid);
         u32 m0 = (u32)vm, m1 = (u32)(vm >> 32);
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            const u64 B = __ballot((key[0] >> j) & 1);
+            const u64 B = ballot64((key[0] >> j) & 1);
             m0 = and_xor(m0, (u32)B, inv[j]); m1 = and_xor(m1, (u32)(B >> 32), inv[j]);
         }
         { u32 *t0 = TB + lane * M6_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }
@@ -648,8 +644,8 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
             u32 hp = __shfl_up(h_own, 1, 64), rcp = __shfl_up(rel_p, 1, 64);
             if (lane == 0) { hp = wave ? wg_h[wave - 1] : c_h; rcp = wave ? wg_rc[wave - 1] : c_rc; }
             const bool starts_run = h_own != hp;
-            if (__any(have && !starts_run && rel_p <= rcp)) { if (lane == 0) atomicOr(flags, 1u); }      // positions must increase inside a run (see k_match5)
-            const u64 sr = __ballot(starts_run);
+            if (any64(have && !starts_run && rel_p <= rcp)) { if (lane == 0) atomicOr(flags, 1u); }      // positions must increase inside a run (see k_match5)
+            const u64 sr = ballot64(starts_run);
             if (lane == 0) wg_tail[wave] = sr ? (u32)__builtin_clzll(sr) + 1u : 0u;
             __syncthreads();
             u32 t = c_tail;                                         // slots since the last run start before this wave's group
@@ -673,7 +669,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
             if ((u32)(wave >> 1) == ((blk + 1) & 3)) fetch(G0 - (int)jbase - 384 + 64 * (wave & 1), ba);
             if (jbase == qchain && !qtaken) { qbest = best; qdist = bdist; qtaken = true; }      // (chain / 4 a multiple of 128)
             const u32 nbl = nbv > jbase ? (nbv - jbase < 128 ? nbv - jbase : 128) : 0;          // candidates of this lane in the block
-            if (__any(nbl != 0 && !stop)) {
+            if (any64(nbl != 0 && !stop)) {
                 // candidate jj (1 = newest) of this lane is slot i - jbase - jj: bit 128 - jj of the 128 ring positions from lo
                 const u32 lo = (u32)((int)i - (int)jbase - 128) & (M6_RING - 1), w0 = lo >> 5, sh = lo & 31;
                 u32 V[4], A4[4], A5[4], A6[4], A7[4];                 // V = inside the budget; A_d = V & "first d bytes may match"
@@ -708,7 +704,7 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
                 auto walk = [&](const bool u3, const bool u2, const bool u1, const bool u0) __attribute__((always_inline)) {
                     u32 f3 = (stop || !u3) ? 0u : pickw(3), f2 = (stop || !u2) ? 0u : pickw(2);
                     u32 f1 = (stop || !u1) ? 0u : pickw(1), f0 = (stop || !u0) ? 0u : pickw(0);
-                    while (__any((f3 | f2 | f1 | f0) != 0)) {
+                    while (any64((f3 | f2 | f1 | f0) != 0)) {
                         if (f3 | f2 | f1 | f0) {
                             const bool t3 = f3 != 0, t2 = f2 != 0, t1 = f1 != 0;
                             const u32 cur = t3 ? f3 : t2 ? f2 : t1 ? f1 : f0;
