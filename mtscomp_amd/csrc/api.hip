@@ -389,6 +389,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
             int hflags[2] = {0, 0};                              // {changed, match-stage flags}
             MTS_HIP(hipMemcpyAsync(hflags, pb.changed, 8, hipMemcpyDeviceToHost, st));
             MTS_HIP(hipStreamSynchronize(st));
+            if (getenv("MTS_DEBUG_FLAGS")) fprintf(stderr, "[flags] level %d round %d changed %d match-flags %d force_ballot %d\n", level, round, hflags[0], hflags[1], force_ballot);
             if (hflags[1] & 1) { resort = true; break; }
             if (!hflags[0]) break;
             MTS_HIP(hipMemsetAsync(pb.changed, 0, 4, st));

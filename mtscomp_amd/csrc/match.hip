@@ -601,7 +601,13 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
             const bool mism = t > i1 || hash_of(wread(sk[i1 - (t > i1 ? 0 : t)] & REL_MASK)) != c_h;
             if (mism) atomicMin(&wg_min, t);
             __syncthreads();
-            if (wg_min != 0xffffffffu) break;
+            const u32 found = wg_min;
+            // Everybody has read it before anybody goes round again: a wave that read "nothing yet" and went on to the next round's
+            // atomicMin let a slower wave read THAT and leave the loop a round early -- the two then met at different barriers, and
+            // everything behind (ring, run carries) was out of step.  Only budgets > 512 make a second round (level 9, chains that
+            // reach back further than that: zeros), where the run-order guard then fired at random: found by the fuzzer in round 4.
+            __syncthreads();
+            if (found != 0xffffffffu) break;
         }
         c_tail = wg_min < chain ? wg_min : chain;
         __syncthreads();

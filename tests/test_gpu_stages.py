@@ -445,3 +445,16 @@ def test_inflate_full_size_damage_is_refused_quickly():
             assert st == 0 and out == want, i
         print('inflate damaged at byte %d of %d: %.1f ms' % (i, len(z), dt * 1e3))
         assert dt < 0.4, (i, dt)
+
+
+def test_level9_long_zero_runs_many_times():
+    """A chain budget of 4096 makes the match stage's workgroups look back for the start of a run in SEVERAL rounds (512 slots per round)
+    when the run reaches that far -- all-zero chunks.  Round 4's fuzzer found the rounds' exit racing with the next round's atomic
+    (waves left the loop at different barriers; the run-order guard then fired at random and, one call in five, twice in a row =
+    MTS_E_INTERNAL).  The same call many times: every one must succeed and give zlib's bytes."""
+    x = np.zeros((2 * 7500, 1024), dtype=np.int32)
+    flags = hip.make_flags(True, True, 'C')
+    want = zlib.compress(bytes(O.delta_transpose(x[:7500], flags)), 9)
+    for rep in range(16):
+        got = hip.compress_chunks(x, [0, 7500, 15000], flags, 9)
+        assert got[0] == want and got[1] == want, rep

@@ -85,7 +85,12 @@ def main():
             print('case dtype %s nc %d rows %s kind %d flags %d' % (dt, nc, rows, kind, fl), flush=True)
         lv = os.environ.get('FUZZ_LEVELS')
         level = int(r.choice([1, 2, 3, 1, 2, 3, 6, 9])) if lv == '2' else int(r.choice([6, 6, 6, 4, 5, 7, 8, 9])) if lv else 6
-        z = hip.compress_chunks(x, b, fl, level)
+        try:
+            z = hip.compress_chunks(x, b, fl, level)
+        except Exception:
+            print('FAILED case dtype %s nc %d rows %s kind %d flags %d level %d (chunk count so far %d)' % (dt, nc, rows, kind, fl, level, n), flush=True)
+            np.save('gpurun_out/fuzz_fail_x.npy', x)
+            raise
         st, arrs = hip.decompress_chunks(z, rows, nc, dt, fl)
         for i in range(len(rows)):
             c = x[b[i]:b[i + 1]]
