@@ -68,7 +68,8 @@ __device__ __forceinline__ u32 __reduce_max_sync_u32(u32 v)
 // A match-table entry is ONE word per position (see match.hip):  [14:0] dist (0: no match), [22:15] len - 3 = the full-budget result,
 // TE_QNONE / TE_QSIDE say what the quarter-budget result is.
 constexpr u32 TE_DIST = 0x7fffu, TE_QNONE = 1u << 23, TE_QSIDE = 1u << 24;
-__device__ __forceinline__ u32 te_pack(u32 len, u32 dist) { return len >= (u32)MIN_MATCH ? dist | ((len - MIN_MATCH) << 15) : 0u; }
+// (dist is 0 whenever len < MIN_MATCH: the walks only record a distance with a length of 3 and more)
+__device__ __forceinline__ u32 te_pack(u32 len, u32 dist) { return dist | (((len > (u32)MIN_MATCH ? len : (u32)MIN_MATCH) - MIN_MATCH) << 15); }
 __device__ __forceinline__ u32 te_dist(u32 e) { return e & TE_DIST; }
 __device__ __forceinline__ u32 te_len(u32 e) { return (e & TE_DIST) ? ((e >> 15) & 0xffu) + MIN_MATCH : 0u; }
 __device__ __forceinline__ void te_store(u32 *__restrict__ T, u32 *__restrict__ TQ, u32 p, u32 best, u32 bdist, u32 qbest, u32 qdist, u32 good, int all_quarters)

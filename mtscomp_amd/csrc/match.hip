@@ -16,7 +16,7 @@ namespace mts {
 // ================================================================================================
 // The kernel scores a candidate from a 64-bit "entry" built (from the LDS window) for every staged slot:
 //   w0 [17:0]  rel   window-relative position
-//      [26:18] d     9 bits that, TOGETHER WITH AN EQUAL 15-BIT HASH, prove bytes 0..2 equal:
+//      [26:18] d     9 bits that, TOGETHER WITH AN EQUAL 15-BIT HASH, prove bytes 0..2 equal (any order of them does: b1[2:0] : b0[7:5] : b0[2:0] is stored):
 //                    h = (b0<<10 ^ b1<<5 ^ b2) & 0x7fff exposes b0[4:3], b1[4:3], b2[4:0] directly and
 //                    b0[2:0]^b1[7:5], b1[2:0]^b2[7:5]; b0[7:5] not at all.  d = b0[7:5] : b0[2:0] : b1[2:0].
 //      [31:27] low 5 bits of byte 7
@@ -45,8 +45,8 @@ __device__ __forceinline__ u32 sel64(u64 mask, u32 a, u32 b)
 __device__ __forceinline__ u32 and_xor(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x60); }
 __device__ __forceinline__ u64 make_entry(u32 rel, u32 lo, u32 hi)       // lo = bytes 0..3, hi = bytes 4..7
 {
-    const u32 b0 = lo & 0xff, b1 = (lo >> 8) & 0xff;
-    const u32 d = ((b0 >> 5) << 6) | ((b0 & 7) << 3) | (b1 & 7);
+    // (the nine bits in the order they are cheapest to take: b1[2:0] : b0[7:5] is one field of `lo`, b0[2:0] another)
+    const u32 d = (((lo >> 5) & 0x3f) << 3) | (lo & 7);
     const u32 w0 = rel | (d << REL_BITS) | (((hi >> 24) & ((1u << (32 - REL_BITS - 9)) - 1)) << (REL_BITS + 9));
     const u32 w1 = (lo >> 24) | (hi << 8);
     return (u64)w0 | ((u64)w1 << 32);
