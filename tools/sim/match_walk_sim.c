@@ -73,7 +73,7 @@ int main(int argc, char **argv)
     u32 *tf = calloc(n + 4, 4), *tq = calloc(n + 4, 4);          // (len << 16 | dist)
     const u32 ngroups = (wlen + 63) / 64;
     u64 tot1 = 0, tot2 = 0, rounds1 = 0, rounds2 = 0, lanes = 0, hist1[64] = {0}, hist2[64] = {0}, wasted = 0;
-    u64 act1[40] = {0}, act2[40] = {0};
+    u64 act1[40] = {0}, act2[40] = {0}, merged[4] = {0};
     // pooled what-ifs: in-place rounds R for the newest word, everything else as items
     enum { NR = 4 };
     u64 inplace_rounds[NR] = {0}, items[NR] = {0}, item_scorings[NR] = {0}, item_max[NR] = {0};
@@ -138,6 +138,7 @@ int main(int argc, char **argv)
             if (res[lane].n2 > gmax2) gmax2 = res[lane].n2;
         }
         rounds1 += gmax1; rounds2 += gmax2;
+        for (int R = 1; R <= 3; R++) { u32 m = 0; for (int l = 0; l < 64; l++) { const u32 left = (res[l].n1 > (u32)R ? res[l].n1 - R : 0) + res[l].n2; if (left > m) m = left; } merged[R] += (gmax1 < (u32)R ? gmax1 : (u32)R) + m; }
         for (u32 r = 0; r < gmax1 && r < 40; r++) for (int l = 0; l < 64; l++) if (res[l].n1 > r) act1[r]++;
         for (u32 r = 0; r < gmax2 && r < 40; r++) for (int l = 0; l < 64; l++) if (res[l].n2 > r) act2[r]++;
         // what-if: R rounds of the newest word in place, then every lane with anything left becomes an item
@@ -154,6 +155,7 @@ int main(int argc, char **argv)
     printf("scorings per position: newest32 %.3f  other96 %.3f  (wasted %.3f)\n", (double)tot1 / lanes, (double)tot2 / lanes, (double)wasted / lanes);
     printf("rounds per group:      newest32 %.2f  other96 %.2f   lane use %.1f%% / %.1f%%\n", (double)rounds1 / ngroups, (double)rounds2 / ngroups,
            100.0 * tot1 / (rounds1 * 64.0), 100.0 * tot2 / (rounds2 * 64.0));
+    printf("rounds per group if the newest word gets R rounds of its own and its leftovers join the loop of the other 96: R=1 %.2f  R=2 %.2f  R=3 %.2f\n", (double)merged[1] / ngroups, (double)merged[2] / ngroups, (double)merged[3] / ngroups);
     printf("lanes by scorings (newest32): ");
     for (int k = 0; k < 12; k++) printf("%d:%.1f%% ", k, 100.0 * hist1[k] / lanes);
     printf("\nlanes by scorings (other96):  ");
