@@ -8,7 +8,8 @@
   configs[3]  385 ch x 3600 s sharded over 8 GPUs: ONE rank's shard at its size -- chunks 0, 8, 16, ... = 450 chunks, 10.4 GB raw --
               through the device-resident entry points, full round trip, every 25th chunk against zlib.compress
               (mtscomp.py:399-423, :474-483; the other seven shards are the same code on other chunk ids)
-  configs[4]  1024 ch, 0.25 s chunks, 240 chunks, levels 1 / 6 / 9: EVERY chunk against zlib.compress(stream, level)
+  configs[4]  1024 ch, 0.25 s chunks, 240 chunks, levels 1 / 6 / 9: EVERY chunk against zlib.compress(stream, level); and ONE RANK'S SHARD of
+              the 600 s / 2400-chunk form (300 chunks, 4.6 GB) at the three levels
 
 The recordings live in HBM through the library's own allocator (hip.DevBuffer -> mts_dev_alloc / mts_dev_copy): this process
 initialises one HIP runtime, whatever else it imports and in whatever order (test_import_order_* pins both orders with torch).
@@ -137,6 +138,42 @@ def test_config3_one_rank_shard_of_the_3600s_recording():
     # the host-side gather of the sizes (the path's only exchange) puts this shard's chunks where the file has them
     offsets = np.concatenate(([0], np.cumsum(sizes)))
     assert offsets[-1] == sizes.sum() and list(bench.gather_chunk_offsets(sizes, 0, 1)) == list(offsets)
+    for b in (raw, cbuf, back):
+        b.free()
+
+
+def test_config4_one_rank_shard_of_the_600s_recording():
+    """configs[4]: rank 0's shard of the 8-GPU stress run at its real size -- 1024 ch, chunk = 0.25 s, 600 s = 2400 chunks, of which this
+    rank owns chunks 0, 8, 16, ...: 300 chunks of 15.36 MB -- at levels 1, 6 and 9: full round trip on the device, every 20th chunk of
+    the shard against zlib.compress(stream, level)."""
+    nc, rows, world = 1024, 7500, 8
+    ids = bench.shard_ids(0, world, 2400)
+    n = len(ids)
+    assert n == 300
+    chunk_bytes = rows * nc * 2
+    raw = hip.DevBuffer(n * chunk_bytes)
+    for k, g in enumerate(ids):
+        hip.dev_synth_int16(raw, k * chunk_bytes, g * rows, (g + 1) * rows, nc, 0)
+    cb = (hip.compress_bound(chunk_bytes) + 255) // 256 * 256
+    cbuf, back = hip.DevBuffer(n * cb), hip.DevBuffer(n * chunk_bytes)
+    bounds = np.arange(n + 1, dtype=np.int64) * rows
+    slots = np.arange(n, dtype=np.int64) * cb
+    sizes = np.zeros(n, dtype=np.int64)
+    nrows = np.full(n, rows, dtype=np.int64)
+    ooffs = np.arange(n, dtype=np.int64) * chunk_bytes
+    status = np.zeros(n, dtype=np.int32)
+    flags = hip.make_flags(True, False, 'F')
+    picks = list(range(0, n, 20))
+    with ThreadPool(min(32, os.cpu_count() or 1)) as pool:
+        streams = pool.map(lambda k: O.delta_transpose(raw.download(k * chunk_bytes, chunk_bytes, np.int16).reshape(rows, nc), flags).tobytes(), picks)
+        for level in (1, 6, 9):
+            hip.dev_compress_chunks(raw, nc, 2, bounds, flags, level, cbuf, slots, sizes)
+            want = pool.map(lambda j: zlib.compress(streams[j], level), range(len(picks)))
+            diff = [ids[k] for k, w in zip(picks, want) if cbuf.download(int(slots[k]), int(sizes[k])).tobytes() != w]
+            assert diff == [], (level, diff)
+            hip.dev_decompress_chunks(cbuf, slots, sizes, nrows, nc, 2, flags, back, ooffs, status)
+            assert not status.any()
+            assert back.diff(raw) == (0, -1), level
     for b in (raw, cbuf, back):
         b.free()
 
