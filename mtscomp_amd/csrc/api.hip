@@ -257,7 +257,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     const size_t desc_bytes = align_up(sizeof(ChunkDesc) * n_chunks, 256) + align_up(sizeof(TileDesc) * (tiles.size() + 1), 256) +
                               align_up(sizeof(ChunkOut) * n_chunks, 256);
     if ((rc = E.desc.ensure(desc_bytes))) return rc;
-    if ((rc = E.adler.ensure(sizeof(u64) * 2 * n_chunks + 256))) return rc;
+    if ((rc = E.adler.ensure(sizeof(u64) * 2 * n_chunks + 256 + MATCH_SINK_BYTES))) return rc;      // + the flag words and the match stage's sink behind them
     if ((rc = E.init_events())) return rc;
 
     u8 *dp = E.desc.as<u8>();

@@ -83,9 +83,16 @@ __device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
 #define MTS_M5_STATS 0
 #endif
 #if MTS_M5_STATS
-__device__ unsigned long long g_m5_stats[8];          // groups walked, rounds of the newest word, rounds of the other 96, scorings of each
+__device__ unsigned long long g_m5_stats[16];          // groups walked, rounds of the newest word, rounds of the other 96, scorings of each
 #endif
-constexpr int M5_WAVES = 8;
+constexpr int M5_WAVES = 8;                         // k_match6's workgroup
+#ifndef MTS_M5_SX
+#define MTS_M5_SX 1                                  // 1: bytes 7..12 of every slot in LDS beside its entry (2 KB per wave more: 8 waves per workgroup); 0: read from the window when wanted (10 waves)
+#endif
+#ifndef MTS_M5_WAVES
+#define MTS_M5_WAVES (MTS_M5_SX == 1 ? 8 : MTS_M5_SX == 2 ? 9 : 10)
+#endif
+constexpr int M5W = MTS_M5_WAVES;                    // k_match5's waves per workgroup: two workgroups per CU either way
 constexpr int M5_SLICES = 64;                        // workgroups per tile (MTS_MATCH_SLICES overrides: experiments) = the workgroups an XCD holds: ONE tile per XCD at a
                                                      // time.  Round 4, time / bytes written per launch (60 chunks; the table is 5.5 GB): 32 slices 24.7 ms / 38-44 GB (two tiles
                                                      // share an L2: lines leave half filled again and again), 64: 24.9 ms / 13.4 GB, 96: 26.2 ms / 9.7 GB, 128: 7.8 GB (a tile is
@@ -99,14 +106,15 @@ constexpr int M5_ROW_WORDS = M5_RING / 32 + 1;       // a row is 8 words of bits
                                                      // from one address -- four ds_read2_b32 -- and the five words picked in registers save fourteen and cost 0.5 ms: round 4)
 constexpr int M5_TABLE = M5_ROWS * M5_ROW_WORDS * 4; // bytes per table
 constexpr int M5_SLOTS = M5_LEVELS + 1;                // the first table has 64 rows (a 6-bit key of byte 3): two table slots
-constexpr int M5_WAVE_LDS = 2 * M5_RING * 8 + M5_SLOTS * M5_TABLE;      // 9856: entries, bytes 7..12, tables
+constexpr int M5_SX_BYTES = MTS_M5_SX == 1 ? 8 : MTS_M5_SX == 2 ? 4 : 0;      // per slot, of its bytes 7..
+constexpr int M5_WAVE_LDS = M5_RING * (8 + M5_SX_BYTES) + M5_SLOTS * M5_TABLE;      // 9856: entries, bytes 7..12, tables (7808 without the bytes)
 __device__ __forceinline__ constexpr int m5_slot(int d) { return d ? d + 1 : 0; }
 // requested LDS is padded so that TWO workgroups share a CU, not three (16 waves per CU keep the vector units busy)
 #ifndef MTS_M5_LDS_PAD
 #define MTS_M5_LDS_PAD 0
 #endif
 constexpr int M5_VLUT = 129 * 16;                    // the budget masks (one table per workgroup, behind the waves' areas)
-constexpr int MATCH5_LDS = MTS_M5_LDS_PAD ? MTS_M5_LDS_PAD : (M5_WAVES * M5_WAVE_LDS + M5_VLUT > 56 * 1024 ? M5_WAVES * M5_WAVE_LDS + M5_VLUT : 56 * 1024);      // (MTS_M5_LDS_PAD: occupancy experiments)
+constexpr int MATCH5_LDS = MTS_M5_LDS_PAD ? MTS_M5_LDS_PAD : (M5W * M5_WAVE_LDS + M5_VLUT > 56 * 1024 ? M5W * M5_WAVE_LDS + M5_VLUT : 56 * 1024);      // (MTS_M5_LDS_PAD: occupancy experiments)
 
 // 3 + the equal bytes among bytes 3..6 (x1 = their xor): v_ffbl_b32 gives -1 for 0, and 3 + (0xffffffff >> 3) is still more than 7
 __device__ __forceinline__ u32 m5_len37(u32 x1)
@@ -131,7 +139,7 @@ __device__ __forceinline__ void m5_keys(u32 e1, u32 (&k)[M5_LEVELS])
 // at random) stay in its L2 until they are complete (L2 hit rate 12 % -> 92 %, 10x fewer misses: tools/pmc_cache.sh).
 // flags[0] |= 1 when the sorted order is found NOT to be position-ordered inside a hash run (the sort's ranking relies on
 // a hardware property, see rank_pass): the caller then sorts again with the ballot ranking and repeats the stage.
-__global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, int nsl,
+__global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, int nsl,
                                                           const u32 *__restrict__ sorted, u32 *__restrict__ tables, u32 *__restrict__ quarter, LevelCfg cfg,
                                                           u32 *__restrict__ flags, int all_quarters)
 {
@@ -146,16 +154,22 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     const u8 *gwin = stream + td.stream_off + td.w;
     auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
     u64 *SE = (u64 *)(smem + wave * (M5_RING * 8));
-    u64 *SX = (u64 *)(smem + M5_WAVES * M5_RING * 8 + wave * (M5_RING * 8));      // bytes 7..12 of every slot: matches up to 13 never leave the LDS
-    u32 *TB = (u32 *)(smem + 2 * M5_WAVES * M5_RING * 8 + wave * (M5_SLOTS * M5_TABLE));      // [level][row][8 words + 1]
-    const uint4 *VLUT = (const uint4 *)(smem + M5_WAVES * M5_WAVE_LDS);      // [0 .. 128]: the newest n of 128 bits (one table per workgroup)
+    u64 *SX = (u64 *)(smem + M5W * M5_RING * 8 + wave * (M5_RING * 8));      // bytes 7..12 of every slot: matches up to 13 never leave the LDS
+    u32 *TB = (u32 *)(smem + M5W * M5_RING * (8 + M5_SX_BYTES) + wave * (M5_SLOTS * M5_TABLE));      // [level][row][8 words + 1]
+    const uint4 *VLUT = (const uint4 *)(smem + M5W * M5_WAVE_LDS);      // [0 .. 128]: the newest n of 128 bits (one table per workgroup)
     typedef __attribute__((address_space(3))) const u64 *lds_u64p;
     const u32 se_base = (u32)(size_t)(__attribute__((address_space(3))) u8 *)(u8 *)SE;      // (byte address in LDS)
     if (se_base & (M5_RING * 8 - 1)) __builtin_trap();            // (the kernel has no static LDS: the dynamic area starts at 0)
     // entry / bytes 7..12 of the ring slot at byte offset o8 (any multiple of 8; only its low 11 bits count)
     auto ring_e = [&](u32 o8) -> u64 { return *(lds_u64p)(size_t)((o8 & (M5_RING * 8 - 8)) | se_base); };
-    auto ring_x = [&](u32 o8) -> u64 { return *(lds_u64p)(size_t)(((o8 & (M5_RING * 8 - 8)) | se_base) + M5_WAVES * M5_RING * 8); };
+#if MTS_M5_SX == 2
+    typedef __attribute__((address_space(3))) const u32 *lds_u32p;
+    auto ring_x = [&](u32 o8) -> u32 { return *(lds_u32p)(size_t)((((o8 & (M5_RING * 8 - 8)) | se_base) >> 1) + M5W * M5_RING * 8); };      // bytes 7..10
+#else
+    auto ring_x = [&](u32 o8) -> u64 { return *(lds_u64p)(size_t)(((o8 & (M5_RING * 8 - 8)) | se_base) + M5W * M5_RING * 8); };
+#endif
     u32 *T = tables + td.stream_off, *TQ = quarter + td.stream_off;
+    u32 *sink = flags + 63 + (blockIdx.x & (MATCH_SINK_BYTES / 256 - 1)) * 64 + (threadIdx.x & 63);      // (this lane's word of a line per workgroup)
     if (threadIdx.x < 2 && slice == 0) {
         const u32 hashed_end = td.w + td.wlen;
         const u32 p = hashed_end + threadIdx.x;
@@ -167,16 +181,16 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     const u32 ngroups = (wlen + 63) / 64;
     const u32 halo = td.a - td.w;
     const u32 chain = (u32)cfg.chain, qchain = (u32)cfg.chain >> 2;
-    const u32 nwv = (u32)nsl * M5_WAVES;
+    const u32 nwv = (u32)nsl * M5W;
     const u32 gpw = (ngroups + nwv - 1) / nwv;
-    const u32 g_begin = (slice * M5_WAVES + wave) * gpw, g_end = min(ngroups, g_begin + gpw);
-    for (int k = threadIdx.x; k <= 128; k += M5_WAVES * 64) {
+    const u32 g_begin = (slice * M5W + wave) * gpw, g_end = min(ngroups, g_begin + gpw);
+    for (int k = threadIdx.x; k <= 128; k += M5W * 64) {
         uint4 v;
         v.w = k >= 32 ? 0xffffffffu : k ? 0xffffffffu << (32 - k) : 0u;
         v.z = k >= 64 ? 0xffffffffu : k > 32 ? 0xffffffffu << (64 - k) : 0u;
         v.y = k >= 96 ? 0xffffffffu : k > 64 ? 0xffffffffu << (96 - k) : 0u;
         v.x = k >= 128 ? 0xffffffffu : k > 96 ? 0xffffffffu << (128 - k) : 0u;
-        ((uint4 *)(smem + M5_WAVES * M5_WAVE_LDS))[k] = v;
+        ((uint4 *)(smem + M5W * M5_WAVE_LDS))[k] = v;
     }
     __syncthreads();                                               // (the only barrier: every wave is still here)
     if (g_begin >= g_end) return;
@@ -186,6 +200,9 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
     u32 h_carry = 0xffffffffu;                                     // hash of the slot before the one lane 0 commits next
 #if MTS_M5_STATS
     u32 st_groups = 0, st_r1 = 0, st_r2 = 0, st_s1 = 0, st_s2 = 0;
+    u64 st_t[6] = {0, 0, 0, 0, 0, 0};                           // (MTS_M5_STATS=2) wave clocks: commit, masks, newest word, other 96, store, groups without an owned slot
+    u64 st_mark = 0;
+#define M5_MARK(k) do { if (MTS_M5_STATS == 2) { const u64 t_ = (u64)clock64(); st_t[k] += t_ - st_mark; st_mark = t_; } } while (0)
 #endif
     u32 rc_carry = 0;                                              // its position
     u32 run_carry = 0;                                             // slots between the newest run start and lane 0 of the group being committed (capped)
@@ -247,7 +264,11 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         for (int d = 1; d < M5_LEVELS; d++)
             if (valid) atomicOr(&TB[m5_slot(d) * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS + word], bit);
         SE[rp] = ce;
+#if MTS_M5_SX == 1
         SX[rp] = x;
+#elif MTS_M5_SX == 2
+        ((u32 *)(smem + M5W * M5_RING * 8))[wave * M5_RING + rp] = (u32)x;
+#endif
         return ce;
     };
     // bytes 0..12 of the string at window offset r with ONE 16-byte load (the four dwords around it): the lanes are each
@@ -279,14 +300,20 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         commit(i_first - 64, rb, lb, hb, xb, kk, nb);
     }
     // pipeline: (rc, lo, hi) of the group about to be walked, rc of the one after
-    u32 rc_c = slot_rel(i_first), rc_n = slot_rel(i_first + 64);
+    // (in the order of an iteration: the group's bytes, the keys of the next, a store)
+    u32 rc_c = slot_rel(i_first);
     u32 lo_c, hi_c;
     u64 x_c;
     load16(rc_c, lo_c, hi_c, x_c);
+    u32 rc_n = slot_rel(i_first + 64);
+    *sink = 0;
     for (u32 g = g_begin; g < g_end; g++) {
         const u32 i0 = g * 64, i = i0 + lane;
         u32 key[M5_LEVELS], nbv;
         __builtin_amdgcn_wave_barrier();
+#if MTS_M5_STATS == 2
+        st_mark = (u64)clock64();
+#endif
         const u64 e = commit((int)i, rc_c, lo_c, hi_c, x_c, key, nbv);
         const u64 ex = x_c;
         __builtin_amdgcn_wave_barrier();
@@ -297,13 +324,21 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
         const u32 rel_p = e0 & REL_MASK;
         const bool own = i < wlen && rel_p >= halo;
-        if (!any64(own)) continue;
+#if MTS_M5_STATS == 2
+        if (!any64(own)) { *sink = 0; M5_MARK(5); continue; }
+        M5_MARK(0);
+#else
+        if (!any64(own)) { *sink = 0; continue; }                       // (the store every path has: see the end of the loop)
+#endif
         const u32 p_abs = td.w + rel_p;
         const u32 look = n - p_abs;
         const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
         const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
-        const int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
-        const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
+        // window offsets a candidate must lie above: the head of the chain, the others.  A lane whose walk has ended (a candidate
+        // out of range, nice_match reached) has both at INT_MAX: the state the later walks ask for lives in registers the rounds
+        // read anyway, and is written where the rare thing happens
+        int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
+        int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
         // the 128 slots before this lane's own are ring positions lo .. lo + 127 (mod 256); candidate j
         // (1 = newest) is bit 128 - j of the masks.  V = the candidates inside this lane's chain budget.
         const u32 lo = (i + 128) & (M5_RING - 1), w0 = lo >> 5, sh = lo & 31, lo8 = lo << 3;
@@ -325,39 +360,60 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         rowmask(1, A4, A5);
         rowmask(2, A5, A6);
         rowmask(3, A6, A7);
+#if MTS_M5_STATS == 2
+        asm volatile("" :: "v"(A7[0]), "v"(A7[1]), "v"(A7[2]), "v"(A7[3]));
+        M5_MARK(1);
+#endif
         // The walks.  NEAR_END = some lane of the group is within 258 bytes of the end of its chunk (one group in a thousand of a
         // chunk's last tile): match lengths are capped by what is left and nice_match shrinks with it.  Everywhere else both are
         // constants, the cap never binds below the long compare, and nice_match (>= 16 at every level) can only be reached there:
         // the common path of a round carries neither the cap nor the test.
         u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
+        asm volatile("" : "+v"(best), "+v"(bdist));          // (two registers from here on: as constants they are made again on every path that does not change them)
         auto walks = [&](auto near_end) __attribute__((always_inline)) {
         constexpr bool NEAR_END = decltype(near_end)::value;
-        bool stop = false;
-        // one candidate: its match length against this lane's string (0: other bytes behind an equal hash); `kill` = 0 when the
-        // walk ends with it (nice_match reached), all ones otherwise
-        auto score = [&](const u32 o8 /* byte offset of the candidate's ring slot */, const u32 c0, const u32 c1, const u32 rel_c, u32 &kill) __attribute__((always_inline)) -> u32 {
+        auto stopped = [&]() -> bool { return limn == 0x7fffffff; };
+        auto set_stop = [&]() { lim1 = 0x7fffffff; limn = 0x7fffffff; };
+        // one candidate: scored against this lane's string; a longer match than the one held is taken and `narrow()` leaves the
+        // candidates that can still beat it; `finish()` ends the lane's walk (nice_match reached).  Everything a candidate can do
+        // to the walk's state happens in the branch where it is found out: nothing is handed to the code behind through a value
+        // that the other paths would have to make up (each of those was a v_mov per round and path).
+        auto cand = [&](const u32 o8 /* byte offset of the candidate's ring slot */, const u32 c0, const u32 c1, const u32 rel_c, auto &&narrow, auto &&finish) __attribute__((always_inline)) {
             const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
-            kill = 0xffffffffu;
-            if ((x0 & 0x1ff) != 0) return 0u;
-            u32 len = m5_len37(x1);
-            if (len == 7 && (x0 >> 9) == 0) {
-                const u64 y = ring_x(o8) ^ ex;
-                if (y) len = 7 + ((u32)__builtin_ctzll(y) >> 3);
-                else {
-                    const u32 cap = NEAR_END ? maxlen : (u32)MAX_MATCH;
-                    len = 13;
-                    while (len < cap) {
-                        const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
-                        if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
-                        len += 4;
+            if ((x0 & 0x1ff) == 0) {
+                u32 len = m5_len37(x1);
+                if (len == 7 && (x0 >> 9) == 0) {
+#if MTS_M5_SX == 1
+                    const u64 y = ring_x(o8) ^ ex;
+                    const u32 len0 = 13;
+#elif MTS_M5_SX == 2
+                    const u32 y = ring_x(o8) ^ (u32)ex;
+                    const u32 len0 = 11;
+#else
+                    const u32 y = wread(rel_c + 7) ^ (u32)ex;       // bytes 7..10 (this lane's own are in registers)
+                    const u32 len0 = 11;
+#endif
+                    if (y) len = 7 + ((u32)__builtin_ctzll((u64)y) >> 3);
+                    else {
+                        const u32 cap = NEAR_END ? maxlen : (u32)MAX_MATCH;
+                        len = len0;
+                        while (len < cap) {
+                            const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
+                            if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
+                            len += 4;
+                        }
+                        len = len < cap ? len : cap;
+                        // (a candidate that reaches nice_match is an improvement: a match that long already held would have ended the walk)
+                        if (!NEAR_END && len >= (u32)cfg.nice) { best = len; bdist = rel_p - rel_c; set_stop(); finish(); }
                     }
-                    len = len < cap ? len : cap;
-                    // (a candidate that reaches nice_match is an improvement: a match that long already held would have ended the walk)
-                    if (!NEAR_END && len >= (u32)cfg.nice) { kill = 0; stop = true; }
+                }
+                if (NEAR_END) len = len < maxlen ? len : maxlen;
+                if (len > best) {
+                    best = len; bdist = rel_p - rel_c;
+                    narrow();                                           // fewer candidates can still win now
+                    if (NEAR_END && len >= nice) { set_stop(); finish(); }
                 }
             }
-            if (NEAR_END) { len = len < maxlen ? len : maxlen; if (len >= nice) kill = 0; }
-            return len;
         };
         // candidates of word w restricted to `part`, newest first
         auto walk = [&](const u32 tb, const u32 m0, const u32 m1, const u32 m2, const u32 m3, const u32 m4, const u32 part, const bool head) __attribute__((always_inline)) {
@@ -371,7 +427,14 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                 asm volatile("" : "+v"(r));
                 return best >= 6 ? m4 : r;
             };
-            u32 el = stop ? 0 : pick() & part;
+            auto pick_longer = [&]() -> u32 {                      // the same once a match is held (best >= 3)
+                u32 r = best >= 4 ? m2 : m1;
+                asm volatile("" : "+v"(r));
+                r = best >= 5 ? m3 : r;
+                asm volatile("" : "+v"(r));
+                return best >= 6 ? m4 : r;
+            };
+            u32 el = head ? m0 & part : stopped() ? 0 : pick() & part;      // (the head's walk is the first: nothing is held yet)
             if (head) {
                 // The head of the chain (the slot before this lane's own: bit 31 of the newest word) is every lane's first candidate,
                 // and the only one that may be MAX_DIST away (zlib checks the head against MAX_DIST, the others against the limit
@@ -385,15 +448,8 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                     el &= 0x7fffffffu;
                     const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                     const u32 rel_c = c0 & REL_MASK;
-                    if ((int)rel_c > lim1) {
-                        u32 kill;
-                        const u32 len = score(o8, c0, c1, rel_c, kill);
-                        if (len > best) {
-                            best = len; bdist = rel_p - rel_c;
-                            el &= pick() & kill;
-                            if (NEAR_END && kill == 0) stop = true;
-                        }
-                    } else { stop = true; el = 0; }
+                    if ((int)rel_c > lim1) cand(o8, c0, c1, rel_c, [&]() { el &= pick_longer(); }, [&]() { el = 0; });
+                    else el = 0;
                 }
             }
             while (any64(el != 0)) {
@@ -410,15 +466,9 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                     const u32 rel_c = c0 & REL_MASK;
                     // (what ends a lane's walk -- a candidate out of range, a match of nice_match bytes -- is rare: the lane's mask is
                     //  cleared where it happens, not looked at in every round)
-                    if ((int)rel_c > ((!head && t == 127) ? lim1 : limn)) {
-                        u32 kill;
-                        const u32 len = score(o8, c0, c1, rel_c, kill);
-                        if (len > best) {
-                            best = len; bdist = rel_p - rel_c;
-                            el &= pick() & kill;                    // fewer candidates can still win now
-                            if (NEAR_END && kill == 0) stop = true;
-                        }
-                    } else { stop = true; el = 0; }     // out of range: so is everything older
+                    if ((int)rel_c > ((!head && t == 127) ? lim1 : limn)) cand(o8, c0, c1, rel_c, [&]() { el &= pick_longer(); }, [&]() { el = 0; });
+                    else el = 0;                        // out of range: so is everything older (a later walk of the lane finds that out with its
+                                                        // first candidate: rare, and a limit changed on this path is copies in every round)
                 }
             }
         };
@@ -429,26 +479,27 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
         qbest = best; qdist = bdist;
         if (qpart != 0xffffffffu) MTS_WALK(3, ~qpart, false);
 #undef MTS_WALK
+#if MTS_M5_STATS == 2
+        M5_MARK(2);
+#endif
         {
             // The other 96 candidates in ONE loop (a lane takes its own next candidate, whichever of the three words it is in):
             // word by word the wave ran as many rounds as the busiest lane of EACH word needed; together it is the busiest lane
             // over all three.
             auto pickw = [&](const int w) __attribute__((always_inline)) -> u32 {
-                u32 r = best >= 3 ? A4[w] : V[w];
-                asm volatile("" : "+v"(r));
-                r = best >= 4 ? A5[w] : r;
+                u32 r = best >= 4 ? A5[w] : A4[w];                   // (after an improvement: best >= 3)
                 asm volatile("" : "+v"(r));
                 r = best >= 5 ? A6[w] : r;
                 asm volatile("" : "+v"(r));
                 return best >= 6 ? A7[w] : r;
             };
             // (the three words' first picks share their four comparisons: the lane masks are kept and the selects take them as they are)
-            const u64 c3 = ballot64(best >= 3), c4 = ballot64(best >= 4), c5 = ballot64(best >= 5), c6 = ballot64(best >= 6 || stop);
+            const u64 c3 = ballot64(best >= 3), c4 = ballot64(best >= 4), c5 = ballot64(best >= 5), c6 = ballot64(best >= 6 || stopped());
             auto pick0 = [&](const int w) __attribute__((always_inline)) -> u32 {
                 u32 r = sel64(c3, A4[w], V[w]);
                 r = sel64(c4, A5[w], r);
                 r = sel64(c5, A6[w], r);
-                return sel64(c6, stop ? 0u : A7[w], r);
+                return sel64(c6, stopped() ? 0u : A7[w], r);
             };
             u32 f2 = pick0(2), f1 = pick0(1), f0 = pick0(0);
             while (any64((f2 | f1 | f0) != 0)) {
@@ -460,34 +511,46 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match5(const u8 *__restrict__
                     const u32 cur = t2 ? f2 : t1 ? f1 : f0;
                     const u32 tb = t2 ? 64u : t1 ? 32u : 0u;
                     const u32 b = 31 - __builtin_clz(cur);
-                    const u32 clr = ~(1u << b);
-                    f2 = t2 ? f2 & clr : f2;
-                    f1 = (!t2 && t1) ? f1 & clr : f1;
-                    f0 = (!t2 && !t1) ? f0 & clr : f0;
+                    const u32 ncur = cur & ~(1u << b);                  // the word the candidate came from, without it
+                    f2 = t2 ? ncur : f2;
+                    f1 = (!t2 && t1) ? ncur : f1;
+                    f0 = (!t2 && !t1) ? ncur : f0;
                     const u32 o8 = lo8 + ((tb + b) << 3);
                     const u64 c = ring_e(o8);
                     const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                     const u32 rel_c = c0 & REL_MASK;
-                    if ((int)rel_c > limn) {
-                        u32 kill;
-                        const u32 len = score(o8, c0, c1, rel_c, kill);
-                        if (len > best) {
-                            best = len; bdist = rel_p - rel_c;
-                            f2 &= pickw(2) & kill; f1 &= pickw(1) & kill; f0 &= pickw(0) & kill;      // fewer candidates can still win now
-                        }
-                    } else { f2 = 0; f1 = 0; f0 = 0; }  // out of range: so is everything older
+                    if ((int)rel_c > limn) cand(o8, c0, c1, rel_c, [&]() { f2 &= pickw(2); f1 &= pickw(1); f0 &= pickw(0); }, [&]() { f2 = 0; f1 = 0; f0 = 0; });
+                    else { f2 = 0; f1 = 0; f0 = 0; }    // out of range: so is everything older
                 }
             }
         }
         };
         if (any64(own && look < (u32)MAX_MATCH)) walks(std::true_type{}); else walks(std::false_type{});
-        if (own) te_store(T, TQ, p_abs, best, bdist, qbest, qdist, (u32)cfg.good, all_quarters);
+#if MTS_M5_STATS == 2
+        M5_MARK(3);
+#endif
+        {   // te_store(), with the table word stored by EVERY lane, on every path (lanes that own no position: into the sink).  The
+            // loads of the next group's bytes and of the keys behind it went out at the top of this iteration and are waited for at
+            // the top of the next; the counter they are waited on counts stores as well, in order of issue, and the compiler must
+            // allow for the path with the fewest operations behind a load: with the store under a branch that is none, the wait
+            // became vmcnt(0), and every wave sat out the round trip of its own 64 scattered stores before it entered the next
+            // group (a quarter of its time: tools/m5_stats.py with -DMTS_M5_STATS=2).  One store on every path: vmcnt(1).
+            const u32 f = te_pack(best, bdist), q = te_pack(qbest, qdist);
+            u32 e = f;
+            if (q != f) e |= qbest > (u32)cfg.good ? TE_QSIDE : TE_QNONE;
+            if (own && ((e & TE_QSIDE) || all_quarters)) TQ[p_abs] = q;      // (rare; before the table word: the waits allow ONE younger operation)
+            u32 *dst = own ? T + p_abs : sink;
+            *dst = e;
+        }
 #if MTS_M5_STATS
         st_groups++;
+#if MTS_M5_STATS == 2
+        M5_MARK(4);
+#endif
 #endif
     }
 #if MTS_M5_STATS
-    if (lane == 0) { atomicAdd(&g_m5_stats[0], st_groups); atomicAdd(&g_m5_stats[1], st_r1); atomicAdd(&g_m5_stats[2], st_r2); atomicAdd(&g_m5_stats[3], st_s1); atomicAdd(&g_m5_stats[4], st_s2); }
+    if (lane == 0) { atomicAdd(&g_m5_stats[0], st_groups); atomicAdd(&g_m5_stats[1], st_r1); atomicAdd(&g_m5_stats[2], st_r2); atomicAdd(&g_m5_stats[3], st_s1); atomicAdd(&g_m5_stats[4], st_s2); for (int k = 0; k < 6; k++) atomicAdd(&g_m5_stats[5 + k], st_t[k]); }
 #endif
 }
 
@@ -788,7 +851,7 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
         int nsl = M5_SLICES;
         if (const char *e = getenv("MTS_MATCH_SLICES")) nsl = atoi(e) > 0 ? atoi(e) : nsl;
         const int grid = (n_tiles + 7) / 8 * 8 * nsl;
-        hipLaunchKernelGGL(k_match5, dim3(grid), dim3(M5_WAVES * 64), MATCH5_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, d_quarter, cfg, d_flags, all_quarters);
+        hipLaunchKernelGGL(k_match5, dim3(grid), dim3(M5W * 64), MATCH5_LDS, st, d_stream, d_tiles, n_tiles, nsl, d_sorted, d_tables, d_quarter, cfg, d_flags, all_quarters);
     } else {
         if (cfg.chain != 256 && (cfg.chain >> 2) % 128 != 0) { set_error("match: chain budget %d unsupported", cfg.chain); return MTS_E_INTERNAL; }
         const int nsl = M6_SLICES;
@@ -804,8 +867,8 @@ int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, in
 #if MTS_M5_STATS
 extern "C" int mts_debug_m5_stats(unsigned long long *out)      // (instrumented builds only: tools/m5_stats.py)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mts::g_m5_stats), 64) != hipSuccess) return -1;
-    unsigned long long z[8] = {0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(mts::g_m5_stats), z, 64) == hipSuccess ? 0 : -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mts::g_m5_stats), 128) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(mts::g_m5_stats), z, 128) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -14,7 +14,7 @@ hip.dev_synth_int16(raw, 0, 0, n * rate, nc, 0)
 bound = (hip.compress_bound(cb) + 255) // 256 * 256
 cbuf = hip.DevBuffer(n * bound)
 b = np.arange(n + 1, dtype=np.int64) * rate; sl = np.arange(n, dtype=np.int64) * bound; sz = np.zeros(n, dtype=np.int64)
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 L = hip.lib()
 L.mts_debug_m5_stats(out)
 hip.dev_compress_chunks(raw, nc, 2, b, 5, 6, cbuf, sl, sz)
@@ -23,3 +23,10 @@ g, r1, r2, s1, s2 = [int(v) for v in out[:5]]
 print("groups walked %d (%.2f per 64 owned positions)" % (g, g / (n * cb / 64)))
 print("rounds per group: newest word %.2f, other 96 %.2f; lane use %.1f%% / %.1f%%; scorings per owned position %.3f + %.3f"
       % (r1 / g, r2 / g, 100 * s1 / (64 * r1), 100 * s2 / (64 * max(r2, 1)), s1 / (n * cb), s2 / (n * cb)))
+t = [int(v) for v in out[5:11]]
+if sum(t):                                                                       # -DMTS_M5_STATS=2: wave clocks per phase
+    names = ["commit (slot entry, keys, tables)", "budget + row masks", "newest word (head + rounds)", "other 96 (rounds)", "store", "groups without an owned slot"]
+    tot = sum(t)
+    for nm, v in zip(names, t):
+        print("  %-36s %7.0f clocks per group walked (%4.1f %%)" % (nm, v / g, 100.0 * v / tot))
+    print("  all: %.0f clocks of a wave per group walked" % (tot / g))
