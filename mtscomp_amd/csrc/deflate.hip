@@ -143,6 +143,10 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
         u32 key_n[KPL];
 #pragma unroll
         for (int k = 0; k < KPL; k++) key_n[k] = fetch(beg + 64 * k + lane);
+        // (the first keys are waited for HERE: entering the loop with them in flight, the wait at its top has to allow for this
+        //  path -- no stores behind the loads -- and on every later step it then sat out the round trip of the step's own stores)
+#pragma unroll
+        for (int k = 0; k < KPL; k++) asm volatile("" :: "v"(key_n[k]));
         for (u32 base = beg; base < end; base += BK) {
             u32 key[KPL], at[KPL], bf[4];
 #pragma unroll
