@@ -125,13 +125,21 @@ __device__ __forceinline__ u32 m5_len37(u32 x1)
     return l < 7 ? l : 7;
 }
 // 5-bit keys of the prefixes (b3), (b3,b4), (b3..b5), (b3..b6) of e1 = bytes 3..6
-__device__ __forceinline__ u32 m5_hash24(u32 x) { return (__umul24(x, 0x9E3779u) >> 19) & 31; }
+// (v_mul_u32_u24 by name: the compiler sees that the bits taken do not depend on the operand's top byte, drops the mask in front
+//  of the multiplication and is left with a 32-bit multiply -- a quarter-rate instruction, four issue slots instead of one)
+__device__ __forceinline__ u32 m5_mul24(u32 x, u32 c)
+{
+    u32 r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(x), "v"(c));
+    return r;
+}
+__device__ __forceinline__ u32 m5_hash24(u32 x) { return (m5_mul24(x, 0x9E3779u) >> 19) & 31; }
 __device__ __forceinline__ void m5_keys(u32 e1, u32 (&k)[M5_LEVELS])
 {
     k[0] = (__umul24(e1 & 0xff, 0x9E3779u) >> 18) & 63;
-    k[1] = m5_hash24(e1 & 0xffff);
-    k[2] = m5_hash24(e1 & 0xffffff);
-    k[3] = m5_hash24((e1 ^ (e1 >> 11)) & 0xffffff);
+    k[1] = (__umul24(e1 & 0xffff, 0x9E3779u) >> 19) & 31;
+    k[2] = m5_hash24(e1);                                  // (the instruction takes the low 24 bits)
+    k[3] = m5_hash24(e1 ^ (e1 >> 11));
 }
 
 // Workgroups share tiles: `nsl` consecutive workgroups OF ONE XCD (block b runs on XCD b % 8) take the `nsl` slices of one
@@ -215,19 +223,20 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
     // whose keys repeat most -- 32 lanes adding the same bit to the same word would be serialised by the LDS -- is rebuilt
     // from five ballots by the lane that owns the row; the others take one atomic OR per slot).  `nbv` = the chain behind
     // the slot = the slots back to the start of its hash run (at most 128 matter), from the ballot of the run starts.
-    auto commit = [&](int idx, u32 rc, u32 lo, u32 hi, u64 x, u32 (&key)[M5_LEVELS], u32 &nbv) -> u64 {
+    auto commit = [&](int idx, u32 rc, u32 lo, u32 hi, u64 x, u32 (&key)[M5_LEVELS], u32 &nbv, u64 &vm) -> u64 {
         const u32 rp = (u32)idx & (M5_RING - 1), word = rp >> 5, bit = 1u << (rp & 31);
-        const bool valid = idx >= 0 && (u32)idx < wlen;
+        // (lane masks are made by single comparisons and combined as scalars: the ballot of a compound condition goes through a
+        //  0 / 1 register and a second comparison)
+        const bool valid = (u32)idx < wlen;                        // (a negative index is a huge one)
+        vm = ballot64(valid);
         const u64 ce = valid ? make_entry(rc, lo, hi) : ~0ull;
         // a slot starts a run when its hash differs from its predecessor's (slots are committed in order)
         const u32 h = valid ? hash_of(lo) : 0xfffffffeu;
         const u32 hp = prev_lane(h, h_carry), rcp = prev_lane(rc, rc_carry);
-        const bool starts_run = h != hp;
-        const bool disorder = valid && !starts_run && rc <= rcp;      // positions must increase inside a run
-        if (any64(disorder)) { if (lane == 0) atomicOr(flags, 1u); }
+        const u64 sr = ballot64(h != hp);
+        if (vm & ~sr & ballot64(rc <= rcp)) { if (lane == 0) atomicOr(flags, 1u); }      // positions must increase inside a run
         h_carry = (u32)__builtin_amdgcn_readlane((int)h, 63);
         rc_carry = (u32)__builtin_amdgcn_readlane((int)rc, 63);
-        const u64 sr = ballot64(starts_run);
         // slots back to the start of the lane's run: lane + what the groups before carried, or lane - (the last run start at or
         // before the lane).  Runs are long (a few hundred slots on the recordings): the starts of a group are few, and each is two
         // instructions (lanes before a start wrap around to huge values and keep what they have)
@@ -250,7 +259,6 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
             // (atomic ORs for this table as well take 42 vector instructions off a group -- 8 % of the kernel's -- and give them back
             //  as LDS waits: byte 3 of an even position is the high byte of a small delta, two values, 32 lanes per word;
             //  SQ_WAIT_INST_LDS x5, the same 25.2 ms)
-            const u64 vm = ballot64(valid);
             u32 m0 = (u32)vm, m1 = (u32)(vm >> 32);
 #pragma unroll
             for (int j = 0; j < 6; j++) {
@@ -279,8 +287,8 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
         const u32x4_a4 w = *(const u32x4_a4 *)q;
         lo = alignbyte(w.y, w.x, r);
         hi = alignbyte(w.z, w.y, r);
-        const u32 b8 = alignbyte(w.w, w.z, r), b12 = alignbyte(0u, w.w, r) & 0xffu;
-        x = (u64)(hi >> 24) | ((u64)b8 << 8) | ((u64)b12 << 40);                    // bytes 7..12
+        const u32 b8 = alignbyte(w.w, w.z, r), b12 = alignbyte(0u, w.w, r);
+        x = (u64)__builtin_amdgcn_alignbit(b8, hi, 24) | ((u64)(__builtin_amdgcn_alignbit(b12, b8, 24) & 0xffffu) << 32);      // bytes 7..10, 11..12
     };
 #if MTS_M5_NT_KEYS
     auto slot_rel = [&](int idx) -> u32 { return __builtin_nontemporal_load(&sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1]) & REL_MASK; };      // (read once: keep them out of the way of the window and the table lines in L2)
@@ -290,14 +298,15 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
     const int i_first = (int)g_begin * 64 + lane;
     {
         u32 kk[M5_LEVELS], nb;
+        u64 vmm;
         const u32 ra = slot_rel(i_first - 128), rb = slot_rel(i_first - 64);
         u32 la, ha, lb, hb;
         u64 xa, xb;
         load16(ra, la, ha, xa);
         load16(rb, lb, hb, xb);
-        commit(i_first - 128, ra, la, ha, xa, kk, nb);
+        commit(i_first - 128, ra, la, ha, xa, kk, nb, vmm);
         __builtin_amdgcn_wave_barrier();
-        commit(i_first - 64, rb, lb, hb, xb, kk, nb);
+        commit(i_first - 64, rb, lb, hb, xb, kk, nb, vmm);
     }
     // pipeline: (rc, lo, hi) of the group about to be walked, rc of the one after
     // (in the order of an iteration: the group's bytes, the keys of the next, a store)
@@ -314,7 +323,8 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
 #if MTS_M5_STATS == 2
         st_mark = (u64)clock64();
 #endif
-        const u64 e = commit((int)i, rc_c, lo_c, hi_c, x_c, key, nbv);
+        u64 vm;
+        const u64 e = commit((int)i, rc_c, lo_c, hi_c, x_c, key, nbv, vm);
         const u64 ex = x_c;
         __builtin_amdgcn_wave_barrier();
         // next group's words, and the position of the one after
@@ -324,11 +334,12 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
         const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
         const u32 rel_p = e0 & REL_MASK;
         const bool own = i < wlen && rel_p >= halo;
+        const u64 ownm = vm & ballot64(rel_p >= halo);             // (the same as a lane mask, without the ballot of a compound condition)
 #if MTS_M5_STATS == 2
-        if (!any64(own)) { *sink = 0; M5_MARK(5); continue; }
+        if (!ownm) { *sink = 0; M5_MARK(5); continue; }
         M5_MARK(0);
 #else
-        if (!any64(own)) { *sink = 0; continue; }                       // (the store every path has: see the end of the loop)
+        if (!ownm) { *sink = 0; continue; }                             // (the store every path has: see the end of the loop)
 #endif
         const u32 p_abs = td.w + rel_p;
         const u32 look = n - p_abs;
@@ -494,12 +505,13 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
                 return best >= 6 ? A7[w] : r;
             };
             // (the three words' first picks share their four comparisons: the lane masks are kept and the selects take them as they are)
-            const u64 c3 = ballot64(best >= 3), c4 = ballot64(best >= 4), c5 = ballot64(best >= 5), c6 = ballot64(best >= 6 || stopped());
+            const u64 stm = ballot64(limn == 0x7fffffff);          // lanes whose walk has ended
+            const u64 c3 = ballot64(best >= 3), c4 = ballot64(best >= 4), c5 = ballot64(best >= 5), c6 = ballot64(best >= 6) | stm;
             auto pick0 = [&](const int w) __attribute__((always_inline)) -> u32 {
                 u32 r = sel64(c3, A4[w], V[w]);
                 r = sel64(c4, A5[w], r);
                 r = sel64(c5, A6[w], r);
-                return sel64(c6, stopped() ? 0u : A7[w], r);
+                return sel64(c6, sel64(stm, 0u, A7[w]), r);
             };
             u32 f2 = pick0(2), f1 = pick0(1), f0 = pick0(0);
             while (any64((f2 | f1 | f0) != 0)) {
@@ -511,21 +523,25 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
                     const u32 cur = t2 ? f2 : t1 ? f1 : f0;
                     const u32 tb = t2 ? 64u : t1 ? 32u : 0u;
                     const u32 b = 31 - __builtin_clz(cur);
-                    const u32 ncur = cur & ~(1u << b);                  // the word the candidate came from, without it
-                    f2 = t2 ? ncur : f2;
-                    f1 = (!t2 && t1) ? ncur : f1;
-                    f0 = (!t2 && !t1) ? ncur : f0;
                     const u32 o8 = lo8 + ((tb + b) << 3);
                     const u64 c = ring_e(o8);
                     const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                     const u32 rel_c = c0 & REL_MASK;
-                    if ((int)rel_c > limn) cand(o8, c0, c1, rel_c, [&]() { f2 &= pickw(2); f1 &= pickw(1); f0 &= pickw(0); }, [&]() { f2 = 0; f1 = 0; f0 = 0; });
-                    else { f2 = 0; f1 = 0; f0 = 0; }    // out of range: so is everything older
+                    // the word the candidate came from goes back without it -- or, the candidate out of range (so is everything
+                    // older), all three as nothing: by a mask, not in an else branch whose zeros every path would have to carry
+                    const bool in_range = (int)rel_c > limn;
+                    u32 rm = in_range ? 0xffffffffu : 0u;
+                    asm volatile("" : "+v"(rm));                      // (a value: the compiler would make the branch of it again)
+                    const u32 ncur = cur & ~(1u << b);
+                    f2 = (t2 ? ncur : f2) & rm;
+                    f1 = ((!t2 && t1) ? ncur : f1) & rm;
+                    f0 = ((!t2 && !t1) ? ncur : f0) & rm;
+                    if (in_range) cand(o8, c0, c1, rel_c, [&]() { f2 &= pickw(2); f1 &= pickw(1); f0 &= pickw(0); }, [&]() { f2 = 0; f1 = 0; f0 = 0; });
                 }
             }
         }
         };
-        if (any64(own && look < (u32)MAX_MATCH)) walks(std::true_type{}); else walks(std::false_type{});
+        if (ownm & ballot64(look < (u32)MAX_MATCH)) walks(std::true_type{}); else walks(std::false_type{});
 #if MTS_M5_STATS == 2
         M5_MARK(3);
 #endif
