@@ -74,15 +74,26 @@ __device__ __forceinline__ u32 sort_hash(u32 b012)
 #endif
     return h;
 }
+// Where the counter of a digit lives.  The digits that are common on recordings differ in their high bits (zlib's hash of int16
+// deltas: the popular values of the low digit are b1[1:0] << 5 ^ b2 with b2 one of two bytes, those of the high digit multiples
+// of 8 apart) -- and counters 32 apart share an LDS bank: the lanes of a rank instruction met in the same few banks
+// (~21 cycles per instruction by the stream's statistics, the most popular digit alone accounts for ~9).  Folding the high
+// bits into the low ones spreads them over the banks.
+#ifndef MTS_SORT_SWZ
+#define MTS_SORT_SWZ 1
+#endif
+__device__ __forceinline__ u32 cslot(u32 d) { return MTS_SORT_SWZ ? d ^ (d >> 5) : d; }
+
 // per-(wave, digit) counts -> where each wave's keys of each digit start (digit-major, wave-minor: stable)
 template <int NB>
 __device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
 {
     constexpr int NBIN = 1 << NB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 cs = cslot(threadIdx.x);
     if (threadIdx.x < NBIN) {
         u32 run = 0;
-        for (int w = 0; w < SORT_WAVES; w++) { const u32 c = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += c; }
+        for (int w = 0; w < SORT_WAVES; w++) { const u32 c = cnt[w][cs]; cnt[w][cs] = run; run += c; }
         tot[threadIdx.x] = run;
     }
     __syncthreads();
@@ -98,7 +109,7 @@ __device__ __forceinline__ void bin_offsets(u32 (*cnt)[256], u32 *tot)
     __syncthreads();
     if (threadIdx.x < NBIN) {
         const u32 base = tot[threadIdx.x];
-        for (int w = 0; w < SORT_WAVES; w++) cnt[w][threadIdx.x] += base;
+        for (int w = 0; w < SORT_WAVES; w++) cnt[w][cs] += base;
     }
     __syncthreads();
 }
@@ -155,25 +166,25 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
             // digits 4 * lane + j, lanes 8 apart met in one LDS bank on each of these twelve accesses per step)
             constexpr int NJ = NBIN / 64;
 #pragma unroll
-            for (int j = 0; j < NJ; j++) bf[j] = cnt[wave][lane + 64 * j];
+            for (int j = 0; j < NJ; j++) bf[j] = cnt[wave][cslot(lane + 64 * j)];
 #pragma unroll
-            for (int k = 0; k < KPL; k++) at[k] = base + 64 * k + lane < end ? atomicAdd(&cnt[wave][digit_of(key[k])], 1u) : 0u;
+            for (int k = 0; k < KPL; k++) at[k] = base + 64 * k + lane < end ? atomicAdd(&cnt[wave][cslot(digit_of(key[k]))], 1u) : 0u;
             u32 total = 0;
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
-                const u32 lcj = cnt[wave][lane + 64 * j] - bf[j];
+                const u32 lcj = cnt[wave][cslot(lane + 64 * j)] - bf[j];
                 const u32 inc = wave_incl_scan_dpp(lcj);
-                D[lane + 64 * j] = total + inc - lcj - bf[j];
+                D[cslot(lane + 64 * j)] = total + inc - lcj - bf[j];
                 total += (u32)__builtin_amdgcn_readlane((int)inc, 63);
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < KPL; k++) {
                 if (base + 64 * k + lane < end) {
-                    const u32 slot = at[k] + D[digit_of(key[k])];
+                    const u32 slot = at[k] + D[cslot(digit_of(key[k]))];
                     K[slot] = key_of(key[k], base + 64 * k + lane);
                     A[slot] = at[k];
-                    if (NNB > 0) atomicAdd(&cnt2[per_magic ? __umulhi(at[k] >> 6, per_magic) : at[k] >> 6][next_digit_of(key[k])], 1u);
+                    if (NNB > 0) atomicAdd(&cnt2[per_magic ? __umulhi(at[k] >> 6, per_magic) : at[k] >> 6][cslot(next_digit_of(key[k]))], 1u);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -197,12 +208,12 @@ __device__ __forceinline__ void rank_pass(const u8 *__restrict__ s, const u32 *_
         const u64 m = match_digit<NB>(d, actm);
         const u32 rank = __popcll(m & lanemask_lt()), count = __popcll(m);
         u32 off = 0;
-        if (act) off = cnt[wave][d];
+        if (act) off = cnt[wave][cslot(d)];
         __builtin_amdgcn_wave_barrier();
         if (act) {
             dst[off + rank] = key_of(key, i);
-            if (rank == count - 1) cnt[wave][d] = off + count;
-            if (NNB > 0) atomicAdd(&cnt2[per_magic ? __umulhi((off + rank) >> 6, per_magic) : (off + rank) >> 6][next_digit_of(key)], 1u);
+            if (rank == count - 1) cnt[wave][cslot(d)] = off + count;
+            if (NNB > 0) atomicAdd(&cnt2[per_magic ? __umulhi((off + rank) >> 6, per_magic) : (off + rank) >> 6][cslot(next_digit_of(key))], 1u);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ st
 #pragma unroll
                 for (int k = 0; k < CK; k++) { v[k] = vn[k]; vn[k] = gld_u32_unaligned(s, min(i0 + 64 * CK + 64 * k, end - 1)); }
 #pragma unroll
-                for (int k = 0; k < CK; k++) if (i0 + 64 * k < end) atomicAdd(&cnt[wave][sort_hash(v[k]) & ((1u << SORT_B1) - 1)], 1u);
+                for (int k = 0; k < CK; k++) if (i0 + 64 * k < end) atomicAdd(&cnt[wave][cslot(sort_hash(v[k]) & ((1u << SORT_B1) - 1))], 1u);
             }
         }
     }
