@@ -192,6 +192,16 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
     const u32 nwv = (u32)nsl * M5W;
     const u32 gpw = (ngroups + nwv - 1) / nwv;
     const u32 g_begin = (slice * M5W + wave) * gpw, g_end = min(ngroups, g_begin + gpw);
+#if MTS_M5_NT_KEYS
+    auto slot_rel = [&](int idx) -> u32 { return __builtin_nontemporal_load(&sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1]) & REL_MASK; };      // (read once: keep them out of the way of the window and the table lines in L2)
+#else
+    auto slot_rel = [&](int idx) -> u32 { return sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1] & REL_MASK; };
+#endif
+    // A wave walks ~8 groups; its start was four dependent round trips to memory (keys of the history, its bytes, keys of the first
+    // group, its bytes) during which its share of the CU did nothing.  The four key loads go out before anything else (the budget
+    // masks, the barrier and the empty tables are made while they fly), the three loads of bytes together behind them.
+    const int i_first = (int)g_begin * 64 + lane;
+    const u32 r_ha = slot_rel(i_first - 128), r_hb = slot_rel(i_first - 64), r_0 = slot_rel(i_first), r_1 = slot_rel(i_first + 64);
     for (int k = threadIdx.x; k <= 128; k += M5W * 64) {
         uint4 v;
         v.w = k >= 32 ? 0xffffffffu : k ? 0xffffffffu << (32 - k) : 0u;
@@ -290,32 +300,24 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
         const u32 b8 = alignbyte(w.w, w.z, r), b12 = alignbyte(0u, w.w, r);
         x = (u64)__builtin_amdgcn_alignbit(b8, hi, 24) | ((u64)(__builtin_amdgcn_alignbit(b12, b8, 24) & 0xffffu) << 32);      // bytes 7..10, 11..12
     };
-#if MTS_M5_NT_KEYS
-    auto slot_rel = [&](int idx) -> u32 { return __builtin_nontemporal_load(&sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1]) & REL_MASK; };      // (read once: keep them out of the way of the window and the table lines in L2)
-#else
-    auto slot_rel = [&](int idx) -> u32 { return sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1] & REL_MASK; };
-#endif
-    const int i_first = (int)g_begin * 64 + lane;
+    // pipeline: (rc, lo, hi) of the group about to be walked, rc of the one after
+    u32 rc_c = r_0, rc_n = r_1;
+    u32 lo_c, hi_c;
+    u64 x_c;
     {
         u32 kk[M5_LEVELS], nb;
         u64 vmm;
-        const u32 ra = slot_rel(i_first - 128), rb = slot_rel(i_first - 64);
+        const u32 ra = r_ha, rb = r_hb;
         u32 la, ha, lb, hb;
         u64 xa, xb;
         load16(ra, la, ha, xa);
         load16(rb, lb, hb, xb);
+        load16(rc_c, lo_c, hi_c, x_c);
+        *sink = 0;                                                 // (a store behind the loads, as at the end of every iteration)
         commit(i_first - 128, ra, la, ha, xa, kk, nb, vmm);
         __builtin_amdgcn_wave_barrier();
         commit(i_first - 64, rb, lb, hb, xb, kk, nb, vmm);
     }
-    // pipeline: (rc, lo, hi) of the group about to be walked, rc of the one after
-    // (in the order of an iteration: the group's bytes, the keys of the next, a store)
-    u32 rc_c = slot_rel(i_first);
-    u32 lo_c, hi_c;
-    u64 x_c;
-    load16(rc_c, lo_c, hi_c, x_c);
-    u32 rc_n = slot_rel(i_first + 64);
-    *sink = 0;
     for (u32 g = g_begin; g < g_end; g++) {
         const u32 i0 = g * 64, i = i0 + lane;
         u32 key[M5_LEVELS], nbv;
