@@ -347,11 +347,9 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
         const u32 look = n - p_abs;
         const u32 maxlen = look < (u32)MAX_MATCH ? look : (u32)MAX_MATCH;
         const u32 nice = (u32)cfg.nice < look ? (u32)cfg.nice : look;
-        // window offsets a candidate must lie above: the head of the chain, the others.  A lane whose walk has ended (a candidate
-        // out of range, nice_match reached) has both at INT_MAX: the state the later walks ask for lives in registers the rounds
-        // read anyway, and is written where the rare thing happens
-        int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
-        int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
+        // window offsets a candidate must lie above: the head of the chain, the others
+        const int lim1 = (int)(p_abs > (u32)MAX_DIST + 1 ? p_abs - MAX_DIST - 1 : 0) - (int)td.w;
+        const int limn = (int)(p_abs > (u32)MAX_DIST ? p_abs - MAX_DIST : 0) - (int)td.w;
         // the 128 slots before this lane's own are ring positions lo .. lo + 127 (mod 256); candidate j
         // (1 = newest) is bit 128 - j of the masks.  V = the candidates inside this lane's chain budget.
         const u32 lo = (i + 128) & (M5_RING - 1), w0 = lo >> 5, sh = lo & 31, lo8 = lo << 3;
@@ -385,8 +383,12 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
         asm volatile("" : "+v"(best), "+v"(bdist));          // (two registers from here on: as constants they are made again on every path that does not change them)
         auto walks = [&](auto near_end) __attribute__((always_inline)) {
         constexpr bool NEAR_END = decltype(near_end)::value;
-        auto stopped = [&]() -> bool { return limn == 0x7fffffff; };
-        auto set_stop = [&]() { lim1 = 0x7fffffff; limn = 0x7fffffff; };
+        // a lane whose walk has ended (nice_match reached) holds a match of >= 3 bytes: every later pick of it is one of the A masks,
+        // and those are emptied where the walk ends -- nothing asks "has it ended?" afterwards
+        auto set_stop = [&]() {
+#pragma unroll
+            for (int w = 0; w < 4; w++) { A4[w] = 0; A5[w] = 0; A6[w] = 0; A7[w] = 0; }
+        };
         // one candidate: scored against this lane's string; a longer match than the one held is taken and `narrow()` leaves the
         // candidates that can still beat it; `finish()` ends the lane's walk (nice_match reached).  Everything a candidate can do
         // to the walk's state happens in the branch where it is found out: nothing is handed to the code behind through a value
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
             }
         };
         // candidates of word w restricted to `part`, newest first
-        auto walk = [&](const u32 tb, const u32 m0, const u32 m1, const u32 m2, const u32 m3, const u32 m4, const u32 part, const bool head) __attribute__((always_inline)) {
+        auto walk = [&](const u32 tb, const u32 &m0, const u32 &m1, const u32 &m2, const u32 &m3, const u32 &m4, const u32 part, const bool head) __attribute__((always_inline)) {      // (the masks by reference: a walk that ends empties them)
             // (the empty asm statements keep the compiler from turning the select chain into a table in scratch memory)
             auto pick = [&]() -> u32 {
                 u32 r = best >= 3 ? m1 : m0;
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
                 asm volatile("" : "+v"(r));
                 return best >= 6 ? m4 : r;
             };
-            u32 el = head ? m0 & part : stopped() ? 0 : pick() & part;      // (the head's walk is the first: nothing is held yet)
+            u32 el = head ? m0 & part : pick() & part;             // (the head's walk is the first: nothing is held yet)
             if (head) {
                 // The head of the chain (the slot before this lane's own: bit 31 of the newest word) is every lane's first candidate,
                 // and the only one that may be MAX_DIST away (zlib checks the head against MAX_DIST, the others against the limit
@@ -507,13 +509,12 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
                 return best >= 6 ? A7[w] : r;
             };
             // (the three words' first picks share their four comparisons: the lane masks are kept and the selects take them as they are)
-            const u64 stm = ballot64(limn == 0x7fffffff);          // lanes whose walk has ended
-            const u64 c3 = ballot64(best >= 3), c4 = ballot64(best >= 4), c5 = ballot64(best >= 5), c6 = ballot64(best >= 6) | stm;
+            const u64 c3 = ballot64(best >= 3), c4 = ballot64(best >= 4), c5 = ballot64(best >= 5), c6 = ballot64(best >= 6);
             auto pick0 = [&](const int w) __attribute__((always_inline)) -> u32 {
                 u32 r = sel64(c3, A4[w], V[w]);
                 r = sel64(c4, A5[w], r);
                 r = sel64(c5, A6[w], r);
-                return sel64(c6, sel64(stm, 0u, A7[w]), r);
+                return sel64(c6, A7[w], r);
             };
             u32 f2 = pick0(2), f1 = pick0(1), f0 = pick0(0);
             while (any64((f2 | f1 | f0) != 0)) {
