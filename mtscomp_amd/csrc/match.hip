@@ -116,13 +116,14 @@ __device__ __forceinline__ constexpr int m5_slot(int d) { return d ? d + 1 : 0; 
 constexpr int M5_VLUT = 129 * 16;                    // the budget masks (one table per workgroup, behind the waves' areas)
 constexpr int MATCH5_LDS = MTS_M5_LDS_PAD ? MTS_M5_LDS_PAD : (M5W * M5_WAVE_LDS + M5_VLUT > 56 * 1024 ? M5W * M5_WAVE_LDS + M5_VLUT : 56 * 1024);      // (MTS_M5_LDS_PAD: occupancy experiments)
 
-// 3 + the equal bytes among bytes 3..6 (x1 = their xor): v_ffbl_b32 gives -1 for 0, and 3 + (0xffffffff >> 3) is still more than 7
-__device__ __forceinline__ u32 m5_len37(u32 x1)
+// the equal bytes among bytes 3..6 (x1 = their xor), 0..4: v_ffbl_b32 gives -1 for 0, and 0xffffffff >> 3 is still more than 4.
+// (k_match5 keeps match lengths as length - 3 -- what the table word stores --: one addition less per candidate)
+__device__ __forceinline__ int m5_len04(u32 x1)
 {
     u32 f;
     asm("v_ffbl_b32 %0, %1" : "=v"(f) : "v"(x1));
-    const u32 l = 3 + (f >> 3);
-    return l < 7 ? l : 7;
+    const u32 l = f >> 3;
+    return (int)(l < 4 ? l : 4);
 }
 // 5-bit keys of the prefixes (b3), (b3,b4), (b3..b5), (b3..b6) of e1 = bytes 3..6
 // (v_mul_u32_u24 by name: the compiler sees that the bits taken do not depend on the operand's top byte, drops the mask in front
@@ -379,7 +380,8 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
         // chunk's last tile): match lengths are capped by what is left and nice_match shrinks with it.  Everywhere else both are
         // constants, the cap never binds below the long compare, and nice_match (>= 16 at every level) can only be reached there:
         // the common path of a round carries neither the cap nor the test.
-        u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
+        int best = -1, qbest = -1;                                // match lengths - 3 (-1: none)
+        u32 bdist = 0, qdist = 0;
         asm volatile("" : "+v"(best), "+v"(bdist));          // (two registers from here on: as constants they are made again on every path that does not change them)
         auto walks = [&](auto near_end) __attribute__((always_inline)) {
         constexpr bool NEAR_END = decltype(near_end)::value;
@@ -396,8 +398,8 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
         auto cand = [&](const u32 o8 /* byte offset of the candidate's ring slot */, const u32 c0, const u32 c1, const u32 rel_c, auto &&narrow, auto &&finish) __attribute__((always_inline)) {
             const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
             if ((x0 & 0x1ff) == 0) {
-                u32 len = m5_len37(x1);
-                if (len == 7 && (x0 >> 9) == 0) {
+                int len = m5_len04(x1);                               // (length - 3)
+                if (len == 4 && (x0 >> 9) == 0) {
 #if MTS_M5_SX == 1
                     const u64 y = ring_x(o8) ^ ex;
                     const u32 len0 = 13;
@@ -408,25 +410,26 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
                     const u32 y = wread(rel_c + 7) ^ (u32)ex;       // bytes 7..10 (this lane's own are in registers)
                     const u32 len0 = 11;
 #endif
-                    if (y) len = 7 + ((u32)__builtin_ctzll((u64)y) >> 3);
+                    if (y) len = 4 + (int)((u32)__builtin_ctzll((u64)y) >> 3);
                     else {
                         const u32 cap = NEAR_END ? maxlen : (u32)MAX_MATCH;
-                        len = len0;
-                        while (len < cap) {
-                            const u32 x = wread(rel_c + len) ^ wread(rel_p + len);
-                            if (x) { len += (u32)__builtin_ctz(x) >> 3; break; }
-                            len += 4;
+                        u32 full = len0;                                // (bytes, in this branch)
+                        while (full < cap) {
+                            const u32 x = wread(rel_c + full) ^ wread(rel_p + full);
+                            if (x) { full += (u32)__builtin_ctz(x) >> 3; break; }
+                            full += 4;
                         }
-                        len = len < cap ? len : cap;
+                        full = full < cap ? full : cap;
+                        len = (int)full - 3;
                         // (a candidate that reaches nice_match is an improvement: a match that long already held would have ended the walk)
-                        if (!NEAR_END && len >= (u32)cfg.nice) { best = len; bdist = rel_p - rel_c; set_stop(); finish(); }
+                        if (!NEAR_END && full >= (u32)cfg.nice) { best = len; bdist = rel_p - rel_c; set_stop(); finish(); }
                     }
                 }
-                if (NEAR_END) len = len < maxlen ? len : maxlen;
+                if (NEAR_END) len = len < (int)maxlen - 3 ? len : (int)maxlen - 3;
                 if (len > best) {
                     best = len; bdist = rel_p - rel_c;
                     narrow();                                           // fewer candidates can still win now
-                    if (NEAR_END && len >= nice) { set_stop(); finish(); }
+                    if (NEAR_END && len >= (int)nice - 3) { set_stop(); finish(); }
                 }
             }
         };
@@ -434,20 +437,20 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
         auto walk = [&](const u32 tb, const u32 &m0, const u32 &m1, const u32 &m2, const u32 &m3, const u32 &m4, const u32 part, const bool head) __attribute__((always_inline)) {      // (the masks by reference: a walk that ends empties them)
             // (the empty asm statements keep the compiler from turning the select chain into a table in scratch memory)
             auto pick = [&]() -> u32 {
-                u32 r = best >= 3 ? m1 : m0;
+                u32 r = best >= 0 ? m1 : m0;
                 asm volatile("" : "+v"(r));
-                r = best >= 4 ? m2 : r;
+                r = best >= 1 ? m2 : r;
                 asm volatile("" : "+v"(r));
-                r = best >= 5 ? m3 : r;
+                r = best >= 2 ? m3 : r;
                 asm volatile("" : "+v"(r));
-                return best >= 6 ? m4 : r;
+                return best >= 3 ? m4 : r;
             };
             auto pick_longer = [&]() -> u32 {                      // the same once a match is held (best >= 3)
-                u32 r = best >= 4 ? m2 : m1;
+                u32 r = best >= 1 ? m2 : m1;
                 asm volatile("" : "+v"(r));
-                r = best >= 5 ? m3 : r;
+                r = best >= 2 ? m3 : r;
                 asm volatile("" : "+v"(r));
-                return best >= 6 ? m4 : r;
+                return best >= 3 ? m4 : r;
             };
             u32 el = head ? m0 & part : pick() & part;             // (the head's walk is the first: nothing is held yet)
             if (head) {
@@ -502,14 +505,14 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
             // word by word the wave ran as many rounds as the busiest lane of EACH word needed; together it is the busiest lane
             // over all three.
             auto pickw = [&](const int w) __attribute__((always_inline)) -> u32 {
-                u32 r = best >= 4 ? A5[w] : A4[w];                   // (after an improvement: best >= 3)
+                u32 r = best >= 1 ? A5[w] : A4[w];                   // (after an improvement: a match is held)
                 asm volatile("" : "+v"(r));
-                r = best >= 5 ? A6[w] : r;
+                r = best >= 2 ? A6[w] : r;
                 asm volatile("" : "+v"(r));
-                return best >= 6 ? A7[w] : r;
+                return best >= 3 ? A7[w] : r;
             };
             // (the three words' first picks share their four comparisons: the lane masks are kept and the selects take them as they are)
-            const u64 c3 = ballot64(best >= 3), c4 = ballot64(best >= 4), c5 = ballot64(best >= 5), c6 = ballot64(best >= 6);
+            const u64 c3 = ballot64(best >= 0), c4 = ballot64(best >= 1), c5 = ballot64(best >= 2), c6 = ballot64(best >= 3);
             auto pick0 = [&](const int w) __attribute__((always_inline)) -> u32 {
                 u32 r = sel64(c3, A4[w], V[w]);
                 r = sel64(c4, A5[w], r);
@@ -554,9 +557,9 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
             // allow for the path with the fewest operations behind a load: with the store under a branch that is none, the wait
             // became vmcnt(0), and every wave sat out the round trip of its own 64 scattered stores before it entered the next
             // group (a quarter of its time: tools/m5_stats.py with -DMTS_M5_STATS=2).  One store on every path: vmcnt(1).
-            const u32 f = te_pack(best, bdist), q = te_pack(qbest, qdist);
+            const u32 f = bdist | ((u32)(best > 0 ? best : 0) << 15), q = qdist | ((u32)(qbest > 0 ? qbest : 0) << 15);      // te_pack() of lengths - 3
             u32 e = f;
-            if (q != f) e |= qbest > (u32)cfg.good ? TE_QSIDE : TE_QNONE;
+            if (q != f) e |= qbest > (int)cfg.good - 3 ? TE_QSIDE : TE_QNONE;
             if (own && ((e & TE_QSIDE) || all_quarters)) TQ[p_abs] = q;      // (rare; before the table word: the waits allow ONE younger operation)
             u32 *dst = own ? T + p_abs : sink;
             *dst = e;
