@@ -164,8 +164,8 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
     auto wread = [&](u32 addr) -> u32 { return gld_u32_unaligned(gwin, addr); };
     u64 *SE = (u64 *)(smem + wave * (M5_RING * 8));
     u64 *SX = (u64 *)(smem + M5W * M5_RING * 8 + wave * (M5_RING * 8));      // bytes 7..12 of every slot: matches up to 13 never leave the LDS
-    u32 *TB = (u32 *)(smem + M5W * M5_RING * (8 + M5_SX_BYTES) + wave * (M5_SLOTS * M5_TABLE));      // [level][row][8 words + 1]
-    const uint4 *VLUT = (const uint4 *)(smem + M5W * M5_WAVE_LDS);      // [0 .. 128]: the newest n of 128 bits (one table per workgroup)
+    u32 *TB = (u32 *)(smem + M5W * M5_RING * (8 + M5_SX_BYTES) + M5_VLUT + wave * (M5_SLOTS * M5_TABLE));      // [level][row][8 words + 1]
+    const uint4 *VLUT = (const uint4 *)(smem + M5W * M5_RING * (8 + M5_SX_BYTES));      // [0 .. 128]: the newest n of 128 bits (one table per workgroup; behind the rings, where its offset fits a ds instruction's)
     typedef __attribute__((address_space(3))) const u64 *lds_u64p;
     const u32 se_base = (u32)(size_t)(__attribute__((address_space(3))) u8 *)(u8 *)SE;      // (byte address in LDS)
     if (se_base & (M5_RING * 8 - 1)) __builtin_trap();            // (the kernel has no static LDS: the dynamic area starts at 0)
@@ -198,6 +198,11 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
 #else
     auto slot_rel = [&](int idx) -> u32 { return sk[idx < 0 ? 0 : (u32)idx < wlen ? (u32)idx : wlen - 1] & REL_MASK; };
 #endif
+#if MTS_M5_NT_KEYS
+    auto slot_fwd = [&](u32 idx) -> u32 { return __builtin_nontemporal_load(&sk[min(idx, wlen - 1)]) & REL_MASK; };      // (an index that cannot be negative: one v_min)
+#else
+    auto slot_fwd = [&](u32 idx) -> u32 { return sk[min(idx, wlen - 1)] & REL_MASK; };
+#endif
     // A wave walks ~8 groups; its start was four dependent round trips to memory (keys of the history, its bytes, keys of the first
     // group, its bytes) during which its share of the CU did nothing.  The four key loads go out before anything else (the budget
     // masks, the barrier and the empty tables are made while they fly), the three loads of bytes together behind them.
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
         v.z = k >= 64 ? 0xffffffffu : k > 32 ? 0xffffffffu << (64 - k) : 0u;
         v.y = k >= 96 ? 0xffffffffu : k > 64 ? 0xffffffffu << (96 - k) : 0u;
         v.x = k >= 128 ? 0xffffffffu : k > 96 ? 0xffffffffu << (128 - k) : 0u;
-        ((uint4 *)(smem + M5W * M5_WAVE_LDS))[k] = v;
+        ((uint4 *)(smem + M5W * M5_RING * (8 + M5_SX_BYTES)))[k] = v;
     }
     __syncthreads();                                               // (the only barrier: every wave is still here)
     if (g_begin >= g_end) return;
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
         // next group's words, and the position of the one after
         rc_c = rc_n;
         load16(rc_c, lo_c, hi_c, x_c);
-        rc_n = slot_rel((int)i + 128);
+        rc_n = slot_fwd(i + 128);
         const u32 e0 = (u32)e, e1 = (u32)(e >> 32);
         const u32 rel_p = e0 & REL_MASK;
         const bool own = i < wlen && rel_p >= halo;
@@ -361,8 +366,10 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
             V[0] = v.x; V[1] = v.y; V[2] = v.z; V[3] = v.w;
         }
         auto rowmask = [&](const int d, const u32 (&in)[4], u32 (&out)[4]) __attribute__((always_inline)) {
-            const u32 *row = TB + m5_slot(d) * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS;
-            const u32 W0 = row[w0 & 7], W1 = row[(w0 + 1) & 7], W2 = row[(w0 + 2) & 7], W3 = row[(w0 + 3) & 7], W4 = row[(w0 + 4) & 7];
+            const u8 *row = (const u8 *)(TB + m5_slot(d) * (M5_TABLE / 4) + key[d] * M5_ROW_WORDS);
+            // (byte offsets ((w0 + k) << 2) & 28: an add-shift and an AND per word; as (w0 + k) & 7 first it was an add, an AND and a shift)
+            auto word = [&](const u32 k) -> u32 { return *(const u32 *)(row + (((w0 + k) << 2) & 28u)); };
+            const u32 W0 = word(0), W1 = word(1), W2 = word(2), W3 = word(3), W4 = word(4);
             out[0] = in[0] & __builtin_amdgcn_alignbit(W1, W0, sh);
             out[1] = in[1] & __builtin_amdgcn_alignbit(W2, W1, sh);
             out[2] = in[2] & __builtin_amdgcn_alignbit(W3, W2, sh);
