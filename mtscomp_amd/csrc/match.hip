@@ -135,6 +135,13 @@ __device__ __forceinline__ u32 m5_mul24(u32 x, u32 c)
     return r;
 }
 __device__ __forceinline__ u32 m5_hash24(u32 x) { return (m5_mul24(x, 0x9E3779u) >> 19) & 31; }
+// k - 8 z in one instruction (the ring offset of the candidate at bit 31 - z of a mask word whose bit 31 is at offset k)
+__device__ __forceinline__ u32 m5_off8(u32 z, u32 k)
+{
+    u32 r;
+    asm("v_mad_i32_i24 %0, %1, -8, %2" : "=v"(r) : "v"(z), "v"(k));
+    return r;
+}
 __device__ __forceinline__ void m5_keys(u32 e1, u32 (&k)[M5_LEVELS])
 {
     k[0] = (__umul24(e1 & 0xff, 0x9E3779u) >> 18) & 63;
@@ -482,10 +489,11 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
                 st_r1++; st_s1 += (u32)__popcll(ballot64(el != 0));
 #endif
                 if (el) {
-                    const u32 b = 31 - __builtin_clz(el);
-                    el &= ~(1u << b);
-                    const u32 t = tb + b;
-                    const u32 o8 = lo8 + (t << 3);
+                    // the newest candidate left: bit 31 - z; out of the mask by a shifted constant, its ring offset by one multiply-add
+                    const u32 z = (u32)__builtin_clz(el);
+                    el &= ~(0x80000000u >> z);
+                    const u32 t = tb + 31 - z;
+                    const u32 o8 = m5_off8(z, lo8 + ((tb + 31) << 3));
                     const u64 c = ring_e(o8);
                     const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                     const u32 rel_c = c0 & REL_MASK;
@@ -527,6 +535,8 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
                 return sel64(c6, A7[w], r);
             };
             u32 f2 = pick0(2), f1 = pick0(1), f0 = pick0(0);
+            u32 ko2 = lo8 + ((64 + 31) << 3), ko1 = lo8 + ((32 + 31) << 3), ko0 = lo8 + (31 << 3);
+            asm volatile("" : "+v"(ko2), "+v"(ko1), "+v"(ko0));      // (three registers for the loop: taken apart again they are an addition per round)
             while (any64((f2 | f1 | f0) != 0)) {
 #if MTS_M5_STATS
                 st_r2++; st_s2 += (u32)__popcll(ballot64((f2 | f1 | f0) != 0));
@@ -534,9 +544,9 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
                 if (f2 | f1 | f0) {
                     const bool t2 = f2 != 0, t1 = f1 != 0;
                     const u32 cur = t2 ? f2 : t1 ? f1 : f0;
-                    const u32 tb = t2 ? 64u : t1 ? 32u : 0u;
-                    const u32 b = 31 - __builtin_clz(cur);
-                    const u32 o8 = lo8 + ((tb + b) << 3);
+                    const u32 tbo = t2 ? ko2 : t1 ? ko1 : ko0;                   // ring offset of bit 31 of the word taken
+                    const u32 z = (u32)__builtin_clz(cur);
+                    const u32 o8 = m5_off8(z, tbo);
                     const u64 c = ring_e(o8);
                     const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                     const u32 rel_c = c0 & REL_MASK;
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
                     const bool in_range = (int)rel_c > limn;
                     u32 rm = in_range ? 0xffffffffu : 0u;
                     asm volatile("" : "+v"(rm));                      // (a value: the compiler would make the branch of it again)
-                    const u32 ncur = cur & ~(1u << b);
+                    const u32 ncur = cur & ~(0x80000000u >> z);
                     f2 = (t2 ? ncur : f2) & rm;
                     f1 = ((!t2 && t1) ? ncur : f1) & rm;
                     f0 = ((!t2 && !t1) ? ncur : f0) & rm;
