@@ -118,12 +118,12 @@ constexpr int MATCH5_LDS = MTS_M5_LDS_PAD ? MTS_M5_LDS_PAD : (M5W * M5_WAVE_LDS 
 
 // the equal bytes among bytes 3..6 (x1 = their xor), 0..4: v_ffbl_b32 gives -1 for 0, and 0xffffffff >> 3 is still more than 4.
 // (k_match5 keeps match lengths as length - 3 -- what the table word stores --: one addition less per candidate)
-__device__ __forceinline__ int m5_len04(u32 x1)
+__device__ __forceinline__ int m5_len04(u32 x1, bool &all4)
 {
     u32 f;
     asm("v_ffbl_b32 %0, %1" : "=v"(f) : "v"(x1));
-    const u32 l = f >> 3;
-    return (int)(l < 4 ? l : 4);
+    all4 = f > 31;                                       // (no bit set: bytes 3..6 are equal; the caller sets 4 itself, so no v_min here)
+    return (int)(f >> 3);
 }
 // 5-bit keys of the prefixes (b3), (b3,b4), (b3..b5), (b3..b6) of e1 = bytes 3..6
 // (v_mul_u32_u24 by name: the compiler sees that the bits taken do not depend on the operand's top byte, drops the mask in front
@@ -135,6 +135,13 @@ __device__ __forceinline__ u32 m5_mul24(u32 x, u32 c)
     return r;
 }
 __device__ __forceinline__ u32 m5_hash24(u32 x) { return (m5_mul24(x, 0x9E3779u) >> 19) & 31; }
+// leading zeros, -1 for 0 (v_ffbh_u32 by name: __builtin_clz(0) is undefined)
+__device__ __forceinline__ u32 m5_ffbh(u32 x)
+{
+    u32 r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 // k - 8 z in one instruction (the ring offset of the candidate at bit 31 - z of a mask word whose bit 31 is at offset k)
 __device__ __forceinline__ u32 m5_off8(u32 z, u32 k)
 {
@@ -412,8 +419,10 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
         auto cand = [&](const u32 o8 /* byte offset of the candidate's ring slot */, const u32 c0, const u32 c1, const u32 rel_c, auto &&narrow, auto &&finish) __attribute__((always_inline)) {
             const u32 x0 = (c0 ^ e0) >> REL_BITS, x1 = c1 ^ e1;
             if ((x0 & 0x1ff) == 0) {
-                int len = m5_len04(x1);                               // (length - 3)
-                if (len == 4 && (x0 >> 9) == 0) {
+                bool all4;
+                int len = m5_len04(x1, all4);                         // (length - 3)
+                if (all4) len = 4;
+                if (all4 && (x0 >> 9) == 0) {
 #if MTS_M5_SX == 1
                     const u64 y = ring_x(o8) ^ ex;
                     const u32 len0 = 13;
@@ -488,20 +497,25 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
 #if MTS_M5_STATS
                 st_r1++; st_s1 += (u32)__popcll(ballot64(el != 0));
 #endif
-                if (el) {
-                    // the newest candidate left: bit 31 - z; out of the mask by a shifted constant, its ring offset by one multiply-add
-                    const u32 z = (u32)__builtin_clz(el);
-                    el &= ~(0x80000000u >> z);
+                {
+                    // The newest candidate left: bit 31 - z; out of the mask by a shifted constant, its ring offset by one multiply-add.
+                    // EVERY lane goes through this part, also one without candidates (z = -1: it reads some slot of the ring and is
+                    // masked out with the lanes whose candidate is out of range): under `if (el)` the lanes that skip it would need
+                    // their zero made and copied at the join, two moves per round, for instructions the wave issues anyway.
+                    const bool had = el != 0;
+                    const u32 z = m5_ffbh(el);
                     const u32 t = tb + 31 - z;
                     const u32 o8 = m5_off8(z, lo8 + ((tb + 31) << 3));
                     const u64 c = ring_e(o8);
                     const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
                     const u32 rel_c = c0 & REL_MASK;
-                    // (what ends a lane's walk -- a candidate out of range, a match of nice_match bytes -- is rare: the lane's mask is
-                    //  cleared where it happens, not looked at in every round)
-                    if ((int)rel_c > ((!head && t == 127) ? lim1 : limn)) cand(o8, c0, c1, rel_c, [&]() { el &= pick_longer(); }, [&]() { el = 0; });
-                    else el = 0;                        // out of range: so is everything older (a later walk of the lane finds that out with its
-                                                        // first candidate: rare, and a limit changed on this path is copies in every round)
+                    // out of range: so is everything older -- the lane's mask goes by an AND, not in an else branch whose zero every path would
+                    // have to carry (a later walk of the lane finds the same out with its first candidate: rare)
+                    const bool in_range = had && (int)rel_c > ((!head && t == 127) ? lim1 : limn);
+                    u32 rm = in_range ? 0xffffffffu : 0u;
+                    asm volatile("" : "+v"(rm));                      // (a value: the compiler would make the branch of it again)
+                    el = el & ~(0x80000000u >> (z & 31)) & rm;
+                    if (in_range) cand(o8, c0, c1, rel_c, [&]() { el &= pick_longer(); }, [&]() { el = 0; });
                 }
             }
         };
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
 #if MTS_M5_STATS
                 st_r2++; st_s2 += (u32)__popcll(ballot64((f2 | f1 | f0) != 0));
 #endif
-                if (f2 | f1 | f0) {
+                if (f2 | f1 | f0) {                                  // (here the branch is cheaper than masking the lanes without candidates: measured in instructions)
                     const bool t2 = f2 != 0, t1 = f1 != 0;
                     const u32 cur = t2 ? f2 : t1 ? f1 : f0;
                     const u32 tbo = t2 ? ko2 : t1 ? ko1 : ko0;                   // ring offset of bit 31 of the word taken
