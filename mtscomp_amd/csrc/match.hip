@@ -590,8 +590,9 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
             // group (a quarter of its time: tools/m5_stats.py with -DMTS_M5_STATS=2).  One store on every path: vmcnt(1).
             const u32 f = bdist | ((u32)(best > 0 ? best : 0) << 15), q = qdist | ((u32)(qbest > 0 ? qbest : 0) << 15);      // te_pack() of lengths - 3
             u32 e = f;
-            if (q != f) e |= qbest > (int)cfg.good - 3 ? TE_QSIDE : TE_QNONE;
-            if (own && ((e & TE_QSIDE) || all_quarters)) TQ[p_abs] = q;      // (rare; before the table word: the waits allow ONE younger operation)
+            const bool differ = q != f, side = differ && qbest > (int)cfg.good - 3;      // (the side table's word is wanted: asked of the comparisons, not of the flag in e)
+            if (differ) e |= side ? TE_QSIDE : TE_QNONE;
+            if (own && (side || all_quarters)) TQ[p_abs] = q;      // (rare; before the table word: the waits allow ONE younger operation)
             u32 *dst = own ? T + p_abs : sink;
             *dst = e;
         }
