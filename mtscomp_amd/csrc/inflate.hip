@@ -725,12 +725,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
     __shared__ u32 surv[SCAN_SURV_CAP];
     __shared__ u32 wsum[16];
     __shared__ u32 nsurv;
-    __shared__ u16 ktab[4096];                                     // Kraft sum (in 1/128) of four 3-bit code lengths
+    __shared__ u8 ktab[4096];                                      // Kraft sum (in 1/128) of four 3-bit code lengths, saturated at 255 (anything over 128 is
+                                                                   // no code: a byte per entry is indexed by the field itself, two bytes needed a shift more per look-up)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < 4096; i += SCAN_THREADS) {
         u32 k = 0;
         for (int f = 0; f < 4; f++) k += (0x80u >> ((i >> (3 * f)) & 7)) & 0x7f;
-        ktab[i] = (u16)k;
+        ktab[i] = (u8)(k < 255 ? k : 255);
     }
     __shared__ u32 gbase_s;
     // a workgroup takes SCAN_SPANS consecutive spans (the Kraft table above is made once for them)
