@@ -622,7 +622,7 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
 constexpr int M6_RING = 1024;
 constexpr int M6_ROW_WORDS = M6_RING / 32 + 1;
 constexpr int M6_TABLE = M5_ROWS * M6_ROW_WORDS * 4;
-constexpr int MATCH6_LDS = 2 * M6_RING * 8 + M5_SLOTS * M6_TABLE;       // 37504 per workgroup
+constexpr int MATCH6_LDS = 2 * M6_RING * 8 + M5_SLOTS * M6_TABLE + M5_VLUT;       // 39568 per workgroup (rings, tables, the table of budget masks)
 
 __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, int nsl,
                                                           const u32 *__restrict__ sorted, u32 *__restrict__ tables, u32 *__restrict__ quarter, LevelCfg cfg,
@@ -656,6 +656,15 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
     const u32 gb_begin = slice * gpb, gb_end = min(ngroups, gb_begin + gpb);
     if (gb_begin >= gb_end) return;                                // (the whole workgroup)
     for (int k = threadIdx.x; k < M5_SLOTS * M6_TABLE / 4; k += M5_WAVES * 64) TB[k] = 0;
+    const uint4 *VLUT = (const uint4 *)(smem + 2 * M6_RING * 8 + M5_SLOTS * M6_TABLE);      // [0 .. 128]: the newest n of 128 bits (as in k_match5)
+    for (int k = threadIdx.x; k <= 128; k += M5_WAVES * 64) {
+        uint4 v;
+        v.w = k >= 32 ? 0xffffffffu : k ? 0xffffffffu << (32 - k) : 0u;
+        v.z = k >= 64 ? 0xffffffffu : k > 32 ? 0xffffffffu << (64 - k) : 0u;
+        v.y = k >= 96 ? 0xffffffffu : k > 64 ? 0xffffffffu << (96 - k) : 0u;
+        v.x = k >= 128 ? 0xffffffffu : k > 96 ? 0xffffffffu << (128 - k) : 0u;
+        ((uint4 *)(smem + 2 * M6_RING * 8 + M5_SLOTS * M6_TABLE))[k] = v;
+    }
     u32 inv[6];                                                    // lane r builds row r of the first table: bit j of r clear -> all ones
 #pragma unroll
     for (int j = 0; j < 6; j++) inv[j] = ((lane >> j) & 1) ? 0u : 0xffffffffu;
@@ -796,14 +805,14 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
                 // candidate jj (1 = newest) of this lane is slot i - jbase - jj: bit 128 - jj of the 128 ring positions from lo
                 const u32 lo = (u32)((int)i - (int)jbase - 128) & (M6_RING - 1), w0 = lo >> 5, sh = lo & 31;
                 u32 V[4], A4[4], A5[4], A6[4], A7[4];                 // V = inside the budget; A_d = V & "first d bytes may match"
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int s = 32 * k + (int)nbl - 96;           // candidates of word k: bits >= 32 - s
-                    V[k] = s <= 0 ? 0u : s >= 32 ? 0xffffffffu : 0xffffffffu << (32 - s);
+                {   // the newest nbl of the 128 bits: one 16-byte read of the table of the 129 masks
+                    const uint4 v = VLUT[nbl];
+                    V[0] = v.x; V[1] = v.y; V[2] = v.z; V[3] = v.w;
                 }
                 auto rowmask = [&](const int d, const u32 (&in)[4], u32 (&out)[4]) __attribute__((always_inline)) {
-                    const u32 *row = TB + m5_slot(d) * (M6_TABLE / 4) + key[d] * M6_ROW_WORDS;
-                    const u32 W0 = row[w0], W1 = row[(w0 + 1) & 31], W2 = row[(w0 + 2) & 31], W3 = row[(w0 + 3) & 31], W4 = row[(w0 + 4) & 31];
+                    const u8 *row = (const u8 *)(TB + m5_slot(d) * (M6_TABLE / 4) + key[d] * M6_ROW_WORDS);
+                    auto word = [&](const u32 k) -> u32 { return *(const u32 *)(row + (((w0 + k) << 2) & 124u)); };      // (byte offsets: see k_match5)
+                    const u32 W0 = word(0), W1 = word(1), W2 = word(2), W3 = word(3), W4 = word(4);
                     out[0] = in[0] & __builtin_amdgcn_alignbit(W1, W0, sh);
                     out[1] = in[1] & __builtin_amdgcn_alignbit(W2, W1, sh);
                     out[2] = in[2] & __builtin_amdgcn_alignbit(W3, W2, sh);
