@@ -841,13 +841,13 @@ __global__ __launch_bounds__(M5_WAVES * 64) void k_match6(const u8 *__restrict__
                             const bool t3 = f3 != 0, t2 = f2 != 0, t1 = f1 != 0;
                             const u32 cur = t3 ? f3 : t2 ? f2 : t1 ? f1 : f0;
                             const u32 tb = t3 ? 96u : t2 ? 64u : t1 ? 32u : 0u;
-                            const u32 b = 31 - __builtin_clz(cur);
-                            const u32 clr = ~(1u << b);
-                            f3 = t3 ? f3 & clr : f3;
-                            f2 = (!t3 && t2) ? f2 & clr : f2;
-                            f1 = (!t3 && !t2 && t1) ? f1 & clr : f1;
-                            f0 = (!t3 && !t2 && !t1) ? f0 & clr : f0;
-                            const u32 t = tb + b;
+                            const u32 z = (u32)__builtin_clz(cur);
+                            const u32 ncur = cur & ~(0x80000000u >> z);        // the word the candidate came from, without it
+                            f3 = t3 ? ncur : f3;
+                            f2 = (!t3 && t2) ? ncur : f2;
+                            f1 = (!t3 && !t2 && t1) ? ncur : f1;
+                            f0 = (!t3 && !t2 && !t1) ? ncur : f0;
+                            const u32 t = tb + 31 - z;
                             const u32 slot = (lo + t) & (M6_RING - 1);
                             const u64 c = SE[slot];
                             const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
