@@ -38,7 +38,8 @@ extern "C" {
 /* per-chunk status written by mts_decompress_chunks */
 #define MTS_CHUNK_OK 0
 #define MTS_CHUNK_CORRUPT (-1)    /* zlib.decompress would raise  -> IOError, mtscomp.py:618-621 */
-#define MTS_CHUNK_BADSIZE (-2)    /* valid stream of the wrong length -> AssertionError, mtscomp.py:628 */
+#define MTS_CHUNK_BADSIZE (-2)    /* valid stream (check value included) of the wrong length -> AssertionError, mtscomp.py:628;
+                                     a damaged stream of the wrong length is MTS_CHUNK_CORRUPT, as zlib reports it first */
 
 #define MTS_FLAG_TIME_DIFF 1
 #define MTS_FLAG_SPATIAL_DIFF 2

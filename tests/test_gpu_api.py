@@ -72,6 +72,32 @@ def test_corrupt_chunk_is_ioerror_others_readable(tmp_cfg):
     r.close()
 
 
+def test_wrong_size_chunk_gets_the_references_verdict(tmp_cfg, monkeypatch):
+    """mtscomp.py:618-628: zlib.decompress (and its data check) comes first, the size assert after it.  A chunk that inflates to
+    another size than the header says is an AssertionError when its stream is whole and an IOError when it is damaged."""
+    import zlib
+    case = CASES['ar1_8ch_3chunks']
+    meta = json.loads(case['ch_text'])
+    cb = golden_cbin(case)
+    offs = meta['chunk_offsets']
+    arr = make_input(case)
+    other = zlib.compress(zlib.decompress(cb[offs[1]:offs[2]])[:-16])            # a row short
+    damaged = other[:-2] + bytes([other[-2] ^ 0x40]) + other[-1:]                 # ... and its check value broken
+    for k, (chunk1, exc) in enumerate(((other, AssertionError), (damaged, IOError))):
+        m = dict(meta)
+        m['chunk_offsets'] = [offs[0], offs[1], offs[1] + len(chunk1), offs[1] + len(chunk1) + offs[3] - offs[2]]
+        out = tmp_cfg / ('odd%d.cbin' % k)
+        out.write_bytes(cb[:offs[1]] + chunk1 + cb[offs[2]:])
+        out.with_suffix('.ch').write_text(json.dumps(m))
+        for cache_gb in ('0', '1'):                                               # host path and device cache
+            monkeypatch.setenv('MTSCOMP_DEVICE_CACHE_GB', cache_gb)
+            r = mtscomp_amd.decompress(out)
+            assert np.array_equal(r[2000:3000], arr[2000:3000])
+            with pytest.raises(exc):
+                r[1000:1500]
+            r.close()
+
+
 @pytest.mark.parametrize('dtype', ['uint8', 'uint16', 'int8', 'int16', 'int32'])
 def test_dtypes_roundtrip(dtype, tmp_cfg):
     # tests.py:240-243: (100 x 1000) from a transposed non-contiguous array

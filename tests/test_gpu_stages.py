@@ -271,15 +271,24 @@ def test_inflate_errors():
     for b in bad:
         st, _ = hip.debug_inflate(b, len(data))
         assert st == hip.CHUNK_CORRUPT, (len(b), st)
-    # A damaged stream that still parses to its end but yields MORE bytes than the header promises cannot
-    # be adler-checked without storing the surplus: it is reported as BADSIZE (AssertionError in the host
-    # layer) where zlib.decompress reports a data-check error (IOError).  Both refuse the chunk.
     st, _ = hip.debug_inflate(z[:len(z) // 2] + bytes([z[len(z) // 2] ^ 0x55]) + z[len(z) // 2 + 1:], len(data))
     assert st != 0
+    # a VALID stream of another length is a size mismatch (the assert of mtscomp.py:628) ...
     st, _ = hip.debug_inflate(z, len(data) - 1)
     assert st == hip.CHUNK_BADSIZE
     st, _ = hip.debug_inflate(z, len(data) + 1)
     assert st == hip.CHUNK_BADSIZE
+    st, _ = hip.debug_inflate(zlib.compress(b''), len(data))
+    assert st == hip.CHUNK_BADSIZE
+    # ... a DAMAGED one that still parses to its end is zlib's data-check error (IOError, :618-621), whatever its length:
+    # its check value is looked at before its size, as zlib.decompress does
+    for other in (data + b'xyz', data[:-7], data[:5], data * 3):
+        zo = zlib.compress(other)
+        st, _ = hip.debug_inflate(zo, len(data))
+        assert st == hip.CHUNK_BADSIZE
+        for k in (1, 2, 3, 4):                                           # each byte of the check value
+            st, _ = hip.debug_inflate(zo[:-k] + bytes([zo[-k] ^ 0x10]) + zo[len(zo) - k + 1:], len(data))
+            assert st == hip.CHUNK_CORRUPT, (len(other), k)
     r = np.random.RandomState(5)
     for _ in range(60):
         b = bytearray(z)
@@ -292,8 +301,10 @@ def test_inflate_errors():
         t0 = time.perf_counter()
         st, out = hip.debug_inflate(bytes(b), len(data))
         assert time.perf_counter() - t0 < 2.0          # (a copy from before the data once left the resolver's waves waiting for tens of seconds)
-        if want is None or len(want) != len(data):
-            assert st != 0
+        if want is None:
+            assert st == hip.CHUNK_CORRUPT
+        elif len(want) != len(data):
+            assert st == hip.CHUNK_BADSIZE
         else:
             assert st == 0 and out == want
 
@@ -332,8 +343,10 @@ def test_inflate_errors_segmented_resolver(monkeypatch):
         except zlib.error:
             want = None
         st, out = hip.debug_inflate(bytes(b), len(data))
-        if want is None or len(want) != len(data):
-            assert st != 0
+        if want is None:
+            assert st == hip.CHUNK_CORRUPT
+        elif len(want) != len(data):
+            assert st == hip.CHUNK_BADSIZE
         else:
             assert st == 0 and out == want
 
