@@ -1666,8 +1666,7 @@ struct LzPlan {
     u32 g0[LZ_MAXSEG + 1];             // first group of segment k (g0[nseg] = number of groups)
     u32 b0[LZ_MAXSEG + 1];             // first output byte of segment k (b0[nseg] = output size)
 };
-constexpr u32 LZ2_BITS_OFF = 2 * LZ_RING;                // segment kernel: 16-bit cells, bits (+ pad), control words
-constexpr u32 LZ2_CTL_OFF = LZ2_BITS_OFF + LZ_RING / 8 + 16;
+constexpr u32 LZ2_CTL_OFF = 2 * LZ_RING + 16;            // segment kernel: 16-bit cells (+ pad), control words
 constexpr int LZ2_LDS = LZ2_CTL_OFF + 256;
 
 // Output offset of every 64-token group, as a two-level scan:
@@ -1991,25 +1990,33 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
 }
 
 // ---- segment resolver (16-bit cells) -------------------------------------------------------------
-// window of 8 cells (16 bytes at a 2-byte boundary) = five aligned dwords
-__device__ __forceinline__ void lz2_load_window(u32 bits_addr, u32 data_addr, u32 &b0, u32 &b1, u32 &x0, u32 &x1, u32 &x2, u32 &x3, u32 &x4)
+// window of 8 cells (16 bytes at a 2-byte boundary) = five aligned dwords.  A cell holds its value + 1: zero is "not written
+// yet" (the ring is zeroed a lap ahead, as OR-ing into it needs anyway), so that the cells are their own "written" marks -- no
+// bit per position to read, set and clear as the byte resolver keeps: a piece is 3 + 5 LDS instructions instead of 4 + 7, in
+// a kernel that is bound by what the CU's LDS takes.  The flushers take the 1 off again.
+__device__ __forceinline__ void lz2_load_window(u32 data_addr, u32 &x0, u32 &x1, u32 &x2, u32 &x3, u32 &x4)
 {
-    u32x2 b, p, q;
-    asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2_b32 %1, %5 offset1:1\n\tds_read2_b32 %2, %5 offset0:2 offset1:3\n\t"
-                 "ds_read_b32 %3, %5 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(b), "=&v"(p), "=&v"(q), "=&v"(x4) : "v"(bits_addr), "v"(data_addr) : "memory");
-    b0 = b.x; b1 = b.y; x0 = p.x; x1 = p.y; x2 = q.x; x3 = q.y;
+    u32x2 p, q;
+    asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %3 offset0:2 offset1:3\n\t"
+                 "ds_read_b32 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(p), "=&v"(q), "=&v"(x4) : "v"(data_addr) : "memory");
+    x0 = p.x; x1 = p.y; x2 = q.x; x3 = q.y;
 }
-__device__ __forceinline__ void lz2_or_window(u32 data_addr, u32 o0, u32 o1, u32 o2, u32 o3, u32 o4, u32 bits_addr, u32 m0, u32 m1)
+__device__ __forceinline__ void lz2_or_window(u32 data_addr, u32 o0, u32 o1, u32 o2, u32 o3, u32 o4)
 {
     asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4\n\tds_or_b32 %0, %3 offset:8\n\tds_or_b32 %0, %4 offset:12\n\t"
-                 "ds_or_b32 %0, %5 offset:16\n\tds_or_b32 %6, %7\n\tds_or_b32 %6, %8 offset:4"
-                 :: "v"(data_addr), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(o4), "v"(bits_addr), "v"(m0), "v"(m1) : "memory");
+                 "ds_or_b32 %0, %5 offset:16"
+                 :: "v"(data_addr), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(o4) : "memory");
 }
-__device__ __forceinline__ void lz2_load_cell(u32 bits_addr, u32 data_addr, u32 &bits, u32 &data)
+__device__ __forceinline__ void lz2_or_cell(u32 data_addr, u32 w) { asm volatile("ds_or_b32 %0, %1" :: "v"(data_addr), "v"(w) : "memory"); }
+__device__ __forceinline__ u32 lz2_load_cell(u32 data_addr)
 {
-    asm volatile("ds_read_b32 %0, %2\n\tds_read_u16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bits), "=&v"(data) : "v"(bits_addr), "v"(data_addr) : "memory");
+    u32 data;
+    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(data) : "v"(data_addr) : "memory");
+    return data;
 }
+// some 16-bit half of y is zero
+__device__ __forceinline__ u32 lz2_zero_half(u32 y) { return (y - 0x00010001u) & ~y & 0x80008000u; }
 
 // how a chunk is cut (one thread per chunk)
 __global__ __launch_bounds__(64) void k_inf_plan(const InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
@@ -2047,7 +2054,13 @@ __global__ __launch_bounds__(64) void k_inf_plan(const InfResult *__restrict__ r
         }
     }
 }
-
+#ifndef MTS_LZ2_STATS
+#define MTS_LZ2_STATS 0
+#endif
+#if MTS_LZ2_STATS
+__device__ unsigned long long g_lz2_stats[16];     // (instrumented builds: tools/lz2_stats.py)
+#define LZ2_CLK() __builtin_readcyclecounter()
+#endif
 __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict__ tokens, const InfChunk *__restrict__ chunks,
                                                            InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
                                                            const u64 *__restrict__ tb_off, const u32 *__restrict__ gbase,
@@ -2063,12 +2076,11 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
     if (pl->nseg < 2 || (u32)seg >= pl->nseg) return;
     const InfChunk ch = chunks[ci];
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const u32 lds_data = (u32)(uintptr_t)smem;                       // LDS byte offsets of the cell ring, the bit ring, ...
-    const u32 lds_bits = lds_data + LZ2_BITS_OFF;
+    const u32 lds_data = (u32)(uintptr_t)smem;                       // LDS byte offsets of the cell ring, ...
     const u32 lds_prog = lds_data + LZ2_CTL_OFF;                     // [w] = first byte of the group worker w is on
     const u32 lds_flnext = lds_prog + 64;                            // [k] = first byte of the next granule of flusher k
     const u32 lds_bad = lds_prog + 80;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // (the group numbers are scalars then)
     const u32 *tk = tokens + ch.tok_off;
     const u32 *gbl = gbase + gb_off[ci];
     const u32 *tbs = tile_base + tb_off[ci];
@@ -2083,11 +2095,11 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
         lds_st(lds_prog + 4 * threadIdx.x, v);
     }
     __syncthreads();
-    // the unknown window: cell 256 + i at position B - LZ_WIN + i, marked written (segment 0 has none)
+    // the unknown window: value 256 + i at position B - LZ_WIN + i (segment 0 has none)
     if (seg > 0) {
         for (u32 i = threadIdx.x; i < LZ_WIN; i += LZ_THREADS) {
             const u32 ro = (B - LZ_WIN + i) & (LZ_RING - 1);
-            lz_or_byte(lds_data + ((2 * ro) & ~3u), (256 + i) << (16 * (ro & 1)), lds_bits + ((ro >> 5) << 2), 1u << (ro & 31));
+            lz2_or_cell(lds_data + ((2 * ro) & ~3u), (256 + i + 1) << (16 * (ro & 1)));
         }
     }
     u32 t_n = 0, tb0_n = 0, gl0_n = 0, tb1_n = 0, gl1_n = 0;
@@ -2141,6 +2153,10 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                 const u32 o = lo + st * 512 + lane * 8;
                 c[st] = u32x4{0, 0, 0, 0};
                 if (o < hi && o + 8 > B) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(c[st]) : "v"(lds_data + 2 * (o & (LZ_RING - 1))) : "memory");
+                // cells hold value + 1 (see lz2_load_window); every cell of [max(lo, B), hi) is written by now.  (Cells outside
+                // that range -- first and last granule only -- are zero: the borrow spoils their neighbour, which the cell-by-cell
+                // branch below therefore takes from the cell itself)
+                if (whole || (o >= B && o + 8 <= hi)) { c[st].x -= 0x00010001u; c[st].y -= 0x00010001u; c[st].z -= 0x00010001u; c[st].w -= 0x00010001u; }
                 high |= c[st].x | c[st].y | c[st].z | c[st].w;
             }
             if (whole && !__any((high & 0xff00ff00u) != 0)) {
@@ -2165,7 +2181,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                     const u32 o = lo + st * 512 + lane * 8;
                     if (o < hi && o + 8 > B) {
                         if (o >= B && o + 8 <= hi) *(u32x4 *)(out + o) = c[st];
-                        else { const u32 cw[4] = {c[st].x, c[st].y, c[st].z, c[st].w}; for (u32 k = 0; k < 8; k++) if (o + k >= B && o + k < hi) out[o + k] = (u16)(cw[k >> 1] >> (16 * (k & 1))); }
+                        else { const u32 cw[4] = {c[st].x, c[st].y, c[st].z, c[st].w}; for (u32 k = 0; k < 8; k++) if (o + k >= B && o + k < hi) out[o + k] = (u16)((cw[k >> 1] >> (16 * (k & 1))) - 1u); }
                     }
                 }
             }
@@ -2173,7 +2189,6 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                 const u32 zo = ((q - LZ_ZLAG) * LZ_FLUSH) & (LZ_RING - 1);
 #pragma unroll
                 for (u32 o = lane * 16; o < 2 * LZ_FLUSH; o += 1024) lds_zero16(lds_data + 2 * zo + o);
-                if (lane < (int)(LZ_FLUSH / 8 / 16)) lds_zero16(lds_bits + zo / 8 + lane * 16);
             }
             if (lane == 0) lds_st(lds_flnext + 4 * me, lo + LZ_FLUSHERS * LZ_FLUSH);
         }
@@ -2193,8 +2208,14 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
     // ---- workers ----
     if (wave >= LZW) return;
     u32 fl_seen = 0;
-    for (u32 g = g_lo + wave; g < g_hi; g += LZW) {
-        if (lds_ld(lds_bad)) break;
+#if MTS_LZ2_STATS
+    u64 sg = 0, sit = 0, snm = 0, c_wait = 0, c_pre = 0, c_loop = 0, spend = 0, sslow = 0, sfirst = 0, scp = 0, c_ld = 0;
+    const u64 c_start = LZ2_CLK();
+#endif
+    for (u32 g = g_lo + wave; g < g_hi; g += LZW) {          // (a lost chunk is noticed by whoever waits: no look at lds_bad per group)
+#if MTS_LZ2_STATS
+        const u64 c0_ = LZ2_CLK();
+#endif
         const u32 t = t_n, base = tb0_n + gl0_n, next = g + 1 < ngroups ? tb1_n + gl1_n : r.n_out;
         const u32 i = g * 64 + lane;
         const bool act = i < ntok;
@@ -2209,6 +2230,9 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                 __builtin_amdgcn_s_sleep(1);
             }
         }
+#if MTS_LZ2_STATS
+        const u64 c1_ = LZ2_CLK();
+#endif
         const bool cp = act && (t >> 31);
         const u32 len = !act ? 0 : cp ? ((t >> 16) & 0xff) + 3 : 1;
         const u32 dst = base + wave_incl_scan_dpp(len) - len;
@@ -2217,45 +2241,75 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
         const u32 dofs = dst & (LZ_RING - 1), sofs = src & (LZ_RING - 1);
         bool pend = cp;
         if (cp && (dist > dst || len > 8)) { pend = false; lds_st(lds_bad, 1); }
-        if (act && !cp) lz_or_byte(lds_data + ((2 * dofs) & ~3u), (t & 0xff) << (16 * (dofs & 1)), lds_bits + ((dofs >> 5) << 2), 1u << (dofs & 31));
+        if (act && !cp) lz2_or_cell(lds_data + ((2 * dofs) & ~3u), ((t & 0xff) + 1u) << (16 * (dofs & 1)));
         // cell by cell: windows that would run past the ring end, and overlapping copies (dist < len)
         const bool slow = pend && (sofs > LZ_EDGE || dofs > LZ_EDGE || dist < len);
-        const u32 nbits = (1u << len) - 1;
-        const u32 ba = lds_bits + ((sofs >> 5) << 2), da = lds_data + ((2 * sofs) & ~3u);
-        const u32 wa = lds_data + ((2 * dofs) & ~3u), wba = lds_bits + ((dofs >> 5) << 2);
-        const u64 wbits = (u64)nbits << (dofs & 31);
-        u32 spins = 0, k = 0;
+        const u32 da = lds_data + ((2 * sofs) & ~3u), wa = lds_data + ((2 * dofs) & ~3u);
+        // cells at or beyond len are not this piece's: dropped from what is written, and taken as written in the test
+        const u32 m0 = len > 1 ? 0xffffffffu : 0xffffu, m1 = len > 3 ? 0xffffffffu : len > 2 ? 0xffffu : 0u;
+        const u32 m2 = len > 5 ? 0xffffffffu : len > 4 ? 0xffffu : 0u, m3 = len > 7 ? 0xffffffffu : len > 6 ? 0xffffu : 0u;
+        u32 idle = 0, k = 0;                  // idle: rounds in a row in which no lane of the wave moved (wave-uniform)
+#if MTS_LZ2_STATS
+        const u64 c2_ = LZ2_CLK();
+        sg++; scp += __popcll(__ballot(cp)); sslow += __popcll(__ballot(slow));
+        bool first_ = true;
+#endif
         while (__any(pend)) {
+#if MTS_LZ2_STATS
+            sit++; spend += __popcll(__ballot(pend));
+#endif
             bool moved = false;
             if (pend && !slow) {
-                u32 b0, b1, x0, x1, x2, x3, x4;
-                lz2_load_window(ba, da, b0, b1, x0, x1, x2, x3, x4);
-                if ((__builtin_amdgcn_alignbit(b1, b0, sofs & 31) & nbits) == nbits) {
-                    const u32 ssh = 16 * (sofs & 1);
-                    // the 8 cells, two per dword; cells at or beyond len are dropped
-                    const u32 w0 = __builtin_amdgcn_alignbit(x1, x0, ssh) & (len > 1 ? 0xffffffffu : 0xffffu);
-                    const u32 w1 = __builtin_amdgcn_alignbit(x2, x1, ssh) & (len > 3 ? 0xffffffffu : len > 2 ? 0xffffu : 0u);
-                    const u32 w2 = __builtin_amdgcn_alignbit(x3, x2, ssh) & (len > 5 ? 0xffffffffu : len > 4 ? 0xffffu : 0u);
-                    const u32 w3 = __builtin_amdgcn_alignbit(x4, x3, ssh) & (len > 7 ? 0xffffffffu : len > 6 ? 0xffffu : 0u);
+                u32 x0, x1, x2, x3, x4;
+#if MTS_LZ2_STATS
+                const u64 cl0_ = LZ2_CLK();
+#endif
+                lz2_load_window(da, x0, x1, x2, x3, x4);
+#if MTS_LZ2_STATS
+                c_ld += LZ2_CLK() - cl0_;
+#endif
+                const u32 ssh = 16 * (sofs & 1);
+                // the 8 cells from the source on, two per dword
+                const u32 r0 = __builtin_amdgcn_alignbit(x1, x0, ssh), r1 = __builtin_amdgcn_alignbit(x2, x1, ssh);
+                const u32 r2 = __builtin_amdgcn_alignbit(x3, x2, ssh), r3 = __builtin_amdgcn_alignbit(x4, x3, ssh);
+                if ((lz2_zero_half(r0 | ~m0) | lz2_zero_half(r1 | ~m1) | lz2_zero_half(r2 | ~m2) | lz2_zero_half(r3 | ~m3)) == 0) {
+                    const u32 w0 = r0 & m0, w1 = r1 & m1, w2 = r2 & m2, w3 = r3 & m3;
                     const bool odd = dofs & 1;
                     lz2_or_window(wa, odd ? w0 << 16 : w0, odd ? __builtin_amdgcn_alignbit(w1, w0, 16) : w1,
                                   odd ? __builtin_amdgcn_alignbit(w2, w1, 16) : w2, odd ? __builtin_amdgcn_alignbit(w3, w2, 16) : w3,
-                                  odd ? w3 >> 16 : 0u, wba, (u32)wbits, (u32)(wbits >> 32));
+                                  odd ? w3 >> 16 : 0u);
                     pend = false; moved = true;
-                } else if (++spins > (1u << 22)) { pend = false; if (!lds_ld(lds_bad)) lds_st(lds_bad, 2); }
+                }
             } else if (pend) {
                 const u32 so = (src + k) & (LZ_RING - 1), dd = (dst + k) & (LZ_RING - 1);
-                u32 bw, dv;
-                lz2_load_cell(lds_bits + ((so >> 5) << 2), lds_data + 2 * so, bw, dv);
-                if ((bw >> (so & 31)) & 1) {
-                    lz_or_byte(lds_data + ((2 * dd) & ~3u), dv << (16 * (dd & 1)), lds_bits + ((dd >> 5) << 2), 1u << (dd & 31));
+                const u32 dv = lz2_load_cell(lds_data + 2 * so);
+                if (dv) {
+                    lz2_or_cell(lds_data + ((2 * dd) & ~3u), dv << (16 * (dd & 1)));
                     if (++k == len) pend = false;
-                    spins = 0; moved = true;
-                } else if (++spins > (1u << 22)) { pend = false; if (!lds_ld(lds_bad)) lds_st(lds_bad, 2); }
+                    moved = true;
+                }
             }
-            if (!__any(moved)) { if (lds_ld(lds_bad)) pend = false; else __builtin_amdgcn_s_sleep(4); }     // (see k_inf_lz)
+#if MTS_LZ2_STATS
+            if (first_) { sfirst += __popcll(__ballot(moved)); first_ = false; }
+            if (!__any(moved)) snm++;
+#endif
+            // (what a copy waits for may never come -- damage: the wave gives up after 2^22 idle rounds, ~1 s.  The sleep is
+            //  k_inf_lz's; 1, 2 or 8 here: the same 3.4 ms)
+            if (__any(moved)) idle = 0;
+            else if (lds_ld(lds_bad)) pend = false;
+            else if (++idle > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
+            else __builtin_amdgcn_s_sleep(4);
         }
+#if MTS_LZ2_STATS
+        { const u64 c3_ = LZ2_CLK(); c_wait += c1_ - c0_; c_pre += c2_ - c1_; c_loop += c3_ - c2_; }
+#endif
     }
+#if MTS_LZ2_STATS
+    if (lane == 0 && pass == 0) {
+        const u64 v[13] = {sg, sit, snm, LZ2_CLK() - c_start, c_wait, c_pre, c_loop, spend, sslow, sfirst, scp, 1, c_ld};
+        for (int k = 0; k < 13; k++) atomicAdd(&g_lz2_stats[k], v[k]);
+    }
+#endif
     if (lane == 0) lds_st(lds_prog + 4 * wave, 0xffffffffu);
     if (wave == 0) {
         for (u32 waits = 0; flushed() < Bend && waits < 4 * LZ_SPIN_MAX; waits++) __builtin_amdgcn_s_sleep(8);
@@ -2649,3 +2703,13 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
 }
 
 }  // namespace mts
+
+#if MTS_LZ2_STATS
+extern "C" int mts_debug_lz2_stats(unsigned long long *out)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mts::g_lz2_stats), 128) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(mts::g_lz2_stats), z, 128) == hipSuccess ? 0 : -1;
+}
+#endif
+
