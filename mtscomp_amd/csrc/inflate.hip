@@ -1934,7 +1934,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
         const u64 wbits = (u64)((1u << len) - 1) << (dofs & 31);
         const u64 lmask = len >= 8 ? ~0ull : (1ull << (8 * len)) - 1;
         const u32 wsh = 8 * (dofs & 3);
-        u32 spins = 0, k = 0;
+        u32 idle = 0, k = 0;                  // idle: rounds in a row in which no lane of the wave moved (wave-uniform)
         u64 c2_ = prof ? __builtin_readcyclecounter() : 0;
         while (__any(pend)) {
             if (prof) pc_iter++;
@@ -1955,7 +1955,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
                     const u32 w2 = (u32)(((v >> 32) << wsh) >> 32);
                     lz_or_window(wa, (u32)w01, (u32)(w01 >> 32), w2, wba, (u32)wbits, (u32)(wbits >> 32));
                     pend = false; moved = true;
-                } else if (++spins > (1u << 22)) { pend = false; if (!lds_ld(lds_bad)) lds_st(lds_bad, 2); }       // bounded spin: never hang the GPU
+                }
             } else if (pend) {
                 // byte-wise path (window across the ring end): one byte per round
                 const u32 so = (src + k) & (LZ_RING - 1), dd = (dst + k) & (LZ_RING - 1);
@@ -1964,13 +1964,17 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
                 if ((bw >> (so & 31)) & 1) {
                     lz_or_byte(lds_data + (dd & ~3u), dv << (8 * (dd & 3)), lds_bits + ((dd >> 5) << 2), 1u << (dd & 31));
                     if (++k == len) pend = false;
-                    spins = 0; moved = true;
-                } else if (++spins > (1u << 22)) { pend = false; if (!lds_ld(lds_bad)) lds_st(lds_bad, 2); }
+                    moved = true;
+                }
             }
             // nothing of this wave's could commit: its sources are another wave's work.  Step back for a moment -- sixteen
             // waves polling the LDS at full rate leave the one wave that can make progress a sixteenth of it (a chain of
             // dependent copies, e.g. 7-byte matches at distance 8 through int64 data, then runs 100x slower than on one wave)
-            if (!__any(moved)) { if (lds_ld(lds_bad)) pend = false; else __builtin_amdgcn_s_sleep(4); }     // (what it waits for may never come)
+            // What it waits for may never come (damage): after 2^22 idle rounds, ~1 s, the wave gives up -- never hang the GPU.
+            if (__any(moved)) idle = 0;
+            else if (lds_ld(lds_bad)) pend = false;
+            else if (++idle > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
+            else __builtin_amdgcn_s_sleep(4);
         }
         if (prof) { const u64 c3_ = __builtin_readcyclecounter(); pc_wait += c1_ - c0_; pc_pre += c2_ - c1_; pc_loop += c3_ - c2_; pc_groups++; }
     }
