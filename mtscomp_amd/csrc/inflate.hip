@@ -1936,7 +1936,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
         const u32 wsh = 8 * (dofs & 3);
         u32 idle = 0, k = 0;                  // idle: rounds in a row in which no lane of the wave moved (wave-uniform)
         u64 c2_ = prof ? __builtin_readcyclecounter() : 0;
-        while (__any(pend)) {
+        while (any64(pend)) {
             if (prof) pc_iter++;
             bool moved = false;
             if (pend && !slow) {
@@ -1971,7 +1971,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
             // waves polling the LDS at full rate leave the one wave that can make progress a sixteenth of it (a chain of
             // dependent copies, e.g. 7-byte matches at distance 8 through int64 data, then runs 100x slower than on one wave)
             // What it waits for may never come (damage): after 2^22 idle rounds, ~1 s, the wave gives up -- never hang the GPU.
-            if (__any(moved)) idle = 0;
+            if (any64(moved)) idle = 0;
             else if (lds_ld(lds_bad)) pend = false;
             else if (++idle > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
             else __builtin_amdgcn_s_sleep(4);
@@ -2021,6 +2021,8 @@ __device__ __forceinline__ u32 lz2_load_cell(u32 data_addr)
 }
 // some 16-bit half of y is zero
 __device__ __forceinline__ u32 lz2_zero_half(u32 y) { return (y - 0x00010001u) & ~y & 0x80008000u; }
+// the smaller of the two low halves, and of the two high halves
+__device__ __forceinline__ u32 lz2_pk_min(u32 a, u32 b) { u32 d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
 // how a chunk is cut (one thread per chunk)
 __global__ __launch_bounds__(64) void k_inf_plan(const InfResult *__restrict__ res, const u64 *__restrict__ gb_off,
@@ -2163,7 +2165,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                 if (whole || (o >= B && o + 8 <= hi)) { c[st].x -= 0x00010001u; c[st].y -= 0x00010001u; c[st].z -= 0x00010001u; c[st].w -= 0x00010001u; }
                 high |= c[st].x | c[st].y | c[st].z | c[st].w;
             }
-            if (whole && !__any((high & 0xff00ff00u) != 0)) {
+            if (whole && !any64((high & 0xff00ff00u) != 0)) {
 #pragma unroll
                 for (u32 st = 0; st < LZ_FLUSH / 512; st++) {
                     const u32 o = lo + st * 512 + lane * 8;
@@ -2243,27 +2245,33 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
         const u32 dist = (t & 0x7fff) + 1;
         const u32 src = dst - dist;
         const u32 dofs = dst & (LZ_RING - 1), sofs = src & (LZ_RING - 1);
-        bool pend = cp;
-        if (cp && (dist > dst || len > 8)) { pend = false; lds_st(lds_bad, 1); }
+        // (the copy's state as a number: a ballot of `pv != 0` is one compare, the ballot of a flag kept in a mask is two
+        //  instructions more -- and this loop is made of instructions)
+        u32 pv = cp ? 1u : 0u;
+        if (cp && (dist > dst || len > 8)) { pv = 0; lds_st(lds_bad, 1); }
         if (act && !cp) lz2_or_cell(lds_data + ((2 * dofs) & ~3u), ((t & 0xff) + 1u) << (16 * (dofs & 1)));
         // cell by cell: windows that would run past the ring end, and overlapping copies (dist < len)
-        const bool slow = pend && (sofs > LZ_EDGE || dofs > LZ_EDGE || dist < len);
+        const bool slow = sofs > LZ_EDGE || dofs > LZ_EDGE || dist < len;
         const u32 da = lds_data + ((2 * sofs) & ~3u), wa = lds_data + ((2 * dofs) & ~3u);
-        // cells at or beyond len are not this piece's: dropped from what is written, and taken as written in the test
-        const u32 m0 = len > 1 ? 0xffffffffu : 0xffffu, m1 = len > 3 ? 0xffffffffu : len > 2 ? 0xffffu : 0u;
-        const u32 m2 = len > 5 ? 0xffffffffu : len > 4 ? 0xffffu : 0u, m3 = len > 7 ? 0xffffffffu : len > 6 ? 0xffffu : 0u;
-        u32 idle = 0, k = 0;                  // idle: rounds in a row in which no lane of the wave moved (wave-uniform)
+        // cells at or beyond len are not this piece's: dropped from what is written, and taken as written in the test.
+        // n0 .. n3: ones in the cells that are NOT the piece's (cell c at bits 16 c of the 128)
+        const u64 nlo = len >= 4 ? 0ull : ~0ull << (16 * len), nhi = len >= 8 ? 0ull : ~0ull << (16 * max(len, 4u) - 64);
+        const u32 n0 = (u32)nlo, n1 = (u32)(nlo >> 32), n2 = (u32)nhi, n3 = (u32)(nhi >> 32);
+        // a destination at an odd cell takes the eight cells a half dword up: one byte permute per dword written
+        const u32 sel = (dofs & 1) ? 0x05040302u : 0x07060504u;
+        u32 idle = 0, k = 0, spins = 0;       // idle: rounds in a row in which no lane of the wave moved (wave-uniform)
+        const u64 slowm = ballot64(slow);
 #if MTS_LZ2_STATS
         const u64 c2_ = LZ2_CLK();
-        sg++; scp += __popcll(__ballot(cp)); sslow += __popcll(__ballot(slow));
+        sg++; scp += __popcll(__ballot(cp)); sslow += __popcll(__ballot(slow && pv));
         bool first_ = true;
 #endif
-        while (__any(pend)) {
+        u64 pm = ballot64(pv != 0);
+        while (pm) {
 #if MTS_LZ2_STATS
-            sit++; spend += __popcll(__ballot(pend));
+            sit++; spend += __popcll(pm);
 #endif
-            bool moved = false;
-            if (pend && !slow) {
+            if (pv != 0 && !slow) {
                 u32 x0, x1, x2, x3, x4;
 #if MTS_LZ2_STATS
                 const u64 cl0_ = LZ2_CLK();
@@ -2276,33 +2284,38 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                 // the 8 cells from the source on, two per dword
                 const u32 r0 = __builtin_amdgcn_alignbit(x1, x0, ssh), r1 = __builtin_amdgcn_alignbit(x2, x1, ssh);
                 const u32 r2 = __builtin_amdgcn_alignbit(x3, x2, ssh), r3 = __builtin_amdgcn_alignbit(x4, x3, ssh);
-                if ((lz2_zero_half(r0 | ~m0) | lz2_zero_half(r1 | ~m1) | lz2_zero_half(r2 | ~m2) | lz2_zero_half(r3 | ~m3)) == 0) {
-                    const u32 w0 = r0 & m0, w1 = r1 & m1, w2 = r2 & m2, w3 = r3 & m3;
-                    const bool odd = dofs & 1;
-                    lz2_or_window(wa, odd ? w0 << 16 : w0, odd ? __builtin_amdgcn_alignbit(w1, w0, 16) : w1,
-                                  odd ? __builtin_amdgcn_alignbit(w2, w1, 16) : w2, odd ? __builtin_amdgcn_alignbit(w3, w2, 16) : w3,
-                                  odd ? w3 >> 16 : 0u);
-                    pend = false; moved = true;
+                // all written: the smallest of the piece's cells is not zero (half by half over the four dwords)
+                if (lz2_zero_half(lz2_pk_min(lz2_pk_min(r0 | n0, r1 | n1), lz2_pk_min(r2 | n2, r3 | n3))) == 0) {
+                    const u32 w0 = r0 & ~n0, w1 = r1 & ~n1, w2 = r2 & ~n2, w3 = r3 & ~n3;
+                    lz2_or_window(wa, __builtin_amdgcn_perm(w0, 0u, sel), __builtin_amdgcn_perm(w1, w0, sel), __builtin_amdgcn_perm(w2, w1, sel),
+                                  __builtin_amdgcn_perm(w3, w2, sel), __builtin_amdgcn_perm(0u, w3, sel));
+                    pv = 0;
                 }
-            } else if (pend) {
+            } else if (pv != 0) {
                 const u32 so = (src + k) & (LZ_RING - 1), dd = (dst + k) & (LZ_RING - 1);
                 const u32 dv = lz2_load_cell(lds_data + 2 * so);
                 if (dv) {
                     lz2_or_cell(lds_data + ((2 * dd) & ~3u), dv << (16 * (dd & 1)));
-                    if (++k == len) pend = false;
-                    moved = true;
+                    if (++k == len) pv = 0;
+                    spins = 0;
+                } else if ((++spins & 63u) == 0) {                    // (its own bound and its own look at the lost-chunk flag: a round
+                    if (lds_ld(lds_bad)) pv = 0;                      //  with a cell-by-cell copy in it does not count as idle below)
+                    else if (spins > (1u << 22)) { pv = 0; lds_st(lds_bad, 2); }
                 }
             }
+            const u64 pn = ballot64(pv != 0);
 #if MTS_LZ2_STATS
-            if (first_) { sfirst += __popcll(__ballot(moved)); first_ = false; }
-            if (!__any(moved)) snm++;
+            if (first_) { sfirst += __popcll(pm & ~pn); first_ = false; }
+            if (pn == pm) snm++;
 #endif
             // (what a copy waits for may never come -- damage: the wave gives up after 2^22 idle rounds, ~1 s.  The sleep is
             //  k_inf_lz's; 1, 2 or 8 here: the same 3.4 ms)
-            if (__any(moved)) idle = 0;
-            else if (lds_ld(lds_bad)) pend = false;
-            else if (++idle > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
+            u64 nx = pn;
+            if (pn != pm || (pn & slowm)) idle = 0;                      // somebody is done (or goes cell by cell)
+            else if (__builtin_amdgcn_readfirstlane((int)lds_ld(lds_bad))) nx = 0;            // (a scalar: the loop's condition stays one)
+            else if (++idle > (1u << 22)) { nx = 0; lds_st(lds_bad, 2); }
             else __builtin_amdgcn_s_sleep(4);
+            pm = nx;
         }
 #if MTS_LZ2_STATS
         { const u64 c3_ = LZ2_CLK(); c_wait += c1_ - c0_; c_pre += c2_ - c1_; c_loop += c3_ - c2_; }
