@@ -1922,11 +1922,12 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
         const u32 dist = (t & 0x7fff) + 1;
         const u32 src = dst - dist;
         const u32 dofs = dst & (LZ_RING - 1), sofs = src & (LZ_RING - 1);
-        bool pend = cp;
-        if (cp && (dist > dst || len > 8)) { pend = false; lds_st(lds_bad, 1); }      // distance too far back (or a piece this kernel never makes): corrupt
+        u32 pv = cp ? 1u : 0u;                // the copy is pending (as a number: see k_inf_lz_seg)
+        if (cp && (dist > dst || len > 8)) { pv = 0; lds_st(lds_bad, 1); }      // distance too far back (or a piece this kernel never makes): corrupt
         if (act && !cp) lz_or_byte(lds_data + (dofs & ~3u), (t & 0xff) << (8 * (dofs & 3)), lds_bits + ((dofs >> 5) << 2), 1u << (dofs & 31));
         // a piece whose source or destination window would run past the ring end goes byte by byte
-        const bool slow = pend && (sofs > LZ_EDGE || dofs > LZ_EDGE);
+        const bool slow = sofs > LZ_EDGE || dofs > LZ_EDGE;
+        const u64 slowm = ballot64(slow);
         const u32 need = len < dist ? len : dist;                       // source bytes that are not this piece's own output
         const u32 nbits = (1u << need) - 1;
         const u32 ba = lds_bits + ((sofs >> 5) << 2), da = lds_data + (sofs & ~3u);
@@ -1934,12 +1935,12 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
         const u64 wbits = (u64)((1u << len) - 1) << (dofs & 31);
         const u64 lmask = len >= 8 ? ~0ull : (1ull << (8 * len)) - 1;
         const u32 wsh = 8 * (dofs & 3);
-        u32 idle = 0, k = 0;                  // idle: rounds in a row in which no lane of the wave moved (wave-uniform)
+        u32 idle = 0, k = 0, spins = 0;       // idle: rounds in a row in which no lane of the wave moved (wave-uniform)
         u64 c2_ = prof ? __builtin_readcyclecounter() : 0;
-        while (any64(pend)) {
+        u64 pm = ballot64(pv != 0);
+        while (pm) {
             if (prof) pc_iter++;
-            bool moved = false;
-            if (pend && !slow) {
+            if (pv != 0 && !slow) {
                 u32 b0, b1, x0, x1, x2;
                 lz_load_window(ba, da, b0, b1, x0, x1, x2);
                 if ((__builtin_amdgcn_alignbit(b1, b0, sofs & 31) & nbits) == nbits) {
@@ -1954,27 +1955,33 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz(const u32 *__restrict__ t
                     const u64 w01 = v << wsh;
                     const u32 w2 = (u32)(((v >> 32) << wsh) >> 32);
                     lz_or_window(wa, (u32)w01, (u32)(w01 >> 32), w2, wba, (u32)wbits, (u32)(wbits >> 32));
-                    pend = false; moved = true;
+                    pv = 0;
                 }
-            } else if (pend) {
+            } else if (pv != 0) {
                 // byte-wise path (window across the ring end): one byte per round
                 const u32 so = (src + k) & (LZ_RING - 1), dd = (dst + k) & (LZ_RING - 1);
                 u32 bw, dv;
                 lz_load_byte(lds_bits + ((so >> 5) << 2), lds_data + so, bw, dv);
                 if ((bw >> (so & 31)) & 1) {
                     lz_or_byte(lds_data + (dd & ~3u), dv << (8 * (dd & 3)), lds_bits + ((dd >> 5) << 2), 1u << (dd & 31));
-                    if (++k == len) pend = false;
-                    moved = true;
+                    if (++k == len) pv = 0;
+                    spins = 0;
+                } else if ((++spins & 63u) == 0) {                    // (its own bound and look at the lost-chunk flag, as in k_inf_lz_seg)
+                    if (lds_ld(lds_bad)) pv = 0;
+                    else if (spins > (1u << 22)) { pv = 0; lds_st(lds_bad, 2); }
                 }
             }
+            const u64 pn = ballot64(pv != 0);
             // nothing of this wave's could commit: its sources are another wave's work.  Step back for a moment -- sixteen
             // waves polling the LDS at full rate leave the one wave that can make progress a sixteenth of it (a chain of
             // dependent copies, e.g. 7-byte matches at distance 8 through int64 data, then runs 100x slower than on one wave)
             // What it waits for may never come (damage): after 2^22 idle rounds, ~1 s, the wave gives up -- never hang the GPU.
-            if (any64(moved)) idle = 0;
-            else if (lds_ld(lds_bad)) pend = false;
-            else if (++idle > (1u << 22)) { pend = false; lds_st(lds_bad, 2); }
+            u64 nx = pn;
+            if (pn != pm || (pn & slowm)) idle = 0;                      // somebody is done (or goes byte by byte)
+            else if (__builtin_amdgcn_readfirstlane((int)lds_ld(lds_bad))) nx = 0;
+            else if (++idle > (1u << 22)) { nx = 0; lds_st(lds_bad, 2); }
             else __builtin_amdgcn_s_sleep(4);
+            pm = nx;
         }
         if (prof) { const u64 c3_ = __builtin_readcyclecounter(); pc_wait += c1_ - c0_; pc_pre += c2_ - c1_; pc_loop += c3_ - c2_; pc_groups++; }
     }
@@ -2285,8 +2292,9 @@ __global__ __launch_bounds__(LZ_THREADS) void k_inf_lz_seg(const u32 *__restrict
                 const u32 r0 = __builtin_amdgcn_alignbit(x1, x0, ssh), r1 = __builtin_amdgcn_alignbit(x2, x1, ssh);
                 const u32 r2 = __builtin_amdgcn_alignbit(x3, x2, ssh), r3 = __builtin_amdgcn_alignbit(x4, x3, ssh);
                 // all written: the smallest of the piece's cells is not zero (half by half over the four dwords)
-                if (lz2_zero_half(lz2_pk_min(lz2_pk_min(r0 | n0, r1 | n1), lz2_pk_min(r2 | n2, r3 | n3))) == 0) {
-                    const u32 w0 = r0 & ~n0, w1 = r1 & ~n1, w2 = r2 & ~n2, w3 = r3 & ~n3;
+                const u32 y0 = r0 | n0, y1 = r1 | n1, y2 = r2 | n2, y3 = r3 | n3;
+                if (lz2_zero_half(lz2_pk_min(lz2_pk_min(y0, y1), lz2_pk_min(y2, y3))) == 0) {
+                    const u32 w0 = y0 ^ n0, w1 = y1 ^ n1, w2 = y2 ^ n2, w3 = y3 ^ n3;      // (= r & ~n, without the ~n)
                     lz2_or_window(wa, __builtin_amdgcn_perm(w0, 0u, sel), __builtin_amdgcn_perm(w1, w0, sel), __builtin_amdgcn_perm(w2, w1, sel),
                                   __builtin_amdgcn_perm(w3, w2, sel), __builtin_amdgcn_perm(0u, w3, sel));
                     pv = 0;
