@@ -623,19 +623,20 @@ __device__ __forceinline__ int vh_step(VhState &s)
 {
     BitIn &br = s.br;
     br.refill();
+    const u32 pk = br.peek();                                    // >= 32 valid bits: a code (<= 7) and a repeat's extra bits (<= 7)
     u32 clen;
-    const int si = chain_decode<7>(__brev(br.peek()) >> 25, s.CC, clen);
+    const int si = chain_decode<7>(__brev(pk) >> 25, s.CC, clen);
     if (si < 0) return -1;
     const int sym = (int)((si < 12 ? s.t0 >> (5 * si) : s.t1 >> (5 * (si - 12))) & 31);
-    br.skip(clen);
-    int rep = 1, val = sym;
+    // The repeat codes 16, 17, 18 without a branch each (the lanes of a wave are on different symbols, so every branch was
+    // everybody's): extra bits 2 / 3 / 7 and base 3 / 3 / 11 by t = 1, 2, 3 out of two constants, taken from the same 32 bits
+    const u32 t4 = 4u * (u32)(max(sym, 15) - 15);                // 0 for a length, 4 / 8 / 12 for 16 / 17 / 18
+    const u32 xb = (0x7320u >> t4) & 15u;
+    const int rep = (int)(((0xb331u >> t4) & 15u) + __builtin_amdgcn_ubfe(pk, clen, xb));
+    br.skip(clen + xb);
     const int idx = s.idx, nlen = s.nlen;
-    if (sym >= 16) {
-        if (sym == 16) { if (idx == 0) return -1; val = s.prev; rep = 3 + (int)br.get(2); }
-        else if (sym == 17) { val = 0; rep = 3 + (int)br.get(3); }
-        else { val = 0; rep = 11 + (int)br.get(7); }
-        if (idx + rep > s.total) return -1;
-    }
+    const int val = sym < 16 ? sym : sym == 16 ? s.prev : 0;
+    if (sym >= 16 && ((sym == 16 && idx == 0) || idx + rep > s.total)) return -1;
     s.prev = val;
     if (val) {
         const int nl = idx >= nlen ? 0 : (idx + rep <= nlen ? rep : nlen - idx);
