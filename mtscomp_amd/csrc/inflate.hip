@@ -567,7 +567,11 @@ constexpr int SCAN_TAIL = 88;            // words staged past the span: a dynami
 // done after ~50.
 struct VhState {
     BitIn br;
-    u32 CC[8];
+    // the 7-bit code-length code as a compare chain in bytes: lim_l = first code (left-justified to 7 bits) that is longer than l
+    // bits, 128 where there is none.  lima / limb: lim_1..4 / lim_5, lim_6, 128, 128; lo64: byte l = lim_l (byte 0 = 0);
+    // so64: byte l = number of codes of up to l bits
+    u32 lima, limb;
+    u64 lo64, so64;
     u64 t0, t1;                           // sorted symbol k at bits 5*(k%12) of t[k/12]
     int nlen, total, idx, prev, len256, maxl, maxd;
     u32 kl, kd;                           // Kraft sums scaled by 2^15
@@ -593,16 +597,22 @@ __device__ bool vh_setup(VhState &s, const u32 *w, u64 nwords, u64 end, u64 o, c
     u32 firstc = 0, off = 0;
     u64 offp = 0;                         // first sorted slot of each length, 5 bits each
     int left = 1;
-    s.CC[0] = 0;
+    u64 lim64 = 0, so64 = 0;
 #pragma unroll
     for (int l = 1; l <= 7; l++) {
         const u32 c = (u32)(cntp >> (5 * l)) & 31;
         left = (left << 1) - (int)c;
         offp |= (u64)off << (5 * l); off += c;
-        s.CC[l] = (((firstc + c) << (7 - l)) & 0xffff) | (c << 16);
+        if (l <= 6) {                                            // (a complete code: lim_7 = 128, never reached by a 7-bit value)
+            lim64 |= (u64)min((firstc + c) << (7 - l), 128u) << (8 * l);
+            so64 |= (u64)off << (8 * l);
+        }
         firstc = (firstc + c) << 1;
     }
     if (left != 0) return false;
+    s.lo64 = lim64; s.so64 = so64;
+    s.lima = (u32)(lim64 >> 8);
+    s.limb = (u32)(lim64 >> 40) | 0x80800000u;
     u64 t0 = 0, t1 = 0;
 #pragma unroll
     for (int k = 0; k < 19; k++) {
@@ -624,9 +634,11 @@ __device__ __forceinline__ int vh_step(VhState &s)
     BitIn &br = s.br;
     br.refill();
     const u32 pk = br.peek();                                    // >= 32 valid bits: a code (<= 7) and a repeat's extra bits (<= 7)
-    u32 clen;
-    const int si = chain_decode<7>(__brev(pk) >> 25, s.CC, clen);
-    if (si < 0) return -1;
+    // how many of the six limits the next 7 bits reach, all at once: byte k of (v + 128) - lim is 128 or more where v >= lim_k
+    const u32 v7 = __brev(pk) >> 25, vb = __builtin_amdgcn_perm(v7, v7, 0u) | 0x80808080u;     // (v7 in every byte)
+    const u32 nge = (u32)__popc((vb - s.lima) & 0x80808080u) + (u32)__popc((vb - s.limb) & 0x80808080u);
+    const u32 clen = 1 + nge;
+    const int si = (int)(((u32)(s.so64 >> (8 * nge)) & 0xffu) + ((v7 - ((u32)(s.lo64 >> (8 * nge)) & 0xffu)) >> (6 - nge)));
     const int sym = (int)((si < 12 ? s.t0 >> (5 * si) : s.t1 >> (5 * (si - 12))) & 31);
     // The repeat codes 16, 17, 18 without a branch each (the lanes of a wave are on different symbols, so every branch was
     // everybody's): extra bits 2 / 3 / 7 and base 3 / 3 / 11 by t = 1, 2, 3 out of two constants, taken from the same 32 bits
