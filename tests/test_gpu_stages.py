@@ -420,6 +420,21 @@ def _timed_inflate(z, n):
     return st, out, time.perf_counter() - t0
 
 
+def test_inflate_writer_made_chunk_stays_on_the_fast_path():
+    """A chunk as the Writer makes it (zlib level 6, dynamic blocks) is opened up by the block-start scan and its header
+    validator: the block-after-block decoder finds nothing left to do.  (The scan's candidates are hints -- if the validator
+    lost them the chunk would still decode, through that decoder, two orders of magnitude slower: this is the test that notices.)"""
+    n = 385 * 30000 * 2
+    ar = inputs.ar1_stream(30000, 385)
+    for level in (6, 9, 1):
+        z = zlib.compress(ar, level)
+        st, out, dt = _timed_inflate(z, n)
+        assert st == 0 and out == ar
+        ms = dict(hip.last_stage_times())
+        assert ms['inflate_wave_decoder'] < 1.0, (level, ms)
+        assert dt < 0.25, (level, dt)
+
+
 def test_inflate_full_size_streams_without_dynamic_blocks():
     """Chunks of the headline size (385 x 30000 int16 = 23.1 MB) whose streams give the block-start scan nothing to find:
     stored blocks (incompressible data, level 0) and fixed-Huffman blocks (Z_FIXED) go through the wave decoder, not one lane."""
