@@ -55,7 +55,7 @@ CHECK_ATOL = 1e-16              # mtscomp.py:59
 CRITICAL_ERROR_URL = "https://github.com/int-brain-lab/mtscomp/issues/new?title=Critical+error"
 DEFAULT_BATCH_CHUNKS = 64       # chunks handed to one device call
 TOFILE_PIECE_CHUNKS = 8         # chunks per piece of Reader.tofile (decode of one piece under the file writes of the one before)
-TOFILE_WRITERS = 8              # threads writing a piece
+TOFILE_WRITERS = 2              # threads writing a piece: writes to ONE file are serialised by its inode lock, a fresh tmpfs file takes ~6.5 GB/s from one or two threads and less from more (through a shared mapping as well: 6 GB/s from 8 threads)
 DEFAULT_DEVICE_CACHE_GB = 32    # decoded chunks a Reader may keep in HBM for slicing (allocated as touched; env MTSCOMP_DEVICE_CACHE_GB, 0 = off)
 DEVICE_CACHE_MAX_CHUNKS = 8     # longer slices are streamed through the host path instead of the cache
 
@@ -175,6 +175,8 @@ class HipCodec:
         n = hip.require_device()
         self.devices = list(range(n)) if devices is None else [int(d) for d in devices]
         assert self.devices and all(0 <= d < n for d in self.devices), "invalid device list"
+        self._pool = None                       # one host thread per entry of `devices`, kept for the codec's lifetime
+        self._pool_lock = threading.Lock()
 
     # -- transforms alone (diff_along_axis / cumsum_along_axis)
     def delta(self, arr, flags):
@@ -201,20 +203,24 @@ class HipCodec:
             res = hip.compress_chunks(data, bounds, flags, level, device=self.devices[k % len(self.devices)])
             for i, b in zip(ids, res):
                 out[i] = b
-        self._run_shards(run, len(shards))
+        self.run_lanes(run, len(shards))
         return out
 
     takes_out = True
 
-    def decompress(self, cbufs, n_rows, n_channels, dtype, flags, out=None):
+    def decompress(self, cbufs, n_rows, n_channels, dtype, flags, out=None, lane=None):
         """-> (status list, list of (n_rows[i], n_channels) arrays or None).  `out`: optional array of exactly the decoded
-        size; with one device the chunks are decoded straight into it."""
+        size, filled in place when one device does the whole call: a codec with one device, or `lane` = the entry of
+        `devices` (modulo their number) that is to take all of it -- Reader.tofile hands its pieces to the devices in turn."""
+        one = self.devices[lane % len(self.devices)] if lane is not None else self.devices[0] if len(self.devices) == 1 else None
         if isinstance(cbufs, tuple):                        # (buffer, offsets, lengths): chunks already in one buffer
             buf, offs, lens = cbufs
-            if len(self.devices) == 1:
-                return hip.decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=self.devices[0], out=out)
+            if one is not None:
+                return hip.decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=one, out=out)
             mv = memoryview(buf)
             cbufs = [mv[o:o + l] for o, l in zip(offs, lens)]
+        elif one is not None:
+            return hip.decompress_chunks(cbufs, n_rows, n_channels, dtype, flags, device=one, out=out)
         n = len(cbufs)
         status, arrays = [0] * n, [None] * n
         shards = [s for s in self._shards(n) if s]
@@ -225,31 +231,57 @@ class HipCodec:
                                              flags, device=self.devices[k % len(self.devices)])
             for i, s, a in zip(ids, st, arrs):
                 status[i], arrays[i] = s, a
-        self._run_shards(run, len(shards))
+        self.run_lanes(run, len(shards))
         return status, arrays
 
-    # -- decoded-chunk cache in HBM (Reader random access); lives on the first device
+    # -- decoded-chunk cache in HBM (Reader random access): one cache per lane, chunk k lives on lane k mod n_lanes
     device_cache = True
     leading_channels = True      # cache_read_slices(..., n_leading=): chunks decoded up to the leading channels a request needs
 
-    def cache_create(self, capacity_bytes):
-        return hip.cache_create(capacity_bytes, device=self.devices[0])
+    @property
+    def n_lanes(self):
+        return len(self.devices)
 
-    host_buffer = staticmethod(hip.HostBuffer)            # page-locked host memory for Reader.tofile's pieces
+    def cache_create(self, capacity_bytes, lane=0):
+        return hip.cache_create(capacity_bytes, device=self.devices[lane % len(self.devices)])
+
+    # page-locked host memory (Reader.tofile's pieces, the compressed bytes of slices): from a pool that outlives the call
+    host_buffer = staticmethod(hip.HostBuffer)
+    host_buffer_take = staticmethod(hip.pinned_pool.take)
+    host_buffer_give = staticmethod(hip.pinned_pool.give)
 
     cache_destroy = staticmethod(hip.cache_destroy)
     cache_query = staticmethod(hip.cache_query)
     cache_read_rows = staticmethod(hip.cache_read_rows)
     cache_read_slices = staticmethod(hip.cache_read_slices)
 
-    @staticmethod
-    def _run_shards(fn, n):
+    def run_lanes(self, fn, n):
+        """fn(0) ... fn(n - 1), each on a host thread of its own (ctypes releases the GIL): the threads are the codec's, made on
+        first use and kept -- a ThreadPool per call cost a thread start and a join per device and call."""
         if n <= 1:
             if n:
                 fn(0)
             return
-        with ThreadPool(n) as pool:          # one host thread per GPU; ctypes releases the GIL
-            pool.map(fn, range(n))
+        with self._pool_lock:
+            if self._pool is None or self._pool_size < n:
+                if self._pool is not None:
+                    self._pool.close()
+                self._pool_size = max(n, len(self.devices))
+                self._pool = ThreadPool(self._pool_size)
+            pool = self._pool
+        pool.map(fn, range(n), chunksize=1)
+
+    def close(self):
+        with self._pool_lock:
+            if self._pool is not None:
+                self._pool.close()
+                self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 _default_codec = None
@@ -497,6 +529,21 @@ def _join_rows(chunks):
     return np.concatenate(chunks, axis=0)
 
 
+def _unlink_lazily(path):
+    """path.unlink() whose page-cache work happens off the caller's thread: the name is gone on return (a new file of that name
+    is a new file), the old file's pages -- a few hundred thousand of them for a recording on a RAM-backed file system, freed one
+    by one when its last reference goes -- are released by a thread that only closes a descriptor."""
+    try:
+        fd = os.open(str(path), os.O_RDONLY)
+    except OSError:
+        Path(path).unlink()
+        return
+    try:
+        Path(path).unlink()
+    finally:
+        threading.Thread(target=os.close, args=(fd,), daemon=True).start()
+
+
 class Reader:
     """NumPy-style read access to a compressed file; chunks are decoded on the device."""
 
@@ -514,7 +561,7 @@ class Reader:
         self.partial_decode = bool(self.config.get('partial_decode', False))
         self._codec = codec
         self._cache = OrderedDict()
-        self._dev_cache = None
+        self._dev_caches = None                                   # decoded-chunk caches in HBM, one per lane of the codec (chunk k -> lane k mod lanes)
         self._dev_cache_lock = threading.Lock()
         self._cache_lock = threading.RLock()                      # the host LRU is shared by the threads that slice (mtscomp.py:648)
         self._dev_cache_bytes = int(float(os.environ.get('MTSCOMP_DEVICE_CACHE_GB', DEFAULT_DEVICE_CACHE_GB)) * 2 ** 30)
@@ -592,7 +639,7 @@ class Reader:
         the device by DMA from where the file system put them -- no fresh pages to fault in for every read, no staging copy);
         reads of a few MB and more are split over four threads.  The caller holds self._pin_lock while the view is in use.
         None when the codec has no such buffers (the caller reads into a bytes object then)."""
-        alloc = getattr(self.codec, 'host_buffer', None)
+        alloc = getattr(self.codec, 'host_buffer_take', None) or getattr(self.codec, 'host_buffer', None)
         if alloc is None or not hasattr(os, 'preadv'):
             return None
         if self._pin is None or self._pin.nbytes < length + 64:
@@ -601,7 +648,7 @@ class Reader:
             except Exception:  # noqa: BLE001
                 return None
             if self._pin is not None:
-                self._pin.free()
+                (getattr(self.codec, 'host_buffer_give', None) or (lambda h: h.free()))(self._pin)
             self._pin = new
         mv = memoryview(self._pin.array)
         fd = self.cdata.fileno()
@@ -683,6 +730,37 @@ class Reader:
                 for idx in ids:
                     self._cache[idx] = self._cache[idx].copy()
 
+    # -- the decoded-chunk caches in HBM: one per lane of the codec (a HipCodec has a lane per device), chunk k on lane k mod lanes
+    def _n_lanes(self):
+        return max(1, int(getattr(self.codec, 'n_lanes', 1)))
+
+    def _cache_for(self, lane):
+        """The cache id of `lane` (created on first use; every lane gets the capacity the Reader was given)."""
+        with self._dev_cache_lock:                             # slices may come from several threads (mtscomp.py:422, :648)
+            if self._dev_caches is None:
+                self._dev_caches = [None] * self._n_lanes()
+            if self._dev_caches[lane] is None:
+                if len(self._dev_caches) > 1:
+                    self._dev_caches[lane] = self.codec.cache_create(self._dev_cache_bytes, lane)
+                else:
+                    self._dev_caches[lane] = self.codec.cache_create(self._dev_cache_bytes)
+            return self._dev_caches[lane]
+
+    @property
+    def _dev_cache(self):
+        """Lane 0's cache id, None before its first use."""
+        return self._dev_caches[0] if self._dev_caches else None
+
+    @staticmethod
+    def _raise_for(status_by_chunk):
+        """The reference's errors for the first chunk (in file order) that did not decode (mtscomp.py:618-628)."""
+        for k in sorted(status_by_chunk):
+            st = status_by_chunk[k]
+            if st == hip.CHUNK_BADSIZE:
+                raise AssertionError("Chunk #%d does not have the expected size." % k)
+            if st != hip.CHUNK_OK:
+                raise IOError("Compressed chunk #%d is corrupted." % k)
+
     def _slice_from_device_cache(self, first, last, i0, i1):
         """Rows [i0, i1) -- inside chunks first..last -- through the codec's decoded-chunk cache in HBM: chunks that are
         not resident are read from the file and decoded in one batch (and stay on the device), and only the requested
@@ -696,45 +774,66 @@ class Reader:
             return None
         if all(i in self._cache for i in range(first, last + 1)):
             return None
-        with self._dev_cache_lock:                             # slices may come from several threads (mtscomp.py:422, :648)
-            if self._dev_cache is None:
-                self._dev_cache = self.codec.cache_create(self._dev_cache_bytes)
+        lanes = self._n_lanes()
+        if lanes > 1:
+            return self._slice_from_lane_caches(first, last, i0, i1, lanes)
+        cache = self._cache_for(0)
         keys = list(range(first, last + 1))
         a, b = i0 - self.chunk_bounds[first], i1 - self.chunk_bounds[first]
-        present = [int(p) >= self.n_channels for p in self.codec.cache_query(self._dev_cache, keys)]      # (entries of leading channels only do not count)
+        present = [int(p) >= self.n_channels for p in self.codec.cache_query(cache, keys)]      # (entries of leading channels only do not count)
         for attempt in range(2):
             need = [k for k, p in zip(keys, present) if not p]
             offs, lens = [0] * n, [0] * n
-            buf, locked = b'', False
-            if need:
-                base = self.chunk_offsets[need[0]]                 # one read from the first to the last missing chunk
-                nbytes = self.chunk_offsets[need[-1] + 1] - base
-                self._pin_lock.acquire()
-                locked = True
-                buf = self._pread_pinned(nbytes, base)
+            base = self.chunk_offsets[need[0]] if need else 0      # one read from the first to the last missing chunk
+            nbytes = self.chunk_offsets[need[-1] + 1] - base if need else 0
+            for k in need:
+                offs[k - first] = self.chunk_offsets[k] - base
+                lens[k - first] = self.chunk_offsets[k + 1] - self.chunk_offsets[k]
+            # (the page-locked buffer is the Reader's: held from the read until the codec has taken the bytes, released whatever
+            #  either of them raises -- a short read of a truncated file is the reference's AssertionError, not a lock left behind)
+            with self._pin_lock:
+                buf = self._pread_pinned(nbytes, base) if need else b''
                 if buf is None:
-                    self._pin_lock.release()
-                    locked = False
                     buf = self._pread(nbytes, base)
-                for k in need:
-                    offs[k - first] = self.chunk_offsets[k] - base
-                    lens[k - first] = self.chunk_offsets[k + 1] - self.chunk_offsets[k]
-            try:
-                status, out = self.codec.cache_read_rows(self._dev_cache, keys, buf, offs, lens, rows, self.n_channels,
-                                                         self.dtype, self._flags(), a, b)
-                break
-            except hip.HipError as e:
-                if e.code != hip.E_MISS or attempt:
-                    raise
-                present = [False] * n                          # dropped since the query: send everything
-            finally:
-                if locked:
-                    self._pin_lock.release()
-        for k, st in zip(keys, status):
-            if st == hip.CHUNK_BADSIZE:
-                raise AssertionError("Chunk #%d does not have the expected size." % k)
-            if st != hip.CHUNK_OK:
-                raise IOError("Compressed chunk #%d is corrupted." % k)
+                try:
+                    status, out = self.codec.cache_read_rows(cache, keys, buf, offs, lens, rows, self.n_channels,
+                                                             self.dtype, self._flags(), a, b)
+                    break
+                except hip.HipError as e:
+                    if e.code != hip.E_MISS or attempt:
+                        raise
+                    present = [False] * n                          # dropped since the query: send everything
+        self._raise_for(dict(zip(keys, status)))
+        return out
+
+    def _slice_from_lane_caches(self, first, last, i0, i1, lanes):
+        """The same over several lanes: every lane reads, decodes and keeps its own chunks (k mod lanes) and copies the rows of
+        [i0, i1) they hold straight into their place in the result, all lanes at once."""
+        out = np.empty((i1 - i0, self.n_channels), dtype=self.dtype)
+        keys = list(range(first, last + 1))
+        status = {}
+
+        def run(g):
+            cache = self._cache_for(g)
+            for k in keys[(g - first) % lanes::lanes]:
+                c0, c1 = self.chunk_bounds[k], self.chunk_bounds[k + 1]
+                lo, hi = max(i0, c0), min(i1, c1)
+                present = int(self.codec.cache_query(cache, [k])[0]) >= self.n_channels
+                for attempt in range(2):
+                    length = 0 if present else self.chunk_offsets[k + 1] - self.chunk_offsets[k]
+                    buf = self._pread(length, self.chunk_offsets[k]) if length else b''
+                    try:
+                        st, _ = self.codec.cache_read_rows(cache, [k], buf, [0], [length], [c1 - c0], self.n_channels, self.dtype,
+                                                           self._flags(), lo - c0, hi - c0, out=out[lo - i0:hi - i0])
+                        break
+                    except hip.HipError as e:
+                        if e.code != hip.E_MISS or attempt:
+                            raise
+                        present = False                            # dropped since the query: send the bytes
+                status[k] = st[0]
+        owners = sorted({k % lanes for k in keys})
+        self.codec.run_lanes(lambda j: run(owners[j]), len(owners))
+        self._raise_for(status)
         return out
 
     def _gather_request(self, item):
@@ -764,14 +863,15 @@ class Reader:
         return i0, max(i0, i1), int(rs), c0, c1, cs, squeeze
 
     def read_slices(self, items, _fallback=True):
-        """Several index expressions ``r[rows, columns]`` / ``r[rows]`` in ONE device call: the chunks they touch are decoded
-        (or found in the decoded-chunk cache in HBM), the requested rows and columns are gathered on the device and only
+        """Several index expressions ``r[rows, columns]`` / ``r[rows]`` in ONE device call per lane: the chunks they touch are
+        decoded (or found in the decoded-chunk cache in HBM), the requested rows and columns are gathered on the device and only
         they cross the bus (the reference decodes whole chunks and slices on the host, mtscomp.py:835-842).  Returns the list
         of arrays; items the device gather does not serve go through ``__getitem__`` one by one."""
         reqs = [self._gather_request(it) for it in items]
         usable = getattr(self.codec, 'device_cache', False) and hasattr(self.codec, 'cache_read_slices') and \
             self._dev_cache_bytes > 0 and all(r is not None for r in reqs)
         spans = []
+        lanes = self._n_lanes()
         if usable:
             for i0, i1, _, _, _, _, _ in reqs:
                 if i1 <= i0:
@@ -783,20 +883,10 @@ class Reader:
                 spans.append((first, last))
             keys = sorted({k for sp in spans if sp for k in range(sp[0], sp[1] + 1)})
             rows = [self.chunk_bounds[k + 1] - self.chunk_bounds[k] for k in keys]
-            usable = 0 < len(keys) <= DEVICE_CACHE_MAX_CHUNKS and \
-                2 * sum(rows) * self.n_channels * self.dtype.itemsize <= self._dev_cache_bytes
+            usable = 0 < len(keys) <= DEVICE_CACHE_MAX_CHUNKS * lanes and \
+                2 * sum(rows) * self.n_channels * self.dtype.itemsize <= self._dev_cache_bytes * lanes
         if not usable:
             return [self[it] for it in items] if _fallback else None
-        with self._dev_cache_lock:
-            if self._dev_cache is None:
-                self._dev_cache = self.codec.cache_create(self._dev_cache_bytes)
-        where = {k: j for j, k in enumerate(keys)}
-        cum = np.concatenate(([0], np.cumsum(rows)))
-        requests = []
-        for (i0, i1, rs, c0, c1, cs, _), sp in zip(reqs, spans):
-            a = int(cum[where[sp[0]]]) + i0 - self.chunk_bounds[sp[0]] if sp else 0
-            requests.append((a, a + (i1 - i0), rs, c0, c1, cs))
-        held = self.codec.cache_query(self._dev_cache, keys)            # channels every resident entry holds (0: not resident)
         # Requests that stay within the leading channels of channel-major chunks need only a prefix of every chunk's stream:
         # the codec inflates a chunk that is not resident just that far, from a prefix of its compressed bytes (the channels
         # compress about equally: the share of the bytes plus a margin; if that falls short the codec says so and the whole
@@ -805,18 +895,74 @@ class Reader:
         n_lead = max([r[4] for r in reqs] or [self.n_channels])     # (over ALL requests: the codec checks every one against it)
         leading = self.partial_decode and bool(getattr(self.codec, 'leading_channels', False)) and self.chunk_order == 'F' and \
             self.dtype.kind in 'iu' and 0 < 2 * n_lead <= self.n_channels
-        present = [int(h) >= (n_lead if leading else self.n_channels) for h in held]      # bytes are sent for entries that are too narrow only
+        if lanes == 1:
+            where = {k: j for j, k in enumerate(keys)}
+            cum = np.concatenate(([0], np.cumsum(rows)))
+            requests = []
+            for (i0, i1, rs, c0, c1, cs, _), sp in zip(reqs, spans):
+                a = int(cum[where[sp[0]]]) + i0 - self.chunk_bounds[sp[0]] if sp else 0
+                requests.append((a, a + (i1 - i0), rs, c0, c1, cs))
+            status, arrays = self._lane_read_slices(self._cache_for(0), keys, requests, n_lead if leading else None)
+            self._raise_for(dict(zip(keys, status)))
+            return [a[:, 0] if r[6] else a for a, r in zip(arrays, reqs)]
+        # several lanes: a request is cut where it crosses from one chunk into the next; every lane gathers the pieces that lie in
+        # its chunks (k mod lanes) in one call, all lanes at once; the pieces of a request are joined on the host
+        lane_keys = {g: [k for k in keys if k % lanes == g] for g in sorted({k % lanes for k in keys})}
+        lane_reqs = {g: [] for g in lane_keys}                      # per lane: (request index, piece index, request tuple)
+        n_pieces = []
+        for q, ((i0, i1, rs, c0, c1, cs, _), sp) in enumerate(zip(reqs, spans)):
+            pieces = 0
+            for k in (range(sp[0], sp[1] + 1) if sp else ()):
+                b0, b1 = self.chunk_bounds[k], self.chunk_bounds[k + 1]
+                lo, hi = max(i0, b0), min(i1, b1)
+                start = i0 + -(-(lo - i0) // rs) * rs               # the first row of the request's grid inside the chunk
+                if start >= hi:
+                    continue
+                g = k % lanes
+                before = sum(self.chunk_bounds[j + 1] - self.chunk_bounds[j] for j in lane_keys[g] if j < k)      # rows of the lane's chunks in front
+                lane_reqs[g].append((q, pieces, (before + start - b0, before + hi - b0, rs, c0, c1, cs)))
+                pieces += 1
+            n_pieces.append(pieces)
+        parts = [[None] * n for n in n_pieces]
+        status = {}
+        owners = list(lane_keys)
+
+        def run(j):
+            g = owners[j]
+            st, arrays = self._lane_read_slices(self._cache_for(g), lane_keys[g], [r for _, _, r in lane_reqs[g]], None)
+            status.update(zip(lane_keys[g], st))
+            for (q, piece, _), arr in zip(lane_reqs[g], arrays):
+                parts[q][piece] = arr
+        self.codec.run_lanes(run, len(owners))
+        self._raise_for(status)
+        out = []
+        for q, r in enumerate(reqs):
+            ncol = len(range(r[3], r[4], r[5]))
+            arr = parts[q][0] if len(parts[q]) == 1 else np.concatenate(parts[q], axis=0) if parts[q] else np.zeros((0, ncol), dtype=self.dtype)
+            out.append(arr[:, 0] if r[6] else arr)
+        return out
+
+    def _lane_read_slices(self, cache, keys, requests, n_lead):
+        """One cache_read_slices call on one lane's cache: `requests` index the concatenation of the chunks `keys`; the bytes of the
+        chunks that are not resident are read first (one read per run of neighbours).  n_lead: the requests stay below that many
+        leading channels and a chunk that is not resident is decoded only that far, from a prefix of its bytes; if that falls short
+        -- or an entry was dropped between the query and the call -- everything is sent once more, whole.  -> (status, arrays)."""
+        where = {k: j for j, k in enumerate(keys)}
+        rows = [self.chunk_bounds[k + 1] - self.chunk_bounds[k] for k in keys]
+        held = self.codec.cache_query(cache, keys)                  # channels every resident entry holds (0: not resident)
+        present = [int(h) >= (n_lead or self.n_channels) for h in held]      # bytes are sent for entries that are too narrow only
         for attempt in range(2):
+            leading = bool(n_lead) and attempt == 0
             offs, lens, parts, at = [0] * len(keys), [0] * len(keys), [], 0
             need = [k for k, p in zip(keys, present) if not p]
             j = 0
             while j < len(need):                                # one read per run of neighbouring missing chunks
                 e = j
-                while not (leading and attempt == 0) and e + 1 < len(need) and need[e + 1] == need[e] + 1:
+                while not leading and e + 1 < len(need) and need[e + 1] == need[e] + 1:
                     e += 1
                 base = self.chunk_offsets[need[j]]
                 nbytes = self.chunk_offsets[need[e] + 1] - base
-                if leading and attempt == 0:                    # (one chunk: a prefix of its bytes)
+                if leading:                                     # (one chunk: a prefix of its bytes)
                     nbytes = min(nbytes, int(nbytes * n_lead / self.n_channels * 1.3) + 32768)
                 parts.append(self._pread(nbytes, base))
                 for k in need[j:e + 1]:
@@ -827,41 +973,32 @@ class Reader:
             try:
                 # the second attempt is a plain whole-chunk decode (every check runs: a chunk the prefix decoder cannot follow, or
                 # one damaged inside the prefix, gets the reference's verdict instead of a miss)
-                extra = {'n_leading': n_lead} if leading and attempt == 0 else {}
-                status, arrays = self.codec.cache_read_slices(self._dev_cache, keys, b''.join(parts), offs, lens, rows,
-                                                              self.n_channels, self.dtype, self._flags(), requests, **extra)
-                break
+                extra = {'n_leading': n_lead} if leading else {}
+                return self.codec.cache_read_slices(cache, keys, b''.join(parts), offs, lens, rows,
+                                                    self.n_channels, self.dtype, self._flags(), requests, **extra)
             except hip.HipError as e:
                 if e.code != hip.E_MISS or attempt:
                     raise
                 present = [False] * len(keys)                  # dropped since the query (or a prefix fell short): send everything
-        for k, st in zip(keys, status):
-            if st == hip.CHUNK_BADSIZE:
-                raise AssertionError("Chunk #%d does not have the expected size." % k)
-            if st != hip.CHUNK_OK:
-                raise IOError("Compressed chunk #%d is corrupted." % k)
-        return [a[:, 0] if r[6] else a for a, r in zip(arrays, reqs)]
 
     def _read_range(self, b0, b1):
         """The compressed bytes of chunks b0 .. b1-1 in one read."""
         base = self.chunk_offsets[b0]
         return self._pread(self.chunk_offsets[b1] - base, base)
 
-    def _decode_into(self, b0, b1, dst, buf=None):
+    def _decode_into(self, b0, b1, dst, buf=None, lane=None):
         """Chunks b0 .. b1-1 (consecutive in the file) decoded straight into `dst` (their rows, C-contiguous): one read (or
-        the bytes read ahead by the caller), one codec call, no copy on the host and nothing left in the chunk cache."""
+        the bytes read ahead by the caller), one codec call (on `lane` of the codec, if given), no copy on the host and
+        nothing left in the chunk cache."""
         base = self.chunk_offsets[b0]
         if buf is None:
             buf = self._read_range(b0, b1)
         offs = [self.chunk_offsets[i] - base for i in range(b0, b1)]
         lens = [self.chunk_offsets[i + 1] - self.chunk_offsets[i] for i in range(b0, b1)]
         rows = [self.chunk_bounds[i + 1] - self.chunk_bounds[i] for i in range(b0, b1)]
-        status, _ = self.codec.decompress((buf, offs, lens), rows, self.n_channels, self.dtype, self._flags(), out=dst)
-        for idx, st in zip(range(b0, b1), status):
-            if st == hip.CHUNK_BADSIZE:
-                raise AssertionError("Chunk #%d does not have the expected size." % idx)
-            if st != hip.CHUNK_OK:
-                raise IOError("Compressed chunk #%d is corrupted." % idx)
+        extra = {} if lane is None else {'lane': lane}
+        status, _ = self.codec.decompress((buf, offs, lens), rows, self.n_channels, self.dtype, self._flags(), out=dst, **extra)
+        self._raise_for(dict(zip(range(b0, b1), status)))
 
     def read_chunk(self, chunk_idx, chunk_start, chunk_length):
         """One decoded chunk, (n_samples_chunk, n_channels), C-contiguous (mtscomp.py:602-635)."""
@@ -929,8 +1066,8 @@ class Reader:
             raise ValueError("The output file %s already exists, use --overwrite or specify another "
                              "output path." % out)
         elif overwrite and out.exists():
-            out.unlink()
-        direct = getattr(self.codec, 'takes_out', False) and len(getattr(self.codec, 'devices', [0])) == 1
+            _unlink_lazily(out)
+        direct = getattr(self.codec, 'takes_out', False)
         if direct and self.n_chunks > 1:
             dsize = self._tofile_pipelined(out)
         else:
@@ -949,26 +1086,38 @@ class Reader:
             check(decompressed, self.cdata, self.cmeta, codec=self._codec)
 
     def _tofile_pipelined(self, out):
-        """The file written piece by piece with three things in flight: the compressed bytes of piece k + 1 being read, piece k
-        on the device (decoded straight into one of two reused host buffers: no fresh pages per piece), piece k - 1 being
-        written by a few threads (pwrite on disjoint ranges; file writes, reads and ctypes calls all release the GIL).  A piece
-        is a fraction of a device batch so that even a one-batch file overlaps its copies with its writes.  Returns the size."""
+        """The file written piece by piece.  Per lane of the codec (a HipCodec has one per device; piece k goes to lane k mod
+        lanes) three things are in flight: the compressed bytes of the lane's next piece being read, a piece on the device
+        (decoded straight into one of the lane's two host buffers), the piece before being written by a few threads (pwrite on
+        disjoint ranges; file writes, reads and ctypes calls all release the GIL).  A piece is a fraction of a device batch so
+        that even a one-batch file overlaps its copies with its writes.  The host buffers are page-locked when the codec has
+        such memory -- the decoded rows arrive by DMA, without a copy out of a staging piece -- and come from a pool that outlives
+        the call (pinning a few hundred MB takes longer than writing them).  Returns the size of the file."""
+        lanes = self._n_lanes() if getattr(self.codec, 'takes_out', False) else 1
         piece = max(1, min(self.batch_size, TOFILE_PIECE_CHUNKS))
         starts = list(range(0, self.n_chunks, piece))
+        lanes = max(1, min(lanes, len(starts)))
         row_bytes = self.n_channels * self.dtype.itemsize
         max_rows = max(self.chunk_bounds[min(b0 + piece, self.n_chunks)] - self.chunk_bounds[b0] for b0 in starts)
-        # page-locked buffers when the codec has them: the decoded rows arrive by DMA, without a copy out of a staging piece
-        pinned = []
-        if hasattr(self.codec, 'host_buffer'):
+        n_bufs = min(2 * lanes, len(starts))
+        take, give = getattr(self.codec, 'host_buffer_take', None), getattr(self.codec, 'host_buffer_give', None)
+        max_cbytes = max(self.chunk_offsets[min(b0 + piece, self.n_chunks)] - self.chunk_offsets[b0] for b0 in starts)
+        pinned, pinned_in = [], []
+        if take is not None and give is not None and hasattr(os, 'preadv'):
             try:
-                pinned = [self.codec.host_buffer(max_rows * row_bytes) for _ in range(min(2, len(starts)))]
+                for _ in range(n_bufs):
+                    pinned.append(take(max_rows * row_bytes))
+                for _ in range(n_bufs):                             # the compressed bytes of a piece are read into page-locked memory too:
+                    pinned_in.append(take(max_cbytes + 64))          # no fresh pages to fault in per piece, and the DMA reads them where they are
             except Exception:  # noqa: BLE001  (no page-locked memory to be had: pageable buffers do)
-                pinned = []
+                for h in pinned + pinned_in:
+                    give(h)
+                pinned, pinned_in = [], []
         if pinned:
-            bufs = [h.array.view(self.dtype).reshape(max_rows, self.n_channels) for h in pinned]
+            bufs = [h.array[:max_rows * row_bytes].view(self.dtype).reshape(max_rows, self.n_channels) for h in pinned]
         else:
-            bufs = [np.empty((max_rows, self.n_channels), dtype=self.dtype) for _ in range(min(2, len(starts)))]
-        n_writers = max(1, int(TOFILE_WRITERS))
+            bufs = [np.empty((max_rows, self.n_channels), dtype=self.dtype) for _ in range(n_bufs)]
+        n_writers = max(1, int(os.environ.get('MTSCOMP_TOFILE_WRITERS', TOFILE_WRITERS)))
         fd = os.open(str(out), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
 
         def write_piece(arr, offset):
@@ -984,47 +1133,81 @@ class Reader:
             if len(parts) == 1:
                 one(0)
             else:
-                wpool.map(one, parts)
+                wpool.map(one, parts, chunksize=1)
 
-        try:
-            with ThreadPool(n_writers) as wpool, ThreadPool(3) as aux:
-                nxt = aux.apply_async(self._read_range, (starts[0], min(starts[0] + piece, self.n_chunks)))
-                pending = [None] * len(bufs)
-                for k, b0 in enumerate(starts):
-                    b1 = min(b0 + piece, self.n_chunks)
+        def piece_range(k):
+            return starts[k], min(starts[k] + piece, self.n_chunks)
+
+        def read_piece(k, into):
+            """The compressed bytes of piece k: into the page-locked buffer `into` (-> a view of it, 16 spare bytes behind the last
+            chunk zeroed: the kernels may read a few bytes past a stream), or as a bytes object."""
+            b0, b1 = piece_range(k)
+            if into is None:
+                return self._read_range(b0, b1)
+            base, n = self.chunk_offsets[b0], self.chunk_offsets[b1] - self.chunk_offsets[b0]
+            mv, a = memoryview(into.array), 0
+            while a < n:
+                got = os.preadv(self.cdata.fileno(), [mv[a:n]], base + a)
+                if got <= 0:
+                    break
+                a += got
+            assert a == n
+            into.array[n:n + 16] = 0
+            return into.array[:n + 16]
+
+        def lane_loop(g):
+            mine = list(range(g, len(starts), lanes))            # this lane's pieces
+            my_bufs = bufs[g::lanes]
+            my_in = pinned_in[g::lanes] or [None]                   # (the read ahead fills the one the device is not reading)
+            with ThreadPool(2) as aux:                              # (one thread reads ahead, one hands pieces to the writers)
+                nxt = aux.apply_async(read_piece, (mine[0], my_in[0]))
+                pending = [None] * len(my_bufs)
+                for j, k in enumerate(mine):
+                    b0, b1 = piece_range(k)
                     buf = nxt.get()
-                    nxt = aux.apply_async(self._read_range, (starts[k + 1], min(starts[k + 1] + piece, self.n_chunks))) if k + 1 < len(starts) else None
-                    slot = k % len(bufs)
+                    nxt = aux.apply_async(read_piece, (mine[j + 1], my_in[(j + 1) % len(my_in)])) if j + 1 < len(mine) else None
+                    slot = j % len(my_bufs)
                     if pending[slot] is not None:
                         pending[slot].get()                         # (the write that used this buffer two pieces ago)
                     rows = self.chunk_bounds[b1] - self.chunk_bounds[b0]
-                    dst = bufs[slot][:rows]
-                    self._decode_into(b0, b1, dst, buf)
+                    dst = my_bufs[slot][:rows]
+                    self._decode_into(b0, b1, dst, buf, lane=g if lanes > 1 else None)
                     pending[slot] = aux.apply_async(write_piece, (dst, self.chunk_bounds[b0] * row_bytes))
                 for p in pending:
                     if p is not None:
                         p.get()
+
+        try:
+            with ThreadPool(n_writers) as wpool:
+                if lanes == 1:
+                    lane_loop(0)
+                else:
+                    self.codec.run_lanes(lane_loop, lanes)
             return os.fstat(fd).st_size
         finally:
             os.close(fd)
             del bufs
-            for h in pinned:
-                h.free()
+            for h in pinned + pinned_in:
+                give(h)
 
     def close(self):
         """mtscomp.py:745-748."""
-        if self._dev_cache is not None:
-            cache, self._dev_cache = self._dev_cache, None
-            try:
-                self.codec.cache_destroy(cache)
-            except Exception:  # pragma: no cover
-                pass
-        if self._io_pool is not None:
-            self._io_pool.close()
-            self._io_pool = None
-        if self._pin is not None:
-            self._pin.free()
-            self._pin = None
+        with self._dev_cache_lock:
+            caches, self._dev_caches = self._dev_caches or [], None
+        for cache in caches:
+            if cache is not None:
+                try:
+                    self.codec.cache_destroy(cache)
+                except Exception:  # pragma: no cover
+                    pass
+        with self._pin_lock:                                      # (a slice on another thread may be reading into the buffer)
+            if self._io_pool is not None:
+                self._io_pool.close()
+                self._io_pool = None
+            if self._pin is not None:
+                pin, self._pin = self._pin, None
+                give = getattr(self.codec, 'host_buffer_give', None)
+                (give or (lambda h: h.free()))(pin)
         if self.cdata:
             self.cdata.close()
 
@@ -1075,25 +1258,34 @@ class Reader:
                 # whole slice in device memory, and the chunk cache could not hold it anyway)
                 r0 = self.chunk_bounds[first]
                 whole = np.empty((self.chunk_bounds[last + 1] - r0, self.n_channels), dtype=self.dtype)   # whole chunks first..last
-                direct = getattr(self.codec, 'takes_out', False) and len(getattr(self.codec, 'devices', [0])) == 1
-                starts = list(range(first, last + 1, self.batch_size))
-                ahead = ThreadPool(1) if direct and len(starts) > 1 else None      # the next batch's bytes are read while this one is on the device
-                nxt = ahead.apply_async(self._read_range, (starts[0], min(starts[0] + self.batch_size, last + 1))) if ahead else None
-                for k, b0 in enumerate(starts):
-                    b1 = min(b0 + self.batch_size, last + 1)
-                    dst = whole[self.chunk_bounds[b0] - r0:self.chunk_bounds[b1] - r0]
-                    if direct:
-                        buf = nxt.get() if nxt is not None else None
-                        nxt = ahead.apply_async(self._read_range, (starts[k + 1], min(starts[k + 1] + self.batch_size, last + 1))) \
-                            if ahead and k + 1 < len(starts) else None
-                        self._decode_into(b0, b1, dst, buf)
-                    else:
-                        chunks = self.decompress_chunks(range(b0, b1))
-                        for idx in range(b0, b1):
-                            dst[self.chunk_bounds[idx] - self.chunk_bounds[b0]:self.chunk_bounds[idx + 1] - self.chunk_bounds[b0]] = chunks[idx]
-                        del chunks
-                if ahead:
-                    ahead.close()
+                direct = getattr(self.codec, 'takes_out', False)
+                per_call = max(1, self.batch_chunks) if direct else self.batch_size      # (direct: a call is one lane's, i.e. one device's)
+                starts = list(range(first, last + 1, per_call))
+                lanes = max(1, min(self._n_lanes(), len(starts))) if direct else 1
+
+                def lane_loop(g):
+                    mine = starts[g::lanes]
+                    ahead = ThreadPool(1) if direct and len(mine) > 1 else None      # the next batch's bytes are read while this one is on the device
+                    nxt = ahead.apply_async(self._read_range, (mine[0], min(mine[0] + per_call, last + 1))) if ahead else None
+                    for k, b0 in enumerate(mine):
+                        b1 = min(b0 + per_call, last + 1)
+                        dst = whole[self.chunk_bounds[b0] - r0:self.chunk_bounds[b1] - r0]
+                        if direct:
+                            buf = nxt.get() if nxt is not None else None
+                            nxt = ahead.apply_async(self._read_range, (mine[k + 1], min(mine[k + 1] + per_call, last + 1))) \
+                                if ahead and k + 1 < len(mine) else None
+                            self._decode_into(b0, b1, dst, buf, lane=g if lanes > 1 else None)
+                        else:
+                            chunks = self.decompress_chunks(range(b0, b1))
+                            for idx in range(b0, b1):
+                                dst[self.chunk_bounds[idx] - self.chunk_bounds[b0]:self.chunk_bounds[idx + 1] - self.chunk_bounds[b0]] = chunks[idx]
+                            del chunks
+                    if ahead:
+                        ahead.close()
+                if lanes == 1:
+                    lane_loop(0)
+                else:
+                    self.codec.run_lanes(lane_loop, lanes)
                 out = whole[i0 - r0:i1 - r0:item.step, :]
                 assert out.shape[0] == len(range(i0, i1, item.step or 1))
                 return out

@@ -82,6 +82,10 @@ struct Engine {
     hipEvent_t fast_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // host-API staging
     DBuf h_in, h_out;
+    // host copies of a batch's descriptors on their way to the device: they live here until the next batch replaces them, i.e.
+    // past the hipStreamSynchronize that ends the batch they belong to (hipMemcpyAsync from pageable memory is not promised to
+    // have read its source when it returns)
+    std::vector<u8> host_stage[2];
     // pinned pieces the host entry points move user memory through (pageable memory crosses the bus at a fraction of the
     // link's rate, and a fresh destination array takes its page faults on the copying thread): two pieces, so that the
     // DMA of one overlaps the host threads copying the other
@@ -389,7 +393,8 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
             int hflags[2] = {0, 0};                              // {changed, match-stage flags}
             MTS_HIP(hipMemcpyAsync(hflags, pb.changed, 8, hipMemcpyDeviceToHost, st));
             MTS_HIP(hipStreamSynchronize(st));
-            if (getenv("MTS_DEBUG_FLAGS")) fprintf(stderr, "[flags] level %d round %d changed %d match-flags %d force_ballot %d\n", level, round, hflags[0], hflags[1], force_ballot);
+            static const bool debug_flags = getenv("MTS_DEBUG_FLAGS") != nullptr;      // (read once)
+            if (debug_flags) fprintf(stderr, "[flags] level %d round %d changed %d match-flags %d force_ballot %d\n", level, round, hflags[0], hflags[1], force_ballot);
             if (hflags[1] & 1) { resort = true; break; }
             if (!hflags[0]) break;
             MTS_HIP(hipMemsetAsync(pb.changed, 0, 4, st));
@@ -623,7 +628,8 @@ static int dev_compress(Engine &E, hipStream_t st, const void *d_raw, int nc, in
 // ------------------------------------------------------------------------------------------------
 static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const long *c_off, const long *c_len,
                             const long *n_rows, int n_chunks, int nc, int sz, int flags, u8 *d_out, const long *out_off,
-                            int *status, bool accumulate_times, u8 *stream_copy_host /* debug: first chunk's stream */,
+                            int *status, int times /* 0: these stages replace the recorded ones, 1: are added, 2: are not recorded */,
+                            u8 *stream_copy_host /* debug: first chunk's stream */,
                             int nc_full = 0 /* > nc: the chunks have nc_full channels and only the first nc are decoded */,
                             bool size_verdict = true /* a chunk of another size than expected gets its check value looked at */)
 {
@@ -672,13 +678,14 @@ static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const 
         if ((rc = E.inf_scratch.ensure(inflate_scratch_bytes(n_chunks, clens.data(), nn.data())))) return rc;
     }
     {
-        std::vector<u8> hst(o_res, 0);
+        std::vector<u8> &hst = E.host_stage[0];
+        hst.assign(o_res, 0);
         memcpy(hst.data() + o_ic, ic.data(), sizeof(InfChunk) * n_chunks);
         memcpy(hst.data() + o_so, so.data(), 8 * (size_t)n_chunks);
         memcpy(hst.data() + o_nn, nn.data(), 4 * (size_t)n_chunks);
         memcpy(hst.data() + o_oo, oo.data(), 8 * (size_t)n_chunks);
         memcpy(hst.data() + o_rows, rows.data(), 4 * (size_t)n_chunks);
-        MTS_HIP(hipMemcpyAsync(dp, hst.data(), o_res, hipMemcpyHostToDevice, st));      // (pageable: staged before the call returns)
+        MTS_HIP(hipMemcpyAsync(dp, hst.data(), o_res, hipMemcpyHostToDevice, st));
     }
     E.t_begin(st);
     if ((rc = launch_inflate(st, d_cdata, d_ic, ic.data(), n_chunks, E.stream.as<u8>(), E.tokens.as<u32>(), d_res, E.adler.as<u64>(),
@@ -690,7 +697,7 @@ static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const 
     }
     MTS_HIP(hipMemcpyAsync(status, d_status, 4 * (size_t)n_chunks, hipMemcpyDeviceToHost, st));
     MTS_HIP(hipStreamSynchronize(st));
-    E.t_collect(accumulate_times);
+    if (times != 2) E.t_collect(times == 1);
     if (stream_copy_host && nn[0]) MTS_HIP(hipMemcpy(stream_copy_host, E.stream.as<u8>() + so[0], nn[0], hipMemcpyDeviceToHost));
     // A stream that parses to its end, but to another size than the caller expects: the reference inflates it whole and has its
     // adler32 checked before it looks at the size (zlib.decompress raises at mtscomp.py:618-621, the assert comes at :628).  The
@@ -710,7 +717,7 @@ static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const 
             if (o.second >= (1u << 31)) { status[i] = MTS_CHUNK_CORRUPT; continue; }     // beyond what a pass can hold: damage, by all odds
             const long rows1 = (long)o.second, off0 = 0;
             int st1 = MTS_CHUNK_CORRUPT;
-            const int rc1 = decompress_batch(E, st, d_cdata, c_off + i, c_len + i, &rows1, 1, 1, 1, 0, nullptr, &off0, &st1, true, nullptr, 0, false);
+            const int rc1 = decompress_batch(E, st, d_cdata, c_off + i, c_len + i, &rows1, 1, 1, 1, 0, nullptr, &off0, &st1, 2, nullptr, 0, false);
             if (rc1 == MTS_E_NOMEM) { status[i] = MTS_CHUNK_CORRUPT; continue; }         // (the same call: a size nobody wrote)
             if (rc1) return rc1;
             if (st1 != MTS_CHUNK_OK) status[i] = MTS_CHUNK_CORRUPT;
@@ -720,6 +727,7 @@ static int decompress_batch(Engine &E, hipStream_t st, const u8 *d_cdata, const 
 }
 
 void inflate_mark(void *engine, hipStream_t st, const char *name) { ((Engine *)engine)->t_mark(st, name); }
+u8 *inflate_host_stage(void *engine, size_t bytes) { auto &v = ((Engine *)engine)->host_stage[1]; v.assign(bytes, 0); return v.data(); }
 
 static int dev_decompress(Engine &E, hipStream_t st, const u8 *d_cdata, const long *c_off, const long *c_len, const long *n_rows,
                           int n_chunks, int nc, int sz, int flags, u8 *d_out, const long *out_off, int *status, int nc_full = 0)
@@ -741,7 +749,7 @@ static int dev_decompress(Engine &E, hipStream_t st, const u8 *d_cdata, const lo
             acc += n; j++;
         }
         int rc = decompress_batch(E, st, d_cdata, c_off + i, c_len + i, n_rows + i, j - i, nc, sz, flags, d_out, out_off + i,
-                                  status + i, !first, nullptr, nc_full);
+                                  status + i, first ? 0 : 1, nullptr, nc_full);
         if (rc) return rc;
         first = false;
         i = j;
@@ -1398,7 +1406,7 @@ int mts_debug_inflate(int device, const unsigned char *zbytes, long zlen, unsign
     if (zlen) MTS_HIP(hipMemcpy(E->h_in.p, zbytes, (size_t)zlen, hipMemcpyHostToDevice));
     // the expected size is the caller's out_cap: status BADSIZE when the stream inflates to anything else
     const long coff = 0, clen = zlen, rows = out_cap, ooff = 0;
-    rc = decompress_batch(*E, nullptr, E->h_in.as<u8>(), &coff, &clen, &rows, 1, 1, 1, 0, nullptr, &ooff, status, false, out);
+    rc = decompress_batch(*E, nullptr, E->h_in.as<u8>(), &coff, &clen, &rows, 1, 1, 1, 0, nullptr, &ooff, status, 0, out);
     if (rc) return rc;
     if (out_len) *out_len = *status == MTS_CHUNK_OK ? out_cap : 0;
     return MTS_OK;

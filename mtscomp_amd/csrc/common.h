@@ -221,5 +221,6 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
                    void *d_scratch, void *engine);
 size_t inflate_scratch_bytes(int n_chunks, const u64 *c_lens, const u32 *n_expect);
 void inflate_mark(void *engine, hipStream_t st, const char *name);   // stage timing hook (api.hip)
+u8 *inflate_host_stage(void *engine, size_t bytes);                    // zeroed host bytes the engine keeps until the next batch (api.hip)
 
 }  // namespace mts

@@ -2617,10 +2617,11 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
     // candidate / true-block slot belongs to -- ~6000 words per chunk -- is filled in on the device (the 60-chunk batch spent
     // 0.9 ms of host time and a 1.5 MB pageable copy on it before its first kernel)
     u8 *S = (u8 *)d_scratch;
-    std::vector<u8> hst(l.cand_cnt - l.so, 0);
-    u64 *h_so = (u64 *)(hst.data() + (l.so - l.so)), *h_gb = (u64 *)(hst.data() + (l.gb_off - l.so)), *h_tb = (u64 *)(hst.data() + (l.tb_off - l.so));
-    u32 *h_nn = (u32 *)(hst.data() + (l.nn - l.so));
-    InfFast *h_fast = (InfFast *)(hst.data() + (l.fast - l.so));
+    const size_t hst_bytes = l.cand_cnt - l.so;
+    u8 *hst = inflate_host_stage(engine, hst_bytes);          // (kept by the engine until the next batch: the copy below is asynchronous)
+    u64 *h_so = (u64 *)(hst + (l.so - l.so)), *h_gb = (u64 *)(hst + (l.gb_off - l.so)), *h_tb = (u64 *)(hst + (l.tb_off - l.so));
+    u32 *h_nn = (u32 *)(hst + (l.nn - l.so));
+    InfFast *h_fast = (InfFast *)(hst + (l.fast - l.so));
     {
         u64 a = 0, b2 = 0, co = 0;
         u32 to = 0;
@@ -2634,7 +2635,7 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
             co += h_fast[i].cand_cap; to += h_fast[i].true_cap;
         }
     }
-    MTS_HIP(hipMemcpyAsync(S + l.so, hst.data(), hst.size(), hipMemcpyHostToDevice, st));      // (pageable: staged before the call returns)
+    MTS_HIP(hipMemcpyAsync(S + l.so, hst, hst_bytes, hipMemcpyHostToDevice, st));
     MTS_HIP(hipMemsetAsync(S + l.cand_cnt, 0, 4 * (size_t)n_chunks, st));
     hipLaunchKernelGGL(k_inf_fill_slots, dim3(n_chunks), dim3(256), 0, st, (const InfFast *)(S + l.fast), (u32 *)(S + l.slot_chunk), (u32 *)(S + l.tslot_chunk));
     const InfFast *d_fast = (const InfFast *)(S + l.fast);

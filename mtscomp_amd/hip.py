@@ -267,16 +267,20 @@ def cache_query(cache_id, keys):
     return present
 
 
-def cache_read_rows(cache_id, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, row_begin, row_end):
+def cache_read_rows(cache_id, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, row_begin, row_end, out=None):
     """Rows [row_begin, row_end) of the concatenation of the chunks `keys` (file order).  Chunks with lens[i] == 0 must be
-    resident (HipError with code E_MISS otherwise).  Returns (status list, (row_end - row_begin, n_channels) array)."""
+    resident (HipError with code E_MISS otherwise).  Returns (status list, (row_end - row_begin, n_channels) array); `out`: a
+    C-contiguous array of exactly that shape to fill instead of a new one."""
     dtype = check_dtype(dtype)
     keys, offs, lens, rows = _longs(keys), _longs(offs), _longs(lens), _longs(n_rows)
     n = int(keys.size)
     cdata = np.frombuffer(cdata, dtype=np.uint8) if len(cdata) else np.zeros(16, dtype=np.uint8)
     if n and int((offs + lens).max()) + 16 > cdata.size:          # the kernels may read a few bytes past a stream
         cdata = np.concatenate((cdata, np.zeros(16, dtype=np.uint8)))
-    out = np.empty((int(row_end - row_begin), n_channels), dtype=dtype)
+    if out is None:
+        out = np.empty((int(row_end - row_begin), n_channels), dtype=dtype)
+    else:
+        assert out.flags.c_contiguous and out.dtype == dtype and out.shape == (int(row_end - row_begin), n_channels)
     status = np.zeros(n, dtype=np.int32)
     _check(lib().mts_cache_read_rows(int(cache_id), n, _lp(keys), _ptr(cdata), _lp(offs), _lp(lens), _lp(rows), n_channels,
                                      dtype.itemsize, _dflags(flags, dtype), int(row_begin), int(row_end), _ptr(out),
@@ -334,6 +338,52 @@ class HostBuffer:
             self.free()
         except Exception:  # noqa: BLE001
             pass
+
+
+class PinnedPool:
+    """Page-locked buffers kept between calls.  hipHostMalloc pins its pages one by one (a few hundred MB take a good part of a
+    second) and hipHostFree unpins them again: a Reader.tofile that allocated its two piece buffers per call spent more time on
+    that than on the file.  take() hands out an idle buffer of at least the size asked for (the smallest that fits, grown by
+    a quarter when a new one has to be made); give() returns it; at most `keep_bytes` stay idle, the largest first."""
+
+    def __init__(self, keep_bytes=2 << 30):
+        import threading
+        self.keep_bytes = int(keep_bytes)
+        self._idle = []
+        self._lock = threading.Lock()
+
+    def take(self, nbytes):
+        nbytes = int(nbytes)
+        with self._lock:
+            fits = [b for b in self._idle if b.nbytes >= nbytes]
+            if fits:
+                best = min(fits, key=lambda b: b.nbytes)
+                self._idle.remove(best)
+                return best
+        return HostBuffer(nbytes + nbytes // 4)
+
+    def give(self, buf):
+        if buf is None or not buf.ptr:
+            return
+        drop = []
+        with self._lock:
+            self._idle.append(buf)
+            self._idle.sort(key=lambda b: -b.nbytes)
+            while sum(b.nbytes for b in self._idle) > self.keep_bytes and len(self._idle) > 1:
+                drop.append(self._idle.pop())
+            if self._idle and self._idle[0].nbytes > self.keep_bytes:
+                drop.append(self._idle.pop(0))
+        for b in drop:
+            b.free()
+
+    def clear(self):
+        with self._lock:
+            idle, self._idle = self._idle, []
+        for b in idle:
+            b.free()
+
+
+pinned_pool = PinnedPool()
 
 
 class DevBuffer:

@@ -191,3 +191,70 @@ class LeadingOracleCodec(CachingOracleCodec):
 
     def cache_query(self, cid, keys):
         return np.array([self.cols[(cid, k)] if k in self.caches[cid] else 0 for k in keys], dtype=np.int32)
+
+
+class LaneOracleCodec(CachingOracleCodec):
+    """CachingOracleCodec with several lanes, the way HipCodec has one per device: a cache per lane (cache_create(capacity, lane)),
+    run_lanes() on host threads, decompress(..., out=, lane=) for Reader.tofile's pieces.  Records which lane served what, so the
+    CPU suite can check that chunk k is read, decoded and kept on lane k mod n_lanes and nowhere else."""
+    takes_out = True
+    takes_ranges = True
+
+    def __init__(self, n_lanes=2, **kw):
+        super().__init__(n_devices=n_lanes, **kw)
+        self.n_lanes = n_lanes
+        self.cache_lane = {}                      # cache id -> lane
+        self.lane_keys = {}                       # lane -> set of chunk keys its cache was asked for
+        self.lane_calls = []                      # (lane, n_chunks) of decompress(..., lane=)
+
+    def cache_create(self, capacity_bytes, lane=0):
+        cid = super().cache_create(capacity_bytes)
+        self.cache_lane[cid] = lane
+        return cid
+
+    def run_lanes(self, fn, n):
+        import threading
+        errors = []
+
+        def guarded(k):
+            try:
+                fn(k)
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+        threads = [threading.Thread(target=guarded, args=(k,)) for k in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+
+    def _note(self, cid, keys):
+        self.lane_keys.setdefault(self.cache_lane[cid], set()).update(int(k) for k in keys)
+
+    def cache_read_rows(self, cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, row_begin, row_end, out=None):
+        self._note(cid, keys)
+        status, got = super().cache_read_rows(cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, row_begin, row_end)
+        if out is not None:
+            out[...] = got
+            got = out
+        return status, got
+
+    def cache_read_slices(self, cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, requests):
+        self._note(cid, keys)
+        return super().cache_read_slices(cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, requests)
+
+    def decompress(self, cbufs, n_rows, n_channels, dtype, flags, out=None, lane=None):
+        if isinstance(cbufs, tuple):
+            buf, offs, lens = cbufs
+            cbufs = [bytes(memoryview(buf)[o:o + n]) for o, n in zip(offs, lens)]
+        if lane is not None:
+            self.lane_calls.append((lane, len(cbufs)))
+        status, arrays = super().decompress(cbufs, n_rows, n_channels, dtype, flags)
+        if out is not None:
+            r0 = 0
+            for nr, a in zip(n_rows, arrays):
+                if a is not None:
+                    out[r0:r0 + nr] = a
+                r0 += nr
+        return status, arrays

@@ -418,7 +418,7 @@ def test_long_slices_decode_into_the_result(tmp_cfg):
 
 
 def test_two_shards_on_one_device_match_the_goldens(tmp_cfg):
-    # HipCodec drives its devices from one host thread each (api.py: _run_shards); with devices=[0, 0] the two shard
+    # HipCodec drives its devices from one host thread each (api.py: run_lanes); with devices=[0, 0] the two shard
     # threads meet on one engine: round-robin sharding, the engine lock and the gather of the streams in chunk order
     api.set_codec(api.HipCodec(devices=[0, 0]))
     try:
@@ -437,6 +437,57 @@ def test_two_shards_on_one_device_match_the_goldens(tmp_cfg):
             r.close()
     finally:
         api.set_codec(None)
+
+
+def test_reader_and_tofile_over_two_lanes_of_one_device(tmp_cfg, monkeypatch):
+    # the in-process multi-device paths on the one device a test box has: HipCodec(devices=[0, 0]) has two lanes -- two decoded-chunk
+    # caches (chunk k in cache k mod 2), two tofile pipelines with their own page-locked buffers, long slices batch by batch on
+    # alternating lanes -- which meet on one engine.  Against the goldens' decode, numpy indexing and the file the Writer read.
+    codec = api.HipCodec(devices=[0, 0])
+    api.set_codec(codec)
+    made = []
+    real_create = hip.cache_create
+    monkeypatch.setattr(hip, 'cache_create', lambda cap, device=0: made.append(real_create(cap, device=device)) or made[-1])
+    try:
+        arr = synth_int16(0, 30450, 96, 21)                            # 21 chunks of 1450 rows
+        raw, out, outmeta, back = tmp_cfg / 'x.bin', tmp_cfg / 'x.cbin', tmp_cfg / 'x.ch', tmp_cfg / 'back.bin'
+        arr.tofile(raw)
+        mtscomp_amd.compress(raw, out, outmeta, sample_rate=1450., n_channels=96, dtype=arr.dtype, check_after_compress=False)
+        want = [O.ref_compress_chunk(arr[k * 1450:(k + 1) * 1450]) for k in range(21)]
+        assert out.read_bytes() == b''.join(want)
+        r = mtscomp_amd.decompress(out, outmeta, check_after_decompress=False)
+        for s_ in (slice(100, 1300), slice(1400, 4400, 3), slice(30440, None), slice(2900, 4350), slice(0, 11600, 7)):
+            assert np.array_equal(r[s_], arr[s_]), s_
+        assert len(made) == 2                                        # one cache per lane ...
+        held = [set(np.nonzero(hip.cache_query(c, list(range(21))))[0].tolist()) for c in made]
+        assert held[0] and held[1] and all(k % 2 == 0 for k in held[0]) and all(k % 2 == 1 for k in held[1])      # ... chunk k in cache k mod 2
+        items = [(slice(10, 50), slice(1, 5)), (slice(1200, 9000, 7), slice(None, None, 2)), slice(30400, None), (slice(3000, 3010), 4),
+                 (slice(40, 40), slice(0, 3)), (slice(1449, 1452), slice(0, 96)), (slice(0, 30450, 1450), 0)]
+        got = r.read_slices(items)
+        assert all(np.array_equal(g, arr[it]) and g.shape == arr[it].shape for g, it in zip(got, items))
+        monkeypatch.setattr(api, 'TOFILE_PIECE_CHUNKS', 3)
+        r.tofile(back, overwrite=True)                               # 7 pieces, lanes in turn
+        assert back.read_bytes() == raw.read_bytes()
+        r.tofile(back, overwrite=True)                               # once more over the existing file (the buffers come from the pool)
+        assert back.read_bytes() == raw.read_bytes()
+        r.batch_chunks = r.batch_size = 4
+        assert np.array_equal(r[700:29000], arr[700:29000])          # long slice: batches of 4 chunks on alternating lanes
+        # decompress() of a list / a range with two lanes: shards of one call
+        st, arrs = codec.decompress(want, [1450] * 21, 96, np.int16, hip.make_flags(True, False, 'F'))
+        assert st == [0] * 21 and all(np.array_equal(a, arr[k * 1450:(k + 1) * 1450]) for k, a in enumerate(arrs))
+        b = bytearray(out.read_bytes())
+        b[r.chunk_offsets[13] + 40] ^= 0x20
+        out.write_bytes(bytes(b))
+        r2 = mtscomp_amd.decompress(out, outmeta, check_after_decompress=False)
+        with pytest.raises(IOError, match='#13'):
+            r2[17400:20300]
+        with pytest.raises(IOError, match='#13'):
+            r2.tofile(back, overwrite=True)
+        assert np.array_equal(r2[0:5000], arr[0:5000])
+        r.close(); r2.close()
+    finally:
+        api.set_codec(None)
+        codec.close()
 
 
 def test_concurrent_calls_into_one_engine():

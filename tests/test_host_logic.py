@@ -348,3 +348,84 @@ def test_leading_channel_reads_send_prefixes_and_fall_back(tmp_cfg):
     got = r.read_slices([(slice(3000, 3100), slice(0, 4)), (slice(5, 5), slice(None))])
     assert np.array_equal(got[0], arr[3000:3100, 0:4]) and got[1].shape == (0, 200)
     r.close()
+
+
+@pytest.mark.parametrize('n_lanes', [2, 3])
+def test_reader_over_several_lanes(tmp_cfg, n_lanes):
+    """A codec with several lanes (HipCodec: one per device): chunk k is read, decoded and kept by lane k mod lanes only; slices,
+    rectangles that cross chunks (row and column steps included) and tofile give what numpy gives; errors name the chunk."""
+    from tests.codec_oracle import LaneOracleCodec
+    arr = (np.random.RandomState(11).randn(9000, 7) * 700).astype(np.int16)
+    codec = LaneOracleCodec(n_lanes=n_lanes, capacity_chunks=8)
+    r, _ = _write(tmp_cfg, arr, check_after_compress=False, codec=codec)             # 8 chunks of 1234 rows (the last: 362)
+    r.close()
+    r = mtscomp_amd.decompress(tmp_cfg / 'data.cbin', tmp_cfg / 'data.ch', codec=codec, check_after_decompress=False)
+    assert r.n_chunks == 8
+    for a, b, step in ((100, 1300, None), (1300, 5000, 3), (8990, 9000, None), (0, 9000, 7), (2468, 3702, None)):
+        assert np.array_equal(r[a:b:step], arr[a:b:step])
+    for lane, keys in codec.lane_keys.items():
+        assert keys and all(k % n_lanes == lane for k in keys)
+    assert sorted(k for keys in codec.lane_keys.values() for k in keys) == list(range(8))
+    items = [(slice(10, 50), slice(1, 5)), (slice(1200, 6000, 7), slice(None, None, 2)), slice(8990, None), (slice(3000, 3010), 4),
+             (slice(40, 40), slice(0, 3)), (slice(1233, 1236), slice(0, 7)), (slice(0, 9000, 1234), 0)]
+    got = r.read_slices(items)
+    assert all(np.array_equal(g, arr[it]) and g.shape == arr[it].shape for g, it in zip(got, items))
+    assert np.array_equal(r[5:8000:11, 2:6:3], arr[5:8000:11, 2:6:3])
+    # tofile: the pieces go to the lanes in turn, every lane decodes straight into its own buffers
+    monkey_piece = api.TOFILE_PIECE_CHUNKS
+    api.TOFILE_PIECE_CHUNKS = 2
+    try:
+        r.tofile(tmp_cfg / 'back.bin', overwrite=True)
+    finally:
+        api.TOFILE_PIECE_CHUNKS = monkey_piece
+    assert np.array_equal(np.fromfile(tmp_cfg / 'back.bin', dtype=np.int16).reshape(-1, 7), arr)
+    assert sorted(codec.lane_calls) == sorted((k % n_lanes, 2) for k in range(4))
+    # a long slice (more chunks than a batch): batches go to the lanes in turn, straight into the result
+    r.batch_chunks = r.batch_size = 1
+    codec.lane_calls.clear()
+    api_max = api.DEVICE_CACHE_MAX_CHUNKS
+    api.DEVICE_CACHE_MAX_CHUNKS = 1
+    try:
+        assert np.array_equal(r[600:8000], arr[600:8000])
+    finally:
+        api.DEVICE_CACHE_MAX_CHUNKS = api_max
+    assert sorted(codec.lane_calls) == sorted((j % n_lanes, 1) for j in range(7))
+    r.close()
+    assert codec.caches == {}
+    # damage in chunk 5: the slice that touches it raises with its index, from whichever lane found it
+    b = bytearray((tmp_cfg / 'data.cbin').read_bytes())
+    b[r.chunk_offsets[5] + 20] ^= 0xff
+    (tmp_cfg / 'data.cbin').write_bytes(bytes(b))
+    r2 = mtscomp_amd.decompress(tmp_cfg / 'data.cbin', tmp_cfg / 'data.ch', codec=LaneOracleCodec(n_lanes=n_lanes))
+    with pytest.raises(IOError, match='#5'):
+        r2[4000:8000]
+    with pytest.raises(IOError, match='#5'):
+        r2.read_slices([(slice(4000, 8000, 5), slice(0, 3))])
+    assert np.array_equal(r2[0:3000], arr[0:3000])
+    r2.close()
+
+
+def test_a_failed_read_leaves_the_readers_pinned_buffer_unlocked(tmp_cfg, monkeypatch):
+    """A short read of a truncated .cbin inside the page-locked read path raises the reference's AssertionError -- and the next
+    slice on the same Reader gets the same answer instead of waiting for a lock nobody releases (round-4 advisor finding)."""
+    from tests.codec_oracle import CachingOracleCodec
+
+    class Pinned:
+        def __init__(self, n):
+            self.nbytes, self.ptr = n, 1
+            self.array = np.zeros(n, dtype=np.uint8)
+
+        def free(self):
+            self.ptr = 0
+    codec = CachingOracleCodec()
+    codec.host_buffer = Pinned
+    arr = (np.random.RandomState(12).randn(5000, 4) * 300).astype(np.int16)
+    r, _ = _write(tmp_cfg, arr, check_after_compress=False, codec=codec)
+    assert np.array_equal(r[10:20], arr[10:20])                      # (the pinned path works)
+    size = (tmp_cfg / 'data.cbin').stat().st_size
+    os.truncate(tmp_cfg / 'data.cbin', size - 100)
+    for _ in range(2):
+        with pytest.raises(AssertionError):
+            r[4900:5000]
+        assert not r._pin_lock.locked()
+    r.close()
