@@ -418,9 +418,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
         if ((rc = launch_parse_count(st, d_tables, d_chunks, pb, (int)nseg, n_chunks, cfg, d_cout))) return rc;
         u32 max_nseg = 0;
         for (int i = 0; i < n_chunks; i++) if (cd[i].nseg > max_nseg) max_nseg = cd[i].nseg;
-        if (getenv("MTS_PARSE_EMIT_WALK")) {                     // (A/B: the tokens by a third walk instead of from the marks of the first two)
-            if ((rc = launch_parse_emit(st, d_stream, d_tables, d_quarter, d_chunks, pb, (int)nseg, cfg, d_tokens, d_blk_in_start, d_cout, n_chunks, max_nseg))) return rc;
-        } else if ((rc = launch_parse_emit_marks(st, d_stream, d_tables, d_quarter, d_chunks, pb, fix_rounds, d_tokens, d_blk_in_start, d_cout, n_chunks, max_nseg))) return rc;
+        if ((rc = launch_parse_emit_marks(st, d_stream, d_tables, d_quarter, d_chunks, pb, fix_rounds, d_tokens, d_blk_in_start, d_cout, n_chunks, max_nseg))) return rc;
     }
     E.t_mark(st, "parse_emit");
     if ((rc = launch_block_trees(st, d_chunks, d_blk_chunk, (int)nblk, d_tokens, d_blk_in_start, d_cout, d_blocks,

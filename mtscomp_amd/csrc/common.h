@@ -43,7 +43,11 @@ constexpr int STREAM_ALIGN = 256;
 constexpr int REL_BITS = MTS_REL_BITS;     // 18 or 19 (a match entry word holds rel : 9 bits : the low bits of byte 7)
 constexpr int HALO = 32768;                // history a tile additionally needs (>= MAX_DIST)
 constexpr int WIN = 1 << REL_BITS;         // hashed window of a tile
-constexpr int TILE = WIN - HALO;           // positions a match-stage workgroup owns (229376 / 491520)
+#ifndef MTS_TILE
+#define MTS_TILE (WIN - HALO)
+#endif
+constexpr int TILE = MTS_TILE;             // positions a match-stage workgroup owns (229376 / 491520; anything up to WIN - HALO)
+static_assert(TILE > 0 && TILE + HALO <= WIN && TILE % 64 == 0, "a tile and its history fit the window");
 constexpr u32 REL_MASK = (1u << REL_BITS) - 1;
 
 constexpr int SEG = 1024;                  // parse segment (positions per speculative walker); measured 512: 9.0, 1024: 8.5, 2048: 8.9, 4096: 9.3 ms (fixpoint + emit)
@@ -170,9 +174,6 @@ int launch_parse_count(hipStream_t st, const u32 *d_tables, const ChunkDesc *d_c
 int launch_parse_emit_marks(hipStream_t st, const u8 *d_stream, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks,
                             ParseBufs pb, int rounds_done, u32 *d_tokens, u32 *d_blk_in_start, ChunkOut *d_cout, int n_chunks, u32 max_nseg);
 size_t parse_marks_words(size_t n_segs);
-int launch_parse_emit(hipStream_t st, const u8 *d_stream, const u32 *d_tables, const u32 *d_quarter,
-                      const ChunkDesc *d_chunks, ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens,
-                      u32 *d_blk_in_start, ChunkOut *d_cout, int n_chunks, u32 max_nseg);
 int launch_block_trees(hipStream_t st, const ChunkDesc *d_chunks, const u32 *d_blk_chunk, int total_blk_cap,
                        const u32 *d_tokens, const u32 *d_blk_in_start, const ChunkOut *d_cout,
                        BlockRec *d_blocks, u32 *d_blk_codes, u32 *d_blk_hdr, int fast /* levels 1..3: deflate_fast's flush points */);

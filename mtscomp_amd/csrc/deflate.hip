@@ -392,31 +392,36 @@ __device__ __forceinline__ u32 lazy_step(RDU &&rdu /* p0 .. p0 + 3: no bounds ch
 // Staged walkers.  A wave walks 64 segments, one lane each, and every lane is somewhere else in memory: read entry by entry,
 // each load instruction of the wave touched 64 different cache lines (the address unit takes a cycle per line: ~70 cycles per
 // load instruction and CU, measured by doubling the loads) and every step of the walk waited for memory (75 % of the wave
-// cycles).  So the table is brought in window by window: the wave loads, for every lane, the PARSE_WIN_N entries that start at
+// cycles).  So the table is brought in window by window: the wave loads, for every lane, the PARSE_WIN entries that start at
 // the lane's current window base -- 16 bytes per lane and instruction with neighbouring lanes on neighbouring addresses,
-// several lanes' windows per instruction -- into LDS, and the lanes then walk PARSE_WIN positions in LDS (a window holds four
-// entries more than it is wide: the lazy evaluation looks a position or two ahead; whatever lies farther comes from memory,
-// rarely).  The loads of the next window are in flight while the current one is walked.
+// eight lanes' windows per instruction -- into LDS, and the lanes then walk PARSE_WIN positions there.
+// Round 5: a window is exactly one 128-byte line of the table (PARSE_WIN = 32 entries at a 32-entry boundary).  The lazy
+// evaluation looks up to four entries ahead; until round 4 a window therefore held 32 entries and advanced by 28, so that nearly
+// every window straddled two lines and -- with 67 MB of windows in flight and the L2 keeping nothing of them -- every line of
+// the table was fetched twice (FETCH_SIZE 5.75 GB raw = 2.07 x the table once doubled, §6 of DESIGN.md; 2.86 GB now).  The
+// look-ahead of a window's last four positions is the head of the NEXT window, which is in flight while the window is walked:
+// the walk of a window stops four positions short, the heads of the next window (the first 16-byte piece of every lane's, by
+// then in the registers of the lanes that asked for them) go behind the window in LDS, and the last four positions follow.
+// (A ring of two whole windows per lane was built first: 16.6 KB of LDS per wave instead of 9.5, 9 waves per CU instead of 16
+// -- and 2.90 ms against 2.47 with half the bytes: what the kernel lives on is waves per CU, not bandwidth.)
 // The 64 segments of a wave are consecutive segments of ONE chunk (the grid is laid out per chunk), so the window of lane l
 // starts at  base + l * SEG + w * PARSE_WIN: plain arithmetic, no pointer per lane.
 // ------------------------------------------------------------------------------------------------
-#ifndef MTS_PARSE_WIN_N
-#define MTS_PARSE_WIN_N 32
-#endif
-constexpr int PARSE_WIN_N = MTS_PARSE_WIN_N;        // entries staged per window (32 or 64)
-constexpr int PARSE_WIN = PARSE_WIN_N - 4;          // positions walked per window (window bases stay 16-byte aligned)
-constexpr int PARSE_WIN_PITCH = PARSE_WIN_N + 1;    // LDS pitch in words: odd, so the lanes' reads fall into different banks
-constexpr int PARSE_NWIN = (SEG + PARSE_WIN - 1) / PARSE_WIN;
-constexpr int PARSE_PIECES = PARSE_WIN_N / 4;       // 16-byte pieces per window = lanes per window = load instructions per window step
-constexpr int PARSE_BYTES_PITCH = PARSE_WIN_N / 4 + 1;      // words per lane of the staged stream bytes (emit walk)
-constexpr int PARSE_BPIECES = PARSE_WIN_N / 16;     // 16-byte pieces of a lane's PARSE_WIN_N stream bytes
+constexpr int PARSE_WIN = 32;                       // entries per window: one 128-byte line per lane
+constexpr int PARSE_AHEAD = 4;                      // entries of the next window kept behind it
+constexpr int PARSE_ROW = PARSE_WIN + PARSE_AHEAD;  // entries a lane has in LDS
+constexpr int PARSE_WIN_PITCH = PARSE_ROW + 1;      // LDS pitch in words: odd, so the lanes' reads fall into different banks
+constexpr int PARSE_NWIN = SEG / PARSE_WIN;
+constexpr int PARSE_PIECES = PARSE_WIN / 4;         // 16-byte pieces per window = lanes per window = load instructions per window step
+static_assert(SEG % PARSE_WIN == 0 && 64 % PARSE_PIECES == 0, "windows tile a segment, eight lanes load one");
 
 struct ParseStage {
     u32 *win;                   // LDS [64][PARSE_WIN_PITCH]
-    const u32 *base;            // table entry of the first lane's segment start
+    const u32 *base;            // table entry of the first lane's segment start (a 128-byte boundary)
     int nlanes;                 // lanes that have a segment (the others' windows hold something harmless)
-    u32x4_v pre[PARSE_PIECES];  // the pieces of the next window this lane has asked for
-    __device__ __forceinline__ void request(int w)              // ask for window w (of every lane)
+    // ask for window w of every lane: lane l takes piece l % 8 of the windows of lanes it * 8 + l / 8.  head_only: only the first
+    // piece (the four entries the last window of a segment looks ahead to)
+    __device__ __forceinline__ void request(int w, u32x4_v (&pre)[PARSE_PIECES], bool head_only = false) const
     {
         const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -424,10 +429,10 @@ struct ParseStage {
             int wl = it * (64 / PARSE_PIECES) + lane / PARSE_PIECES;
             wl = wl < nlanes ? wl : nlanes - 1;
             const u32 *src = base + (size_t)wl * SEG + (size_t)w * PARSE_WIN + 4 * (lane % PARSE_PIECES);
-            pre[it] = *(gptr_uint4)(u64)src;
+            if (!head_only || lane % PARSE_PIECES == 0) pre[it] = *(gptr_uint4)(u64)src;
         }
     }
-    __device__ __forceinline__ void land()                      // the requested window goes to LDS
+    __device__ __forceinline__ void land(const u32x4_v (&pre)[PARSE_PIECES]) const      // the requested window becomes the rows' window
     {
         const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -436,43 +441,25 @@ struct ParseStage {
             d[0] = pre[it].x; d[1] = pre[it].y; d[2] = pre[it].z; d[3] = pre[it].w;
         }
     }
-};
-// the same for the stream's bytes (the emitting walk: literals), PARSE_WIN_N bytes per lane and window at 4-byte alignment
-struct ParseStageBytes {
-    u32 *win;                   // LDS [64][PARSE_BYTES_PITCH]
-    const u8 *base;             // stream byte of the first lane's segment start
-    int nlanes;
-    u32x4_v pre[PARSE_BPIECES];
-    __device__ __forceinline__ void request(int w)
+    __device__ __forceinline__ void land_heads(const u32x4_v (&pre)[PARSE_PIECES]) const      // its first piece goes behind the rows' current window
     {
         const int lane = threadIdx.x & 63;
+        if (lane % PARSE_PIECES == 0) {
 #pragma unroll
-        for (int it = 0; it < PARSE_BPIECES; it++) {
-            const int idx = it * 64 + lane;                     // piece idx of window-lane idx / PARSE_BPIECES
-            int wl = idx / PARSE_BPIECES;
-            wl = wl < nlanes ? wl : nlanes - 1;
-            const u8 *src = base + (size_t)wl * SEG + (size_t)w * PARSE_WIN + 16 * (idx % PARSE_BPIECES);
-            const u32x4_a4 v = *(gptr_uint4_a4)(u64)src;
-            pre[it] = u32x4_v{v.x, v.y, v.z, v.w};
-        }
-    }
-    __device__ __forceinline__ void land()
-    {
-        const int lane = threadIdx.x & 63;
-#pragma unroll
-        for (int it = 0; it < PARSE_BPIECES; it++) {
-            const int idx = it * 64 + lane;
-            u32 *d = win + (idx / PARSE_BPIECES) * PARSE_BYTES_PITCH + 4 * (idx % PARSE_BPIECES);
-            d[0] = pre[it].x; d[1] = pre[it].y; d[2] = pre[it].z; d[3] = pre[it].w;
+            for (int it = 0; it < PARSE_PIECES; it++) {
+                u32 *d = win + (it * (64 / PARSE_PIECES) + lane / PARSE_PIECES) * PARSE_WIN_PITCH + PARSE_WIN;
+                d[0] = pre[it].x; d[1] = pre[it].y; d[2] = pre[it].z; d[3] = pre[it].w;
+            }
         }
     }
 };
-// readers of a lane whose window starts at position wb (entries wb .. wb + PARSE_WIN_N - 1 are in the LDS row `row`)
-#define MTS_PARSE_STAGED_READERS(T, TQ, row, wb)                                                                  \
-    auto rdu = [&](u32 q) -> u32 { return (row)[q - (wb)]; };     /* (q within the window: a step's first four entries are) */ \
+// readers of a lane whose window starts at position wb (entries wb .. wb + rv - 1 are in the LDS row `row`: rv = PARSE_WIN while
+// the heads of the next window are not there yet, PARSE_ROW after)
+#define MTS_PARSE_STAGED_READERS(T, TQ, row, wb, rv)                                                              \
+    auto rdu = [&](u32 q) -> u32 { return (row)[q - (wb)]; };     /* (q within the row: a step's first four entries are) */ \
     auto rd = [&](u32 q) -> u32 {                                                                                 \
         const u32 o = q - (wb);                                                                                   \
-        if (o < (u32)PARSE_WIN_N) return (row)[o];                                                                \
+        if (o < (rv)) return (row)[o];                                                                            \
         return *(gptr_u32c)(u64)&(T)[q];                                                                          \
     };                                                                                                            \
     auto rdq = [&](u32 q) -> u32 { return *(gptr_u32c)(u64)&(TQ)[q]; };
@@ -564,8 +551,11 @@ struct MarkW {
 };
 // marks of the step that went from p0 to the token at mp (literals before it)
 #define MTS_MARK_STEP(mk, s, p0, mp, ml, mside) (mk).step((p0) - (s), (mp) - (p0), (ml) ? 2u + (mside) : 1u)
+#ifndef MTS_PARSE_SPEC_WAVES
+#define MTS_PARSE_SPEC_WAVES 4          // waves per SIMD the speculative walk's registers leave room for
+#endif
 
-__global__ __launch_bounds__(64) void k_parse_spec(const u32 *__restrict__ tables, const u32 *__restrict__ quarter, const ChunkDesc *__restrict__ chunks,
+__global__ __launch_bounds__(64, MTS_PARSE_SPEC_WAVES) void k_parse_spec(const u32 *__restrict__ tables, const u32 *__restrict__ quarter, const ChunkDesc *__restrict__ chunks,
                                                    ParseBufs pb, int n_segs, LevelCfg cfg)
 {
     __shared__ u32 win[64 * PARSE_WIN_PITCH];
@@ -579,28 +569,38 @@ __global__ __launch_bounds__(64) void k_parse_spec(const u32 *__restrict__ table
     const u32 s = (k0seg + (u32)(valid ? lane : nlanes - 1)) * SEG, n = ch.n;
     const u32 segend = valid ? min(s + (u32)SEG, n) : 0;
     const u32 *T = tables + ch.stream_off, *TQ = quarter + ch.stream_off;
-    ParseStage st{win, T + (size_t)k0seg * SEG, nlanes};
+    const ParseStage st{win, T + (size_t)k0seg * SEG, nlanes};
     const u32 *row = win + lane * PARSE_WIN_PITCH;
     u32 *cp = pb.cp + (u64)g * 16;
     u32 pos = s, mp, ml, md, ms, cnt = 0, k = 1;
     MarkW mk;
     mk.start(mark_base(pb.marks, (u32)g), 0, valid);
-    st.request(0);
+    u32x4_v pre[PARSE_PIECES];
+    st.request(0, pre);
     for (int w = 0; w < PARSE_NWIN; w++) {
         __syncthreads();                                         // (everybody is done with the window before)
-        st.land();
+        st.land(pre);
         __syncthreads();
         mk.anchor(((u32)w * PARSE_WIN) >> 4);                    // (the marks below this window: stored before the next loads are asked for)
-        if (w + 1 < PARSE_NWIN) st.request(w + 1);
+        st.request(w + 1, pre, w + 1 == PARSE_NWIN);             // (of the window behind the segment only what the last one looks ahead to)
         const u32 wb = s + (u32)w * PARSE_WIN;
         const u32 wend = min(wb + (u32)PARSE_WIN, segend);
-        MTS_PARSE_STAGED_READERS(T, TQ, row, wb)
-        while (pos < wend) {
-            while (k < 8 && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++; }
-            const u32 p0 = pos;
-            pos = lazy_step<true>(rdu, rd, rdq, pos, n, cfg, mp, ml, md, ms);
-            cnt += mp - p0 + 1;
-            MTS_MARK_STEP(mk, s, p0, mp, ml, ms);
+#pragma unroll 1
+        for (int part = 0; part < 2; part++) {                   // all but the last four positions; then those, with the next window's heads behind the row
+            const u32 rv = part ? (u32)PARSE_ROW : (u32)PARSE_WIN;
+            const u32 lim = part ? wend : min(wend, wb + (u32)(PARSE_WIN - PARSE_AHEAD));
+            if (part) {
+                st.land_heads(pre);
+                __syncthreads();
+            }
+            MTS_PARSE_STAGED_READERS(T, TQ, row, wb, rv)
+            while (pos < lim) {
+                while (k < 8 && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++; }
+                const u32 p0 = pos;
+                pos = lazy_step<true>(rdu, rd, rdq, pos, n, cfg, mp, ml, md, ms);
+                cnt += mp - p0 + 1;
+                MTS_MARK_STEP(mk, s, p0, mp, ml, ms);
+            }
         }
         if (!__any(pos < segend)) break;
     }
@@ -734,113 +734,6 @@ __global__ __launch_bounds__(256) void k_seg_scan(const ChunkDesc *__restrict__ 
     }
 }
 
-// The final walk.  A lane's tokens go to consecutive addresses, but the 64 lanes of a wave are in 64 different
-// segments: stored one by one, every token would be a 4-byte partial write.  So the tokens of a round are
-// collected in a short LDS row per lane and the rows are written out one after the other (consecutive
-// lanes write consecutive tokens of ONE segment).
-#ifndef MTS_PTCAP
-#define MTS_PTCAP 16
-#endif
-constexpr int PTCAP = MTS_PTCAP;           // tokens buffered per lane (0: every token straight to memory).  Measured with the staged walk, whose
-                                           // LDS footprint sets how many waves a CU holds: 8: 4.0 ms, 12: 3.9, 16: 3.6, 24: 3.7, 32: 3.85, 0: 5.2
-constexpr int PTROW = PTCAP + 1;
-constexpr int PTROWS_LDS = PTCAP ? 64 * PTROW : 1;
-
-__global__ __launch_bounds__(64) void k_parse_emit(const u8 *__restrict__ stream, const u32 *__restrict__ tables, const u32 *__restrict__ quarter,
-                                                   const ChunkDesc *__restrict__ chunks, ParseBufs pb, int n_segs,
-                                                   LevelCfg cfg, u32 *__restrict__ tokens, u32 *__restrict__ blk_in_start,
-                                                   ChunkOut *__restrict__ cout)
-{
-    __shared__ u32 tokb[PTROWS_LDS];
-    __shared__ u32 win[64 * PARSE_WIN_PITCH];
-    __shared__ u32 bwin[64 * PARSE_BYTES_PITCH];
-    const int lane = threadIdx.x;
-    const u32 ci = blockIdx.y;                                  // grid: x = wave within the chunk, y = chunk
-    const ChunkDesc ch = chunks[ci];
-    const u32 k0seg = blockIdx.x * 64;
-    if (k0seg >= ch.nseg) return;
-    const int nlanes = (int)min(64u, ch.nseg - k0seg);
-    const bool valid = lane < nlanes;
-    const int gc = (int)(ch.seg0 + k0seg) + (valid ? lane : nlanes - 1);
-    const u32 s = (k0seg + (u32)(valid ? lane : nlanes - 1)) * SEG, n = ch.n;
-    const u32 segend = valid ? min(s + (u32)SEG, n) : 0;
-    const u32 *T = tables + ch.stream_off, *TQ = quarter + ch.stream_off;
-    const u8 *b = stream + ch.stream_off;
-    u32 *tk = tokens + ch.tok_off;
-    u32 *bis = blk_in_start + ch.blk0;
-    // the staged windows are laid over [s, s + SEG) like the speculative walk's; the walk itself starts at the segment's entry,
-    // at or a little beyond s (the exit of the segment before)
-    ParseStage st{win, T + (size_t)k0seg * SEG, nlanes};
-    ParseStageBytes sb{bwin, b + (size_t)k0seg * SEG, nlanes};
-    const u32 *row = win + lane * PARSE_WIN_PITCH;
-    const u32 *brow = bwin + lane * PARSE_BYTES_PITCH;
-    u32 pos = valid ? pb.entry[gc] : 0, mp, ml, md, k = pb.tokbase[gc];
-    u32 kmod = k % BLOCK_TOKENS;                 // k mod BLOCK_TOKENS, kept by counting
-    u32 k0 = k;                                  // token index of the first token in this lane's LDS row
-    auto put = [&](u32 v, u32 at) {
-        if (kmod == 0) bis[k / BLOCK_TOKENS] = at;                           // first token of a block: where its input starts
-        kmod = kmod + 1 == (u32)BLOCK_TOKENS ? 0 : kmod + 1;
-        const u32 j = k - k0;
-        if (j < (u32)PTCAP) tokb[lane * PTROW + j] = v; else tk[k] = v;      // (a step longer than the row: straight to memory)
-        k++;
-    };
-    auto flush = [&]() {                         // the rows go to memory one after the other, the lanes side by side
-        if (PTCAP == 0) { k0 = k; return; }
-        __builtin_amdgcn_wave_barrier();
-        const u32 nloc = min(k - k0, (u32)PTCAP);
-        const int sub = lane & 31, half = lane >> 5;
-#pragma unroll 1
-        for (int rb = 0; rb < 64; rb += 16) {                   // two rows per store: lanes 0..31 one row, 32..63 the next
-            u32 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = tokb[(rb + 2 * j + half) * PTROW + sub];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int r0 = rb + 2 * j;
-                typedef __attribute__((address_space(1))) u32 *gptr_u32;      // (a global pointer: a generic one makes flat stores)
-                gptr_u32 d0 = (gptr_u32)readlane_u64((u64)(tk + k0), r0), d1 = (gptr_u32)readlane_u64((u64)(tk + k0), r0 + 1);
-                const u32 c0 = (u32)__builtin_amdgcn_readlane((int)nloc, r0), c1 = (u32)__builtin_amdgcn_readlane((int)nloc, r0 + 1);
-                if ((u32)sub < (half ? c1 : c0)) (half ? d1 : d0)[sub] = v[j];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        k0 = k;
-    };
-    st.request(0);
-    sb.request(0);
-    for (int w = 0; w < PARSE_NWIN; w++) {
-        __syncthreads();
-        st.land();
-        sb.land();
-        __syncthreads();
-        if (w + 1 < PARSE_NWIN) { st.request(w + 1); sb.request(w + 1); }
-        const u32 wb = s + (u32)w * PARSE_WIN;
-        const u32 wend = min(wb + (u32)PARSE_WIN, segend);
-        MTS_PARSE_STAGED_READERS(T, TQ, row, wb)
-        auto byte_at = [&](u32 q) -> u32 {                       // the stream's byte at q (a literal)
-            const u32 o = q - wb;
-            if (o < (u32)PARSE_WIN_N) return (brow[o >> 2] >> (8 * (o & 3))) & 0xffu;
-            return b[q];
-        };
-        for (;;) {
-            while (pos < wend && (PTCAP == 0 || k - k0 < (u32)PTCAP)) {
-                const u32 p0 = pos;
-                u32 ms;
-                pos = lazy_step<true>(rdu, rd, rdq, pos, n, cfg, mp, ml, md, ms);
-                if (pos >= n) cout[ci].trailing = (ml == 0) ? 1u : 0u;       // last token of the chunk
-                const u32 nlit = ml ? mp - p0 : 1;
-                for (u32 q = 0; q < nlit; q++) put(byte_at(p0 + q) << 16, p0 + q);
-                if (ml) put(((ml - MIN_MATCH) << 16) | md, mp);
-            }
-            if (!__any(pos < wend)) break;                       // (whoever stopped before the window's end has a full row)
-            flush();
-        }
-        if (PTCAP && __any(k - k0 >= (u32)PTCAP)) flush();      // a full row: make room before the next window
-        if (!__any(pos < segend)) break;
-    }
-    flush();
-}
-
 // The tokens from the marks (see MarkW): a wave per segment, a lane per word of 16 positions.  The segment's first token index
 // is known (k_seg_scan), a wave scan of the words' token counts gives every lane its own, and a token is the stream's byte or
 // the table's entry at the marked position: nothing is walked.  (The walking version above read the table a second time entry
@@ -958,16 +851,6 @@ int launch_parse_count(hipStream_t st, const u32 *d_tables, const ChunkDesc *d_c
     MTS_HIP(hipGetLastError());
     return MTS_OK;
 }
-int launch_parse_emit(hipStream_t st, const u8 *d_stream, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks,
-                      ParseBufs pb, int n_segs, LevelCfg cfg, u32 *d_tokens, u32 *d_blk_in_start, ChunkOut *d_cout, int n_chunks, u32 max_nseg)
-{
-    if (n_segs == 0) return MTS_OK;
-    hipLaunchKernelGGL(k_parse_emit, dim3((max_nseg + 63) / 64, n_chunks), dim3(64), 0, st, d_stream, d_tables, d_quarter, d_chunks, pb, n_segs,
-                       cfg, d_tokens, d_blk_in_start, d_cout);
-    MTS_HIP(hipGetLastError());
-    return MTS_OK;
-}
-
 // ================================================================================================
 // F: levels 1..3 (zlib's deflate_fast) -- orc_deflate()'s fast branch is the oracle
 // ================================================================================================

@@ -113,18 +113,26 @@ def test_deflate_bytes_ballot_sort(monkeypatch):
         assert hip.debug_deflate(data, 6) == zlib.compress(data, 6), name
 
 
-def test_deflate_bytes_emitting_walk(monkeypatch):
-    """The tokens are written from the marks the parse walks leave (k_parse_emit_marks); MTS_PARSE_EMIT_WALK=1 has them written by
-    a third walk instead (the version before, kept for A/B runs).  Both must give zlib's bytes, also where a re-walk meets the
-    first one (every segment), where it does not (zeros: the parse never re-synchronises) and at levels whose lazy evaluation
-    moves on more than twelve times in a step."""
+def test_deflate_bytes_from_the_marks_of_the_walks():
+    """The tokens are written from the marks the parse walks leave (k_parse_emit_marks).  They must give zlib's bytes where a
+    re-walk meets the first one (every segment), where it does not (zeros: the parse never re-synchronises), at levels whose lazy
+    evaluation moves on more than twelve times in a step, and where a step looks past the two table windows a walker has in LDS
+    (long lazy runs at the end of a segment's last window)."""
     big = inputs.repeats(300000, 21) + bytes(200000) + inputs.textlike(150000, 22) + inputs.skewlen(150000, 23)
-    for env in (None, '1'):
-        if env:
-            monkeypatch.setenv('MTS_PARSE_EMIT_WALK', env)
-        for level in (6, 9):
-            for data in (CASES['text_100k'], CASES['ar1_64ch_4k'], CASES['zeros_999468'], big):
-                assert hip.debug_deflate(data, level) == zlib.compress(data, level), (env, level, len(data))
+    # lazy runs across segment ends: at every position a match one longer than the one before (a staircase), laid over the
+    # last bytes of several 1024-position segments
+    r = np.random.RandomState(77)
+    stairs = bytearray(r.randint(0, 256, size=40000).astype(np.uint8).tobytes())
+    unit = bytes(r.randint(0, 256, size=64).astype(np.uint8).tobytes())
+    for segend in (4096, 9216, 20480, 30720):
+        for j in range(12):                                           # position segend - 14 + j starts a copy of unit[j:] of length 3 + j ... + tail
+            at = segend - 14 + j
+            stairs[at:at + 1] = unit[j:j + 1]
+        stairs[segend - 14:segend + 50] = unit
+        stairs[segend - 300:segend - 300 + 64] = unit
+    for level in (6, 9):
+        for data in (CASES['text_100k'], CASES['ar1_64ch_4k'], CASES['zeros_999468'], big, bytes(stairs)):
+            assert hip.debug_deflate(data, level) == zlib.compress(data, level), (level, len(data))
 
 
 def test_deflate_block_boundaries():
