@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -1249,6 +1250,10 @@ static int cache_ensure(DevCache *c, Engine *E, int n_chunks, const long *chunk_
         return MTS_OK;
     };
     if (miss.empty()) return all_resident();
+    static const bool times = getenv("MTS_CACHE_TIMES") != nullptr;      // (where a cold read's time goes: stderr, one line per call)
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count(); };
+    double t_h2d = 0, t_dec = 0;
     const int m = (int)miss.size();
     const u64 row_bytes = (u64)n_cols * itemsize;              // of what is decoded and kept
     std::vector<long> coff(m), clen(m), rows(m), ooff(m);
@@ -1264,9 +1269,11 @@ static int cache_ensure(DevCache *c, Engine *E, int n_chunks, const long *chunk_
     if ((rc = E->h_out.ensure(otot + 256))) return rc;
     for (int k = 0; k < m; k++)
         MTS_HIP(hipMemcpyAsync(E->h_in.as<u8>() + coff[k], cdata + c_offsets[miss[k]], (size_t)clen[k], hipMemcpyHostToDevice, nullptr));
+    if (times) { (void)hipStreamSynchronize(nullptr); t_h2d = since(); }
     rc = dev_decompress(*E, nullptr, E->h_in.as<u8>(), coff.data(), clen.data(), rows.data(), m, n_cols, itemsize, flags,
                         E->h_out.as<u8>(), ooff.data(), st.data(), n_channels);
     if (rc) return rc;
+    if (times) t_dec = since();
     for (int k = 0; k < m; k++) {
         const int i = miss[k];
         if (st[k] == MTS_CHUNK_NEEDMORE) {
@@ -1284,6 +1291,7 @@ static int cache_ensure(DevCache *c, Engine *E, int n_chunks, const long *chunk_
         c->used += e.cap;
         c->map[chunk_keys[i]] = e;
     }
+    if (times) { (void)hipStreamSynchronize(nullptr); fprintf(stderr, "[cache] %d chunks: copy in %.3f ms, decode %.3f ms, entries %.3f ms\n", m, t_h2d, t_dec - t_h2d, since() - t_dec); }
     return all_resident();
 }
 

@@ -2363,10 +2363,22 @@ __global__ __launch_bounds__(64) void k_inf_lz_settle(InfResult *__restrict__ re
     if (ci < n_chunks && res[ci].status == LZ_STATUS_RETRY) res[ci].status = MTS_CHUNK_OK;
 }
 
+// The windows of a chunk's segments, one after the other: window k = the last 32 KiB of segment k - 1, its cells translated with
+// window k - 1.  A step depends on the step before through those look-ups alone -- where its cells come from does not -- so the
+// cells of step k + 1 are asked for before step k is translated, and the window a step translates with is the one the step
+// before left in LDS.  A thread takes 32 CONSECUTIVE positions at a 32-byte boundary of the stream: 64 bytes of cells and 32
+// bytes of the stream in six 16-byte loads, 32 bytes of window in two 16-byte stores; a window is therefore kept ROTATED, the
+// byte of stream position q at q mod 32 KiB (k_inf_translate looks it up the same way), and the 32-byte block that holds the
+// window's two ends is put together byte by byte, by thread 0 (its lower end) and the threads that take one extra position of
+// the upper end each.
+// (Until round 5 a thread took its 32 cells one by one, each three dependent trips to memory -- granule flag, cell, byte of the
+// previous window, which lived in memory behind a __threadfence --: 24 us per step, i.e. 0.75 ms for the 32 segments a chunk is
+// cut into when few chunks are decoded: a quarter of a cold read.)
 __global__ __launch_bounds__(1024) void k_inf_windows(const InfChunk *__restrict__ chunks, const InfResult *__restrict__ res,
                                                       const LzPlan *__restrict__ plan, const u16 *__restrict__ sym, u8 *__restrict__ win,
                                                       const u8 *__restrict__ stream, const u8 *__restrict__ gflag)
 {
+    __shared__ __attribute__((aligned(16))) u8 wl[2][LZ_WIN];      // the window made by the step before, the one being made (both rotated)
     const int ci = blockIdx.x;
     if (res[ci].status != MTS_CHUNK_OK) return;
     const LzPlan *pl = plan + ci;
@@ -2375,16 +2387,59 @@ __global__ __launch_bounds__(1024) void k_inf_windows(const InfChunk *__restrict
     const u16 *cells = sym + chunks[ci].stream_off;
     const u8 *bytes = stream + chunks[ci].stream_off;                 // (granules without a flag left the resolver as bytes)
     const u8 *gf = gflag + (chunks[ci].stream_off >> 12) + ci;
-    u8 *W = win + (size_t)ci * LZ_MAXSEG * LZ_WIN;                  // W[k] = window of segment k
-    for (u32 k = 1; k < nseg; k++) {
+    u8 *W = win + (size_t)ci * LZ_MAXSEG * LZ_WIN;                  // W[k] = window of segment k, rotated
+    const u32 t = threadIdx.x;
+    struct Blk { uint4 c[4]; uint4 b[2]; u32 f; u32 xc; };             // a thread's 32 positions: cells, bytes, granule flag; its extra position's cell or byte
+    // what step k translates.  Thread t: positions (p0 / 32 + t) * 32 ... + 31 -- thread 0's block starts p0 % 32 positions before
+    // the window, and as many positions of the window's upper end lie in a block of their own: thread j < p0 % 32 takes one.
+    auto fetch = [&](u32 k, Blk &x) {
         const u32 p0 = pl->b0[k] - LZ_WIN;                           // >= b0[k - 1]: segments are at least a window long
-        const u8 *prev = W + (size_t)(k - 1) * LZ_WIN;
-        for (u32 i = threadIdx.x; i < LZ_WIN; i += 1024) {
-            const u32 c = gf[(p0 + i) / LZ_FLUSH] ? cells[p0 + i] : bytes[p0 + i];
-            W[(size_t)k * LZ_WIN + i] = (u8)(c < 256 ? c : prev[(c - 256) & (LZ_WIN - 1)]);
+        const u32 q = ((p0 >> 5) + t) << 5;
+        x.f = gf[q / LZ_FLUSH];                                      // (a block lies in one granule)
+#pragma unroll
+        for (int j = 0; j < 4; j++) x.c[j] = *(const uint4 *)(cells + q + 8 * j);
+        x.b[0] = *(const uint4 *)(bytes + q); x.b[1] = *(const uint4 *)(bytes + q + 16);
+        x.xc = 0;
+        if (t < (p0 & 31)) { const u32 qx = (p0 & ~31u) + LZ_WIN + t; x.xc = gf[qx / LZ_FLUSH] ? cells[qx] : bytes[qx]; }
+    };
+    Blk cur, nxt;
+    fetch(1, cur);
+    for (u32 k = 1; k < nseg; k++) {
+        if (k + 1 < nseg) fetch(k + 1, nxt);
+        const u32 p0 = pl->b0[k] - LZ_WIN, rot = pl->b0[k - 1];     // window k - 1 holds position q at q % 32 Ki; its byte i is position b0[k - 1] - 32 Ki + i
+        const u8 *prev = wl[(k - 1) & 1];                           // (step 1 never looks: segment 0 has no cells that point before it)
+        u8 *mine = wl[k & 1];
+        auto tr = [&](u32 c) -> u32 { return c < 256 ? c : (u32)prev[(rot + c - 256) & (LZ_WIN - 1)]; };
+        const u32 cw[16] = {cur.c[0].x, cur.c[0].y, cur.c[0].z, cur.c[0].w, cur.c[1].x, cur.c[1].y, cur.c[1].z, cur.c[1].w,
+                            cur.c[2].x, cur.c[2].y, cur.c[2].z, cur.c[2].w, cur.c[3].x, cur.c[3].y, cur.c[3].z, cur.c[3].w};
+        const u32 bw[8] = {cur.b[0].x, cur.b[0].y, cur.b[0].z, cur.b[0].w, cur.b[1].x, cur.b[1].y, cur.b[1].z, cur.b[1].w};
+        u32 ow[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            u32 v = bw[j];
+            if (cur.f) {
+                const u32 a = cw[2 * j], b2 = cw[2 * j + 1];
+                v = tr(a & 0xffff) | (tr(a >> 16) << 8) | (tr(b2 & 0xffff) << 16) | (tr(b2 >> 16) << 24);
+            }
+            ow[j] = v;
         }
-        __threadfence();
+        const u32 slot = (((p0 >> 5) + t) << 5) & (LZ_WIN - 1);
+        const u32 lowcut = p0 & 31;                                  // positions of thread 0's block below the window
+        if (t == 0 && lowcut) {
+            for (u32 j = lowcut; j < 32; j++) { const u8 v = (u8)(ow[j >> 2] >> (8 * (j & 3))); mine[slot + j] = v; W[(size_t)k * LZ_WIN + slot + j] = v; }
+        } else {
+            *(uint4 *)(mine + slot) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            *(uint4 *)(mine + slot + 16) = make_uint4(ow[4], ow[5], ow[6], ow[7]);
+            *(uint4 *)(W + (size_t)k * LZ_WIN + slot) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            *(uint4 *)(W + (size_t)k * LZ_WIN + slot + 16) = make_uint4(ow[4], ow[5], ow[6], ow[7]);
+        }
+        if (t < lowcut) {                                            // one position of the window's upper end: the same block as thread 0's, its lower bytes
+            const u8 v = (u8)tr(cur.xc);
+            const u32 sx = ((p0 & ~31u) & (LZ_WIN - 1)) + t;
+            mine[sx] = v; W[(size_t)k * LZ_WIN + sx] = v;
+        }
         __syncthreads();
+        cur = nxt;
     }
 }
 
@@ -2465,7 +2520,7 @@ __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restric
         for (int j = 0; j < 16; j++) {
             const u32 c = (cw[j >> 1] >> (16 * (j & 1))) & 0xffff;
             u32 v = c;
-            if (c >= 256) { const u32 k = (k_lo == k_hi) ? k_lo : seg_of(p + j); v = W[(size_t)k * LZ_WIN + ((c - 256) & (LZ_WIN - 1))]; }
+            if (c >= 256) { const u32 k = (k_lo == k_hi) ? k_lo : seg_of(p + j); v = W[(size_t)k * LZ_WIN + ((b0s[k] + c - 256) & (LZ_WIN - 1))]; }      // (the windows are kept rotated: k_inf_windows)
             ow[j >> 2] |= (v & 0xff) << (8 * (j & 3));
             s1 += v & 0xff; s2 += (u32)j * (v & 0xff);
         }
@@ -2474,7 +2529,8 @@ __global__ __launch_bounds__(256) void k_inf_translate(const InfChunk *__restric
     } else {
         for (u32 q = p; q < r.n_out; q++) {
             const u32 c = cells[q];
-            const u8 v = (u8)(c < 256 ? c : W[(size_t)seg_of(q) * LZ_WIN + ((c - 256) & (LZ_WIN - 1))]);
+            const u32 kq = seg_of(q);
+            const u8 v = (u8)(c < 256 ? c : W[(size_t)kq * LZ_WIN + ((b0s[kq] + c - 256) & (LZ_WIN - 1))]);
             out[q] = v;
             sa += v; sb += (nn - q) * (u64)v;
         }
