@@ -25,13 +25,30 @@ enum { MAX_DIST = 32506, MAX_MATCH = 258, CHAIN = 128, QCHAIN = 32, NICE = 128, 
 static u32 hash_of(const u8 *b) { return ((b[0] << 10) ^ (b[1] << 5) ^ b[2]) & 0x7fff; }
 static u32 umul24(u32 a, u32 b) { return (a & 0xffffff) * (b & 0xffffff); }
 static u32 h24(u32 x) { return (umul24(x, 0x9E3779u) >> 19) & 31; }
+#ifndef KEYS
+#define KEYS 1            // 0: the keys of rounds 2-4, 1: round 5 (one multiplication for the first three), 9: a strong mixer (what 6 + 5 + 5 + 5 bits can do at best)
+#endif
+static u32 mix32(u32 x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 static void keys(const u8 *b, u32 k[6])
 {
     const u32 e1 = b[3] | (b[4] << 8) | (b[5] << 16) | ((u32)b[6] << 24);
+#if KEYS == 0
     k[0] = (umul24(e1 & 0xff, 0x9E3779u) >> 18) & 63;
     k[1] = h24(e1 & 0xffff);
     k[2] = h24(e1 & 0xffffff);
     k[3] = h24((e1 ^ (e1 >> 11)) & 0xffffff);
+#elif KEYS == 1
+    { const u32 p = umul24(e1, 0x9E3779u); k[0] = (p >> 2) & 63; k[1] = (p >> 11) & 31; k[2] = (p >> 19) & 31; }
+    k[3] = h24((e1 ^ (e1 >> 11)) & 0xffffff);
+#elif KEYS == 2
+    { const u32 p = umul24(e1, 0x9E3779u); k[0] = (p >> 2) & 63; k[1] = (p >> 11) & 31; k[2] = (p >> 19) & 31; }
+    { const u32 q = umul24(e1 ^ (e1 >> 12), 0x9E3779u); k[3] = (q >> 19) & 31; }
+#elif KEYS == 3
+    { const u32 p = umul24(e1, 0x9E3779u); k[0] = (p >> 2) & 63; k[1] = (p >> 11) & 31; k[2] = (p >> 19) & 31; }
+    { const u32 q = (e1 >> 8) * 0x9E3779B1u; k[3] = ((q >> 27) ^ k[0]) & 31; }
+#elif KEYS == 9
+    k[0] = mix32(e1 & 0xff) & 63; k[1] = mix32(e1 & 0xffff) & 31; k[2] = mix32(e1 & 0xffffff) & 31; k[3] = mix32(e1) & 31;
+#endif
     k[4] = b[7] & 31;                                    // extra levels (what-if): byte 7 (5 bits, exact within them), byte 8
     k[5] = (b[8] ^ (b[8] >> 3)) & 31;
 }
