@@ -743,11 +743,20 @@ __global__ __launch_bounds__(256) void k_parse_emit_marks(const u8 *__restrict__
                                                           u32 *__restrict__ tokens, u32 *__restrict__ blk_in_start, ChunkOut *__restrict__ cout)
 {
     __shared__ u32 tokst[4][64 * 16];                           // a wave's tokens of one pass, in order: they leave by consecutive lanes
-    const u32 ci = blockIdx.y;                                  // grid: x = four segments of the chunk, y = chunk
+    const u32 ci = blockIdx.y;                                  // grid: x = four segments of the chunk (see below), y = chunk
     const ChunkDesc ch = chunks[ci];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 seg = blockIdx.x * 4 + (u32)wave;
-    if (seg >= ch.nseg) return;
+    // The marks of 64 consecutive segments are interleaved (mark_base): a 128-byte line of them belongs to 32 segments, i.e. to
+    // eight of these workgroups -- which, numbered in a row, are one on each XCD: every XCD's L2 fetched every line of marks for
+    // itself (FETCH_SIZE 2 x 4.94 GB where table, stream and marks are 7.4: round 5).  So the 16 workgroups of a group of 64
+    // segments are put on ONE XCD, one after the other: block 8 j + c (XCD c: the grid's width is a multiple of 128) takes
+    // quad j % 16 of segment group (j / 16) * 8 + c.  FETCH_SIZE 2 x 3.65 GB = what the kernel needs -- and the same 1.55-1.65 ms:
+    // the lines the other XCDs had fetched came out of the Infinity Cache, not out of HBM; the kernel moves its 8.5 GB at 5.5 TB/s
+    // either way.  (All of a segment's loads asked for before any is waited for, independent of its marks: 96 registers, 20 waves
+    // per CU instead of 32, 1.83 ms -- built, measured, not kept.)
+    const u32 xj = blockIdx.x >> 3, xc = blockIdx.x & 7;
+    const u32 seg = ((((xj >> 4) * 8 + xc) * 16 + (xj & 15)) * 4 + (u32)wave) - (ch.seg0 & 63);      // (the chunk's first segment need not start a group: segment numbers count from the group's start)
+    if (seg >= ch.nseg) return;                                 // (also what lies before the chunk's first segment: a huge number)
     const u32 g = ch.seg0 + seg, s = seg * SEG;
     const u32 entry = pb.entry[g], ex = exits[g], k0 = pb.tokbase[g], ntok = cout[ci].ntok;
     const u32 *T = tables + ch.stream_off, *TQ = quarter + ch.stream_off;
@@ -812,7 +821,8 @@ int launch_parse_emit_marks(hipStream_t st, const u8 *d_stream, const u32 *d_tab
 {
     if (max_nseg == 0) return MTS_OK;
     const u32 *exits = ((rounds_done - 1) & 1) ? pb.exit_a : pb.exit_b;      // where the last fix round left the exits
-    hipLaunchKernelGGL(k_parse_emit_marks, dim3((max_nseg + 3) / 4, n_chunks), dim3(256), 0, st, d_stream, d_tables, d_quarter, d_chunks, pb, exits,
+    // (width: quads of 4 segments, 63 segments of slack for a chunk whose first segment is not the first of its group of 64, rounded up to 16 quads on each of 8 XCDs)
+    hipLaunchKernelGGL(k_parse_emit_marks, dim3((max_nseg + 63 + 3) / 4 / 128 * 128 + 128, n_chunks), dim3(256), 0, st, d_stream, d_tables, d_quarter, d_chunks, pb, exits,
                        d_tokens, d_blk_in_start, d_cout);
     MTS_HIP(hipGetLastError());
     return MTS_OK;
