@@ -255,7 +255,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     const size_t table_words = align_up(stream_bytes + 64, 64);
     if ((rc = E.tables.ensure(table_words * 4 * (level < 4 ? 1 : 2)))) return rc;
     if ((rc = E.tokens.ensure((toff + 64) * 4))) return rc;
-    if ((rc = E.segbuf.ensure((size_t)(nseg + 64) * 4 * (7 + 16) + 256))) return rc;
+    if ((rc = E.segbuf.ensure((size_t)(nseg + 64) * 4 * (7 + parse_cp_words()) + 256))) return rc;
     if ((rc = E.blk.ensure((size_t)(nblk + 1) * (sizeof(BlockRec) + 8) + 256))) return rc;
     if ((rc = E.blkcodes.ensure((size_t)(nblk + 1) * BLK_CODE_WORDS * 4))) return rc;
     if ((rc = E.blkhdr.ensure((size_t)(nblk + 1) * BLK_HDR_WORDS * 4))) return rc;

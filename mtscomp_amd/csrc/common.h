@@ -174,6 +174,7 @@ int launch_parse_count(hipStream_t st, const u32 *d_tables, const ChunkDesc *d_c
 int launch_parse_emit_marks(hipStream_t st, const u8 *d_stream, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks,
                             ParseBufs pb, int rounds_done, u32 *d_tokens, u32 *d_blk_in_start, ChunkOut *d_cout, int n_chunks, u32 max_nseg);
 size_t parse_marks_words(size_t n_segs);
+size_t parse_cp_words();                                          // words of checkpoints per segment
 int launch_block_trees(hipStream_t st, const ChunkDesc *d_chunks, const u32 *d_blk_chunk, int total_blk_cap,
                        const u32 *d_tokens, const u32 *d_blk_in_start, const ChunkOut *d_cout,
                        BlockRec *d_blocks, u32 *d_blk_codes, u32 *d_blk_hdr, int fast /* levels 1..3: deflate_fast's flush points */);

@@ -473,7 +473,11 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int k)
 // segment end) and the token count it records checkpoints: the first base position at or beyond
 // s + k * PARSE_CP (k = 1..7) and the tokens emitted before it.  A later walk from a corrected entry only
 // has to run until it lands on a recorded checkpoint: from there on the two walks are the same walk.
-constexpr int PARSE_CP = SEG / 8;
+#ifndef MTS_PARSE_NCP
+#define MTS_PARSE_NCP 8
+#endif
+constexpr int PARSE_NCP = MTS_PARSE_NCP;           // checkpoints per segment + 1 (8: every 128 positions)
+constexpr int PARSE_CP = SEG / PARSE_NCP;
 
 // The walks also leave MARKS: two bits per position of what the walk did there -- 0 nothing (inside a copy), 1 a literal, 2 a
 // copy taken from the table's entry of the position, 3 a copy taken from the side table's -- in MARK_WORDS words per segment
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(64, MTS_PARSE_SPEC_WAVES) void k_parse_spec(const u
     const u32 *T = tables + ch.stream_off, *TQ = quarter + ch.stream_off;
     const ParseStage st{win, T + (size_t)k0seg * SEG, nlanes};
     const u32 *row = win + lane * PARSE_WIN_PITCH;
-    u32 *cp = pb.cp + (u64)g * 16;
+    u32 *cp = pb.cp + (u64)g * (2 * PARSE_NCP);
     u32 pos = s, mp, ml, md, ms, cnt = 0, k = 1;
     MarkW mk;
     mk.start(mark_base(pb.marks, (u32)g), 0, valid);
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(64, MTS_PARSE_SPEC_WAVES) void k_parse_spec(const u
             }
             MTS_PARSE_STAGED_READERS(T, TQ, row, wb, rv)
             while (pos < lim) {
-                while (k < 8 && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++; }
+                while (k < (u32)PARSE_NCP && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[PARSE_NCP + k - 1] = cnt; k++; }
                 const u32 p0 = pos;
                 pos = lazy_step<true>(rdu, rd, rdq, pos, n, cfg, mp, ml, md, ms);
                 cnt += mp - p0 + 1;
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(64, MTS_PARSE_SPEC_WAVES) void k_parse_spec(const u
     }
     if (!valid) return;
     mk.finish(pos - s);
-    for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }      // checkpoints past the exit
+    for (; k < (u32)PARSE_NCP; k++) { cp[k - 1] = pos; cp[PARSE_NCP + k - 1] = cnt; }      // checkpoints past the exit
     pb.entry[g] = s;
     pb.exit_a[g] = pos;
     pb.cnt[g] = cnt;
@@ -621,21 +625,21 @@ __device__ __forceinline__ u32 parse_rewalk(const u32 *__restrict__ T, const u32
     const u32 s = pb.seg_start[g], n = ch.n;
     const u32 segend = min(s + (u32)SEG, n);
     MTS_PARSE_GLOBAL_READERS(T, TQ)
-    u32 *cp = pb.cp + (u64)g * 16;
+    u32 *cp = pb.cp + (u64)g * (2 * PARSE_NCP);
     const u32 old_cnt = pb.cnt[g];
     u32 pos = ne, mp, ml, md, ms, cnt = 0, k = 1;
     MarkW mk;
     mk.start(mark_base(pb.marks, g), ne - s, true);
     while (pos < segend) {
         bool merged = false;
-        while (k < 8 && pos >= s + k * PARSE_CP) {
+        while (k < (u32)PARSE_NCP && pos >= s + k * PARSE_CP) {
             if (cp[k - 1] == pos) { merged = true; break; }
-            cp[k - 1] = pos; cp[8 + k - 1] = cnt; k++;               // this walk's own checkpoint
+            cp[k - 1] = pos; cp[PARSE_NCP + k - 1] = cnt; k++;               // this walk's own checkpoint
         }
         if (merged) {
             // same walk from here on: keep the exit (and the marks), shift the counts of the remaining checkpoints
-            const u32 at_old = cp[8 + k - 1];
-            for (u32 q = k; q < 8; q++) cp[8 + q - 1] = cp[8 + q - 1] - at_old + cnt;
+            const u32 at_old = cp[PARSE_NCP + k - 1];
+            for (u32 q = k; q < (u32)PARSE_NCP; q++) cp[PARSE_NCP + q - 1] = cp[PARSE_NCP + q - 1] - at_old + cnt;
             pb.cnt[g] = cnt + (old_cnt - at_old);
             mk.merge(pos - s);
             return old_exit;
@@ -647,7 +651,7 @@ __device__ __forceinline__ u32 parse_rewalk(const u32 *__restrict__ T, const u32
         MTS_MARK_STEP(mk, s, p0, mp, ml, ms);
     }
     mk.finish(pos - s);
-    for (; k < 8; k++) { cp[k - 1] = pos; cp[8 + k - 1] = cnt; }
+    for (; k < (u32)PARSE_NCP; k++) { cp[k - 1] = pos; cp[PARSE_NCP + k - 1] = cnt; }
     pb.cnt[g] = cnt;
     return pos;
 }
@@ -814,6 +818,7 @@ __global__ __launch_bounds__(256) void k_parse_emit_marks(const u8 *__restrict__
     }
 }
 
+size_t parse_cp_words() { return 2 * (size_t)PARSE_NCP; }
 size_t parse_marks_words(size_t n_segs) { return (n_segs + 64) / 64 * 64 * MARK_WORDS; }
 
 int launch_parse_emit_marks(hipStream_t st, const u8 *d_stream, const u32 *d_tables, const u32 *d_quarter, const ChunkDesc *d_chunks,
