@@ -190,10 +190,8 @@ def measured_traffic(kernel, n_chunks, nc):
     process).  Only valid for the profiled workload (60 chunks x 385 ch) and for a kernel the profile lists; null otherwise."""
     if n_chunks != 60 or nc != 385:
         return None, None
-    for name in ('r4_traffic.json', 'r3_traffic.json', 'r2_traffic.json', 'r1_traffic.json'):
+    for name in sorted((q.name for q in (ROOT / 'profiles').glob('r*_traffic.json')), key=lambda n: -int(n[1:].split('_')[0])):      # newest round first
         p = ROOT / 'profiles' / name
-        if not p.exists():
-            continue
         d = json.loads(p.read_text())
         per = d.get('kernels', {d.get('kernel'): d.get('traffic_bytes_per_launch')})
         if per.get(kernel) is not None:

@@ -77,7 +77,7 @@ struct Engine {
     std::mutex mu;
     hipStream_t own = nullptr;
     // compress workspace
-    DBuf stream, sort_a, sort_b, tables, tokens, marks, segbuf, blk, blkcodes, blkhdr, desc, adler, misc;
+    DBuf stream, sort_a, sort_b, sort_ws, tables, tokens, marks, segbuf, blk, blkcodes, blkhdr, desc, adler, misc;
     DBuf fast_lists, fast_state;         // levels 1..3: candidate lists of two phases, per-chunk state of the in-order walk
     hipStream_t fast_st = nullptr;       // ... and the stream the lists are made on, with its events (lists ready x2, lists read x2, inputs ready)
     hipEvent_t fast_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -143,7 +143,7 @@ struct Engine {
     }
     void release_all()
     {
-        DBuf *all[] = {&stream, &sort_a, &sort_b, &tables, &tokens, &marks, &segbuf, &blk, &blkcodes, &blkhdr, &desc,
+        DBuf *all[] = {&stream, &sort_a, &sort_b, &sort_ws, &tables, &tokens, &marks, &segbuf, &blk, &blkcodes, &blkhdr, &desc,
                        &adler, &misc, &h_in, &h_out, &inf_scratch, &inf_desc, &segsums, &fast_lists, &fast_state};
         for (DBuf *b : all) b->release();
         geo_n.clear();
@@ -250,6 +250,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     const size_t marks_words = parse_marks_words((size_t)nseg + 64);
     if ((rc = E.sort_a.ensure((sort_n > marks_words ? sort_n : marks_words) * 4))) return rc;
     if ((rc = E.sort_b.ensure(sort_n * 4))) return rc;
+    if ((rc = E.sort_ws.ensure(hash_sort_ws_bytes((int)tiles.size())))) return rc;
     // one word per position (levels 1..3: the inverse map) + for levels 4..9 the side table of the quarter-budget results, which is
     // written and read at a fraction of a percent of the positions only
     const size_t table_words = align_up(stream_bytes + 64, 64);
@@ -340,7 +341,7 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
     u32 *d_inv = (u32 *)d_tables;                             // levels 1..3: the inverse map lives where the other levels keep the candidate tables
     int fix_rounds = 0;                                       // parallel fix rounds of the parse that counted (they say where the exits are)
     for (;;) {
-        if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, force_ballot))) return rc;
+        if ((rc = launch_hash_sort(st, d_stream, d_tiles, (int)tiles.size(), tmp_k, srt_k, force_ballot, E.sort_ws.p))) return rc;
         E.t_mark(st, force_ballot == 1 ? "hash_sort_retry" : "hash_sort");
         int round = 0;
         bool resort = false;

@@ -149,8 +149,9 @@ int launch_gather_slices(hipStream_t st, const GatherChunk *d_chunks, int n_chun
                          int n_channels, int itemsize, u8 *d_out);
 
 // deflate.hip
+size_t hash_sort_ws_bytes(int n_tiles);                            // the one-pass sort's per-tile records
 int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp, u32 *d_sorted,
-                     int force_ballot /* 1: ballot ranking, 2 (test hook): sort, then damage the run order */);
+                     int force_ballot, void *d_ws);
 constexpr int MATCH_SINK_BYTES = 65536;         // behind the flag words, 256 bytes after the first: where the lanes of the match stage that own no position store (match.hip)
 int launch_match(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, const u32 *d_sorted, u32 *d_tables, u32 *d_quarter,
                  LevelCfg cfg, u32 *d_flags /* [0] |= 1: a hash run out of position order; [63 ...]: MATCH_SINK_BYTES of sink */,

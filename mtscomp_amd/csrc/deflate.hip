@@ -240,9 +240,13 @@ __global__ __launch_bounds__(1024) void k_probe_lds_order(u32 *bad, int iters)
     if (nbad) atomicAdd(bad, nbad);
 }
 
+struct OpTile;                                               // (the one-pass sort's per-tile record, below)
+__device__ __forceinline__ bool op_two_pass(const OpTile *ot, u32 tile);
 __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles,
-                                                    u32 *__restrict__ tmp, u32 *__restrict__ sorted, int lane_ordered)
+                                                    u32 *__restrict__ tmp, u32 *__restrict__ sorted, int lane_ordered,
+                                                    const OpTile *__restrict__ only /* null: every tile; else the tiles the one-pass sort left to this one */)
 {
+    if (only && !op_two_pass(only, blockIdx.x)) return;
     const TileDesc td = tiles[blockIdx.x];
     __shared__ u32 cnt[SORT_WAVES][256];
     __shared__ u32 cnt2[SORT_WAVES][1 << SORT_B2];
@@ -290,6 +294,248 @@ __global__ __launch_bounds__(SORT_NT) void k_hash_sort(const u8 *__restrict__ st
     // whatever its stores look like)
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// One-pass hash sort (round 5).  A recording's positions fall into few of the 32768 hash buckets (~970 per tile on the synthetic
+// recordings: int16 deltas are small), so the 15-bit hash can be ranked in ONE scatter instead of two radix passes that write
+// and read the 32-bit keys twice (28 GB per launch for 6.3 GB of sorted keys): a tile's live buckets get dense numbers in
+// ascending hash order -- the same order the two passes produce, so the sorted keys are the same words -- and the keys go
+// straight from the stream to their place.  Stability (positions ascending inside a bucket: the hash chains) by construction:
+// a tile is cut into slices of OP_SLICE consecutive positions, a slice is a workgroup whose 8 waves take consecutive eighths,
+// and a key's destination is  bucket start + keys of the bucket in earlier slices + in earlier waves of its slice + in earlier
+// instructions / lower lanes of its wave (the lane-ordered LDS atomic the two-pass kernel ranks with, guarded the same way).
+//   k_op_live     per tile (8 workgroups): bitmap of the hashes that occur                     [1 LDS read per key]
+//   k_op_prefix   per tile: bucket numbers = prefix popcounts of the bitmap; tiles with more than OP_LMAX live buckets (uniform
+//                 random data) or fewer than OP_MIN_KEYS keys are left to the two-pass kernel
+//   k_op_count    per slice: keys per bucket                                                    [2 LDS reads + 1 atomic per key]
+//   k_op_scan     per tile: bucket starts, and per slice and bucket the keys of earlier slices
+//   k_op_scatter  per slice: per-wave counts, then rank and store                               [~8 LDS operations per key]
+// The 64 workgroups of a tile's slices run on ONE XCD, like the match stage's (blockIdx -> tile as there): the tile's 1 MB of
+// sorted keys, written four bytes at a time, and the counts between the kernels stay in that XCD's L2 until they are complete.
+// Scratch: an OpTile per tile (8 KB) and, in the tile's part of the two-pass kernel's first-pass buffer, 6 KB per slice.
+// ------------------------------------------------------------------------------------------------
+#ifndef MTS_OP_SLICE
+#define MTS_OP_SLICE 8192
+#endif
+constexpr int OP_SLICE = MTS_OP_SLICE;              // keys per slice = per workgroup of k_op_count / k_op_scatter
+constexpr int OP_TILE_SLICES = WIN / OP_SLICE;       // slices of a full tile = workgroups of a tile side by side on its XCD
+#ifndef MTS_OP_WAVES
+#define MTS_OP_WAVES 16
+#endif
+constexpr int OP_WAVES = MTS_OP_WAVES;
+constexpr int OP_NT = OP_WAVES * 64;
+constexpr int OP_KPL = OP_SLICE / (OP_WAVES * 64);   // keys per lane
+constexpr int OP_LMAX = 1024;                        // live buckets a tile may have
+constexpr int OP_MIN_KEYS = 2 * OP_SLICE;            // smaller tiles: the two-pass kernel (their part of the scratch buffer is too small)
+constexpr int OP_ROW_WORDS = 512 + 1024;             // a slice's row in the scratch: 1024 counts (u16), 1024 offsets (u32)
+constexpr int OP_LIVE_PARTS = 8;                     // workgroups of k_op_live per tile
+struct OpTile {
+    uint2 bp[1024];                                  // .x: which of the hashes 32 w .. 32 w + 31 occur, .y: live buckets below hash 32 w (side by side: a key's bucket is ONE 8-byte LDS read)
+    u32 live, two_pass;
+    u32 pad[62];
+};
+__device__ __forceinline__ bool op_two_pass(const OpTile *ot, u32 tile) { return ot[tile].two_pass != 0; }
+__device__ __forceinline__ u32 op_slices(u32 wlen) { return (wlen + OP_SLICE - 1) / OP_SLICE; }
+// the workgroups of one tile side by side on one XCD (block b runs on XCD b % 8): tile and part of it for this block
+__device__ __forceinline__ bool op_tile_part(int n_tiles, u32 parts, u32 &tile, u32 &part)
+{
+    const u32 xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    tile = (jb / parts) * 8 + xcd; part = jb % parts;
+    return tile < (u32)n_tiles;
+}
+static unsigned op_grid(int n_tiles, unsigned parts) { return 8u * (((unsigned)n_tiles + 7) / 8) * parts; }
+
+// four consecutive positions' hashes from the eight bytes at position p (a multiple of 4: one 8-byte load instead of the two
+// 4-byte loads per position of gld_u32_unaligned)
+typedef u32 u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ u32x2_a4 op_load8(const u8 *s, u32 p) { return *(const __attribute__((address_space(1))) u32x2_a4 *)(u64)(s + p); }
+__device__ __forceinline__ u32 op_hash_at(u32x2_a4 x, int k /* 0 .. 3 */) { return sort_hash(k ? __builtin_amdgcn_alignbyte(x.y, x.x, (u32)k) : x.x); }
+
+__global__ __launch_bounds__(512) void k_op_live(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles, OpTile *__restrict__ ot)
+{
+    __shared__ u32 bm[1024];
+    u32 tile, part;
+    if (!op_tile_part(n_tiles, OP_LIVE_PARTS, tile, part)) return;
+    const TileDesc td = tiles[tile];
+    if (td.wlen < (u32)OP_MIN_KEYS) return;
+    const u32 per = ((td.wlen + OP_LIVE_PARTS - 1) / OP_LIVE_PARTS + 3) & ~3u, beg = min(part * per, td.wlen), end = min(beg + per, td.wlen);
+    if (beg >= end) return;
+    const u8 *s = stream + td.stream_off + td.w;                   // (4-byte aligned: stream_off and w are multiples of 64)
+    for (int i = threadIdx.x; i < 1024; i += 512) bm[i] = 0;
+    __syncthreads();
+    constexpr int U = 8;                                          // loads in flight per lane: 32 positions
+    for (u32 i0 = beg + 4 * threadIdx.x; i0 < end; i0 += 4 * 512 * U) {
+        u32x2_a4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) v[k] = op_load8(s, min(i0 + 4u * 512 * k, (end - 1) & ~3u));
+#pragma unroll
+        for (int k = 0; k < U; k++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (i0 + 4u * 512 * k + q < end) {
+                    const u32 h = op_hash_at(v[k], q), bit = 1u << (h & 31);
+                    if (!(bm[h >> 5] & bit)) atomicOr(&bm[h >> 5], bit);   // (nearly always set already: a read, not an atomic)
+                }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 512) if (bm[i]) atomicOr(&ot[tile].bp[i].x, bm[i]);
+}
+
+__global__ __launch_bounds__(1024) void k_op_prefix(const TileDesc *__restrict__ tiles, OpTile *__restrict__ ot)
+{
+    __shared__ u32 wsum[16];
+    const u32 tile = blockIdx.x, w = threadIdx.x;
+    const u32 c = (u32)__builtin_popcount(ot[tile].bp[w].x);
+    u32 tot;
+    const u32 ex = wave_excl_scan_u32(c, tot);
+    if ((w & 63) == 0) wsum[w >> 6] = tot;
+    __syncthreads();
+    u32 before = 0, all = 0;
+    for (u32 q = 0; q < 16; q++) { if (q < (w >> 6)) before += wsum[q]; all += wsum[q]; }
+    ot[tile].bp[w].y = before + ex;
+    if (w == 0) { ot[tile].live = all; ot[tile].two_pass = (tiles[tile].wlen < (u32)OP_MIN_KEYS || all > (u32)OP_LMAX) ? 1u : 0u; }
+}
+
+// a key's bucket number: live buckets below its hash
+__device__ __forceinline__ u32 op_bucket(const uint2 *bp, u32 h)
+{
+    const uint2 e = bp[h >> 5];
+    return e.y + (u32)__builtin_popcount(e.x & ((1u << (h & 31)) - 1u));
+}
+
+constexpr int OP_CNT_NT = 512;                      // threads of k_op_count (16 waves: 1.72 ms against 1.44)
+__global__ __launch_bounds__(OP_CNT_NT) void k_op_count(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles,
+                                                        const OpTile *__restrict__ ot, u32 *__restrict__ scratch)
+{
+    __shared__ uint2 bp[1024];
+    __shared__ u32 cnt[OP_LMAX];
+    u32 tile, slice;
+    if (!op_tile_part(n_tiles, OP_TILE_SLICES, tile, slice)) return;
+    if (ot[tile].two_pass) return;
+    const TileDesc td = tiles[tile];
+    if (slice >= op_slices(td.wlen)) return;
+    const u8 *s = stream + td.stream_off + td.w;
+    for (int i = threadIdx.x; i < 1024; i += OP_CNT_NT) { bp[i] = ot[tile].bp[i]; cnt[i] = 0; }
+    const u32 beg = slice * OP_SLICE, end = min(beg + (u32)OP_SLICE, td.wlen);
+    constexpr int U = OP_SLICE / (4 * OP_CNT_NT);                 // 8-byte loads per lane: four consecutive positions each
+    static_assert(OP_SLICE % (4 * OP_CNT_NT) == 0, "whole loads");
+    u32x2_a4 v[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) v[k] = op_load8(s, min(beg + 4u * (OP_CNT_NT * k + threadIdx.x), (end - 1) & ~3u));
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < U; k++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (beg + 4u * (OP_CNT_NT * k + threadIdx.x) + q < end) atomicAdd(&cnt[op_bucket(bp, op_hash_at(v[k], q))], 1u);
+    __syncthreads();
+    u16 *row = (u16 *)(scratch + td.sorted_off + (size_t)slice * OP_ROW_WORDS);
+    for (int i = threadIdx.x; i < 512; i += OP_CNT_NT) ((u32 *)row)[i] = cnt[2 * i] | (cnt[2 * i + 1] << 16);      // (a slice has at most OP_SLICE < 65536 keys)
+}
+
+__global__ __launch_bounds__(1024) void k_op_scan(const TileDesc *__restrict__ tiles, const OpTile *__restrict__ ot, u32 *__restrict__ scratch)
+{
+    __shared__ u32 wsum[16];
+    const u32 tile = blockIdx.x, b = threadIdx.x;
+    if (ot[tile].two_pass) return;
+    const TileDesc td = tiles[tile];
+    const u32 ns = op_slices(td.wlen);
+    u32 *rows = scratch + td.sorted_off;
+    u32 total = 0;
+    for (u32 sl = 0; sl < ns; sl++) total += ((const u16 *)(rows + (size_t)sl * OP_ROW_WORDS))[b];
+    u32 tot;
+    const u32 ex = wave_excl_scan_u32(total, tot);
+    if ((b & 63) == 0) wsum[b >> 6] = tot;
+    __syncthreads();
+    u32 run = ex;
+    for (u32 q = 0; q < (b >> 6); q++) run += wsum[q];
+    for (u32 sl = 0; sl < ns; sl++) {
+        u32 *row = rows + (size_t)sl * OP_ROW_WORDS;
+        const u32 c = ((const u16 *)row)[b];
+        row[512 + b] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(OP_NT) void k_op_scatter(const u8 *__restrict__ stream, const TileDesc *__restrict__ tiles, int n_tiles,
+                                                    const OpTile *__restrict__ ot, const u32 *__restrict__ scratch, u32 *__restrict__ sorted)
+{
+    // The slice's 4096 keys are first put in destination order in LDS -- bucket after bucket, as they will lie in memory -- and
+    // then stored by consecutive threads: stored straight from the lanes that ranked them (4 bytes each, every lane of an
+    // instruction somewhere else) the kernel was bound by the number of write requests the L2s take (1.58e9 of them: 6.4 ms).
+    // An entry is position | bucket << REL_BITS: the bucket says where the entry goes (D[bucket] + its place in the slice), and
+    // what lies above the position in a sorted key is nobody's business (every reader masks it).
+    __shared__ uint2 bp[1024];
+    __shared__ u32 D[OP_LMAX];                                    // first: where the bucket's keys of this slice go; then: that minus the bucket's first place in the slice
+    __shared__ u32 cw[OP_WAVES][OP_LMAX / 2];                     // per wave and bucket: two 16-bit counters a word
+    __shared__ u32 S[OP_SLICE];
+    __shared__ u32 wsum[OP_WAVES];
+    static_assert(OP_LMAX <= (1 << (32 - REL_BITS)) && OP_SLICE < 65536 && OP_SLICE % (OP_WAVES * 64) == 0, "position and bucket share a word; places in a slice are 16-bit");
+    u32 tile, slice;
+    if (!op_tile_part(n_tiles, OP_TILE_SLICES, tile, slice)) return;
+    if (ot[tile].two_pass) return;
+    const TileDesc td = tiles[tile];
+    if (slice >= op_slices(td.wlen)) return;
+    const u8 *s = stream + td.stream_off + td.w;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 *row = scratch + td.sorted_off + (size_t)slice * OP_ROW_WORDS;
+    for (int i = threadIdx.x; i < 1024; i += OP_NT) { bp[i] = ot[tile].bp[i]; D[i] = row[512 + i]; }
+    for (int i = threadIdx.x; i < OP_WAVES * (OP_LMAX / 2); i += OP_NT) (&cw[0][0])[i] = 0;
+    // wave w: keys beg + 64 k + lane, k = 0 .. 7 (ascending with k and with the lane: the order of the ranks below)
+    const u32 s0 = slice * OP_SLICE, beg = s0 + (u32)wave * (OP_SLICE / OP_WAVES), end = min(s0 + (u32)OP_SLICE, td.wlen);
+    u32 v[OP_KPL];
+#pragma unroll
+    for (int k = 0; k < OP_KPL; k++) v[k] = gld_u32_unaligned(s, min(beg + 64u * k + lane, td.wlen - 1));
+    __syncthreads();
+    u32 id[OP_KPL];
+#pragma unroll
+    for (int k = 0; k < OP_KPL; k++) {
+        id[k] = op_bucket(bp, sort_hash(v[k]));
+        if (beg + 64u * k + lane < end) atomicAdd(&cw[wave][id[k] >> 1], 1u << (16 * (id[k] & 1)));
+    }
+    __syncthreads();
+    {   // thread j: buckets 2 j and 2 j + 1.  Their first places in the slice (an exclusive scan over the buckets), and per wave
+        // where its keys of the bucket start (both halves of a word at once: no half exceeds 4096)
+        const int j = threadIdx.x & (OP_LMAX / 2 - 1);              // (more threads than bucket pairs: the rest go along and write nothing)
+        const bool mine = threadIdx.x < OP_LMAX / 2;
+        u32 c[OP_WAVES], tot = 0;
+#pragma unroll
+        for (int w = 0; w < OP_WAVES; w++) { c[w] = mine ? cw[w][j] : 0u; tot += c[w]; }
+        const u32 c0 = tot & 0xffffu, c1 = tot >> 16;
+        u32 wtot;
+        const u32 ex = wave_excl_scan_u32(c0 + c1, wtot);
+        if (lane == 0) wsum[wave] = wtot;
+        __syncthreads();
+        u32 st0 = ex;
+        for (int w = 0; w < wave; w++) st0 += wsum[w];
+        const u32 st1 = st0 + c0;
+        u32 run = st0 | (st1 << 16);
+        if (mine) {
+#pragma unroll
+            for (int w = 0; w < OP_WAVES; w++) { cw[w][j] = run; run += c[w]; }
+            D[2 * j] -= st0; D[2 * j + 1] -= st1;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < OP_KPL; k++) {
+        const u32 i = beg + 64u * k + lane;
+        if (i < end) {
+            const u32 sh = 16 * (id[k] & 1);
+            const u32 slot = (atomicAdd(&cw[wave][id[k] >> 1], 1u << sh) >> sh) & 0xffffu;      // lane-ordered: earlier lanes get lower places
+            S[slot] = i | (id[k] << REL_BITS);
+        }
+    }
+    __syncthreads();
+    u32 *out = sorted + td.sorted_off;
+    const u32 nk = end - s0;
+#pragma unroll
+    for (int k = 0; k < OP_KPL; k++) {
+        const u32 j = threadIdx.x + (u32)OP_NT * k;
+        if (j < nk) { const u32 e = S[j]; out[D[e >> REL_BITS] + j] = e; }
+    }
+}
+
 // 1 if this device's LDS retires same-address atomics of a wave instruction in lane order (probed once per device)
 static int lds_lane_ordered()
 {
@@ -324,11 +570,25 @@ __global__ void k_inject_disorder(const u8 *__restrict__ stream, const TileDesc 
     }
 }
 
-int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp, u32 *d_sorted, int force_ballot)
+size_t hash_sort_ws_bytes(int n_tiles) { return (size_t)(n_tiles + 1) * sizeof(OpTile); }
+
+int launch_hash_sort(hipStream_t st, const u8 *d_stream, const TileDesc *d_tiles, int n_tiles, u32 *d_tmp, u32 *d_sorted, int force_ballot, void *d_ws)
 {
     if (n_tiles == 0) return MTS_OK;
     const int ordered = (force_ballot == 1 || getenv("MTS_SORT_BALLOT")) ? 0 : lds_lane_ordered();      // MTS_SORT_BALLOT=1: force the ballot ranking (tests)
-    hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(SORT_NT), 0, st, d_stream, d_tiles, d_tmp, d_sorted, ordered);
+    // the one-pass sort ranks with lane-ordered LDS atomics: without them (or MTS_SORT_TWO_PASS=1: A/B runs, tests) everything is the two-pass kernel's
+    static const bool two_pass_only = getenv("MTS_SORT_TWO_PASS") != nullptr;
+    if (ordered && d_ws && !two_pass_only) {
+        OpTile *ot = (OpTile *)d_ws;
+        MTS_HIP(hipMemsetAsync(ot, 0, sizeof(OpTile) * (size_t)n_tiles, st));
+        hipLaunchKernelGGL(k_op_live, dim3(op_grid(n_tiles, OP_LIVE_PARTS)), dim3(512), 0, st, d_stream, d_tiles, n_tiles, ot);
+        hipLaunchKernelGGL(k_op_prefix, dim3(n_tiles), dim3(1024), 0, st, d_tiles, ot);
+        hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(SORT_NT), 0, st, d_stream, d_tiles, d_tmp, d_sorted, ordered, (const OpTile *)ot);      // (the tiles left to it: usually none)
+        hipLaunchKernelGGL(k_op_count, dim3(op_grid(n_tiles, OP_TILE_SLICES)), dim3(OP_CNT_NT), 0, st, d_stream, d_tiles, n_tiles, (const OpTile *)ot, d_tmp);
+        hipLaunchKernelGGL(k_op_scan, dim3(n_tiles), dim3(1024), 0, st, d_tiles, (const OpTile *)ot, d_tmp);
+        hipLaunchKernelGGL(k_op_scatter, dim3(op_grid(n_tiles, OP_TILE_SLICES)), dim3(OP_NT), 0, st, d_stream, d_tiles, n_tiles, (const OpTile *)ot, (const u32 *)d_tmp, d_sorted);
+    } else
+        hipLaunchKernelGGL(k_hash_sort, dim3(n_tiles), dim3(SORT_NT), 0, st, d_stream, d_tiles, d_tmp, d_sorted, ordered, (const OpTile *)nullptr);
     if (force_ballot == 2) hipLaunchKernelGGL(k_inject_disorder, dim3(1), dim3(1), 0, st, d_stream, d_tiles, d_sorted);      // (test hook: damage the order)
     MTS_HIP(hipGetLastError());
     return MTS_OK;

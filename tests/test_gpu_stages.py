@@ -2,6 +2,7 @@
 
 Bit-exact everywhere: these are integer / byte / index computations."""
 import time
+from pathlib import Path
 import zlib
 
 import numpy as np
@@ -13,6 +14,7 @@ from oracle import oracle as O
 from tests import inputs
 from tests.inputs import cases_small, ar1_stream, repeats
 
+ROOT = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
 CASES = cases_small()
 
@@ -111,6 +113,40 @@ def test_deflate_bytes_ballot_sort(monkeypatch):
     for name in ('text_100k', 'ar1_64ch_4k', 'repeats_200k', 'rand4_50k'):
         data = CASES[name]
         assert hip.debug_deflate(data, 6) == zlib.compress(data, 6), name
+
+
+def test_deflate_bytes_one_pass_and_two_pass_sort_tiles(monkeypatch):
+    """The hash sort takes a tile in one pass when it has few live hash buckets (recordings: small deltas) and leaves it to the
+    two-pass kernel otherwise (uniform random bytes: all 32768 buckets) or when it is small -- decided per tile, on the device.
+    A stream whose tiles (224 Ki positions) go either way, with runs and far copies in between; zlib's bytes at levels 6 and 9,
+    with the default, with the two-pass kernel alone (MTS_SORT_TWO_PASS: read once per process, so that run is a process of its
+    own) and with the ballot ranking."""
+    import subprocess, sys, hashlib
+    r = np.random.RandomState(123)
+    few = inputs.ar1_stream(2400, 128, 7)                                 # ~600 KB of int16 deltas: few buckets
+    rnd = r.randint(0, 256, size=700000).astype(np.uint8).tobytes()       # every bucket
+    mid = inputs.repeats(300000, 31) + bytes(200000) + inputs.farcopies(250000, 32)
+    data = few + rnd + mid + few[:300000] + rnd[:100000] + inputs.textlike(400000, 33)
+    assert len(data) > 3 * 229376
+    for level in (6, 9):
+        want = zlib.compress(data, level)
+        assert hip.debug_deflate(data, level) == want, level
+    want6 = zlib.compress(data, 6)
+    monkeypatch.setenv('MTS_SORT_BALLOT', '1')
+    assert hip.debug_deflate(data, 6) == want6
+    monkeypatch.delenv('MTS_SORT_BALLOT')
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r); from mtscomp_amd import hip; "
+            "d = open(sys.argv[1], 'rb').read(); print(hashlib.sha1(hip.debug_deflate(d, 6)).hexdigest())" % str(ROOT))
+    import tempfile, os
+    with tempfile.NamedTemporaryFile(delete=False) as f:
+        f.write(data)
+    try:
+        env = dict(os.environ, MTS_SORT_TWO_PASS='1')
+        out = subprocess.run([sys.executable, '-c', code, f.name], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-1000:]
+        assert out.stdout.strip().split()[-1] == hashlib.sha1(want6).hexdigest()
+    finally:
+        os.unlink(f.name)
 
 
 def test_deflate_bytes_from_the_marks_of_the_walks():

@@ -47,8 +47,12 @@ for k in agg:
                   "traffic_bytes_per_launch": (2 * agg[k]["FETCH_SIZE"] + agg[k]["WRITE_SIZE"]) / L * 1024, "launches": L}
 json.dump({"kernels": {k: v["traffic_bytes_per_launch"] for k, v in per.items()}, "detail": per,
            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 1 (60 x 23.1 MB chunks), bytes per launch = counter sum / launches x 1024; "
-                  "traffic = 2 x FETCH_SIZE + WRITE_SIZE: calibrated on this box with tools/microbench/hbm_counter_calibration.hip (tools/mb_calib.sh) -- FETCH_SIZE = 0.500 x the bytes of the "
-                  "128-B lines fetched for 16-B streams, 4-B streams and 16-B gathers (one per line) alike; WRITE_SIZE = 1.000 x for coalesced 16-B and 4-B stores, 32 B per isolated 4-B store (sectors)",
+                  "traffic = 2 x FETCH_SIZE + WRITE_SIZE: calibrated with tools/microbench/hbm_counter_calibration.hip (tools/mb_calib.sh, profiles/r5_hbm_counter_calibration.txt) -- every read request "
+                  "of an L2 to the fabric is a 128-B line (TCC_EA0_RDREQ x 128 B = the lines touched, TCC_EA0_RDREQ_32B = 0 in every pattern: 16-B streams, 4-B streams, one 16-B gather per line, "
+                  "the 112-B stride of the old parse windows) and FETCH_SIZE tallies it as 64 B (its expression's 128-B term, TCC_BUBBLE, stays 0 on gfx950): x 2 is exact, not an estimate; WRITE_SIZE = "
+                  "1.000 x for coalesced stores, 32 B per isolated 4-B store (sectors).  The figure is what the L2s ask of the fabric: lines that another XCD fetched a moment ago come out of the 256 MB "
+                  "Infinity Cache and never reach HBM (k_parse_emit_marks in round 4: 2 x 4.94 + 1.21 GB in 1.53 ms = 7.25 TB/s, above the 5.6 TB/s a pure-read kernel and the 6.3 TB/s the 112-B stride "
+                  "pattern reach in the microbenchmark -- a third of its lines were such re-fetches by other XCDs; with its workgroups of one segment group on one XCD it asks for 2 x 3.65 GB and takes the same time)",
            "calibration": {"fetch_factor": 2.0, "write_factor": 1.0, "write_granule_bytes": 32, "read_granule_bytes": 128},
            "source": "profiles/%s_bench_pmc_hbm_bytes.csv" % tag}, open(out + "/%s_traffic.json" % tag, "w"), indent=1)
 print(open(out + "/%s_bench_default.jsonl" % tag).read()[:600])
