@@ -58,6 +58,7 @@ TOFILE_PIECE_CHUNKS = 8         # chunks per piece of Reader.tofile (decode of o
 TOFILE_WRITERS = 2              # threads writing a piece: writes to ONE file are serialised by its inode lock, a fresh tmpfs file takes ~6.5 GB/s from one or two threads and less from more (through a shared mapping as well: 6 GB/s from 8 threads)
 DEFAULT_DEVICE_CACHE_GB = 32    # decoded chunks a Reader may keep in HBM for slicing (allocated as touched; env MTSCOMP_DEVICE_CACHE_GB, 0 = off)
 DEVICE_CACHE_MAX_CHUNKS = 8     # longer slices are streamed through the host path instead of the cache
+PREAD_THREADS = int(os.environ.get('MTSCOMP_PREAD_THREADS', 8))      # threads that read the compressed bytes of a slice's missing chunks (a few MB and more)
 
 logger = logging.getLogger('mtscomp_amd')
 logger.setLevel(logging.INFO)
@@ -637,7 +638,7 @@ class Reader:
     def _pread_pinned(self, length, start):
         """`length` bytes at `start` of the compressed file as a uint8 view of a page-locked buffer (the codec's: the bytes go to
         the device by DMA from where the file system put them -- no fresh pages to fault in for every read, no staging copy);
-        reads of a few MB and more are split over four threads.  The caller holds self._pin_lock while the view is in use.
+        reads of a few MB and more are split over PREAD_THREADS threads.  The caller holds self._pin_lock while the view is in use.
         None when the codec has no such buffers (the caller reads into a bytes object then)."""
         alloc = getattr(self.codec, 'host_buffer_take', None) or getattr(self.codec, 'host_buffer', None)
         if alloc is None or not hasattr(os, 'preadv'):
@@ -661,10 +662,11 @@ class Reader:
                 a += got
             return a
         if length >= (4 << 20):
+            nt = PREAD_THREADS
             if self._io_pool is None:
-                self._io_pool = ThreadPool(4)
-            per = (length + 3) // 4
-            ends = self._io_pool.starmap(part, [(k * per, min((k + 1) * per, length)) for k in range(4) if k * per < length])
+                self._io_pool = ThreadPool(nt)
+            per = (length + nt - 1) // nt
+            ends = self._io_pool.starmap(part, [(k * per, min((k + 1) * per, length)) for k in range(nt) if k * per < length])
             assert all(e == min((k + 1) * per, length) for k, e in enumerate(ends))
         else:
             assert part(0, length) == length

@@ -328,7 +328,10 @@ constexpr int OP_KPL = OP_SLICE / (OP_WAVES * 64);   // keys per lane
 constexpr int OP_LMAX = 1024;                        // live buckets a tile may have
 constexpr int OP_MIN_KEYS = 2 * OP_SLICE;            // smaller tiles: the two-pass kernel (their part of the scratch buffer is too small)
 constexpr int OP_ROW_WORDS = 512 + 1024;             // a slice's row in the scratch: 1024 counts (u16), 1024 offsets (u32)
-constexpr int OP_LIVE_PARTS = 8;                     // workgroups of k_op_live per tile
+#ifndef MTS_OP_LIVE_PARTS
+#define MTS_OP_LIVE_PARTS 8
+#endif
+constexpr int OP_LIVE_PARTS = MTS_OP_LIVE_PARTS;     // workgroups of k_op_live per tile
 struct OpTile {
     uint2 bp[1024];                                  // .x: which of the hashes 32 w .. 32 w + 31 occur, .y: live buckets below hash 32 w (side by side: a key's bucket is ONE 8-byte LDS read)
     u32 live, two_pass;
