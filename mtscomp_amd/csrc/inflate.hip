@@ -1718,21 +1718,38 @@ __global__ __launch_bounds__(GS_TILE) void k_inf_gsum(const u32 *__restrict__ to
     if (blockIdx.x * GS_TILE >= ngroups && !(blockIdx.x == 0)) return;
     const u32 *tk = tokens + chunks[ci].tok_off;
     u32 sum = 0;
-    if (g < ngroups) {
-        const u32 t0 = g * 64;
-        if (t0 + 64 <= ntok) {
-            const uint4 *q = (const uint4 *)(tk + t0);              // tok_off and t0 are multiples of... see note
+    {
+        // A wave takes the 64 groups of its threads TOGETHER (round 5): 16 loads of 16 bytes per lane over consecutive addresses -- a
+        // group's 64 tokens are the 16 lanes of a row in one of them, its sum a row reduction on the DPP network --, instead of a
+        // thread reading its own group's 256 bytes with the lanes 256 bytes apart (64 lines per load instruction: the kernel spent
+        // 70 % of its cycles waiting to issue).
+        const int lane_ = threadIdx.x & 63;
+        const u32 g0w = g - (u32)lane_;                              // the wave's first group
+        const uint4 *q = (const uint4 *)(tk + (size_t)g0w * 64);      // (tok_off and 64 g are multiples of 4 tokens)
+        const u32 nq = ntok > g0w * 64 ? (ntok - g0w * 64) / 4 : 0;   // whole 16-byte pieces of the chunk's tokens from there on
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint4 v = q[k];
-                sum += (v.x >> 31) ? ((v.x >> 16) & 0xff) + 3 : 1;
-                sum += (v.y >> 31) ? ((v.y >> 16) & 0xff) + 3 : 1;
-                sum += (v.z >> 31) ? ((v.z >> 16) & 0xff) + 3 : 1;
-                sum += (v.w >> 31) ? ((v.w >> 16) & 0xff) + 3 : 1;
+        for (int it = 0; it < 16; it++) {
+            const u32 i = (u32)it * 64 + (u32)lane_;
+            u32 part = 0;
+            if (i < nq) {
+                const uint4 v = q[i];
+                part = ((v.x >> 31) ? ((v.x >> 16) & 0xff) + 3 : 1) + ((v.y >> 31) ? ((v.y >> 16) & 0xff) + 3 : 1) +
+                       ((v.z >> 31) ? ((v.z >> 16) & 0xff) + 3 : 1) + ((v.w >> 31) ? ((v.w >> 16) & 0xff) + 3 : 1);
             }
-        } else {
-            for (u32 i = t0; i < ntok; i++) { const u32 t = tk[i]; sum += (t >> 31) ? ((t >> 16) & 0xff) + 3 : 1; }
+            // sum of the row's 16 lanes into its last lane
+            part += (u32)__builtin_amdgcn_update_dpp(0, (int)part, 0x111, 0xf, 0xf, false);     // row_shr:1
+            part += (u32)__builtin_amdgcn_update_dpp(0, (int)part, 0x112, 0xf, 0xf, false);     // row_shr:2
+            part += (u32)__builtin_amdgcn_update_dpp(0, (int)part, 0x114, 0xf, 0xf, false);     // row_shr:4
+            part += (u32)__builtin_amdgcn_update_dpp(0, (int)part, 0x118, 0xf, 0xf, false);     // row_shr:8
+            // group 4 it + r is row r's: to lane 4 it + r
+            const u32 got = (u32)__shfl((int)part, (lane_ & 3) * 16 + 15, 64);
+            if ((lane_ >> 2) == it) sum = got;
         }
+        // the chunk's last tokens, fewer than four
+        if (g < ngroups) {
+            const u32 t0 = g * 64, t1 = min(t0 + 64, ntok);
+            for (u32 i = max(t0, (g0w * 64 + nq * 4)); i < t1; i++) { const u32 t = tk[i]; sum += (t >> 31) ? ((t >> 16) & 0xff) + 3 : 1; }
+        } else sum = 0;
     }
     __shared__ u32 wtot[GS_TILE / 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
