@@ -131,6 +131,10 @@ def test_deflate_bytes_one_pass_and_two_pass_sort_tiles(monkeypatch):
     for level in (6, 9):
         want = zlib.compress(data, level)
         assert hip.debug_deflate(data, level) == want, level
+    # tiles around the one-pass limit (1024 live buckets): symbols below 32 hash without collisions, so an alphabet of 10 gives
+    # 10^3 = 1000 buckets (one pass, nearly all of its counters in use), alphabets of 11 and 12 give 1331 and 1728 (two passes)
+    edge = b''.join(r.randint(0, a, size=n).astype(np.uint8).tobytes() for a, n in ((10, 500000), (11, 300000), (10, 250000), (12, 120000)))
+    assert hip.debug_deflate(edge, 6) == zlib.compress(edge, 6)
     want6 = zlib.compress(data, 6)
     monkeypatch.setenv('MTS_SORT_BALLOT', '1')
     assert hip.debug_deflate(data, 6) == want6

@@ -91,17 +91,21 @@ int main(int argc, char **argv)
     const u32 ngroups = (wlen + 63) / 64;
     u64 tot1 = 0, tot2 = 0, rounds1 = 0, rounds2 = 0, lanes = 0, hist1[64] = {0}, hist2[64] = {0}, wasted = 0;
     u64 act1[40] = {0}, act2[40] = {0}, merged[4] = {0};
+    u64 hy_bad = 0, hy_tot = 0, hy_rounds = 0, hy_act[40] = {0}; u32 hy_n[64];
+    u64 oor1 = 0, oor2 = 0, td_fp_r1 = 0, td_oor_r1 = 0, td_l7_r1 = 0, td_fp_groups = 0; int g_fp = 0;
+    u64 td_bad = 0, td_badq = 0, td_tot1 = 0, td_tot2 = 0, td_rounds1 = 0, td_rounds2 = 0, td_act1[40] = {0}, td_act2[40] = {0};
+    u32 td_n1[64], td_n2[64];
     // pooled what-ifs: in-place rounds R for the newest word, everything else as items
     enum { NR = 4 };
     u64 inplace_rounds[NR] = {0}, items[NR] = {0}, item_scorings[NR] = {0}, item_max[NR] = {0};
     LaneRes *res = malloc(sizeof(LaneRes) * 64);
     u32 (*seq)[160] = malloc(64 * 160 * 4);                 // per lane: scorings in walk order (candidate index j), for the what-ifs
     for (u32 g = 0; g < ngroups; g++) {
-        u32 gmax1 = 0, gmax2 = 0;
+        u32 gmax1 = 0, gmax2 = 0; g_fp = 0;
         u32 nseq[64];
         for (int lane = 0; lane < 64; lane++) {
             const u32 i = g * 64 + lane;
-            nseq[lane] = 0;
+            nseq[lane] = 0; td_n1[lane] = td_n2[lane] = 0; hy_n[lane] = 0;
             res[lane].n1 = res[lane].n2 = 0;
             if (i >= wlen) continue;
             const u32 p = sorted[i];
@@ -121,6 +125,8 @@ int main(int argc, char **argv)
                 for (int l = 0; l < NLEV; l++) if (ck[l] == mk[l]) b |= 1 << l;
                 lev_bits[j] = b;
             }
+            u8 levj_h[CHAIN + 1];
+            for (u32 j = 1; j <= nbv; j++) { u32 l = 0; while (l < (u32)NLEV && ((lev_bits[j] >> l) & 1)) l++; levj_h[j] = (u8)(3 + l); }
             u32 best = 2, bdist = 0, qbest = 2, qdist = 0;
             int stop = 0, qset = 0;
             lanes++;
@@ -138,7 +144,7 @@ int main(int argc, char **argv)
                 const u32 c = sorted[i - j];
                 // zlib: the head of the chain may be MAX_DIST away, the others must be nearer; position 0 is NIL
                 const u32 lim = j == 1 ? (p > MAX_DIST + 1 ? p - MAX_DIST - 1 : 0) : (p > MAX_DIST ? p - MAX_DIST : 0);
-                if (!(c > lim)) { stop = 1; break; }
+                if (!(c > lim)) { stop = 1; if (j > QCHAIN) oor2++; else oor1++; break; }
                 if (memcmp(s + c, me, 3)) { wasted++; continue; }                       // same hash, other bytes
                 const u32 len = lcp(s + c, me, maxlen);
                 if (len > best) { best = len; bdist = p - c; if (len >= nice) stop = 1; }
@@ -146,6 +152,96 @@ int main(int argc, char **argv)
             }
             if (!qset) { qbest = best; qdist = bdist; }             // the walk ended inside the newest QCHAIN candidates
             res[lane].best = best; res[lane].bdist = bdist; res[lane].qbest = qbest; res[lane].qdist = qdist;
+            {   // what-if: TOP-DOWN walks.  Word by word (newest first), inside a word the candidates of the highest non-empty filter level
+                // first: one that verifies at its level d < 7 ends the word at once (nothing in the word can be longer, ties go to
+                // the newer one), level 7 is walked newest-first as before, a false positive leaves the candidates that can still tie
+                // or win.  Same results (checked below), fewer scorings per lane -- and per group?
+                u32 tb_len = 2, tb_pos = 0, tq_len = 2, tq_pos = 0, td1 = 0, td2 = 0;
+                int dead = 0, tstop = 0;
+                u8 levj[CHAIN + 1];
+                for (u32 j = 1; j <= nbv; j++) { u32 l = 0; while (l < (u32)NLEV && ((lev_bits[j] >> l) & 1)) l++; levj[j] = (u8)(3 + l); }
+                for (int w = 3; w >= 0 && !dead && !tstop; w--) {
+                    const u32 j0 = (u32)(3 - w) * 32 + 1, j1 = j0 + 31 < nbv ? j0 + 31 : nbv;
+                    if (w == 2) { tq_len = tb_len; tq_pos = tb_pos; }
+                    if (j0 > nbv) break;
+                    u8 inR[33];
+                    u32 need0 = tb_len >= 3 ? tb_len + 1 : 3;
+                    if (need0 > 7) need0 = 7;
+                    for (u32 j = j0; j <= j1; j++) inR[j - j0] = levj[j] >= need0;
+                    for (;;) {
+                        u32 dstar = 0, cj = 0;
+                        for (u32 j = j0; j <= j1; j++) if (inR[j - j0] && levj[j] > dstar) { dstar = levj[j]; cj = j; }
+                        if (!cj) break;
+                        if (w == 3) td1++; else td2++;
+                        const u32 c = sorted[i - cj];
+                        const u32 lim = cj == 1 ? (p > MAX_DIST + 1 ? p - MAX_DIST - 1 : 0) : (p > MAX_DIST ? p - MAX_DIST : 0);
+                        if (!(c > lim)) { for (u32 j = cj; j <= j1; j++) inR[j - j0] = 0; dead = 1; if (w == 3 && td1 == 1) { td_oor_r1++; g_fp = 1; } continue; }
+                        inR[cj - j0] = 0;
+                        u32 len = memcmp(s + c, me, 3) ? 0 : lcp(s + c, me, maxlen);
+                        if (len >= 3 && (len > tb_len || (len == tb_len && c > tb_pos))) { tb_len = len; tb_pos = c; }
+                        if (len >= nice) { tstop = 1; break; }
+                        if (w == 3 && td1 == 1) { if (len < dstar) { td_fp_r1++; g_fp = 1; } else if (dstar == 7) td_l7_r1++; }
+                        if (len >= dstar) {
+                            if (dstar < 7) break;
+                            for (u32 j = j0; j <= j1; j++) if (levj[j] < 7) inR[j - j0] = 0;
+                        } else {
+                            const u32 keep = tb_len >= 3 ? (tb_len > 7 ? 7 : tb_len) : 3;
+                            for (u32 j = j0; j <= j1; j++) if (levj[j] < keep) inR[j - j0] = 0;
+                        }
+                    }
+                }
+                if (nbv <= 32 || 1) { if (!(nbv > 32) || 0) { } }
+                if (nbv <= 32) { tq_len = tb_len; tq_pos = tb_pos; }
+                else if (tstop && td2 == 0 && tq_len == 2 && tb_len > 2 && 0) { }
+                // (a walk that ended inside the newest word: the quarter result is what it holds)
+                if (nbv > 32 && (tstop || dead) && td2 == 0) { /* ended in word 3 or at its border */ if (tq_len == 2 && tq_pos == 0) { tq_len = tb_len; tq_pos = tb_pos; } }
+                const u32 rb = best >= 3 ? best : 2, rq = qbest >= 3 ? qbest : 2;
+                if (tb_len != rb || (rb >= 3 && p - tb_pos != bdist)) { td_bad++; if (getenv("TD_DEBUG")) printf("p %u nbv %u look %u: ref %u/%u q %u/%u  td %u/%u q %u/%u dead %d stop %d td1 %u td2 %u\n", p, nbv, look, best, bdist, qbest, qdist, tb_len, p - tb_pos, tq_len, p - tq_pos, dead, tstop, td1, td2); }
+                if (tq_len != rq || (rq >= 3 && p - tq_pos != qdist)) td_badq++;
+                td_n1[lane] = td1; td_n2[lane] = td2; td_tot1 += td1; td_tot2 += td2;
+            }
+            {   // what-if: HYBRID.  Round 1 of the newest word top-down (every lane scores the newest candidate of its highest non-empty
+                // level); a lane whose candidate verifies below level 7 is done, one at level 7 goes on through A7; a false positive
+                // (shorter than its level said) or an out-of-range candidate falls back to the newest-first walk with a floor:
+                // best = len - 1 held by nobody, candidates = those that may be >= len long (the scored one among them), resp.
+                // from scratch over the candidates newer than the one out of range.  Newest-first with strict improvement from there.
+                u32 hy = 0, hb = 2, hpos = 0;
+                const u32 j1 = nbv < 32 ? nbv : 32;
+                if (j1) {
+                    u32 dstar = 0, cj = 0;
+                    for (u32 j = 1; j <= j1; j++) if (levj_h[j] > dstar) { dstar = levj_h[j]; cj = j; }
+                    hy = 1;
+                    const u32 c = sorted[i - cj];
+                    const u32 lim = cj == 1 ? (p > MAX_DIST + 1 ? p - MAX_DIST - 1 : 0) : (p > MAX_DIST ? p - MAX_DIST : 0);
+                    u32 floor_ = 2, jlo = 1, jhi = j1, needlev = 3; int skip_c = 0, done = 0;
+                    if (!(c > lim)) { jhi = cj - 1; }
+                    else {
+                        const u32 len = memcmp(s + c, me, 3) ? 0 : lcp(s + c, me, maxlen);
+                        if (len >= nice) { hb = len; hpos = c; done = 1; }
+                        else if (len >= dstar) { hb = len; hpos = c; floor_ = len; if (dstar < 7) done = 1; else { needlev = 7; skip_c = 1; } }
+                        else if (len >= 3) { floor_ = len - 1; needlev = len > 7 ? 7 : len; }
+                        else { skip_c = 1; }
+                    }
+                    if (!done) {
+                        u32 b = floor_;
+                        for (u32 j = jlo; j <= jhi; j++) {
+                            if (skip_c && j == cj) continue;
+                            u32 need = b >= 3 ? b + 1 : 3; if (need > 7) need = 7;
+                            if (b == floor_ && floor_ >= 2 && needlev > need) need = needlev;
+                            if (levj_h[j] < need) continue;
+                            hy++;
+                            const u32 cc = sorted[i - j];
+                            const u32 lm = j == 1 ? (p > MAX_DIST + 1 ? p - MAX_DIST - 1 : 0) : (p > MAX_DIST ? p - MAX_DIST : 0);
+                            if (!(cc > lm)) break;
+                            const u32 len = memcmp(s + cc, me, 3) ? 0 : lcp(s + cc, me, maxlen);
+                            if (len > b) { b = len; hb = len; hpos = cc; if (len >= nice) break; }
+                        }
+                    }
+                }
+                const u32 rq = qbest >= 3 ? qbest : 2;
+                if (look >= MAX_MATCH && (hb != rq || (rq >= 3 && p - hpos != qdist))) hy_bad++;
+                hy_n[lane] = hy; hy_tot += hy;
+            }
             tf[p] = best >= 3 ? (best << 16) | bdist : 0;
             tq[p] = qbest >= 3 ? (qbest << 16) | qdist : 0;
             tot1 += res[lane].n1; tot2 += res[lane].n2;
@@ -154,7 +250,11 @@ int main(int argc, char **argv)
             if (res[lane].n1 > gmax1) gmax1 = res[lane].n1;
             if (res[lane].n2 > gmax2) gmax2 = res[lane].n2;
         }
-        rounds1 += gmax1; rounds2 += gmax2;
+        rounds1 += gmax1; rounds2 += gmax2; td_fp_groups += g_fp;
+        { u32 m = 0; for (int l = 0; l < 64; l++) if (hy_n[l] > m) m = hy_n[l]; hy_rounds += m; for (u32 r = 0; r < m && r < 40; r++) for (int l = 0; l < 64; l++) if (hy_n[l] > r) hy_act[r]++; }
+        { u32 m1 = 0, m2 = 0; for (int l = 0; l < 64; l++) { if (td_n1[l] > m1) m1 = td_n1[l]; if (td_n2[l] > m2) m2 = td_n2[l]; } td_rounds1 += m1; td_rounds2 += m2;
+          for (u32 r = 0; r < m1 && r < 40; r++) for (int l = 0; l < 64; l++) if (td_n1[l] > r) td_act1[r]++;
+          for (u32 r = 0; r < m2 && r < 40; r++) for (int l = 0; l < 64; l++) if (td_n2[l] > r) td_act2[r]++; }
         for (int R = 1; R <= 3; R++) { u32 m = 0; for (int l = 0; l < 64; l++) { const u32 left = (res[l].n1 > (u32)R ? res[l].n1 - R : 0) + res[l].n2; if (left > m) m = left; } merged[R] += (gmax1 < (u32)R ? gmax1 : (u32)R) + m; }
         for (u32 r = 0; r < gmax1 && r < 40; r++) for (int l = 0; l < 64; l++) if (res[l].n1 > r) act1[r]++;
         for (u32 r = 0; r < gmax2 && r < 40; r++) for (int l = 0; l < 64; l++) if (res[l].n2 > r) act2[r]++;
@@ -173,6 +273,11 @@ int main(int argc, char **argv)
     printf("rounds per group:      newest32 %.2f  other96 %.2f   lane use %.1f%% / %.1f%%\n", (double)rounds1 / ngroups, (double)rounds2 / ngroups,
            100.0 * tot1 / (rounds1 * 64.0), 100.0 * tot2 / (rounds2 * 64.0));
     printf("rounds per group if the newest word gets R rounds of its own and its leftovers join the loop of the other 96: R=1 %.2f  R=2 %.2f  R=3 %.2f\n", (double)merged[1] / ngroups, (double)merged[2] / ngroups, (double)merged[3] / ngroups);
+    printf("TOP-DOWN: scorings per position %.3f + %.3f, rounds per group %.2f + %.2f, results differing: %llu full, %llu quarter\n", (double)td_tot1 / lanes, (double)td_tot2 / lanes, (double)td_rounds1 / ngroups, (double)td_rounds2 / ngroups, (unsigned long long)td_bad, (unsigned long long)td_badq);
+    printf("TOP-DOWN active lanes per round: "); for (int r = 0; r < 8; r++) printf("%.1f ", (double)td_act1[r] / ngroups); printf(" | "); for (int r = 0; r < 8; r++) printf("%.1f ", (double)td_act2[r] / ngroups); printf("\n");
+    printf("scorings that only find the candidate out of range: newest32 %.3f other96 %.3f per position\n", (double)oor1 / lanes, (double)oor2 / lanes);
+    printf("TOP-DOWN round 1 of the newest word, per group: %.2f lanes with a false positive, %.2f out of range, %.2f verified at level 7; groups with a false positive or out-of-range lane: %.1f%%\n", (double)td_fp_r1 / ngroups, (double)td_oor_r1 / ngroups, (double)td_l7_r1 / ngroups, 100.0 * td_fp_groups / ngroups);
+    printf("HYBRID (round 1 top-down, the rest newest-first): scorings per position %.3f, rounds per group %.2f, results differing %llu; active lanes per round: ", (double)hy_tot / lanes, (double)hy_rounds / ngroups, (unsigned long long)hy_bad); for (int r = 0; r < 8; r++) printf("%.1f ", (double)hy_act[r] / ngroups); printf("\n");
     printf("lanes by scorings (newest32): ");
     for (int k = 0; k < 12; k++) printf("%d:%.1f%% ", k, 100.0 * hist1[k] / lanes);
     printf("\nlanes by scorings (other96):  ");
