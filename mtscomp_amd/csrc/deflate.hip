@@ -682,6 +682,7 @@ struct ParseStage {
     u32 *win;                   // LDS [64][PARSE_WIN_PITCH]
     const u32 *base;            // table entry of the first lane's segment start (a 128-byte boundary)
     int nlanes;                 // lanes that have a segment (the others' windows hold something harmless)
+    long floor_off;             // lowest entry (relative to base) a window may start at: the chunk's first
     // ask for window w of every lane: lane l takes piece l % 8 of the windows of lanes it * 8 + l / 8.  head_only: only the first
     // piece (the four entries the last window of a segment looks ahead to)
     __device__ __forceinline__ void request(int w, u32x4_v (&pre)[PARSE_PIECES], bool head_only = false) const
@@ -691,7 +692,9 @@ struct ParseStage {
         for (int it = 0; it < PARSE_PIECES; it++) {
             int wl = it * (64 / PARSE_PIECES) + lane / PARSE_PIECES;
             wl = wl < nlanes ? wl : nlanes - 1;
-            const u32 *src = base + (size_t)wl * SEG + (size_t)w * PARSE_WIN + 4 * (lane % PARSE_PIECES);
+            long off = (long)wl * SEG + (long)w * PARSE_WIN;
+            if (off < floor_off) off = floor_off;                  // (a warm-up window of the chunk's first segment: nobody walks it)
+            const u32 *src = base + off + 4 * (lane % PARSE_PIECES);
             if (!head_only || lane % PARSE_PIECES == 0) pre[it] = *(gptr_uint4)(u64)src;
         }
     }
@@ -740,6 +743,10 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int k)
 #define MTS_PARSE_NCP 8
 #endif
 constexpr int PARSE_NCP = MTS_PARSE_NCP;           // checkpoints per segment + 1 (8: every 128 positions)
+#ifndef MTS_PARSE_WARM
+#define MTS_PARSE_WARM 2
+#endif
+constexpr int PARSE_WARM = MTS_PARSE_WARM;         // windows the speculative walk starts before its segment (see k_parse_spec)
 constexpr int PARSE_CP = SEG / PARSE_NCP;
 
 // The walks also leave MARKS: two bits per position of what the walk did there -- 0 nothing (inside a copy), 1 a literal, 2 a
@@ -836,22 +843,29 @@ __global__ __launch_bounds__(64, MTS_PARSE_SPEC_WAVES) void k_parse_spec(const u
     const u32 s = (k0seg + (u32)(valid ? lane : nlanes - 1)) * SEG, n = ch.n;
     const u32 segend = valid ? min(s + (u32)SEG, n) : 0;
     const u32 *T = tables + ch.stream_off, *TQ = quarter + ch.stream_off;
-    const ParseStage st{win, T + (size_t)k0seg * SEG, nlanes};
+    const ParseStage st{win, T + (size_t)k0seg * SEG, nlanes, -(long)k0seg * SEG};
     const u32 *row = win + lane * PARSE_WIN_PITCH;
     u32 *cp = pb.cp + (u64)g * (2 * PARSE_NCP);
-    u32 pos = s, mp, ml, md, ms, cnt = 0, k = 1;
+    // The walk starts PARSE_WARM windows BEFORE the segment, in a state that is as much a guess as "a token starts at s" was -- but
+    // the lazy parse falls into step with the true one within a few tokens, whatever it started from: the first base position at
+    // or behind s is the segment's true entry for 98.3 % of the segments after 64 positions (90 % after 32, 99.9 % after 96;
+    // 28 % with no warm-up: tools/sim/match_walk_sim.c), and the fix round that follows re-walks the 1.7 % instead of the 72 %.
+    // Nothing is recorded before s (no marks, no counts, no checkpoints: that stretch is the walk of the segment before).
+    const bool warm = valid && s != 0;
+    u32 pos = warm ? s - (u32)(PARSE_WARM * PARSE_WIN) : s, mp, ml, md, ms, cnt = 0, k = 1, entry = s;
     MarkW mk;
     mk.start(mark_base(pb.marks, (u32)g), 0, valid);
     u32x4_v pre[PARSE_PIECES];
-    st.request(0, pre);
-    for (int w = 0; w < PARSE_NWIN; w++) {
+    st.request(-PARSE_WARM, pre);
+    for (int w = -PARSE_WARM; w < PARSE_NWIN; w++) {
         __syncthreads();                                         // (everybody is done with the window before)
         st.land(pre);
         __syncthreads();
-        mk.anchor(((u32)w * PARSE_WIN) >> 4);                    // (the marks below this window: stored before the next loads are asked for)
+        if (w == 0) entry = pos;                                 // (s, or where the warm-up came out)
+        if (w > 0) mk.anchor(((u32)w * PARSE_WIN) >> 4);         // (the marks below this window: stored before the next loads are asked for)
         st.request(w + 1, pre, w + 1 == PARSE_NWIN);             // (of the window behind the segment only what the last one looks ahead to)
-        const u32 wb = s + (u32)w * PARSE_WIN;
-        const u32 wend = min(wb + (u32)PARSE_WIN, segend);
+        const u32 wb = s + (u32)(w * PARSE_WIN);                 // (a warm-up window of a lane without one: wrapped around, and wend = 0 keeps the lane out)
+        const u32 wend = w < 0 ? (warm ? wb + (u32)PARSE_WIN : 0u) : min(wb + (u32)PARSE_WIN, segend);
 #pragma unroll 1
         for (int part = 0; part < 2; part++) {                   // all but the last four positions; then those, with the next window's heads behind the row
             const u32 rv = part ? (u32)PARSE_ROW : (u32)PARSE_WIN;
@@ -865,16 +879,18 @@ __global__ __launch_bounds__(64, MTS_PARSE_SPEC_WAVES) void k_parse_spec(const u
                 while (k < (u32)PARSE_NCP && pos >= s + k * PARSE_CP) { cp[k - 1] = pos; cp[PARSE_NCP + k - 1] = cnt; k++; }
                 const u32 p0 = pos;
                 pos = lazy_step<true>(rdu, rd, rdq, pos, n, cfg, mp, ml, md, ms);
-                cnt += mp - p0 + 1;
-                MTS_MARK_STEP(mk, s, p0, mp, ml, ms);
+                if (w >= 0) {
+                    cnt += mp - p0 + 1;
+                    MTS_MARK_STEP(mk, s, p0, mp, ml, ms);
+                }
             }
         }
-        if (!__any(pos < segend)) break;
+        if (w >= 0 && !__any(pos < segend)) break;
     }
     if (!valid) return;
     mk.finish(pos - s);
     for (; k < (u32)PARSE_NCP; k++) { cp[k - 1] = pos; cp[PARSE_NCP + k - 1] = cnt; }      // checkpoints past the exit
-    pb.entry[g] = s;
+    pb.entry[g] = entry;
     pb.exit_a[g] = pos;
     pb.cnt[g] = cnt;
 }

@@ -330,5 +330,27 @@ int main(int argc, char **argv)
         printf("\n");
         free(vis);
     }
+    // The speculative parse (k_parse_spec) starts a segment's walk AT the segment start; the true entry is where the walk of the
+    // segment before ends.  What if it started W positions earlier and took its first base position at or behind the start as
+    // the entry: how often is that the true one (the re-walk of the fix round then has nothing to do)?
+    {
+        u8 *is_base = calloc(n + 600, 1);
+        #define STEP(p0, out) do { u32 p_ = (p0), len_ = tf[p_] >> 16, dist_ = tf[p_] & 0xffff; if (len_ == 3 && dist_ > TOO_FAR) len_ = 0; \
+            if (len_ < 3) { (out) = p_ + 1; break; } \
+            for (;;) { const u32 q_ = p_ + 1; if (q_ < n && len_ < LAZY) { const u32 d_ = len_ >= GOOD ? tq[q_] : tf[q_]; if ((d_ >> 16) > len_) { p_ = q_; len_ = d_ >> 16; continue; } } break; } \
+            (out) = p_ + len_; } while (0)
+        for (u32 p = 0; p < n;) { is_base[p] = 1; u32 nx; STEP(p, nx); p = nx; }
+        const int Ws[5] = {16, 32, 64, 96, 128};
+        for (int wi = 0; wi < 5; wi++) {
+            u32 segs = 0, good = 0, good0 = 0;
+            for (u32 sgs = 1024; sgs + 1024 < n; sgs += 1024) {
+                u32 t = sgs; while (!is_base[t]) t++;               // the true entry
+                u32 p = sgs - Ws[wi]; while (p < sgs) { u32 nx; STEP(p, nx); p = nx; }
+                segs++; good += p == t; good0 += sgs == t;
+            }
+            printf("spec walk started %3d positions early: entry right for %.1f%% of the segments (started at the segment start: %.1f%%)\n", Ws[wi], 100.0 * good / segs, 100.0 * good0 / segs);
+        }
+        free(is_base);
+    }
     return 0;
 }
