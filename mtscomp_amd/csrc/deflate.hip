@@ -444,19 +444,23 @@ __global__ __launch_bounds__(1024) void k_op_scan(const TileDesc *__restrict__ t
     const TileDesc td = tiles[tile];
     const u32 ns = op_slices(td.wlen);
     u32 *rows = scratch + td.sorted_off;
-    u32 total = 0;
-    for (u32 sl = 0; sl < ns; sl++) total += ((const u16 *)(rows + (size_t)sl * OP_ROW_WORDS))[b];
+    // a bucket's counts of all slices at once (a loop over the slices, as it was, waited for every load before it asked for the
+    // next: 56 round trips per workgroup, 0.37 ms of nothing but waiting)
+    u32 c[OP_TILE_SLICES], total = 0;
+#pragma unroll
+    for (int sl = 0; sl < OP_TILE_SLICES; sl++) c[sl] = (u32)sl < ns ? ((const u16 *)(rows + (size_t)sl * OP_ROW_WORDS))[b] : 0u;
+#pragma unroll
+    for (int sl = 0; sl < OP_TILE_SLICES; sl++) total += c[sl];
     u32 tot;
     const u32 ex = wave_excl_scan_u32(total, tot);
     if ((b & 63) == 0) wsum[b >> 6] = tot;
     __syncthreads();
     u32 run = ex;
     for (u32 q = 0; q < (b >> 6); q++) run += wsum[q];
-    for (u32 sl = 0; sl < ns; sl++) {
-        u32 *row = rows + (size_t)sl * OP_ROW_WORDS;
-        const u32 c = ((const u16 *)row)[b];
-        row[512 + b] = run;
-        run += c;
+#pragma unroll
+    for (int sl = 0; sl < OP_TILE_SLICES; sl++) {
+        if ((u32)sl < ns) rows[(size_t)sl * OP_ROW_WORDS + 512 + b] = run;
+        run += c[sl];
     }
 }
 
