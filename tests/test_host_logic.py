@@ -350,6 +350,31 @@ def test_leading_channel_reads_send_prefixes_and_fall_back(tmp_cfg):
     r.close()
 
 
+def test_tofile_writes_over_an_existing_file_in_place(tmp_cfg):
+    """tofile(overwrite=True) over an existing regular file keeps the inode (what the reference's open(out, 'wb') truncates and
+    refills) and writes over its pages; a longer old file is cut to the new length, a shorter one grows; the content is the
+    recording either way, and a name that is not a regular file is replaced."""
+    from tests.codec_oracle import LaneOracleCodec
+    arr = (np.random.RandomState(12).randn(5000, 5) * 300).astype(np.int16)
+    codec = LaneOracleCodec(n_lanes=1, capacity_chunks=8)
+    r, _ = _write(tmp_cfg, arr, check_after_compress=False, codec=codec)
+    r.close()
+    r = mtscomp_amd.decompress(tmp_cfg / 'data.cbin', tmp_cfg / 'data.ch', codec=codec, check_after_decompress=False)
+    assert r.n_chunks > 2
+    back = tmp_cfg / 'back.bin'
+    for old_len in (arr.nbytes + 12345, 100, arr.nbytes):
+        back.write_bytes(b'\xa5' * old_len)
+        ino = back.stat().st_ino
+        r.tofile(back, overwrite=True)
+        assert back.stat().st_ino == ino and back.stat().st_size == arr.nbytes
+        assert np.array_equal(np.fromfile(back, dtype=np.int16).reshape(-1, 5), arr)
+    back.unlink()
+    back.symlink_to(tmp_cfg / 'elsewhere.bin')                       # (dangling or not: the name is what gets the file)
+    r.tofile(back, overwrite=True) if back.exists() else r.tofile(back)
+    assert np.array_equal(np.fromfile(back, dtype=np.int16).reshape(-1, 5), arr)
+    r.close()
+
+
 @pytest.mark.parametrize('n_lanes', [2, 3])
 def test_reader_over_several_lanes(tmp_cfg, n_lanes):
     """A codec with several lanes (HipCodec: one per device): chunk k is read, decoded and kept by lane k mod lanes only; slices,
