@@ -58,6 +58,7 @@ TOFILE_PIECE_CHUNKS = 8         # chunks per piece of Reader.tofile (decode of o
 TOFILE_WRITERS = 4              # threads writing a piece: a fresh tmpfs file takes ~6.5 GB/s whatever their number (its pages are allocated and zeroed under the inode's lock), an existing file written over in place 6-9 GB/s from four (round 5: 2 against 4 writers, new files 2.8-6.2 / 4.0-5.1 GB/s from call to call, over existing files 6.3-8.9 / 6.7-9.0)
 DEFAULT_DEVICE_CACHE_GB = 32    # decoded chunks a Reader may keep in HBM for slicing (allocated as touched; env MTSCOMP_DEVICE_CACHE_GB, 0 = off)
 DEVICE_CACHE_MAX_CHUNKS = 8     # longer slices are streamed through the host path instead of the cache
+READ_AHEAD_MAX = int(os.environ.get('MTSCOMP_READ_AHEAD', 4))   # chunks a cold slice may decode ahead of itself into the device cache (0 = off)
 PREAD_THREADS = int(os.environ.get('MTSCOMP_PREAD_THREADS', 8))      # threads that read the compressed bytes of a slice's missing chunks (a few MB and more)
 
 logger = logging.getLogger('mtscomp_amd')
@@ -567,6 +568,7 @@ class Reader:
         self._cache_lock = threading.RLock()                      # the host LRU is shared by the threads that slice (mtscomp.py:648)
         self._dev_cache_bytes = int(float(os.environ.get('MTSCOMP_DEVICE_CACHE_GB', DEFAULT_DEVICE_CACHE_GB)) * 2 ** 30)
         self._pin = None                                          # page-locked buffer the compressed bytes of slices are read into
+        self._ra, self._ra_calls, self._ra_pending = 1, 0, {}     # read-ahead of the device cache (see _read_ahead)
         self._pin_lock = threading.Lock()
         self._io_pool = None
 
@@ -783,6 +785,11 @@ class Reader:
         keys = list(range(first, last + 1))
         a, b = i0 - self.chunk_bounds[first], i1 - self.chunk_bounds[first]
         present = [int(p) >= self.n_channels for p in self.codec.cache_query(cache, keys)]      # (entries of leading channels only do not count)
+        ahead = self._read_ahead(cache, keys, present)              # chunks behind the slice decoded along with its missing ones
+        if ahead:
+            keys, present = keys + ahead, present + [False] * len(ahead)
+            rows = rows + [self.chunk_bounds[k + 1] - self.chunk_bounds[k] for k in ahead]
+            n += len(ahead)
         for attempt in range(2):
             need = [k for k, p in zip(keys, present) if not p]
             offs, lens = [0] * n, [0] * n
@@ -805,8 +812,42 @@ class Reader:
                     if e.code != hip.E_MISS or attempt:
                         raise
                     present = [False] * n                          # dropped since the query: send everything
-        self._raise_for(dict(zip(keys, status)))
+        for k, st in zip(keys[n - len(ahead):], status[n - len(ahead):]) if ahead else ():
+            if st == 0:
+                self._ra_pending[k] = True                         # (a damaged chunk ahead is reported when somebody reads it)
+        self._raise_for(dict(zip(keys[:n - len(ahead)], status[:n - len(ahead)])))
         return out
+
+    def _read_ahead(self, cache, keys, present):
+        """Chunks right behind a slice that are decoded in the same device call as the slice's missing chunks -- a batch of one
+        or two chunks costs the device nearly what a batch of four does (the inflate stages of a small batch are one dependency
+        chain each), so a reader that comes to them later (the next window of a sequential reader; sooner or later every chunk,
+        for random windows over a recording that fits the cache) finds them decoded.  Adaptive like a file system's read-ahead:
+        starts at one chunk, one more (up to READ_AHEAD_MAX) whenever a chunk read ahead is used, one less whenever one leaves
+        the list of pending ones unused (the list is half the cache long at most); at none, one chunk is tried every 32nd time.
+        Nothing is read ahead when all of a slice's chunks are resident."""
+        for k, p in zip(keys, present):
+            if p and self._ra_pending.pop(k, None):
+                self._ra = min(self._ra + 1, READ_AHEAD_MAX)
+        if all(present) or READ_AHEAD_MAX <= 0:
+            return []
+        self._ra_calls += 1
+        ra = self._ra if self._ra > 0 else (1 if self._ra_calls % 32 == 0 else 0)
+        chunk_bytes = max(1, (self.chunk_bounds[1] - self.chunk_bounds[0]) * self.n_channels * self.dtype.itemsize)
+        cap = max(8, min(self._dev_cache_bytes // chunk_bytes // 2, 1024))
+        ra = min(ra, max(0, DEVICE_CACHE_MAX_CHUNKS - len(keys)), int(self._dev_cache_bytes // chunk_bytes // 4))
+        cand = list(range(keys[-1] + 1, min(keys[-1] + 1 + ra, self.n_chunks)))
+        if not cand:
+            return []
+        ahead = []
+        for k, p in zip(cand, self.codec.cache_query(cache, cand)):
+            if int(p) >= self.n_channels:
+                break                                              # (one read covers the missing chunks: it ends at the first resident one)
+            ahead.append(k)
+        while len(self._ra_pending) + len(ahead) > cap:             # the oldest pending ones have had their chance
+            self._ra_pending.pop(next(iter(self._ra_pending)))
+            self._ra = max(self._ra - 1, 0)
+        return ahead
 
     def _slice_from_lane_caches(self, first, last, i0, i1, lanes):
         """The same over several lanes: every lane reads, decodes and keeps its own chunks (k mod lanes) and copies the rows of

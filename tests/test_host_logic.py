@@ -253,10 +253,12 @@ def test_host_cache_is_safe_under_concurrent_slicing(tmp_cfg):
     r.close()
 
 
-def test_slices_through_the_decoded_chunk_cache_interface(tmp_cfg):
+def test_slices_through_the_decoded_chunk_cache_interface(tmp_cfg, monkeypatch):
     """Reader slices against a codec that offers the cache interface (CPU stand-in for mts_cache_*): only missing chunks are
-    read and sent, a miss after the query is retried with all bytes, corrupt chunks map to IOError with their index."""
+    read and sent, a miss after the query is retried with all bytes, corrupt chunks map to IOError with their index.
+    (Read-ahead off: the calls are counted.)"""
     from tests.codec_oracle import CachingOracleCodec
+    monkeypatch.setattr(api, 'READ_AHEAD_MAX', 0)
     arr = (np.random.RandomState(10).randn(6997, 6) * 700).astype(np.int16)
     codec = CachingOracleCodec(capacity_chunks=3)
     r, _ = _write(tmp_cfg, arr, check_after_compress=False, codec=codec)             # 6 chunks of 1234 rows
@@ -288,6 +290,44 @@ def test_slices_through_the_decoded_chunk_cache_interface(tmp_cfg):
     assert r[200:100:-1].shape == arr[200:100:-1][0:0].shape          # (like the reference: a negative row step gives nothing)
     r.close(); r2.close()
     assert codec.caches == {}
+
+
+def test_cold_slices_read_ahead_into_the_decoded_chunk_cache(tmp_cfg, monkeypatch):
+    """A slice with missing chunks has the chunks right behind it decoded in the same codec call: one at first, one more
+    every time a chunk read ahead is used (a sequential reader gets to READ_AHEAD_MAX), none when the slice's chunks are all
+    resident, never past the end of the file or beyond a resident chunk; a damaged chunk ahead does not fail the read that
+    did not ask for it, and the one that does gets the reference's IOError; the slices are numpy's throughout."""
+    from tests.codec_oracle import CachingOracleCodec
+    monkeypatch.setattr(api, 'READ_AHEAD_MAX', 3)
+    arr = (np.random.RandomState(13).randn(14000, 4) * 500).astype(np.int16)
+    codec = CachingOracleCodec(capacity_chunks=64)
+    r, _ = _write(tmp_cfg, arr, check_after_compress=False, codec=codec)             # 12 chunks of 1234 rows (the last: 426)
+    assert r.n_chunks == 12
+    codec.calls.clear()
+    assert np.array_equal(r[10:20], arr[10:20])                                      # chunk 0, and chunk 1 ahead
+    assert codec.calls == [('cache_read', 2)] and sorted(codec.caches[1]) == [0, 1]
+    assert np.array_equal(r[1300:1310], arr[1300:1310])                              # chunk 1: resident, nothing is read; the read-ahead was used
+    assert codec.calls[-1] == ('cache_read', 0) and r._ra == 2
+    assert np.array_equal(r[2500:2510], arr[2500:2510])                              # chunk 2 missing: 3 and 4 ahead
+    assert codec.calls[-1] == ('cache_read', 3) and sorted(codec.caches[1]) == [0, 1, 2, 3, 4]
+    assert np.array_equal(r[3800:5000:7], arr[3800:5000:7]) and r._ra == 3             # chunks 3 and 4: used
+    assert np.array_equal(r[8700:8710], arr[8700:8710])                              # chunk 7 missing: 8, 9, 10 ahead
+    assert codec.calls[-1] == ('cache_read', 4)
+    assert np.array_equal(r[6200:6300], arr[6200:6300])                              # chunk 5 missing: 6 ahead, 7 is resident
+    assert codec.calls[-1] == ('cache_read', 2)
+    assert np.array_equal(r[13900:], arr[13900:])                                    # the last chunk: nothing behind it
+    assert codec.calls[-1] == ('cache_read', 1)
+    r.close()
+    # damage in chunk 3: reading chunk 2 (which reads 3 ahead) succeeds, reading chunk 3 raises
+    b = bytearray((tmp_cfg / 'data.cbin').read_bytes())
+    b[r.chunk_offsets[3] + 20] ^= 0xff
+    (tmp_cfg / 'data.cbin').write_bytes(bytes(b))
+    r2 = mtscomp_amd.decompress(tmp_cfg / 'data.cbin', tmp_cfg / 'data.ch', codec=CachingOracleCodec(capacity_chunks=64))
+    assert np.array_equal(r2[2500:2510], arr[2500:2510])
+    with pytest.raises(IOError, match='#3'):
+        r2[3800:3810]
+    assert np.array_equal(r2[5000:5010], arr[5000:5010])
+    r2.close()
 
 
 def test_trim_cache_copies_only_what_pins_a_big_buffer(tmp_cfg):
