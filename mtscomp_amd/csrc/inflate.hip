@@ -292,6 +292,140 @@ __device__ int parse_tables(BitIn &br, LaneLds &L, u32 type, CHAIN &&LC, CHAIN &
     return INF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same for a table set that a whole wave shares (pass A: stride 1, every lane used to run parse_tables() redundantly --
+// 316 code lengths decoded one after the other by 64 lanes in step, and three counting / placing loops over the symbols:
+// 0.40 ms of pass A's 3.03).  Here the wave works together:
+//   * the code-length symbol that WOULD start at every bit position of the header (64 positions a step, 512 at a time, on
+//     demand) goes to LDS as symbol | code length << 5 | extra-bit value << 8;
+//   * the walk from the first position hops over that table (one LDS read and a dozen instructions per symbol instead of
+//     a refill, a 7-step compare chain and a table look-up) and notes runs (first index, count, value);
+//   * the runs are filled in by the lanes, and the two code tables are counted and put in order with ballots (a symbol's
+//     place = start of its length + symbols of that length before it: the same order as the serial loops give).
+// Same verdicts in the same order as parse_tables().  `scratch`: PARSE_WAVE_WORDS words of LDS; br must read through an LDS
+// copy (br.lw) that covers the header.
+// ------------------------------------------------------------------------------------------------
+constexpr int PARSE_WAVE_POS = 2560 + 64;                     // a dynamic header is < 2560 bits long (316 lengths of <= 7 bits + 74)
+constexpr int PARSE_WAVE_WORDS = PARSE_WAVE_POS / 2 + 320;   // the position table (u16), the runs
+
+template <int MAXL, bool DIST, class CHAIN>
+__device__ int build_chain_wave(LaneLds &L, int first, int nsym, CHAIN &&lc, int &maxlen, int lane)
+{
+    constexpr int R = DIST ? 1 : 5;                            // rounds of 64 symbols (<= 32 distance / code-length, <= 288 literal/length symbols)
+    const u64 lt = ((u64)1 << lane) - 1;
+    u32 mylen[R], cn[MAXL + 1];
+#pragma unroll
+    for (int l = 0; l <= MAXL; l++) cn[l] = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int s_ = r * 64 + lane;
+        mylen[r] = s_ < nsym ? (u32)L.len(first + s_) : 0u;
+#pragma unroll
+        for (int l = 1; l <= MAXL; l++) cn[l] += (u32)__popcll(__ballot(mylen[r] == (u32)l));
+    }
+    int left = 1, ml = 0;
+    u32 off = 0, firstc = 0, short_codes = 0, base[MAXL + 1];
+#pragma unroll
+    for (int l = 1; l <= MAXL; l++) {
+        left = (left << 1) - (int)cn[l];
+        if (cn[l]) ml = l;
+        base[l] = off;
+        off += cn[l];
+        if (l <= (DIST ? CHAIN_LUT_DBITS : CHAIN_LUT_LBITS)) short_codes += cn[l];
+        const u32 lim = (firstc + cn[l]) << (MAXL - l);
+        lc[l] = (lim & 0xffff) | (cn[l] << 16);
+        firstc = (firstc + cn[l]) << 1;
+    }
+    lc[0] = short_codes;
+    maxlen = ml;
+    if (left < 0) return -1;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int s_ = r * 64 + lane;
+#pragma unroll
+        for (int l = 1; l <= MAXL; l++) {
+            const u64 m = __ballot(mylen[r] == (u32)l);
+            if (mylen[r] == (u32)l) {
+                const u32 o = base[l] + (u32)__popcll(m & lt);
+                if (DIST) L.ds(o) = (u16)s_; else L.ls(o) = (u16)s_;
+            }
+            base[l] += (u32)__popcll(m);
+        }
+    }
+    return left > 0 ? 1 : 0;
+}
+
+template <class CHAIN>
+__device__ int parse_tables_wave(BitIn &br, LaneLds &L, u32 type, CHAIN &&LC, CHAIN &&DC, u32 *scratch, int lane)
+{
+    if (type != 2 || br.lw == nullptr) return parse_tables(br, L, type, LC, DC);
+    const int nlen_codes = (int)br.get(5) + 257;
+    const int ndist_codes = (int)br.get(5) + 1;
+    const int ncode = (int)br.get(4) + 4;
+    if (nlen_codes > 286 || ndist_codes > 30) return INF_CORRUPT;
+    const u8 order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    constexpr int CL0 = INF_LENS - 19;
+    for (int i = 0; i < 19; i++) L.len(CL0 + i) = 0;
+    for (int i = 0; i < ncode; i++) L.len(CL0 + order[i]) = (u8)br.get(3);
+    if (br.pos > br.end) return INF_CORRUPT;
+    u32 CC[8];
+    int ml;
+    if (build_chain<7, true>(L, CL0, 19, CC, ml) != 0) return INF_CORRUPT;
+    u16 *dec = (u16 *)scratch;
+    u32 *runs = scratch + PARSE_WAVE_POS / 2;
+    const u64 p0 = br.pos;
+    const int total = nlen_codes + ndist_codes;
+    u32 limit = 0, p = 0;
+    int idx = 0, prev = 0, nruns = 0;
+    while (idx < total) {
+        if (limit + 512 > (u32)PARSE_WAVE_POS) return INF_CORRUPT;          // (cannot happen: see PARSE_WAVE_POS)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int r = 0; r < 8; r++) {
+            const u32 q = limit + (u32)r * 64 + (u32)lane;
+            const u64 ap = p0 + q, wi = (ap >> 5) - br.lw0;
+            u32 bits = 0;
+            if (wi + 1 < br.lwn) bits = __builtin_amdgcn_alignbit(br.lw[wi + 1], br.lw[wi], (u32)(ap & 31));
+            u32 cl;
+            const int si = chain_decode<7>(__brev(bits) >> 25, CC, cl);     // (the code is complete: every 7 bits are a symbol)
+            const u32 sym = L.ds(si < 0 ? 0 : si);
+            const u32 xb = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
+            dec[q] = (u16)(sym | (cl << 5) | (((bits >> cl) & ((1u << xb) - 1u)) << 8));
+        }
+        limit += 512;
+        __builtin_amdgcn_wave_barrier();
+        while (idx < total && p < limit) {
+            const u32 d = dec[p];
+            const u32 sym = d & 31, x = d >> 8;
+            u32 adv = (d >> 5) & 7;
+            int rep = 1, val = (int)sym;
+            if (sym >= 16) {
+                if (sym == 16) { if (idx == 0) return INF_CORRUPT; val = prev; rep = 3 + (int)x; adv += 2; }
+                else if (sym == 17) { val = 0; rep = 3 + (int)x; adv += 3; }
+                else { val = 0; rep = 11 + (int)x; adv += 7; }
+                if (idx + rep > total) return INF_CORRUPT;
+            }
+            runs[nruns++] = (u32)idx | ((u32)rep << 9) | ((u32)val << 17);
+            idx += rep; prev = val; p += adv;
+            if (p0 + p > br.end) return INF_CORRUPT;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int r = lane; r < nruns; r += 64) {
+        const u32 e = runs[r];
+        const int i0 = (int)(e & 511), rep = (int)((e >> 9) & 255), val = (int)(e >> 17);
+        for (int k = 0; k < rep; k++) L.len(i0 + k) = (u8)val;
+    }
+    __builtin_amdgcn_wave_barrier();
+    br.seek(p0 + p);
+    if (L.len(256) == 0) return INF_CORRUPT;                     // missing end-of-block code
+    int e = build_chain_wave<15, false>(L, 0, nlen_codes, LC, ml, lane);
+    if (e < 0 || (e > 0 && ml != 1)) return INF_CORRUPT;
+    e = build_chain_wave<15, true>(L, nlen_codes, ndist_codes, DC, ml, lane);
+    if (e < 0 || (e > 0 && ml > 1)) return INF_CORRUPT;
+    return INF_OK;
+}
+
 constexpr u32 LZ_PIECE = 8;          // longest copy handed to one lane of the LZ resolver
 constexpr u32 LZ_WINDOW_BYTES = 32768; // the deflate window (= LZ_WIN of the segmented resolver)
 __device__ __forceinline__ u32 lz_pieces(u32 tok, u32 olen) { return (tok >> 31) ? (olen + LZ_PIECE - 1) / LZ_PIECE : 1; }
@@ -1026,8 +1160,9 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     __shared__ u32 lut_s[LUT_BYTES / 4];
     u32 *lutl = lut_s, *lutd = lut_s + (1 << LUT_LBITS);
     u32 *LC = lutd + (1 << LUT_DBITS), *DC = LC + 16;               // the compare chains live in LDS (wave-shared)
-    // every lane parses the header redundantly (identical control flow, identical LDS writes)
-    const int rc = parse_tables(br, L, hdr >> 1, LC, DC);
+    // the header is parsed by the wave together (parse_tables_wave; its scratch: the staged words behind the header's)
+    static_assert(SCAN_TAIL + 8 + PARSE_WAVE_WORDS <= PASSA_STAGE_WORDS, "the header's words and the parse's scratch fit the stage");
+    const int rc = parse_tables_wave(br, L, hdr >> 1, LC, DC, stage + SCAN_TAIL + 8, lane);
     if (rc != INF_OK) { if (lane == 0) cres[slot] = r; return; }
     __builtin_amdgcn_wave_barrier();
     build_luts(L, lutl, lutd, lane);
