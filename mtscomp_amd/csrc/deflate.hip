@@ -1836,50 +1836,126 @@ __device__ void tw_gen_codes(const TreeWS &t, int lane, u32 *out, int elems)
     }
 }
 
-__device__ void tw_scan_tree(const u16 *len, int max_code, u16 *blfreq)
-{
-    int prevlen = -1, curlen, nextlen = len[0], count = 0, max_count = 7, min_count = 4;
-    if (nextlen == 0) { max_count = 138; min_count = 3; }
-    for (int n = 0; n <= max_code; n++) {
-        curlen = nextlen; nextlen = n + 1 <= max_code ? len[n + 1] : 0xffff;
-        if (++count < max_count && curlen == nextlen) continue;
-        else if (count < min_count) blfreq[curlen] += (u16)count;
-        else if (curlen != 0) { if (curlen != prevlen) blfreq[curlen]++; blfreq[16]++; }
-        else if (count <= 10) blfreq[17]++;
-        else blfreq[18]++;
-        count = 0; prevlen = curlen;
-        if (nextlen == 0) { max_count = 138; min_count = 3; }
-        else if (curlen == nextlen) { max_count = 6; min_count = 3; }
-        else { max_count = 7; min_count = 4; }
-    }
-}
-
 struct BitW { u32 *w; u64 acc; int nb; u32 pos; };   // sequential LSB-first writer into zeroed words
 __device__ __forceinline__ void bw_put(BitW &b, u32 v, int n)
 {
     b.acc |= (u64)v << b.nb; b.nb += n;
     if (b.nb >= 32) { b.w[b.pos++] = (u32)b.acc; b.acc >>= 32; b.nb -= 32; }
 }
-__device__ void tw_send_tree(BitW &bw, const u16 *len, int max_code, const u32 *blc)
+// ------------------------------------------------------------------------------------------------
+// scan_tree / send_tree by the whole wave.  zlib walks the code lengths symbol by symbol and flushes a count when it reaches
+// max_count or the value changes; what it emits for a MAXIMAL run of R equal lengths v depends on v and R alone:
+//   v = 0 :  R div 138 times code 18 (138 zeros), then for the rest r: nothing (0), r zeros (r < 3), code 17 (r <= 10), code 18;
+//   v > 0 :  the run starts with max_count 7 / min_count 4 (the length before it differs): c = min(R, 7) of it are v x c (c < 4)
+//            or v followed by code 16 for c - 1; after a full 7, groups of 6 are code 16 each (max_count 6 / min_count 3, the
+//            length before is v now), and the rest r is v x r (r < 3) or one more code 16.
+// A lane per symbol finds the runs (ballots of "differs from the symbol before"), the lane of a run's first symbol counts
+// (scan) or writes (send: bit offsets by a wave scan of the runs' sizes, codes OR-ed into an LDS image of the header) what the
+// run emits.  Lane 0 doing both walks alone was a quarter of the kernel's scalar instructions (k_block_trees is bound by the
+// CU's scalar unit: the compiler runs one-lane code there).
+// ------------------------------------------------------------------------------------------------
+struct TreeRun { u32 v, nlit, n16, x16_first, q6, r16, n17, x17, n18_full, n18, x18; };    // what a run emits (see above)
+__device__ __forceinline__ TreeRun tree_run(u32 v, u32 R)
 {
-    int prevlen = -1, curlen, nextlen = len[0], count = 0, max_count = 7, min_count = 4;
-    if (nextlen == 0) { max_count = 138; min_count = 3; }
-#define SEND_BL(c) bw_put(bw, blc[c] & 0xffff, (int)(blc[c] >> 16))
-    for (int n = 0; n <= max_code; n++) {
-        curlen = nextlen; nextlen = n + 1 <= max_code ? len[n + 1] : 0xffff;
-        if (++count < max_count && curlen == nextlen) continue;
-        else if (count < min_count) { do { SEND_BL(curlen); } while (--count != 0); }
-        else if (curlen != 0) {
-            if (curlen != prevlen) { SEND_BL(curlen); count--; }
-            SEND_BL(16); bw_put(bw, (u32)(count - 3), 2);
-        } else if (count <= 10) { SEND_BL(17); bw_put(bw, (u32)(count - 3), 3); }
-        else { SEND_BL(18); bw_put(bw, (u32)(count - 11), 7); }
-        count = 0; prevlen = curlen;
-        if (nextlen == 0) { max_count = 138; min_count = 3; }
-        else if (curlen == nextlen) { max_count = 6; min_count = 3; }
-        else { max_count = 7; min_count = 4; }
+    TreeRun t = {v, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (v == 0) {
+        t.n18_full = R / 138;
+        const u32 r = R - t.n18_full * 138;
+        if (r < 3) t.nlit = r;
+        else if (r <= 10) { t.n17 = 1; t.x17 = r - 3; }
+        else { t.n18 = 1; t.x18 = r - 11; }
+    } else {
+        const u32 c = R < 7 ? R : 7;
+        if (c < 4) t.nlit = c;
+        else { t.nlit = 1; t.n16 = 1; t.x16_first = c - 4; }
+        const u32 rest = R - c;                                   // (only behind a full 7)
+        t.q6 = rest / 6;
+        const u32 r = rest - t.q6 * 6;
+        if (r < 3) t.nlit += r; else t.r16 = r;                  // r16: a last code 16 for r (3..5) lengths
     }
-#undef SEND_BL
+    return t;
+}
+// the runs of len[0 .. max_code]: calls f(k, is_start, v, R) for every symbol 64 k + lane, all lanes together, k ascending
+template <class F>
+__device__ __forceinline__ void tree_runs(const u16 *len, int max_code, int lane, F &&f)
+{
+    constexpr int RK = (L_CODES + 63) / 64;
+    u64 M[RK];
+    u32 v[RK];
+#pragma unroll
+    for (int k = 0; k < RK; k++) {
+        const int n = 64 * k + lane;
+        v[k] = n <= max_code ? (u32)len[n] : 0xffffu;
+        const u32 pv = (n > 0 && n <= max_code) ? (u32)len[n - 1] : 0xfffeu;
+        M[k] = __ballot(n <= max_code && v[k] != pv);
+    }
+#pragma unroll
+    for (int k = 0; k < RK; k++) {
+        const int n = 64 * k + lane;
+        const bool st = (M[k] >> lane) & 1;
+        // the next run start behind this symbol (or the end)
+        u32 next = (u32)max_code + 1;
+        const u64 above = lane == 63 ? 0 : M[k] & (~0ull << (lane + 1));
+        if (above) next = 64 * k + (u32)__ffsll((long long)above) - 1;
+        else {
+            bool found = false;
+#pragma unroll
+            for (int kk = k + 1; kk < RK; kk++)
+                if (!found && M[kk]) { next = 64 * kk + (u32)__ffsll((long long)M[kk]) - 1; found = true; }
+        }
+        f(k, st, v[k], st ? next - (u32)n : 0u);
+    }
+}
+// scan_tree: blf[0 .. 18] += the codes the tree's runs emit (blf in LDS, zeroed by the caller)
+__device__ void tw_scan_tree_wave(const u16 *len, int max_code, u32 *blf, int lane)
+{
+    tree_runs(len, max_code, lane, [&](int, bool st, u32 v, u32 R) {
+        if (!st) return;
+        const TreeRun t = tree_run(v, R);
+        if (t.nlit) atomicAdd(&blf[v], t.nlit);
+        const u32 n16 = t.n16 + t.q6 + (t.r16 ? 1u : 0u);
+        if (n16) atomicAdd(&blf[16], n16);
+        if (t.n17) atomicAdd(&blf[17], 1u);
+        if (t.n18_full + t.n18) atomicAdd(&blf[18], t.n18_full + t.n18);
+    });
+}
+// send_tree: the runs' codes into the header image `img` (LDS words, zero where nothing has been written) from bit `bit0` on;
+// returns the bit behind them.  blc[c] = code | length << 16.
+__device__ u32 tw_send_tree_wave(const u16 *len, int max_code, const u32 *blc, u32 *img, u32 bit0, int lane)
+{
+    u32 carry = bit0;
+    auto put = [&](u32 &pos, u32 val, u32 nb) {                   // nb <= 14 bits at `pos`
+        const u32 w = pos >> 5, sh = pos & 31;
+        atomicOr(&img[w], val << sh);
+        if (sh + nb > 32) atomicOr(&img[w + 1], val >> (32 - sh));
+        pos += nb;
+    };
+    tree_runs(len, max_code, lane, [&](int, bool st, u32 v, u32 R) {
+        TreeRun t = tree_run(st ? v : 0u, st ? R : 0u);
+        const u32 lv = st ? blc[v] >> 16 : 0u, l16 = blc[16] >> 16, l17 = blc[17] >> 16, l18 = blc[18] >> 16;
+        const u32 n16 = t.n16 + t.q6 + (t.r16 ? 1u : 0u);
+        const u32 bits = st ? t.nlit * lv + n16 * (l16 + 2) + t.n17 * (l17 + 3) + (t.n18_full + t.n18) * (l18 + 7) : 0u;
+        u32 tot;
+        u32 pos = carry + wave_excl_scan_u32(bits, tot);
+        carry += tot;
+        if (!st) return;
+        const u32 cv = blc[v] & 0xffff, c16 = blc[16] & 0xffff, c17 = blc[17] & 0xffff, c18 = blc[18] & 0xffff;
+        if (v == 0) {
+            for (u32 k = 0; k < t.n18_full; k++) put(pos, c18 | (127u << l18), l18 + 7);
+            for (u32 k = 0; k < t.nlit; k++) put(pos, cv, lv);
+            if (t.n17) put(pos, c17 | (t.x17 << l17), l17 + 3);
+            if (t.n18) put(pos, c18 | (t.x18 << l18), l18 + 7);
+        } else {
+            const u32 c = R < 7 ? R : 7;
+            if (c < 4) { for (u32 k = 0; k < c; k++) put(pos, cv, lv); }
+            else { put(pos, cv, lv); put(pos, c16 | (t.x16_first << l16), l16 + 2); }
+            for (u32 k = 0; k < t.q6; k++) put(pos, c16 | (3u << l16), l16 + 2);
+            const u32 r = R - c - t.q6 * 6;
+            if (r >= 3) put(pos, c16 | ((r - 3) << l16), l16 + 2);
+            else for (u32 k = 0; k < r; k++) put(pos, cv, lv);
+        }
+    });
+    return carry;
 }
 
 __device__ __forceinline__ u32 chunk_nblk(u32 ntok, u32 trailing)
@@ -1967,12 +2043,14 @@ __global__ __launch_bounds__(64) void k_block_trees(const ChunkDesc *__restrict_
     tw_gen_codes(tw, lane, codes + L_CODES, D_CODES);
     __syncthreads();
     // bit-length tree
-    if (lane < BL_CODES) tw.freq[lane] = 0;
+    __shared__ u32 blf[BL_CODES + 1];
+    __shared__ u32 hdr_img[BLK_HDR_WORDS];
+    if (lane < BL_CODES) blf[lane] = 0;
     __syncthreads();
-    if (lane == 0) {
-        tw_scan_tree(llen_s, l_max, tw.freq);
-        tw_scan_tree(dlen_s, d_max, tw.freq);
-    }
+    tw_scan_tree_wave(llen_s, l_max, blf, lane);
+    tw_scan_tree_wave(dlen_s, d_max, blf, lane);
+    __syncthreads();
+    if (lane < BL_CODES) tw.freq[lane] = (u16)blf[lane];
     __syncthreads();
     tw_build(tw, 2, lane, opt_len, static_len);
     int max_blindex;
@@ -2012,19 +2090,19 @@ __global__ __launch_bounds__(64) void k_block_trees(const ChunkDesc *__restrict_
     } else {
         r.btype = 2; r.nbits = (u32)(3 + opt_len);
         u32 *hw = blk_hdr + (u64)b * BLK_HDR_WORDS;
-        for (int i = lane; i < BLK_HDR_WORDS; i += 64) hw[i] = 0;
+        __shared__ u32 blc[BL_CODES + 1];
+        for (int i = lane; i < BLK_HDR_WORDS; i += 64) hdr_img[i] = 0;
+        if (lane == 0) {
+            u32 next_code[16], code = 0;
+            for (int bits = 1; bits <= 7; bits++) { code = (code + tw.bl_count[bits - 1]) << 1; next_code[bits] = code; }
+            for (int n = 0; n < BL_CODES; n++) {
+                const int l = n <= tw.max_code ? tw.len[n] : 0;
+                blc[n] = l ? (bit_reverse(next_code[l]++, l) | ((u32)l << 16)) : 0;
+            }
+        }
         __syncthreads();
         if (lane == 0) {
-            u32 blc[BL_CODES];
-            {
-                u32 next_code[16], code = 0;
-                for (int bits = 1; bits <= 7; bits++) { code = (code + tw.bl_count[bits - 1]) << 1; next_code[bits] = code; }
-                for (int n = 0; n < BL_CODES; n++) {
-                    const int l = n <= tw.max_code ? tw.len[n] : 0;
-                    blc[n] = l ? (bit_reverse(next_code[l]++, l) | ((u32)l << 16)) : 0;
-                }
-            }
-            BitW bw = {hw, 0, 0, 0};
+            BitW bw = {hdr_img, 0, 0, 0};
             bw_put(bw, (u32)(l_max + 1 - 257), 5);
             bw_put(bw, (u32)(d_max + 1 - 1), 5);
             bw_put(bw, (u32)(max_blindex + 1 - 4), 4);
@@ -2032,11 +2110,15 @@ __global__ __launch_bounds__(64) void k_block_trees(const ChunkDesc *__restrict_
                 const int sym = c_bl_order[rank];
                 bw_put(bw, sym <= tw.max_code ? tw.len[sym] : 0, 3);
             }
-            tw_send_tree(bw, llen_s, l_max, blc);
-            tw_send_tree(bw, dlen_s, d_max, blc);
-            r.hdr_bits = bw.pos * 32 + bw.nb;
-            if (bw.nb) hw[bw.pos] = (u32)bw.acc;
+            if (bw.nb) hdr_img[bw.pos] = (u32)bw.acc;              // (at most 71 bits: the runs' codes are OR-ed in behind them)
         }
+        __syncthreads();
+        u32 hb = 14u + 3u * (u32)(max_blindex + 1);
+        hb = tw_send_tree_wave(llen_s, l_max, blc, hdr_img, hb, lane);
+        hb = tw_send_tree_wave(dlen_s, d_max, blc, hdr_img, hb, lane);
+        __syncthreads();
+        for (int i = lane; i < BLK_HDR_WORDS; i += 64) hw[i] = hdr_img[i];
+        r.hdr_bits = hb;
     }
     if (lane != 0) return;
     blocks[b] = r;
