@@ -1638,14 +1638,16 @@ struct TreeWS {
 
 typedef u32 tw_pair __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32 tw_entry(u32 freq, u32 depth, u32 node) { return freq << 15 | depth << 10 | node; }
-__device__ void tw_downheap(TreeWS &t, int k)
+// (the heap's length comes by value: read from the structure it was loaded again at every level -- the stores into the heap
+//  might have changed it, for all the compiler knows)
+__device__ __forceinline__ void tw_downheap(TreeWS &t, int k, const int heap_len)
 {
     const u32 v = t.hp[k];
     int j = k << 1;
-    while (j <= t.heap_len) {
+    while (j <= heap_len) {
         const tw_pair pr = *(const tw_pair *)&t.hp[j];                // children j, j + 1 (j is even)
         u32 c = pr.x;
-        if (j < t.heap_len && (pr.y >> 10) <= (c >> 10)) { j++; c = pr.y; }
+        if (j < heap_len && (pr.y >> 10) <= (c >> 10)) { j++; c = pr.y; }
         if ((v >> 10) <= (c >> 10)) break;
         t.hp[k] = c; k = j; j <<= 1;
     }
@@ -1739,21 +1741,23 @@ __device__ void tw_build(TreeWS &t, int kind, int lane, long &opt_len, long &sta
             if (kind == 0) sa -= static_llen(node); else if (kind == 1) sa -= 5;
         }
         t.opt_acc = oa; t.static_acc = sa;
-        t.heap_len = heap_len; t.heap_max = HEAP_SIZE; t.max_code = max_code;
-        for (int n = heap_len / 2; n >= 1; n--) tw_downheap(t, n);
+        t.heap_len = heap_len; t.max_code = max_code;
+        int hl = heap_len, hmax = HEAP_SIZE;                          // (heap_len / heap_max of zlib, in registers while the heap is worked)
+        for (int n = hl / 2; n >= 1; n--) tw_downheap(t, n, hl);
         node = elems;
         do {
             const u32 en = t.hp[1];
-            t.hp[1] = t.hp[t.heap_len--]; tw_downheap(t, 1);
+            t.hp[1] = t.hp[hl--]; tw_downheap(t, 1, hl);
             const u32 em = t.hp[1];
-            t.hp[--t.heap_max] = en; t.hp[--t.heap_max] = em;
+            t.hp[--hmax] = en; t.hp[--hmax] = em;
             const u32 dn = (en >> 10) & 31, dm = (em >> 10) & 31;
             t.dad[en & 1023] = t.dad[em & 1023] = (u16)node;
             t.hp[1] = tw_entry((en >> 15) + (em >> 15), (dn >= dm ? dn : dm) + 1, (u32)node);
             node++;
-            tw_downheap(t, 1);
-        } while (t.heap_len >= 2);
-        t.heap_max--; t.hp[t.heap_max] = t.hp[1];
+            tw_downheap(t, 1, hl);
+        } while (hl >= 2);
+        hmax--; t.hp[hmax] = t.hp[1];
+        t.heap_len = hl; t.heap_max = hmax;
         t.n_nodes = node;
         t.height = (int)((t.hp[1] >> 10) & 31);
         t.serial_lengths = t.height > max_length;
