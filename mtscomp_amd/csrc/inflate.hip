@@ -1286,6 +1286,7 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
 // ================================================================================================
 constexpr int CHAIN_NEED_SEQ = 1;     // value of seq_flag: the wave decoder finishes the chunk
 constexpr u64 CHAIN_INLINE_BYTES = 4096;   // longest unannounced Huffman block (bytes of output) the chain walk counts itself
+constexpr int CHAIN_LDS_CAND = 1024;      // candidates of a chunk the chain walk holds in LDS (a 23 MB chunk has ~320 blocks)
 
 __global__ __launch_bounds__(64) void k_inf_chain(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
                                                   const InfFast *__restrict__ fast, const u64 *__restrict__ cand_pos,
@@ -1324,6 +1325,54 @@ __global__ __launch_bounds__(64) void k_inf_chain(const u8 *__restrict__ cdata, 
     // of 64 candidates at a time are kept in the lanes' registers (round 5): the search for the candidate at `pos` and the look at
     // its result are a ballot and a few shuffles instead of two dependent trips to memory per block (0.23 ms for the 320 blocks of
     // a chunk, whatever the number of chunks: 8 % of a cold read).
+    // Round 5, second half: the whole walk out of LDS.  All of a chunk's candidates (a few hundred) are loaded at once, every
+    // candidate finds the one that starts where it ends (a binary search over the sorted positions, all candidates at a time),
+    // and the walk is a hop from record to record: ~0.1 us per block instead of 0.5 (a lone wave's dependent instructions: the
+    // ballot, eight v_readlane and the reload every 64 candidates).  Where the walk does not find a block announced -- or a
+    // chunk has more candidates than the LDS holds -- the loop below takes over where it stands.
+    {
+        __shared__ uint4 c_rec[CHAIN_LDS_CAND];                  // end bit (x, y), tokens (z), bytes | ok << 30 | bfinal << 31 (w)
+        __shared__ u64 c_pos[CHAIN_LDS_CAND];
+        __shared__ u16 c_succ[CHAIN_LDS_CAND];
+        if (ncand <= (u32)CHAIN_LDS_CAND && ncand > 0 && !need_seq) {
+            for (u32 i = lane; i < ncand; i += 64) {
+                const CandRes c = cres[f.cand_off + i];
+                c_pos[i] = cp[i];
+                c_rec[i] = make_uint4((u32)c.end_bit, (u32)(c.end_bit >> 32), c.ntok, (c.nout & 0x3fffffffu) | (c.ok ? 1u << 30 : 0u) | (c.bfinal ? 1u << 31 : 0u));
+            }
+            __builtin_amdgcn_wave_barrier();
+            auto find = [&](u64 p) -> u32 {                         // the candidate at exactly p, or 0xffff
+                u32 lo = 0, hi = ncand;
+                while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (c_pos[mid] < p) lo = mid + 1; else hi = mid; }
+                return (lo < ncand && c_pos[lo] == p) ? lo : 0xffffu;
+            };
+            for (u32 i = lane; i < ncand; i += 64) {
+                const uint4 e = c_rec[i];
+                c_succ[i] = (u16)(((e.w >> 30) & 1) ? find((u64)e.x | ((u64)e.y << 32)) : 0xffffu);
+            }
+            __builtin_amdgcn_wave_barrier();
+            u32 i = find(pos);
+            while (i != 0xffffu) {
+                const uint4 e = c_rec[i];
+                if (!((e.w >> 30) & 1)) break;                       // announced, but pass A could not finish it: the loop below looks at it
+                const u32 b_ntok = e.z, b_nout = e.w & 0x3fffffffu;
+                if (ntrue >= f.true_cap || (u64)ntok + b_ntok > (u64)ch.n_expect + 1 || nout + b_nout > ch.n_expect) { need_seq = true; break; }
+                if (lane == 0) {
+                    TrueBlk tb;
+                    tb.start_bit = pos; tb.cand = (u32)(f.cand_off + i); tb.tok_off = ntok; tb.ntok = b_ntok; tb.chunk = (u32)ci;
+                    tblk[f.true_off + ntrue] = tb;
+                }
+                ntrue++;
+                ntok += b_ntok; nout += b_nout;
+                pos = (u64)e.x | ((u64)e.y << 32);
+                cur = i + 1;
+                last = (e.w >> 31) != 0;
+                if (last) break;
+                if (ch.n_need && nout >= ch.n_need) { enough = true; break; }
+                i = c_succ[i];
+            }
+        }
+    }
     u32 hb = 0;                    // the candidates held: hb + lane
     bool have = false;
     u64 hv = ~0ull, h_end = 0;
