@@ -569,6 +569,7 @@ class Reader:
         self._dev_cache_bytes = int(float(os.environ.get('MTSCOMP_DEVICE_CACHE_GB', DEFAULT_DEVICE_CACHE_GB)) * 2 ** 30)
         self._pin = None                                          # page-locked buffer the compressed bytes of slices are read into
         self._ra, self._ra_calls, self._ra_pending = 1, 0, {}     # read-ahead of the device cache (see _read_ahead)
+        self._ra_lock = threading.Lock()                          # (slices may come from several threads)
         self._pin_lock = threading.Lock()
         self._io_pool = None
 
@@ -812,9 +813,10 @@ class Reader:
                     if e.code != hip.E_MISS or attempt:
                         raise
                     present = [False] * n                          # dropped since the query: send everything
-        for k, st in zip(keys[n - len(ahead):], status[n - len(ahead):]) if ahead else ():
-            if st == 0:
-                self._ra_pending[k] = True                         # (a damaged chunk ahead is reported when somebody reads it)
+        with self._ra_lock:
+            for k, st in zip(keys[n - len(ahead):], status[n - len(ahead):]) if ahead else ():
+                if st == 0:
+                    self._ra_pending[k] = True                     # (a damaged chunk ahead is reported when somebody reads it)
         self._raise_for(dict(zip(keys[:n - len(ahead)], status[:n - len(ahead)])))
         return out
 
@@ -826,13 +828,14 @@ class Reader:
         starts at one chunk, one more (up to READ_AHEAD_MAX) whenever a chunk read ahead is used, one less whenever one leaves
         the list of pending ones unused (the list is half the cache long at most); at none, one chunk is tried every 32nd time.
         Nothing is read ahead when all of a slice's chunks are resident."""
-        for k, p in zip(keys, present):
-            if p and self._ra_pending.pop(k, None):
-                self._ra = min(self._ra + 1, READ_AHEAD_MAX)
-        if all(present) or READ_AHEAD_MAX <= 0:
-            return []
-        self._ra_calls += 1
-        ra = self._ra if self._ra > 0 else (1 if self._ra_calls % 32 == 0 else 0)
+        with self._ra_lock:
+            for k, p in zip(keys, present):
+                if p and self._ra_pending.pop(k, None):
+                    self._ra = min(self._ra + 1, READ_AHEAD_MAX)
+            if all(present) or READ_AHEAD_MAX <= 0:
+                return []
+            self._ra_calls += 1
+            ra = self._ra if self._ra > 0 else (1 if self._ra_calls % 32 == 0 else 0)
         chunk_bytes = max(1, (self.chunk_bounds[1] - self.chunk_bounds[0]) * self.n_channels * self.dtype.itemsize)
         cap = max(8, min(self._dev_cache_bytes // chunk_bytes // 2, 1024))
         ra = min(ra, max(0, DEVICE_CACHE_MAX_CHUNKS - len(keys)), int(self._dev_cache_bytes // chunk_bytes // 4))
@@ -844,9 +847,10 @@ class Reader:
             if int(p) >= self.n_channels:
                 break                                              # (one read covers the missing chunks: it ends at the first resident one)
             ahead.append(k)
-        while len(self._ra_pending) + len(ahead) > cap:             # the oldest pending ones have had their chance
-            self._ra_pending.pop(next(iter(self._ra_pending)))
-            self._ra = max(self._ra - 1, 0)
+        with self._ra_lock:
+            while self._ra_pending and len(self._ra_pending) + len(ahead) > cap:      # the oldest pending ones have had their chance
+                self._ra_pending.pop(next(iter(self._ra_pending)))
+                self._ra = max(self._ra - 1, 0)
         return ahead
 
     def _slice_from_lane_caches(self, first, last, i0, i1, lanes):
