@@ -205,6 +205,25 @@ def test_full_size_chunk_properties():
     assert 0.35 < ratio < 0.37
 
 
+def test_one_chunk_with_more_blocks_than_the_chain_walk_holds():
+    """A single chunk of 4 s (92 MB, ~1280 deflate blocks): more candidates than the inflate chain walk keeps in LDS (1024), so
+    the walk takes its older path, 64 candidates at a time; byte identity with zlib and the round trip, next to a chunk of the
+    usual size in the same batch (which takes the LDS path)."""
+    import zlib
+    x = synth_int16(0, 5 * 30000, 385, 3)
+    bounds = [0, 4 * 30000, 5 * 30000]
+    flags = hip.make_flags(True, False, 'F')
+    got = hip.compress_chunks(x, bounds, flags, 6)
+    assert got[0] == zlib.compress(O.delta_transpose(x[:120000], flags).tobytes(), 6)
+    assert got[1] == O.ref_compress_chunk(x[120000:])
+    st, arrs = hip.decompress_chunks(got, [120000, 30000], 385, 'int16', flags)
+    assert st == [0, 0] and np.array_equal(arrs[0], x[:120000]) and np.array_equal(arrs[1], x[120000:])
+    bad = bytearray(got[0])
+    bad[len(bad) // 2] ^= 0x10
+    st, _ = hip.decompress_chunks([bytes(bad), got[1]], [120000, 30000], 385, 'int16', flags)
+    assert st[0] != 0 and st[1] == 0
+
+
 def test_stress_shape_1024_channels_levels():
     """BASELINE configs[4] chunk shape (1024 ch x 7500 rows, chunk = 0.25 s): byte identity vs zlib at levels 1, 2, 3
     (deflate_fast), 6 and 9 through the C ABI's level parameter (the Python API, like the reference, always uses 6), round trip."""
