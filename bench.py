@@ -424,29 +424,33 @@ def extra_file_to_file(x, nc, with_cpu):
     try:
         x.tofile(raw)
         nbytes = raw.stat().st_size
-        best_c = best_d = None
+        best_c = None
         d_calls = []
-        # call 0 also allocates the engine's staging buffers and writes a NEW file; call 1 writes a new file again (the old one
-        # unlinked first); calls 2 and 3 write over the existing file, in place (Reader.tofile: its pages are there already)
-        for rep in range(4):
+        # calls 0..2 write a NEW file each (Reader.tofile unlinks an existing one first, as the reference does, mtscomp.py:711-717;
+        # call 0 also allocates the engine's staging buffers); calls 3 and 4 write over the existing file in place -- the library's
+        # opt-in (MTSCOMP_TOFILE_IN_PLACE=1), NOT the reference's behaviour: reported beside, never as decompress_gbps
+        for rep in range(5):
             t0 = time.perf_counter()
             ratio = mtscomp_amd.compress(raw, out, outmeta, sample_rate=float(RATE), n_channels=nc, dtype=np.int16, check_after_compress=False)
             tc = time.perf_counter() - t0
-            if rep == 1:
-                back.unlink()
-            t1 = time.perf_counter()
-            r = mtscomp_amd.decompress(out, outmeta, back, overwrite=True, check_after_decompress=False)
-            r.close()
-            t2 = time.perf_counter()
+            if rep >= 3:
+                os.environ['MTSCOMP_TOFILE_IN_PLACE'] = '1'
+            try:
+                t1 = time.perf_counter()
+                r = mtscomp_amd.decompress(out, outmeta, back, overwrite=True, check_after_decompress=False)
+                r.close()
+                t2 = time.perf_counter()
+            finally:
+                os.environ.pop('MTSCOMP_TOFILE_IN_PLACE', None)
             d_calls.append(nbytes / (t2 - t1) / 1e9)
             best_c = tc if best_c is None else min(best_c, tc)
-            best_d = t2 - t1 if best_d is None else min(best_d, t2 - t1)
         meta = json.loads(outmeta.read_text())
         sha_c = hashlib.sha1(out.read_bytes()).hexdigest()
         same = np.array_equal(np.memmap(back, dtype=np.int16, mode='r'), np.memmap(raw, dtype=np.int16, mode='r'))
         res = {'workload': '%d ch @ 30 kHz, %.0f s int16 file on tmpfs (%.2f GB), chunk = 1 s, level 6; check_after_* off' % (nc, x.shape[0] / RATE, nbytes / 1e9),
-               'compress_gbps': nbytes / best_c / 1e9, 'decompress_gbps': nbytes / best_d / 1e9, 'ratio': ratio,
-               'decompress_gbps_by_call': {'new_file_first_call': d_calls[0], 'new_file': d_calls[1], 'over_existing_file': d_calls[2:]},
+               'compress_gbps': nbytes / best_c / 1e9, 'decompress_gbps': max(d_calls[1:3]), 'ratio': ratio,
+               'decompress_semantics': "new file per call (an existing one unlinked first): the reference's open(out, 'wb'), mtscomp.py:711-717",
+               'decompress_gbps_by_call': {'new_file_first_call': d_calls[0], 'new_file': d_calls[1:3], 'in_place_opt_in': d_calls[3:]},
                'header_sha1_matches_file': bool(meta['sha1_compressed'] == sha_c), 'round_trip_file_identical': bool(same),
                'sha1_compressed': sha_c}
         if with_cpu:

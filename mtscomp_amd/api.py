@@ -274,10 +274,13 @@ class HipCodec:
         pool.map(fn, range(n), chunksize=1)
 
     def close(self):
+        """Ends the lane threads and frees the page-locked buffers the process-wide pool keeps idle for Reader.tofile and the
+        slice reads (hip.pinned_pool: up to MTSCOMP_PINNED_KEEP_MB, default 2 GiB, would stay pinned otherwise)."""
         with self._pool_lock:
             if self._pool is not None:
                 self._pool.close()
                 self._pool = None
+        hip.pinned_pool.clear()
 
     def __del__(self):
         try:
@@ -930,8 +933,10 @@ class Reader:
                 spans.append((first, last))
             keys = sorted({k for sp in spans if sp for k in range(sp[0], sp[1] + 1)})
             rows = [self.chunk_bounds[k + 1] - self.chunk_bounds[k] for k in keys]
-            usable = 0 < len(keys) <= DEVICE_CACHE_MAX_CHUNKS * lanes and \
-                2 * sum(rows) * self.n_channels * self.dtype.itemsize <= self._dev_cache_bytes * lanes
+            # the limits are PER LANE (chunk k lives on lane k mod lanes: every other chunk with two lanes lands on one of them)
+            per_lane = [[r for k, r in zip(keys, rows) if k % lanes == g] for g in range(lanes)]
+            usable = len(keys) > 0 and all(len(rs) <= DEVICE_CACHE_MAX_CHUNKS and
+                                           2 * sum(rs) * self.n_channels * self.dtype.itemsize <= self._dev_cache_bytes for rs in per_lane)
         if not usable:
             return [self[it] for it in items] if _fallback else None
         # Requests that stay within the leading channels of channel-major chunks need only a prefix of every chunk's stream:
@@ -976,7 +981,7 @@ class Reader:
 
         def run(j):
             g = owners[j]
-            st, arrays = self._lane_read_slices(self._cache_for(g), lane_keys[g], [r for _, _, r in lane_reqs[g]], None)
+            st, arrays = self._lane_read_slices(self._cache_for(g), lane_keys[g], [r for _, _, r in lane_reqs[g]], n_lead if leading else None)
             status.update(zip(lane_keys[g], st))
             for (q, piece, _), arr in zip(lane_reqs[g], arrays):
                 parts[q][piece] = arr
@@ -1104,23 +1109,27 @@ class Reader:
             self.pool.join()
         self.pool = None
 
-    def tofile(self, out, overwrite=False):
-        """Decompress the whole file to a flat binary file (mtscomp.py:701-743)."""
+    def tofile(self, out, overwrite=False, in_place=None):
+        """Decompress the whole file to a flat binary file (mtscomp.py:701-743).  With `overwrite` an existing file is unlinked
+        first and a NEW file written, as the reference does (mtscomp.py:711-715): hard links to the old file, memory maps of it and
+        its owner / mode are left alone.  `in_place=True` (or MTSCOMP_TOFILE_IN_PLACE=1) is an opt-in that is NOT the reference's
+        behaviour: an existing regular file is written over where it is (same inode, cut to the new length at the end) -- faster
+        on a RAM-backed file system, whose pages are there already; readers of the old file see their data change."""
         if out is None:
             out = Path(self.cdata.name).with_suffix('.bin')
         out = Path(out)
         if not overwrite and out.exists():  # pragma: no cover
             raise ValueError("The output file %s already exists, use --overwrite or specify another "
                              "output path." % out)
+        if in_place is None:
+            in_place = os.environ.get('MTSCOMP_TOFILE_IN_PLACE', '0') not in ('', '0')
         direct = getattr(self.codec, 'takes_out', False)
         pipelined = direct and self.n_chunks > 1
-        if overwrite and out.exists() and not (pipelined and out.is_file() and not out.is_symlink()):
+        keep_inode = bool(in_place) and pipelined and out.is_file() and not out.is_symlink()
+        if overwrite and out.exists() and not keep_inode:
             _unlink_lazily(out)
-        # (an existing regular file is written over IN PLACE by the pipelined path -- the inode the reference's open(out, 'wb')
-        #  would truncate and refill, cut to the new length at the end: on a RAM-backed file system the pages are there already,
-        #  where a fresh file has every one of them allocated and zeroed under the writers' feet)
         if pipelined:
-            dsize = self._tofile_pipelined(out)
+            dsize = self._tofile_pipelined(out, keep_inode)
         else:
             with open(out, 'wb') as fb:
                 for batch in range(self.n_batches):
@@ -1136,7 +1145,7 @@ class Reader:
             decompressed = load_raw_data(out, n_channels=self.n_channels, dtype=self.dtype)
             check(decompressed, self.cdata, self.cmeta, codec=self._codec)
 
-    def _tofile_pipelined(self, out):
+    def _tofile_pipelined(self, out, keep_inode=False):
         """The file written piece by piece.  Per lane of the codec (a HipCodec has one per device; piece k goes to lane k mod
         lanes) three things are in flight: the compressed bytes of the lane's next piece being read, a piece on the device
         (decoded straight into one of the lane's two host buffers), the piece before being written by a few threads (pwrite on
@@ -1169,7 +1178,9 @@ class Reader:
         else:
             bufs = [np.empty((max_rows, self.n_channels), dtype=self.dtype) for _ in range(n_bufs)]
         n_writers = max(1, int(os.environ.get('MTSCOMP_TOFILE_WRITERS', TOFILE_WRITERS)))
-        fd = os.open(str(out), os.O_WRONLY | os.O_CREAT, 0o644)     # (no O_TRUNC: see tofile; the length is set when everything is written)
+        # a new file (the reference's open(out, 'wb') after its unlink) unless tofile(in_place=True) found a file to write over:
+        # that one keeps its pages and is cut to the new length when everything is written
+        fd = os.open(str(out), os.O_WRONLY | os.O_CREAT | (0 if keep_inode else os.O_TRUNC), 0o644)
         total_bytes = self.chunk_bounds[-1] * row_bytes
 
         def write_piece(arr, offset):
@@ -1211,7 +1222,8 @@ class Reader:
             mine = list(range(g, len(starts), lanes))            # this lane's pieces
             my_bufs = bufs[g::lanes]
             my_in = pinned_in[g::lanes] or [None]                   # (the read ahead fills the one the device is not reading)
-            with ThreadPool(2) as aux:                              # (one thread reads ahead, one hands pieces to the writers)
+            aux = ThreadPool(2)                                     # (one thread reads ahead, one hands pieces to the writers)
+            try:
                 nxt = aux.apply_async(read_piece, (mine[0], my_in[0]))
                 pending = [None] * len(my_bufs)
                 for j, k in enumerate(mine):
@@ -1228,13 +1240,23 @@ class Reader:
                 for p in pending:
                     if p is not None:
                         p.get()
+            finally:
+                # also on the way out of a failure (a corrupt chunk raises in _decode_into): a read or a write still in flight is
+                # waited for -- ThreadPool's context manager terminate()s without joining, and the caller is about to truncate and
+                # close the descriptor and hand the page-locked buffers back to the pool
+                aux.close()
+                aux.join()
 
+        wpool = ThreadPool(n_writers)
         try:
-            with ThreadPool(n_writers) as wpool:
+            try:
                 if lanes == 1:
                     lane_loop(0)
                 else:
                     self.codec.run_lanes(lane_loop, lanes)
+            finally:
+                wpool.close()                                       # (every lane has joined its own helpers by now: nothing writes any more)
+                wpool.join()
             if os.fstat(fd).st_size > total_bytes:
                 os.ftruncate(fd, total_bytes)                       # (what a longer file of that name had behind)
             return os.fstat(fd).st_size

@@ -344,10 +344,13 @@ class PinnedPool:
     """Page-locked buffers kept between calls.  hipHostMalloc pins its pages one by one (a few hundred MB take a good part of a
     second) and hipHostFree unpins them again: a Reader.tofile that allocated its two piece buffers per call spent more time on
     that than on the file.  take() hands out an idle buffer of at least the size asked for (the smallest that fits, grown by
-    a quarter when a new one has to be made); give() returns it; at most `keep_bytes` stay idle, the largest first."""
+    a quarter when a new one has to be made); give() returns it; at most `keep_bytes` stay idle, the largest first
+    (MTSCOMP_PINNED_KEEP_MB, default 2048; 0 keeps nothing).  clear() frees the idle ones: HipCodec.close() and release() call it."""
 
-    def __init__(self, keep_bytes=2 << 30):
+    def __init__(self, keep_bytes=None):
         import threading
+        if keep_bytes is None:
+            keep_bytes = int(os.environ.get('MTSCOMP_PINNED_KEEP_MB', 2048)) << 20
         self.keep_bytes = int(keep_bytes)
         self._idle = []
         self._lock = threading.Lock()
@@ -371,7 +374,7 @@ class PinnedPool:
             self._idle.sort(key=lambda b: -b.nbytes)
             while sum(b.nbytes for b in self._idle) > self.keep_bytes and len(self._idle) > 1:
                 drop.append(self._idle.pop())
-            if self._idle and self._idle[0].nbytes > self.keep_bytes:
+            if self._idle and (self._idle[0].nbytes > self.keep_bytes or self.keep_bytes <= 0):
                 drop.append(self._idle.pop(0))
         for b in drop:
             b.free()
@@ -384,6 +387,14 @@ class PinnedPool:
 
 
 pinned_pool = PinnedPool()
+
+
+def release():
+    """Give back what the process keeps between calls: the idle page-locked buffers of `pinned_pool`, then the library's
+    per-device workspaces (mts_release)."""
+    pinned_pool.clear()
+    if _lib is not None:
+        _lib.mts_release()
 
 
 class DevBuffer:

@@ -162,7 +162,7 @@ class LeadingOracleCodec(CachingOracleCodec):
         self.bytes_given.append(int(sum(lens)))
         status = []
         for k, o, n, nr in zip(keys, offs, lens, n_rows):
-            if k in cache and self.cols[(cid, k)] >= n_lead:
+            if k in cache and self.cols.get((cid, k), 1 << 20) >= n_lead:
                 status.append(0)
                 continue
             if not n:
@@ -190,19 +190,21 @@ class LeadingOracleCodec(CachingOracleCodec):
         return status, arrays
 
     def cache_query(self, cid, keys):
-        return np.array([self.cols[(cid, k)] if k in self.caches[cid] else 0 for k in keys], dtype=np.int32)
+        return np.array([self.cols.get((cid, k), 1 << 20) if k in self.caches[cid] else 0 for k in keys], dtype=np.int32)      # (entries made by cache_read_rows are whole chunks)
 
 
-class LaneOracleCodec(CachingOracleCodec):
+class LaneOracleCodec(LeadingOracleCodec):
     """CachingOracleCodec with several lanes, the way HipCodec has one per device: a cache per lane (cache_create(capacity, lane)),
     run_lanes() on host threads, decompress(..., out=, lane=) for Reader.tofile's pieces.  Records which lane served what, so the
     CPU suite can check that chunk k is read, decoded and kept on lane k mod n_lanes and nowhere else."""
     takes_out = True
     takes_ranges = True
+    leading_channels = False                      # (LaneOracleCodec(leading=True): the lanes decode leading channels only, like HipCodec)
 
-    def __init__(self, n_lanes=2, **kw):
+    def __init__(self, n_lanes=2, leading=False, **kw):
         super().__init__(n_devices=n_lanes, **kw)
         self.n_lanes = n_lanes
+        self.leading_channels = bool(leading)
         self.cache_lane = {}                      # cache id -> lane
         self.lane_keys = {}                       # lane -> set of chunk keys its cache was asked for
         self.lane_calls = []                      # (lane, n_chunks) of decompress(..., lane=)
@@ -240,9 +242,9 @@ class LaneOracleCodec(CachingOracleCodec):
             got = out
         return status, got
 
-    def cache_read_slices(self, cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, requests):
+    def cache_read_slices(self, cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, requests, n_leading=None):
         self._note(cid, keys)
-        return super().cache_read_slices(cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, requests)
+        return super().cache_read_slices(cid, keys, cdata, offs, lens, n_rows, n_channels, dtype, flags, requests, n_leading=n_leading)
 
     def decompress(self, cbufs, n_rows, n_channels, dtype, flags, out=None, lane=None):
         if isinstance(cbufs, tuple):

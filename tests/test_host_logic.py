@@ -390,10 +390,10 @@ def test_leading_channel_reads_send_prefixes_and_fall_back(tmp_cfg):
     r.close()
 
 
-def test_tofile_writes_over_an_existing_file_in_place(tmp_cfg):
-    """tofile(overwrite=True) over an existing regular file keeps the inode (what the reference's open(out, 'wb') truncates and
-    refills) and writes over its pages; a longer old file is cut to the new length, a shorter one grows; the content is the
-    recording either way, and a name that is not a regular file is replaced."""
+def test_tofile_overwrite_makes_a_new_file_like_the_reference(tmp_cfg):
+    """tofile(overwrite=True) unlinks the old file and writes a NEW one (mtscomp.py:711-717): a hard link to the old file and a
+    memory map of it keep the old bytes, a read-only old file in a writable directory is no obstacle, the new file has the
+    recording.  A name that is not a regular file is replaced as well."""
     from tests.codec_oracle import LaneOracleCodec
     arr = (np.random.RandomState(12).randn(5000, 5) * 300).astype(np.int16)
     codec = LaneOracleCodec(n_lanes=1, capacity_chunks=8)
@@ -401,17 +401,113 @@ def test_tofile_writes_over_an_existing_file_in_place(tmp_cfg):
     r.close()
     r = mtscomp_amd.decompress(tmp_cfg / 'data.cbin', tmp_cfg / 'data.ch', codec=codec, check_after_decompress=False)
     assert r.n_chunks > 2
-    back = tmp_cfg / 'back.bin'
+    back, link = tmp_cfg / 'back.bin', tmp_cfg / 'link.bin'
     for old_len in (arr.nbytes + 12345, 100, arr.nbytes):
         back.write_bytes(b'\xa5' * old_len)
+        os.link(back, link)
+        os.chmod(back, 0o444)
+        held = np.memmap(back, dtype=np.uint8, mode='r')
         ino = back.stat().st_ino
         r.tofile(back, overwrite=True)
-        assert back.stat().st_ino == ino and back.stat().st_size == arr.nbytes
+        assert back.stat().st_ino != ino and back.stat().st_size == arr.nbytes
         assert np.array_equal(np.fromfile(back, dtype=np.int16).reshape(-1, 5), arr)
+        assert link.stat().st_ino == ino and link.read_bytes() == b'\xa5' * old_len      # the hard link still has the old file
+        assert held.shape[0] == old_len and bool((held == 0xa5).all())                        # and so does the map
+        del held
+        link.unlink()
     back.unlink()
     back.symlink_to(tmp_cfg / 'elsewhere.bin')                       # (dangling or not: the name is what gets the file)
     r.tofile(back, overwrite=True) if back.exists() else r.tofile(back)
     assert np.array_equal(np.fromfile(back, dtype=np.int16).reshape(-1, 5), arr)
+    r.close()
+
+
+def test_tofile_in_place_is_an_opt_in(tmp_cfg, monkeypatch):
+    """tofile(overwrite=True, in_place=True) -- or MTSCOMP_TOFILE_IN_PLACE=1 -- writes over an existing regular file where it is:
+    same inode, a longer old file cut to the new length, a shorter one grown; not the reference's behaviour, hence not the default."""
+    from tests.codec_oracle import LaneOracleCodec
+    arr = (np.random.RandomState(13).randn(5000, 5) * 300).astype(np.int16)
+    codec = LaneOracleCodec(n_lanes=1, capacity_chunks=8)
+    r, _ = _write(tmp_cfg, arr, check_after_compress=False, codec=codec)
+    r.close()
+    r = mtscomp_amd.decompress(tmp_cfg / 'data.cbin', tmp_cfg / 'data.ch', codec=codec, check_after_decompress=False)
+    back = tmp_cfg / 'back.bin'
+    for how, old_len in (('arg', arr.nbytes + 12345), ('arg', 100), ('env', arr.nbytes)):
+        back.write_bytes(b'\xa5' * old_len)
+        ino = back.stat().st_ino
+        if how == 'env':
+            monkeypatch.setenv('MTSCOMP_TOFILE_IN_PLACE', '1')
+            r.tofile(back, overwrite=True)
+        else:
+            r.tofile(back, overwrite=True, in_place=True)
+        assert back.stat().st_ino == ino and back.stat().st_size == arr.nbytes
+        assert np.array_equal(np.fromfile(back, dtype=np.int16).reshape(-1, 5), arr)
+    r.close()
+
+
+def test_tofile_failure_waits_for_its_writers(tmp_cfg):
+    """A corrupt chunk in the middle of a pipelined tofile: IOError naming the chunk, an empty output file, and no helper thread
+    of the call still alive afterwards (the writers are joined BEFORE the descriptor is truncated and closed and the buffers go
+    back to the pool)."""
+    import threading
+    from tests.codec_oracle import LaneOracleCodec
+    arr = (np.random.RandomState(14).randn(9000, 5) * 300).astype(np.int16)
+    codec = LaneOracleCodec(n_lanes=1, capacity_chunks=8)
+    r, _ = _write(tmp_cfg, arr, check_after_compress=False, codec=codec)
+    r.close()
+    cbin = tmp_cfg / 'data.cbin'
+    blob = bytearray(cbin.read_bytes())
+    r = mtscomp_amd.decompress(cbin, tmp_cfg / 'data.ch', codec=codec, check_after_decompress=False)
+    bad = r.n_chunks - 2
+    off = r.chunk_offsets[bad] + (r.chunk_offsets[bad + 1] - r.chunk_offsets[bad]) // 2
+    r.close()
+    blob[off] ^= 0x5a
+    blob[off + 1] ^= 0xff
+    cbin.write_bytes(bytes(blob))
+    r = mtscomp_amd.decompress(cbin, tmp_cfg / 'data.ch', codec=codec, check_after_decompress=False)
+    before = {t.ident for t in threading.enumerate()}
+    monkey_piece = api.TOFILE_PIECE_CHUNKS
+    api.TOFILE_PIECE_CHUNKS = 1
+    try:
+        with pytest.raises(IOError, match='chunk #%d' % bad):
+            r.tofile(tmp_cfg / 'back.bin', overwrite=True)
+    finally:
+        api.TOFILE_PIECE_CHUNKS = monkey_piece
+    assert (tmp_cfg / 'back.bin').stat().st_size == 0
+    left = [t for t in threading.enumerate() if t.ident not in before and t.is_alive()]
+    assert not left, left
+    r.close()
+
+
+def test_read_slices_limits_are_per_lane_and_lanes_decode_leading_channels(tmp_cfg, monkeypatch):
+    """Two lanes.  (a) Requests whose chunks all live on ONE lane (every other chunk) beyond that lane's per-call limit go
+    through the host path instead of overfilling the lane -- the limits are per lane, not lanes x limit.  (b) With
+    partial_decode=True the lanes are told how many leading channels the requests need (they were handed None before: whole
+    chunks): fewer compressed bytes cross than the chunks have."""
+    from tests.codec_oracle import LaneOracleCodec
+    arr = (np.random.RandomState(15).randn(9000, 40) * 700).astype(np.int16)
+    codec = LaneOracleCodec(n_lanes=2, leading=True, capacity_chunks=8)
+    r, _ = _write(tmp_cfg, arr, check_after_compress=False, codec=codec)             # 8 chunks of 1234 rows
+    r.close()
+    r = mtscomp_amd.decompress(tmp_cfg / 'data.cbin', tmp_cfg / 'data.ch', codec=codec, check_after_decompress=False, partial_decode=True)
+    assert r.n_chunks == 8 and r._n_lanes() == 2
+    sizes = [r.chunk_offsets[k + 1] - r.chunk_offsets[k] for k in range(8)]
+    # (b) leading channels through two lanes
+    items = [(slice(100, 200), slice(0, 4)), (slice(1300, 1400), slice(1, 3))]        # chunk 0 (lane 0), chunk 1 (lane 1)
+    got = r.read_slices(items)
+    assert all(np.array_equal(g, arr[it]) for g, it in zip(got, items))
+    assert len(codec.bytes_given) == 2 and all(b < sizes[k] for b, k in zip(sorted(codec.bytes_given), (0, 1)) if b) and \
+        sum(codec.bytes_given) < sizes[0] + sizes[1]
+    # (a) chunks 0, 2, 4 are all lane 0's: with a limit of two chunks per lane and call the device gather declines
+    monkeypatch.setattr(api, 'DEVICE_CACHE_MAX_CHUNKS', 2)
+    items = [(slice(10, 20), slice(None)), (slice(2500, 2510), slice(None)), (slice(5000, 5010), slice(None))]
+    assert r.read_slices(items, _fallback=False) is None
+    got = r.read_slices(items)
+    assert all(np.array_equal(g, arr[it]) for g, it in zip(got, items))
+    # the same number of chunks spread over both lanes is served: 2 per lane
+    items = [(slice(10, 20), slice(None)), (slice(1300, 1310), slice(None)), (slice(2500, 2510), slice(None)), (slice(3800, 3810), slice(None))]
+    got = r.read_slices(items, _fallback=False)
+    assert got is not None and all(np.array_equal(g, arr[it]) for g, it in zip(got, items))
     r.close()
 
 
