@@ -48,6 +48,9 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
 RATE = 30000
+CONFIG3_CHUNKS_PER_RANK = 450     # BASELINE configs[3]: 385 ch, 3600 s, chunks round robin over 8 GPUs
+STRESS_CHUNKS = 2400              # BASELINE configs[4]: 1024 ch, 600 s in chunks of 0.25 s
+STRESS_ROWS = 7500
 
 
 def parse_args(argv=None):
@@ -55,8 +58,13 @@ def parse_args(argv=None):
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=3)
     p.add_argument('--warmup', type=int, default=1)
-    p.add_argument('--seconds', type=int, default=60, help='recording length per GPU (1 s chunks)')
-    p.add_argument('--channels', type=int, default=385)
+    p.add_argument('--seconds', type=int, default=0,
+                   help='recording length per GPU in chunks of 1 s (default: 60 at N = 1 = BASELINE configs[1]; %d at N > 1 = one '
+                        'rank\'s shard of configs[3], 3600 s over 8 GPUs)' % CONFIG3_CHUNKS_PER_RANK)
+    p.add_argument('--config', default='headline', choices=('headline', 'stress'),
+                   help='headline: 385 ch, 1 s chunks, level 6 (configs[1] / configs[3]); stress: BASELINE configs[4], 1024 ch, 0.25 s chunks, '
+                        '600 s over the ranks, timed at level 6, levels 1 and 9 measured beside it')
+    p.add_argument('--channels', type=int, default=0, help='default: 385 (headline), 1024 (stress)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-chunks', type=int, default=0, help='chunks in the all-cores CPU sample (default: one per host cpu)')
     p.add_argument('--no-extras', action='store_true', help='skip the configs[2] / configs[4] measurements')
@@ -67,7 +75,34 @@ def parse_args(argv=None):
     p.add_argument('--oversubscribe', action='store_true',
                    help='let ranks share devices (rank -> device rank mod visible): smoke test of the N > 1 path on fewer GPUs, not a measurement')
     p.add_argument('--master-port', type=int, default=0, help='rendezvous port of the self-launched ranks (default: a free one)')
-    return p.parse_args(argv)
+    a = p.parse_args(argv)
+    resolve_workload(a)
+    return a
+
+
+def resolve_workload(a):
+    """Fills in what the flags left open: channels, rows per chunk, chunks per GPU and the sentence that names the workload.
+    N = 1: BASELINE configs[1] (60 chunks).  N > 1: every rank owns what a rank of configs[3] owns on 8 GPUs (450 chunks: at N = 8
+    the job IS configs[3], 3600 s; at N = 2 / 4 it is 900 / 1800 s: weak scaling, per-GPU work fixed).  --config stress: configs[4],
+    its 2400 chunks dealt over the ranks (one rank alone takes an 8-GPU rank's 300)."""
+    n = max(a.gpus, 1)
+    if a.config == 'stress':
+        a.channels = a.channels or 1024
+        a.chunk_rows = STRESS_ROWS
+        a.n_chunks = a.seconds or (STRESS_CHUNKS // n if n > 1 else STRESS_CHUNKS // 8)
+        a.levels_beside = (1, 9)
+        a.workload = ('%d ch @ 30 kHz, chunk = 0.25 s (%d samples), %d chunks per GPU (%d GPUs: %.0f s of the 600 s of BASELINE configs[4]), '
+                      'timed at zlib level 6; levels 1 and 9 beside it (level_curve)' % (a.channels, STRESS_ROWS, a.n_chunks, n, a.n_chunks * n * 0.25))
+    else:
+        a.channels = a.channels or 385
+        a.chunk_rows = RATE
+        a.n_chunks = a.seconds or (60 if n == 1 else CONFIG3_CHUNKS_PER_RANK)
+        a.levels_beside = ()
+        which = 'BASELINE configs[1]' if n == 1 and a.n_chunks == 60 else \
+            'BASELINE configs[3]: 3600 s over 8 GPUs' if n == 8 and a.n_chunks == CONFIG3_CHUNKS_PER_RANK else \
+            "a rank's shard of BASELINE configs[3] (450 chunks) on every GPU: %d s in all" % (a.n_chunks * n) if a.n_chunks == CONFIG3_CHUNKS_PER_RANK else \
+            'BASELINE configs[1] shape, %d s per GPU' % a.n_chunks
+        a.workload = '%d ch @ 30 kHz, %d s synthetic AR int16 per GPU (%d chunks per rank), chunk=1 s, zlib level 6 (%s)' % (a.channels, a.n_chunks, a.n_chunks, which)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -470,25 +505,101 @@ def extra_file_to_file(x, nc, with_cpu):
             pass
 
 
+def extra_host_api(hip, dev, x, nc, reps=3):
+    """The drop-in boundary itself: mts_compress_chunks / mts_decompress_chunks (include/mtscomp_hip.h -- HOST pointers in and out,
+    what a reference-side binding calls instead of pool.map(_compress_chunk) / zlib.decompress, mtscomp.py:399-423, 619) on the
+    benchmarked recording, once from ordinary pageable memory and once from page-locked memory of mts_host_alloc; PCIe both ways
+    is inside the timed call.  Best of `reps` calls after one warm-up; the results are checked (round trip on the host, chunk 0
+    against zlib)."""
+    import ctypes as C
+    L = hip.lib()
+    rows = RATE
+    n = x.shape[0] // rows
+    row_b = nc * x.itemsize
+    raw_bytes = n * rows * row_b
+    flags = hip.make_flags(True, False, 'F')
+    bounds = np.arange(n + 1, dtype=np.int64) * rows
+    cb = (hip.compress_bound(rows * row_b) + 15) // 16 * 16
+    slots = np.arange(n, dtype=np.int64) * cb
+    rws = np.full(n, rows, dtype=np.int64)
+    ooffs = np.arange(n, dtype=np.int64) * (rows * row_b)
+    out = {}
+    for kind in ('pageable', 'page_locked'):
+        held = []
+        if kind == 'pageable':
+            src = np.ascontiguousarray(x[:n * rows]).reshape(-1).view(np.uint8)
+            comp = np.zeros(n * cb + 16, dtype=np.uint8)
+            back = np.zeros(raw_bytes + 256, dtype=np.uint8)
+        else:
+            held = [hip.HostBuffer(raw_bytes), hip.HostBuffer(n * cb + 16), hip.HostBuffer(raw_bytes + 256)]
+            src, comp, back = (h.array for h in held)
+            src[:] = np.ascontiguousarray(x[:n * rows]).reshape(-1).view(np.uint8)
+            comp[:] = 0
+        sizes = np.zeros(n, dtype=np.int64)
+        status = np.zeros(n, dtype=np.int32)
+        packed = None
+        tc, td = [], []
+        for rep in range(reps + 1):
+            t0 = time.perf_counter()
+            rc = L.mts_compress_chunks(dev, src.ctypes.data_as(C.c_void_p), nc, x.itemsize, lp(bounds), n, flags, 6,
+                                       comp.ctypes.data_as(C.c_void_p), lp(slots), lp(sizes))
+            t1 = time.perf_counter()
+            assert rc == 0, L.mts_last_error()
+            # (the decoder takes the chunks where the encoder left them: slot offsets and sizes, as a .cbin reader would pass file offsets)
+            rc = L.mts_decompress_chunks(dev, comp.ctypes.data_as(C.c_void_p), lp(slots), lp(sizes), lp(rws), n, nc, x.itemsize, flags,
+                                         back.ctypes.data_as(C.c_void_p), lp(ooffs), status.ctypes.data_as(C.POINTER(C.c_int)))
+            t2 = time.perf_counter()
+            assert rc == 0 and not status.any(), (L.mts_last_error(), status)
+            if rep:
+                tc.append(t1 - t0)
+                td.append(t2 - t1)
+        ok = bool(np.array_equal(back[:raw_bytes], src[:raw_bytes]))
+        from oracle import oracle as O
+        same0 = comp[:int(sizes[0])].tobytes() == O.ref_compress_chunk(x[:rows])
+        out[kind] = {'compress_gbps': raw_bytes / min(tc) / 1e9, 'decompress_gbps': raw_bytes / min(td) / 1e9,
+                     'compress_gbps_calls': [raw_bytes / t / 1e9 for t in tc], 'decompress_gbps_calls': [raw_bytes / t / 1e9 for t in td],
+                     'round_trip_ok': ok, 'byte_identical_chunk0': bool(same0)}
+        assert ok and same0
+        del src, comp, back
+        for h in held:
+            h.free()
+    csize = int(sizes.sum())
+    out['workload'] = '%d chunks of %d x %d int16 (%.2f GB raw, %.2f GB compressed) per call, host memory in and out, level 6' % (n, rows, nc, raw_bytes / 1e9, csize / 1e9)
+    out['entry_points'] = 'mts_compress_chunks / mts_decompress_chunks (include/mtscomp_hip.h): PCIe both ways inside the call'
+    out['pcie_note'] = 'compress moves R in + C out, decompress C in + R out over PCIe Gen5 x16 (~55 GB/s measured one way from page-locked memory)'
+    return out
+
+
 def extra_in_process_multi_gpu(hip, x, nc, n_dev):
     """What a drop-in user of an N-GPU node gets without torch.distributed: HipCodec(devices=range(N)), one host thread per
-    GPU, chunk i -> GPU i mod N, host buffers in and out (PCIe included)."""
+    GPU, chunk i -> GPU i mod N, host buffers in and out (PCIe included).  Asserted: the lanes sit on N DISTINCT devices, lane g
+    was handed chunks g, g + N, ... and every one of the N devices reports kernel time for the call."""
     from mtscomp_amd.api import HipCodec
     codec = HipCodec(devices=list(range(n_dev)))
+    assert len(set(codec.devices)) == n_dev == codec.n_lanes, codec.devices
     chunks = [x[i * RATE:(i + 1) * RATE] for i in range(x.shape[0] // RATE)]
+    shards = [list(sh) for sh in codec._shards(len(chunks))]
+    assert [sh for sh in shards if sh] == [list(range(g, len(chunks), n_dev)) for g in range(n_dev) if g < len(chunks)], shards
     flags = hip.make_flags(True, False, 'F')
     best_c = best_d = None
     for rep in range(2):
         t0 = time.perf_counter()
         cc = codec.compress(chunks, flags, 6)
         t1 = time.perf_counter()
+        busy_c = {d: sum(ms for _, ms in hip.last_stage_times(d)) for d in codec.devices}
         st, arrs = codec.decompress(cc, [RATE] * len(cc), nc, np.int16, flags)
         t2 = time.perf_counter()
+        busy_d = {d: sum(ms for _, ms in hip.last_stage_times(d)) for d in codec.devices}
         best_c = t1 - t0 if best_c is None else min(best_c, t1 - t0)
         best_d = t2 - t1 if best_d is None else min(best_d, t2 - t1)
+    idle = [d for d in codec.devices[:min(n_dev, len(chunks))] if not (busy_c[d] > 0 and busy_d[d] > 0)]
+    assert not idle, 'devices %s ran no kernel in the in-process multi-GPU call' % idle
     ok = all(s == 0 for s in st) and all(np.array_equal(a, c) for a, c in zip(arrs, chunks))
     nb = len(chunks) * RATE * nc * 2
-    return {'devices': n_dev, 'chunks': len(chunks), 'compress_gbps': nb / best_c / 1e9, 'decompress_gbps': nb / best_d / 1e9, 'round_trip_ok': bool(ok),
+    codec.close()
+    return {'devices': n_dev, 'distinct_devices': sorted(set(codec.devices)), 'chunks': len(chunks), 'chunks_per_lane': [len(sh) for sh in shards],
+            'device_ms_compress': {str(d): busy_c[d] for d in codec.devices}, 'device_ms_decompress': {str(d): busy_d[d] for d in codec.devices},
+            'compress_gbps': nb / best_c / 1e9, 'decompress_gbps': nb / best_d / 1e9, 'round_trip_ok': bool(ok),
             'path': 'HipCodec(devices=range(N)): host arrays in, bytes out, one host thread per GPU (rank 0 of the bench, the other ranks idle)'}
 
 
@@ -563,14 +674,15 @@ def main(argv=None):
         dist, host_group = init_ranks(args, rank, world, dev)
     L = hip.lib()
 
-    nc, rate = args.channels, RATE
-    n_chunks = args.seconds                     # 1 s chunks
+    nc, rate = args.channels, args.chunk_rows   # (rate: samples per chunk -- 30000 = 1 s, 7500 = 0.25 s)
+    n_chunks = args.n_chunks                    # chunks this rank owns
+    level = 6
     row = nc * 2
     chunk_bytes = rate * row
     raw_bytes = n_chunks * chunk_bytes
     sh = None                                   # the library's default stream on `dev`
 
-    # synthetic recording, generated on device: this rank owns global chunks rank, rank + world, ... of a world x 60 s recording
+    # synthetic recording, generated on device: this rank owns global chunks rank, rank + world, ... of a recording of world x n_chunks chunks
     mine = shard_ids(rank, world, n_chunks * world)
     raw = hip.DevBuffer(raw_bytes, dev)
     for k, g in enumerate(mine):
@@ -588,8 +700,8 @@ def main(argv=None):
     status = np.zeros(n_chunks, dtype=np.int32)
     flags = hip.make_flags(True, False, 'F')
 
-    def compress():
-        rc = L.mts_dev_compress_chunks(dev, sh, raw.at(), nc, 2, lp(bounds), n_chunks, flags, 6, cbuf.at(), lp(slots), lp(sizes))
+    def compress(lv=level):
+        rc = L.mts_dev_compress_chunks(dev, sh, raw.at(), nc, 2, lp(bounds), n_chunks, flags, lv, cbuf.at(), lp(slots), lp(sizes))
         assert rc == 0, L.mts_last_error()
 
     def decompress():
@@ -632,8 +744,15 @@ def main(argv=None):
         t_d += c - b
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = None
     if world > 1:
         import torch
+        # every rank's own clock for its steps (compress + decompress + the exchange, without the closing barrier), so that an
+        # imbalance between the ranks shows; the job's time is the slowest rank's, barrier to barrier
+        own = torch.tensor([(t_c + t_d) / max(args.steps, 1) * 1e3], dtype=torch.float64)
+        every = [torch.empty_like(own) for _ in range(world)]
+        dist.all_gather(every, own, group=host_group)
+        per_rank_ms = [float(v.item()) for v in every]
         t = torch.tensor([elapsed, t_c, t_d], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=host_group)
         elapsed, t_c, t_d = t.tolist()
@@ -650,6 +769,41 @@ def main(argv=None):
         z0 = cbuf.download(0, int(sizes[0])).tobytes()
         ok_oracle = z0 == O.ref_compress_chunk(first)
         assert ok_oracle, 'chunk 0 is not byte-identical to zlib level 6'
+
+    # --config stress: levels 1 and 9 beside the timed level 6 (BASELINE configs[4]: "levels {1,6,9} sweep -- ratio vs GB/s curve"):
+    # one warm-up and one timed pass per level on every rank, the slowest rank's time, the ratio over all ranks' chunks; after the
+    # timed region, round trip checked on the device, chunk 0 of rank 0 against zlib at that level
+    level_curve = None
+    if args.levels_beside:
+        level_curve = {'6': {'compress_gbps': raw_bytes * world * args.steps / t_c / 1e9, 'decompress_gbps': raw_bytes * world * args.steps / t_d / 1e9,
+                             'ratio': (int(offsets[-1]) if args.steps else int(sizes.sum())) / (raw_bytes * world)}}
+        for lv in args.levels_beside:
+            compress(lv); decompress()
+            barrier()
+            a = time.perf_counter()
+            compress(lv)
+            hip.dev_sync(dev)
+            b = time.perf_counter()
+            decompress()
+            hip.dev_sync(dev)
+            c = time.perf_counter()
+            offs_lv = gather_sizes()
+            tc_lv, td_lv = b - a, c - b
+            if world > 1:
+                import torch
+                t = torch.tensor([tc_lv, td_lv], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=host_group)
+                tc_lv, td_lv = t.tolist()
+            nd, fd = back.diff(raw)
+            assert nd == 0, 'level %d: round trip mismatch (%d bytes, the first at %d)' % (lv, nd, fd)
+            same = None
+            if rank == 0:
+                from oracle import oracle as O
+                same = cbuf.download(0, int(sizes[0])).tobytes() == O.ref_compress_chunk(raw.download(0, chunk_bytes, np.int16).reshape(rate, nc), level=lv)
+                assert same, 'level %d: chunk 0 is not byte-identical to zlib' % lv
+            level_curve[str(lv)] = {'compress_gbps': raw_bytes * world / tc_lv / 1e9, 'decompress_gbps': raw_bytes * world / td_lv / 1e9,
+                                    'ratio': int(offs_lv[-1]) / (raw_bytes * world), 'byte_identical_chunk0': same}
+        compress(); decompress()                                 # (the buffers hold the level-6 result again: the checks below look at it)
 
     if rank == 0:
         total_raw = raw_bytes * world * args.steps
@@ -682,9 +836,8 @@ def main(argv=None):
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int16',
             'data': 'synthetic',
-            'config': {'workload': '%d ch @ 30 kHz, %d s synthetic AR int16 per GPU, chunk=1 s, zlib level 6 '
-                                   '(BASELINE configs[1])' % (nc, args.seconds),
-                       'n_channels': nc, 'chunks_per_gpu': n_chunks, 'chunk_bytes': chunk_bytes,
+            'config': {'workload': args.workload,
+                       'n_channels': nc, 'chunks_per_gpu': n_chunks, 'chunk_rows': rate, 'chunk_bytes': chunk_bytes,
                        'sharding': 'chunk i -> rank i mod N (round robin), no collective on the data path; the compressed sizes are '
                                    'gathered on the host (gloo, CPU tensors) and prefix-summed into chunk_offsets; process group: %s' % args.dist_backend,
                        'rank_chunks': {str(r): shard_ids(r, world, n_chunks * world) for r in range(world)} if world > 1 else None,
@@ -701,11 +854,16 @@ def main(argv=None):
             'roofline_k1': transform('delta_transpose', 'k_delta_rows'),
             'roofline_k2': transform('cumsum_transpose', 'k_cumsum_rows'),
         }
+        if per_rank_ms is not None:
+            res['per_rank_ms_per_step'] = {'min': min(per_rank_ms), 'max': max(per_rank_ms), 'ranks': per_rank_ms}
+        if level_curve is not None:
+            res['level_curve'] = level_curve
         x_host = None
         cpu_chunks = None
-        if (not args.no_cpu_baseline or not args.no_extras) and world == 1:
+        headline = args.config == 'headline'
+        if (not args.no_cpu_baseline or not args.no_extras) and world == 1 and headline:
             x_host = raw.download(dtype=np.int16).reshape(n_chunks * rate, nc)
-        if not args.no_cpu_baseline and world == 1:             # (the CPU comparison is taken once, at N = 1)
+        if not args.no_cpu_baseline and world == 1 and headline:             # (the CPU comparison is taken once, at N = 1)
             try:
                 res['cpu_baseline'], cpu_chunks = cpu_baseline(x_host, nc, n_chunks, args.cpu_chunks)
             except Exception as e:  # noqa: BLE001  -- the headline line must come out whatever happens here
@@ -721,11 +879,12 @@ def main(argv=None):
             res['cbin_sha1_cpu'] = hashlib.sha1(b''.join(cpu_chunks)).hexdigest()
             del host, mine_c
             assert all(same), 'chunks %s differ from zlib level 6' % [i for i, ok in enumerate(same) if not ok][:8]
-        if not args.no_extras and world == 1:
+        if not args.no_extras and world == 1 and headline:
             for b in (back, cbuf, raw):             # (room for the extras' buffers)
                 b.free()
             extras = {}
-            for name, fn in (('file_to_file', lambda: extra_file_to_file(x_host, nc, not args.no_cpu_baseline)),
+            for name, fn in (('host_api', lambda: extra_host_api(hip, dev, x_host, nc)),
+                             ('file_to_file', lambda: extra_file_to_file(x_host, nc, not args.no_cpu_baseline)),
                              ('random_read', lambda: extra_random_read(hip, dev, args.extras_seconds)),
                              ('level_sweep', lambda: extra_level_sweep(hip, dev))):
                 t1 = time.perf_counter()
@@ -735,10 +894,11 @@ def main(argv=None):
                     extras[name] = {'error': repr(e)}
                 extras[name]['wall_s'] = time.perf_counter() - t1
             res['extras'] = extras
-        if not args.no_extras and world > 1 and not args.oversubscribe:
+        if not args.no_extras and world > 1 and not args.oversubscribe and headline:
             t1 = time.perf_counter()
             try:
-                res['extras'] = {'in_process_multi_gpu': extra_in_process_multi_gpu(hip, raw.download(dtype=np.int16).reshape(n_chunks * rate, nc), nc, world)}
+                n_take = min(n_chunks, 64)                       # (host arrays through PCIe: a sample of the shard is enough to see every lane work)
+                res['extras'] = {'in_process_multi_gpu': extra_in_process_multi_gpu(hip, raw.download(0, n_take * chunk_bytes, np.int16).reshape(n_take * rate, nc), nc, world)}
             except Exception as e:  # noqa: BLE001
                 res['extras'] = {'in_process_multi_gpu': {'error': repr(e)}}
             res['extras']['in_process_multi_gpu']['wall_s'] = time.perf_counter() - t1

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <future>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -90,9 +91,20 @@ struct Engine {
     // pinned pieces the host entry points move user memory through (pageable memory crosses the bus at a fraction of the
     // link's rate, and a fresh destination array takes its page faults on the copying thread): two pieces, so that the
     // DMA of one overlaps the host threads copying the other
-    void *pin[2] = {nullptr, nullptr};
-    hipEvent_t pin_ev[2] = {nullptr, nullptr};
-    hipStream_t copy_st = nullptr;
+    // (round 6: one set per direction -- the host entry points copy the next piece in and the piece before out on two host
+    //  threads while the device works on the current one)
+    struct Stager {
+        void *pin[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        hipStream_t st = nullptr;
+        std::mutex mu;                                   // (a stager's pieces belong to one copy at a time)
+        void release()
+        {
+            for (int k = 0; k < 2; k++) { if (pin[k]) (void)hipHostFree(pin[k]); pin[k] = nullptr; if (ev[k]) (void)hipEventDestroy(ev[k]); ev[k] = nullptr; }
+            if (st) (void)hipStreamDestroy(st);
+            st = nullptr;
+        }
+    } stg[2];                                            // [0]: host -> device, [1]: device -> host
     // inflate workspace
     DBuf inf_scratch, inf_desc, segsums;
     // geometry of the last compress batch whose per-segment / per-block / per-tile descriptors are on the device (a recording is
@@ -147,9 +159,7 @@ struct Engine {
                        &adler, &misc, &h_in, &h_out, &inf_scratch, &inf_desc, &segsums, &fast_lists, &fast_state};
         for (DBuf *b : all) b->release();
         geo_n.clear();
-        for (int k = 0; k < 2; k++) { if (pin[k]) (void)hipHostFree(pin[k]); pin[k] = nullptr; if (pin_ev[k]) (void)hipEventDestroy(pin_ev[k]); pin_ev[k] = nullptr; }
-        if (copy_st) (void)hipStreamDestroy(copy_st);
-        copy_st = nullptr;
+        for (auto &g : stg) g.release();
         if (fast_st) (void)hipStreamDestroy(fast_st);
         fast_st = nullptr;
         for (auto &e : fast_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -495,16 +505,16 @@ static void par_memcpy(void *dst, const void *src, size_t n)
     for (auto &t : th) t.join();
 }
 
-static int pin_init(Engine &E)
+static int pin_init(Engine::Stager &G)
 {
-    if (E.pin[0]) return MTS_OK;
+    if (G.pin[0]) return MTS_OK;
     for (int k = 0; k < 2; k++) {
-        if (hipHostMalloc(&E.pin[k], PIN_PIECE, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); E.pin[k] = nullptr; }
-        if (E.pin[k] && hipEventCreateWithFlags(&E.pin_ev[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(E.pin[k]); E.pin[k] = nullptr; }
+        if (hipHostMalloc(&G.pin[k], PIN_PIECE, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); G.pin[k] = nullptr; }
+        if (G.pin[k] && hipEventCreateWithFlags(&G.ev[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(G.pin[k]); G.pin[k] = nullptr; }
     }
-    if (E.pin[0] && E.pin[1] && hipStreamCreateWithFlags(&E.copy_st, hipStreamNonBlocking) == hipSuccess) return MTS_OK;
+    if (G.pin[0] && G.pin[1] && hipStreamCreateWithFlags(&G.st, hipStreamNonBlocking) == hipSuccess) return MTS_OK;
     (void)hipGetLastError();
-    for (int k = 0; k < 2; k++) { if (E.pin[k]) (void)hipHostFree(E.pin[k]); E.pin[k] = nullptr; }
+    for (int k = 0; k < 2; k++) { if (G.pin[k]) (void)hipHostFree(G.pin[k]); G.pin[k] = nullptr; }
     return MTS_E_NOMEM;           // (the callers fall back to plain copies)
 }
 
@@ -520,6 +530,8 @@ static bool host_ptr_pinned(const void *p)
 
 static int staged_d2h_multi(Engine &E, const std::vector<CopyItem> &segs)
 {
+    Engine::Stager &G = E.stg[1];
+    std::lock_guard<std::mutex> lk(G.mu);
     size_t total = 0;
     for (auto &s : segs) total += s.n;
     // a destination that is pinned already (mts_host_alloc) takes the DMA itself: no pinned piece in between, no host copy
@@ -527,13 +539,13 @@ static int staged_d2h_multi(Engine &E, const std::vector<CopyItem> &segs)
         bool all_pinned = true;
         for (auto &s : segs) if (s.n && !host_ptr_pinned(s.dst)) { all_pinned = false; break; }
         if (all_pinned) {
-            hipStream_t cs = pin_init(E) == MTS_OK ? E.copy_st : nullptr;
+            hipStream_t cs = pin_init(G) == MTS_OK ? G.st : nullptr;
             for (auto &s : segs) if (s.n) MTS_HIP(hipMemcpyAsync(s.dst, s.src, s.n, hipMemcpyDeviceToHost, cs));
             MTS_HIP(hipStreamSynchronize(cs));
             return MTS_OK;
         }
     }
-    if (total < ((size_t)8 << 20) || pin_init(E) != MTS_OK) {
+    if (total < ((size_t)8 << 20) || pin_init(G) != MTS_OK) {
         for (auto &s : segs) if (s.n) MTS_HIP(hipMemcpy(s.dst, s.src, s.n, hipMemcpyDeviceToHost));
         return MTS_OK;
     }
@@ -541,16 +553,16 @@ static int staged_d2h_multi(Engine &E, const std::vector<CopyItem> &segs)
     for (auto &s : segs)
         for (size_t o = 0; o < s.n; o += PIN_PIECE) items.push_back({(u8 *)s.dst + o, (const u8 *)s.src + o, s.n - o < PIN_PIECE ? s.n - o : PIN_PIECE});
     auto issue = [&](size_t k) -> int {
-        MTS_HIP(hipMemcpyAsync(E.pin[k & 1], items[k].src, items[k].n, hipMemcpyDeviceToHost, E.copy_st));
-        MTS_HIP(hipEventRecord(E.pin_ev[k & 1], E.copy_st));
+        MTS_HIP(hipMemcpyAsync(G.pin[k & 1], items[k].src, items[k].n, hipMemcpyDeviceToHost, G.st));
+        MTS_HIP(hipEventRecord(G.ev[k & 1], G.st));
         return MTS_OK;
     };
     int rc;
     if (!items.empty() && (rc = issue(0))) return rc;
     for (size_t k = 0; k < items.size(); k++) {
         if (k + 1 < items.size() && (rc = issue(k + 1))) return rc;
-        MTS_HIP(hipEventSynchronize(E.pin_ev[k & 1]));
-        par_memcpy(items[k].dst, E.pin[k & 1], items[k].n);
+        MTS_HIP(hipEventSynchronize(G.ev[k & 1]));
+        par_memcpy(items[k].dst, G.pin[k & 1], items[k].n);
     }
     return MTS_OK;
 }
@@ -559,22 +571,51 @@ static int staged_d2h(Engine &E, void *dst, const void *d_src, size_t n) { retur
 // user memory -> device; complete on return
 static int staged_h2d(Engine &E, void *d_dst, const void *src, size_t n)
 {
-    if (n >= ((size_t)1 << 20) && host_ptr_pinned(src)) {            // (a pinned source: the DMA reads it directly)
-        MTS_HIP(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, nullptr));
-        MTS_HIP(hipStreamSynchronize(nullptr));
+    Engine::Stager &G = E.stg[0];
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (n >= ((size_t)1 << 20) && host_ptr_pinned(src)) {            // (a pinned source: the DMA reads it directly; on the stager's own
+        hipStream_t cs = pin_init(G) == MTS_OK ? G.st : nullptr;   //  stream, so that it runs beside the kernels of the piece before)
+        MTS_HIP(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, cs));
+        MTS_HIP(hipStreamSynchronize(cs));
         return MTS_OK;
     }
-    if (n < ((size_t)8 << 20) || pin_init(E) != MTS_OK) { MTS_HIP(hipMemcpy(d_dst, src, n, hipMemcpyHostToDevice)); return MTS_OK; }
+    if (n < ((size_t)8 << 20) || pin_init(G) != MTS_OK) { MTS_HIP(hipMemcpy(d_dst, src, n, hipMemcpyHostToDevice)); return MTS_OK; }
     const size_t np = (n + PIN_PIECE - 1) / PIN_PIECE;
     auto len = [&](size_t k) { return k + 1 < np ? PIN_PIECE : n - k * PIN_PIECE; };
     for (size_t k = 0; k < np; k++) {
-        if (k >= 2) MTS_HIP(hipEventSynchronize(E.pin_ev[k & 1]));       // the DMA out of this piece two rounds ago
-        par_memcpy(E.pin[k & 1], (const u8 *)src + k * PIN_PIECE, len(k));
-        MTS_HIP(hipMemcpyAsync((u8 *)d_dst + k * PIN_PIECE, E.pin[k & 1], len(k), hipMemcpyHostToDevice, E.copy_st));
-        MTS_HIP(hipEventRecord(E.pin_ev[k & 1], E.copy_st));
+        if (k >= 2) MTS_HIP(hipEventSynchronize(G.ev[k & 1]));       // the DMA out of this piece two rounds ago
+        par_memcpy(G.pin[k & 1], (const u8 *)src + k * PIN_PIECE, len(k));
+        MTS_HIP(hipMemcpyAsync((u8 *)d_dst + k * PIN_PIECE, G.pin[k & 1], len(k), hipMemcpyHostToDevice, G.st));
+        MTS_HIP(hipEventRecord(G.ev[k & 1], G.st));
     }
-    MTS_HIP(hipStreamSynchronize(E.copy_st));
+    MTS_HIP(hipStreamSynchronize(G.st));
     return MTS_OK;
+}
+
+// The host entry points work piece by piece (round 6): while the device compresses / inflates piece k, one host thread copies
+// piece k + 1 in and another copies the result of piece k - 1 out -- the three used to follow each other (PCIe in, kernels, PCIe
+// out: 21 / 31 GB/s for the 60-chunk recording where the kernels alone do 46 / 134).  A piece is MTS_PIPE_BYTES of raw data
+// (default 256 MiB; 0 = one piece, the old behaviour): big enough that the kernels lose nothing, small enough that a recording
+// of a few hundred MB already overlaps.
+static size_t pipe_piece_bytes()
+{
+    const char *e = getenv("MTS_PIPE_BYTES");
+    return e ? (size_t)atoll(e) : ((size_t)256 << 20);
+}
+static std::vector<int> pipe_pieces(const long *n_rows_or_bounds, bool is_bounds, int n_chunks, u64 row_bytes)
+{
+    std::vector<int> pb = {0};
+    const size_t piece = pipe_piece_bytes();
+    if (piece) {
+        u64 acc = 0;
+        for (int i = 0; i < n_chunks; i++) {
+            const u64 n = (u64)(is_bounds ? n_rows_or_bounds[i + 1] - n_rows_or_bounds[i] : n_rows_or_bounds[i]) * row_bytes;
+            if (acc && acc + n > piece) { pb.push_back(i); acc = 0; }
+            acc += n;
+        }
+    }
+    pb.push_back(n_chunks);
+    return pb;
 }
 
 // split a call into sub-batches that fit the workspace budget (stream bytes per sub-batch) and the grid (several kernels
@@ -591,7 +632,7 @@ static size_t batch_budget_bytes(bool in_order_walk = false)
 }
 
 static int dev_compress(Engine &E, hipStream_t st, const void *d_raw, int nc, int sz, const long *bounds, int n_chunks,
-                        int flags, int level, u8 *d_out, const long *slot_off, long *out_sizes)
+                        int flags, int level, u8 *d_out, const long *slot_off, long *out_sizes, bool add_times = false)
 {
     if (level == -1) level = 6;
     if (level < 1 || level > 9) { set_error("level %d out of range", level); return MTS_E_ARG; }
@@ -602,7 +643,7 @@ static int dev_compress(Engine &E, hipStream_t st, const void *d_raw, int nc, in
     const size_t budget = batch_budget_bytes(level < 4);
     const u64 row_bytes = (u64)nc * sz;
     int i = 0;
-    bool first = true;
+    bool first = !add_times;
     while (i < n_chunks) {
         int j = i;
         size_t acc = 0;
@@ -730,7 +771,8 @@ void inflate_mark(void *engine, hipStream_t st, const char *name) { ((Engine *)e
 u8 *inflate_host_stage(void *engine, size_t bytes) { auto &v = ((Engine *)engine)->host_stage[1]; v.assign(bytes, 0); return v.data(); }
 
 static int dev_decompress(Engine &E, hipStream_t st, const u8 *d_cdata, const long *c_off, const long *c_len, const long *n_rows,
-                          int n_chunks, int nc, int sz, int flags, u8 *d_out, const long *out_off, int *status, int nc_full = 0)
+                          int n_chunks, int nc, int sz, int flags, u8 *d_out, const long *out_off, int *status, int nc_full = 0,
+                          bool add_times = false)
 {
     if (sz != 1 && sz != 2 && sz != 4 && sz != 8) { set_error("itemsize %d unsupported", sz); return MTS_E_ARG; }
     if ((flags & MTS_FLAG_FLOAT) && sz != 4 && sz != 8) { set_error("float items of %d bytes unsupported", sz); return MTS_E_ARG; }
@@ -739,7 +781,7 @@ static int dev_decompress(Engine &E, hipStream_t st, const u8 *d_cdata, const lo
     const size_t budget = batch_budget_bytes() * 4;          // inflate needs ~5 bytes of workspace per byte
     const u64 row_bytes = (u64)(nc_full > nc ? nc_full : nc) * sz;
     int i = 0;
-    bool first = true;
+    bool first = !add_times;
     while (i < n_chunks) {
         int j = i;
         size_t acc = 0;
@@ -910,13 +952,33 @@ int mts_compress_chunks(int device, const void *raw, int n_channels, int itemsiz
     }
     if ((rc = E->h_in.ensure(raw_bytes + 256))) return rc;
     if ((rc = E->h_out.ensure(total + 256))) return rc;
-    if ((rc = staged_h2d(*E, E->h_in.p, raw, raw_bytes))) return rc;
-    rc = dev_compress(*E, nullptr, E->h_in.p, n_channels, itemsize, chunk_bounds, n_chunks, flags, level, E->h_out.as<u8>(),
-                      slots.data(), out_sizes);
-    if (rc) return rc;
-    for (int i = 0; i < n_chunks; i++)
-        MTS_HIP(hipMemcpy(out + out_slot_offsets[i], E->h_out.as<u8>() + slots[i], (size_t)out_sizes[i], hipMemcpyDeviceToHost));
-    return MTS_OK;
+    const std::vector<int> pb = pipe_pieces(chunk_bounds, true, n_chunks, row_bytes);
+    const int np = (int)pb.size() - 1;
+    const int dev = E->dev;
+    auto copy_in = [&](int k) -> int {                               // the raw rows of piece k (on the calling or on a helper thread)
+        MTS_HIP(hipSetDevice(dev));
+        const u64 off = (u64)(chunk_bounds[pb[k]] - chunk_bounds[0]) * row_bytes, len = (u64)(chunk_bounds[pb[k + 1]] - chunk_bounds[pb[k]]) * row_bytes;
+        return len ? staged_h2d(*E, E->h_in.as<u8>() + off, (const u8 *)raw + off, len) : MTS_OK;
+    };
+    auto copy_out = [&](int k) -> int {                              // the streams of piece k, each to its slot in the caller's buffer
+        MTS_HIP(hipSetDevice(dev));
+        std::vector<CopyItem> segs;
+        for (int i = pb[k]; i < pb[k + 1]; i++)
+            if (out_sizes[i] > 0) segs.push_back({out + out_slot_offsets[i], E->h_out.as<u8>() + slots[i], (size_t)out_sizes[i]});
+        return staged_d2h_multi(*E, segs);
+    };
+    if ((rc = copy_in(0))) return rc;
+    for (int k = 0; k < np; k++) {
+        std::future<int> f_in, f_out;
+        if (k + 1 < np) f_in = std::async(std::launch::async, copy_in, k + 1);
+        if (k >= 1) f_out = std::async(std::launch::async, copy_out, k - 1);
+        const u64 off = (u64)(chunk_bounds[pb[k]] - chunk_bounds[0]) * row_bytes;
+        rc = dev_compress(*E, nullptr, E->h_in.as<u8>() + off, n_channels, itemsize, chunk_bounds + pb[k], pb[k + 1] - pb[k], flags, level,
+                          E->h_out.as<u8>(), slots.data() + pb[k], out_sizes + pb[k], k > 0);
+        const int rc_in = f_in.valid() ? f_in.get() : MTS_OK, rc_out = f_out.valid() ? f_out.get() : MTS_OK;      // (always joined: they hold references to this frame)
+        if (rc || rc_in || rc_out) return rc ? rc : rc_in ? rc_in : rc_out;
+    }
+    return copy_out(np - 1);
 }
 
 int mts_delta_transpose(int device, const void *raw, long n_samples, int n_channels, int itemsize, int flags,
@@ -1145,18 +1207,43 @@ int mts_decompress_chunks(int device, const unsigned char *cdata, const long *c_
     if (one_range) { ctot = (u64)(hi - lo) + 16; for (int i = 0; i < n_chunks; i++) coff[i] = c_offsets[i] - lo; }
     if ((rc = E->h_in.ensure(ctot + 256))) return rc;
     if ((rc = E->h_out.ensure(otot + 256))) return rc;
-    if (one_range) { if ((rc = staged_h2d(*E, E->h_in.p, cdata + lo, (size_t)(hi - lo)))) return rc; }
-    else
+    // piece by piece (see pipe_pieces) when the compressed chunks lie in file order in one range: piece k's bytes are then one
+    // range of the caller's buffer as well
+    bool ascending = one_range;
+    for (int i = 1; i < n_chunks && ascending; i++) ascending = c_offsets[i] >= c_offsets[i - 1] + c_lengths[i - 1];
+    std::vector<int> pb = {0, n_chunks};
+    if (ascending) pb = pipe_pieces(n_rows, false, n_chunks, row_bytes);
+    const int np = (int)pb.size() - 1;
+    const int dev = E->dev;
+    auto copy_in = [&](int k) -> int {
+        MTS_HIP(hipSetDevice(dev));
+        if (one_range) {
+            const long a = k == 0 ? lo : c_offsets[pb[k]], b = k + 1 == np ? hi : c_offsets[pb[k + 1]];
+            return b > a ? staged_h2d(*E, E->h_in.as<u8>() + (a - lo), cdata + a, (size_t)(b - a)) : MTS_OK;
+        }
         for (int i = 0; i < n_chunks; i++)
             if (c_lengths[i]) MTS_HIP(hipMemcpyAsync(E->h_in.as<u8>() + coff[i], cdata + c_offsets[i], (size_t)c_lengths[i], hipMemcpyHostToDevice, nullptr));
-    rc = dev_decompress(*E, nullptr, E->h_in.as<u8>(), coff.data(), c_lengths, n_rows, n_chunks, n_channels, itemsize, flags,
-                        E->h_out.as<u8>(), ooff.data(), chunk_status);
-    if (rc) return rc;
-    std::vector<CopyItem> segs;
-    for (int i = 0; i < n_chunks; i++)
-        if (chunk_status[i] == MTS_CHUNK_OK && n_rows[i])
-            segs.push_back({(u8 *)out + out_offsets[i], E->h_out.as<u8>() + ooff[i], (size_t)((u64)n_rows[i] * row_bytes)});
-    return staged_d2h_multi(*E, segs);
+        return MTS_OK;
+    };
+    auto copy_out = [&](int k) -> int {
+        MTS_HIP(hipSetDevice(dev));
+        std::vector<CopyItem> segs;
+        for (int i = pb[k]; i < pb[k + 1]; i++)
+            if (chunk_status[i] == MTS_CHUNK_OK && n_rows[i])
+                segs.push_back({(u8 *)out + out_offsets[i], E->h_out.as<u8>() + ooff[i], (size_t)((u64)n_rows[i] * row_bytes)});
+        return staged_d2h_multi(*E, segs);
+    };
+    if ((rc = copy_in(0))) return rc;
+    for (int k = 0; k < np; k++) {
+        std::future<int> f_in, f_out;
+        if (k + 1 < np) f_in = std::async(std::launch::async, copy_in, k + 1);
+        if (k >= 1) f_out = std::async(std::launch::async, copy_out, k - 1);
+        rc = dev_decompress(*E, nullptr, E->h_in.as<u8>(), coff.data() + pb[k], c_lengths + pb[k], n_rows + pb[k], pb[k + 1] - pb[k], n_channels,
+                            itemsize, flags, E->h_out.as<u8>(), ooff.data() + pb[k], chunk_status + pb[k], 0, k > 0);
+        const int rc_in = f_in.valid() ? f_in.get() : MTS_OK, rc_out = f_out.valid() ? f_out.get() : MTS_OK;
+        if (rc || rc_in || rc_out) return rc ? rc : rc_in ? rc_in : rc_out;
+    }
+    return copy_out(np - 1);
 }
 
 // ---- decoded-chunk cache: entry points (state above mts_release) ----------------------------------

@@ -853,12 +853,13 @@ static inline u64 rows_rounds_of(u64 c_len) { return c_len * 8 / (64 * 640) + 32
 #endif
 constexpr int SCAN_SPANS = MTS_SCAN_SPANS;   // spans per workgroup (2, 4, 8: the stage takes 4.2 ms instead of 3.25 -- the Kraft table made once per
                                              // workgroup does not pay for the fewer, longer workgroups)
+constexpr u64 SCAN_FINAL_ZONE_BITS = 8ull * 256 * 1024;      // candidates with BFINAL = 1 are looked at in the last 256 KiB of a stream only
 constexpr int SCAN_L1_CAP = 14336;       // filter-1 survivors kept per workgroup (expected ~7200 of 32768)
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict__ cdata, const InfChunk *__restrict__ chunks,
                                                            const InfFast *__restrict__ fast, u64 *__restrict__ cand_pos,
                                                            u32 *__restrict__ cand_cnt, u64 *__restrict__ surv_list,
-                                                           u32 *__restrict__ surv_cnt, u32 surv_cap)
+                                                           u32 *__restrict__ surv_cnt, u32 surv_cap, u64 final_zone_bits)
 {
     const int ci = blockIdx.y;
     const InfChunk ch = chunks[ci];
@@ -899,6 +900,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_inf_scan(const u8 *__restrict_
     m &= ~(S_(4) & S_(5) & S_(6) & S_(7));
     m &= ~(S_(9) & S_(10) & S_(11) & S_(12));
 #undef S_
+    // BFINAL: only the LAST block of a stream has it set, and that block starts within a block's length of the end (16383 symbols
+    // of at most 48 bits at zlib's default memLevel; twice that at memLevel 9).  Away from the end a candidate with BFINAL = 1 is
+    // never a block the chain walk can accept: dropping it here halves the survivors of this filter, i.e. the Kraft sums below and
+    // the full validations after them.  A final block longer than SCAN_FINAL_ZONE
+    // is still decoded -- unannounced, by the block-after-block decoder the chain hands the rest of the chunk to.
+    if (span0 + SCAN_SPAN_BITS + final_zone_bits <= end) m &= ~w0;
     // keep only offsets inside the stream
     {
         const u64 o0 = span0 + (u64)tid * 32;
@@ -2927,8 +2934,10 @@ int launch_inflate(hipStream_t st, const u8 *d_cdata, const InfChunk *d_chunks, 
         u64 *d_surv = (u64 *)(S + l.surv);
         u32 *d_surv_cnt = (u32 *)(S + l.surv_cnt);
         MTS_HIP(hipMemsetAsync(d_surv_cnt, 0, 4, st));
+        u64 final_zone_bits = SCAN_FINAL_ZONE_BITS;                  // (MTS_SCAN_FINAL_ZONE = bytes: the tests shrink it below a block's length)
+        if (const char *e = getenv("MTS_SCAN_FINAL_ZONE")) final_zone_bits = 8ull * (u64)atoll(e);
         hipLaunchKernelGGL(k_inf_scan, gscan, dim3(SCAN_THREADS), 0, st, d_cdata, d_chunks, d_fast, d_cand_pos, d_cand_cnt, d_surv,
-                           d_surv_cnt, l.surv_cap);
+                           d_surv_cnt, l.surv_cap, final_zone_bits);
         hipLaunchKernelGGL(k_inf_validate, dim3(std::min((l.surv_cap + 255) / 256, 2048u)), dim3(256), 0, st, d_cdata, d_chunks, d_fast, d_surv,
                            d_surv_cnt, l.surv_cap, d_cand_pos, d_cand_cnt);
         hipLaunchKernelGGL(k_inf_sortc, dim3(n_chunks), dim3(256), 0, st, d_fast, d_cand_pos, d_cand_tmp, d_cand_cnt);

@@ -82,6 +82,9 @@ __device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
 #ifndef MTS_M5_STATS
 #define MTS_M5_STATS 0
 #endif
+#ifndef MTS_M5_BIT_AND
+#define MTS_M5_BIT_AND 0
+#endif
 #if MTS_M5_STATS
 __device__ unsigned long long g_m5_stats[16];          // groups walked, rounds of the newest word, rounds of the other 96, scorings of each
 #endif
@@ -296,7 +299,15 @@ __global__ __launch_bounds__(M5W * 64) void k_match5(const u8 *__restrict__ stre
             u32 m0 = (u32)vm, m1 = (u32)(vm >> 32);
 #pragma unroll
             for (int j = 0; j < 6; j++) {
+#if MTS_M5_BIT_AND
+                // (the bit by v_and_b32, an opcode of the fast class -- profiles/r6_valu_issue_table.txt --, instead of the v_bfe_u32 the
+                //  compiler makes of a shift and a mask)
+                u32 t;
+                asm volatile("v_and_b32 %0, %1, %2" : "=v"(t) : "n"(1 << j), "v"(key[0]));
+                const u64 B = ballot64(t != 0);
+#else
                 const u64 B = ballot64((key[0] >> j) & 1);
+#endif
                 m0 = and_xor(m0, (u32)B, inv[j]); m1 = and_xor(m1, (u32)(B >> 32), inv[j]);
             }
             { u32 *t0 = TB + lane * M5_ROW_WORDS + wp; t0[0] = m0; t0[1] = m1; }

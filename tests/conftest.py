@@ -24,3 +24,12 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The seeds of tests/test_gpu_fuzz.py in the log of every run that executed them (also with -q, also when they pass)."""
+    ran = [r for r in terminalreporter.stats.get('passed', []) + terminalreporter.stats.get('failed', []) if 'test_gpu_fuzz' in r.nodeid]
+    if ran:
+        from tests import test_gpu_fuzz as F
+        terminalreporter.write_line('fuzz: base seed %d (MTS_FUZZ_SEED; case k uses base + k), %.0f s per case (MTS_FUZZ_SECONDS): %s'
+                                    % (F.BASE_SEED, F.SECONDS, ', '.join('%s=%d' % (c[0], F.BASE_SEED + c[2]) for c in F.CASES)))

@@ -483,6 +483,69 @@ def test_inflate_writer_made_chunk_stays_on_the_fast_path():
         assert dt < 0.25, (level, dt)
 
 
+def test_inflate_final_block_outside_the_scan_zone(monkeypatch):
+    """The block-start scan looks at candidates with BFINAL = 1 only near the end of a stream (the last 256 KiB: a final block
+    starts within a block's length of the end).  With the zone shrunk below a block's length (MTS_SCAN_FINAL_ZONE = bytes) the
+    final block of a Writer-made chunk is NOT announced: the chunk must still decode to the same bytes -- the chain walk hands the
+    unannounced block to the block-after-block decoder -- and damage in it must still be refused."""
+    n = 64 * 30000 * 2
+    ar = inputs.ar1_stream(30000, 64)
+    z = zlib.compress(ar, 6)
+    st, out, _ = _timed_inflate(z, n)
+    assert st == 0 and out == ar
+    base = dict(hip.last_stage_times())
+    monkeypatch.setenv('MTS_SCAN_FINAL_ZONE', '1024')
+    st, out, _ = _timed_inflate(z, n)
+    assert st == 0 and out == ar
+    ms = dict(hip.last_stage_times())
+    assert ms['inflate_wave_decoder'] > base['inflate_wave_decoder'], (base, ms)       # (the fallback did run: the test tests what it says)
+    b = bytearray(z)
+    b[len(b) - 3000] ^= 0x10                                         # inside the final block
+    st, out, _ = _timed_inflate(bytes(b), n)
+    assert st != 0
+    monkeypatch.setenv('MTS_SCAN_FINAL_ZONE', '0')                   # no BFINAL = 1 candidate anywhere
+    st, out, _ = _timed_inflate(z, n)
+    assert st == 0 and out == ar
+
+
+def test_host_entry_points_piece_by_piece(monkeypatch):
+    """mts_compress_chunks / mts_decompress_chunks work piece by piece (the next piece's copy in and the last one's copy out on
+    helper threads beside the kernels): MTS_PIPE_BYTES = 1 MiB cuts 11 chunks of 0.3 .. 1.2 MB into ~7 pieces; same bytes as the
+    reference's statements, same verdicts -- a damaged chunk in a middle piece is refused, its neighbours are not --, and the
+    same again as one piece (MTS_PIPE_BYTES = 0) and from page-locked memory."""
+    r = np.random.RandomState(19)
+    chunks = [synth_rows(int(n), 64, 40 + k) for k, n in enumerate(r.randint(2400, 9600, size=11))]
+    rows = [c.shape[0] for c in chunks]
+    bounds = np.concatenate(([0], np.cumsum(rows)))
+    x = np.concatenate(chunks, axis=0)
+    want = [O.ref_compress_chunk(c) for c in chunks]
+    for pipe in ('1048576', '0', '300000'):
+        monkeypatch.setenv('MTS_PIPE_BYTES', pipe)
+        cbufs = hip.compress_chunks(x, bounds, 5, 6)
+        assert [bytes(z) for z in cbufs] == want, pipe
+        st, back = hip.decompress_chunks(cbufs, rows, 64, 'int16', 5)
+        assert st == [0] * len(chunks) and all(np.array_equal(c, b) for c, b in zip(chunks, back)), pipe
+        # chunks handed over as ONE range of a file (what Reader.tofile passes): (buffer, offsets, lengths)
+        blob = b''.join(want)
+        offs = np.concatenate(([0], np.cumsum([len(w) for w in want])))[:-1]
+        bad = bytearray(blob)
+        bad[int(offs[5]) + len(want[5]) // 2] ^= 0x40
+        st, back = hip.decompress_chunks((bytes(bad), list(offs), [len(w) for w in want]), rows, 64, 'int16', 5)
+        assert [s != 0 for s in st] == [k == 5 for k in range(len(chunks))], (pipe, st)
+        assert all(np.array_equal(c, b) for k, (c, b) in enumerate(zip(chunks, back)) if k != 5)
+    # page-locked memory in and out (the DMA reads and writes it directly)
+    monkeypatch.setenv('MTS_PIPE_BYTES', '1048576')
+    src, dst = hip.HostBuffer(x.nbytes), hip.HostBuffer(x.nbytes)
+    try:
+        src.array[:] = x.reshape(-1).view(np.uint8)
+        cbufs = hip.compress_chunks(src.array.view(np.int16).reshape(x.shape), bounds, 5, 6)
+        assert [bytes(z) for z in cbufs] == want
+        st, back = hip.decompress_chunks(cbufs, rows, 64, 'int16', 5, out=dst.array.view(np.int16).reshape(x.shape))
+        assert st == [0] * len(chunks) and np.array_equal(dst.array.view(np.int16).reshape(x.shape), x)
+    finally:
+        src.free(); dst.free()
+
+
 def test_inflate_full_size_streams_without_dynamic_blocks():
     """Chunks of the headline size (385 x 30000 int16 = 23.1 MB) whose streams give the block-start scan nothing to find:
     stored blocks (incompressible data, level 0) and fixed-Huffman blocks (Z_FIXED) go through the wave decoder, not one lane."""
