@@ -336,6 +336,23 @@ def extra_random_read(hip, dev, seconds, n_windows=1000, partial_decode=False):
         cold[key] = (time.perf_counter() - t0) / 100 * 1e3
         ok = ok and np.array_equal(w, r_last[:, 0:cols])
         rc_.close()
+    # ONE cold 1 s window (two chunks nothing has touched), read-ahead off: what a caller waits for a single Reader[a:b] on a file
+    # it has not read before -- pread, copy in, inflate of a two-chunk batch, rows out (the reference: two serial read_chunk calls,
+    # mtscomp.py:798-856, 602-635)
+    from mtscomp_amd import api as _api
+    ra_keep, _api.READ_AHEAD_MAX = _api.READ_AHEAD_MAX, 0
+    try:
+        rc_ = mtscomp_amd.decompress(tmp / 'data.cbin', tmp / 'data.ch')
+        singles = []
+        for k in range(1, min(seconds // 3, 60)):
+            s0 = (3 * k) * RATE + RATE // 2
+            t0 = time.perf_counter()
+            w = rc_[s0:s0 + RATE]
+            singles.append((time.perf_counter() - t0) * 1e3)
+        ok = ok and np.array_equal(w, synth_host(hip, dev, s0, s0 + RATE, nc))
+        rc_.close()
+    finally:
+        _api.READ_AHEAD_MAX = ra_keep
     for p in (tmp / 'data.cbin', tmp / 'data.ch'):
         p.unlink()
     try:
@@ -350,6 +367,8 @@ def extra_random_read(hip, dev, seconds, n_windows=1000, partial_decode=False):
             'columns_0_32_of_256_windows_one_call_ms': t_cols * 1e3, 'columns_bytes_returned': int(sum(g.nbytes for g in got)),
             'cold_ms_per_window_columns_0_32': cold['cols32'], 'cold_ms_per_window_columns_0_32_partial_decode': cold['cols32_partial'],
             'cold_ms_per_window_all_columns': cold['all'],
+            'cold_single_window_ms': float(np.median(singles)) if singles else None, 'cold_single_window_ms_mean': float(np.mean(singles)) if singles else None,
+            'cold_single_window_note': 'one Reader[a:b] of 1 s over two chunks never touched before, read-ahead OFF, median / mean of %d windows' % len(singles),
             'verified': bool(ok), 'build_file_s': t_gen,
             'reader': 'Reader[a:b] through the decoded-chunk cache in HBM (MTSCOMP_DEVICE_CACHE_GB, default 32); pread + H2D + decode on first touch, one D2H of the rows after'}
 

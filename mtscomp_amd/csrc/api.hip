@@ -394,6 +394,8 @@ static int compress_batch(Engine &E, hipStream_t st, const u8 *d_raw, bool raw_i
             MTS_HIP(hipStreamSynchronize(st));
             if (hflags[1] & 1) resort = true;
         } else {
+        if (getenv("MTS_DEBUG_ADDR"))                                 // (tools/m5_addr_times.py: does the match stage's time follow where its buffers lie?)
+            fprintf(stderr, "[addr] stream %p sorted %p tables %p quarter %p tiles %zu\n", (void *)d_stream, (void *)srt_k, (void *)d_tables, (void *)d_quarter, tiles.size());
         if ((rc = launch_match(st, d_stream, d_tiles, (int)tiles.size(), srt_k, d_tables, d_quarter, cfg, d_flags, tap && tap->t_full ? 1 : 0))) return rc;
         E.t_mark(st, "match");
         u32 max_nseg = 0;
@@ -545,7 +547,7 @@ static int staged_d2h_multi(Engine &E, const std::vector<CopyItem> &segs)
             return MTS_OK;
         }
     }
-    if (total < ((size_t)8 << 20) || pin_init(G) != MTS_OK) {
+    if (total < ((size_t)1 << 20) || pin_init(G) != MTS_OK) {
         for (auto &s : segs) if (s.n) MTS_HIP(hipMemcpy(s.dst, s.src, s.n, hipMemcpyDeviceToHost));
         return MTS_OK;
     }
@@ -579,7 +581,9 @@ static int staged_h2d(Engine &E, void *d_dst, const void *src, size_t n)
         MTS_HIP(hipStreamSynchronize(cs));
         return MTS_OK;
     }
-    if (n < ((size_t)8 << 20) || pin_init(G) != MTS_OK) { MTS_HIP(hipMemcpy(d_dst, src, n, hipMemcpyHostToDevice)); return MTS_OK; }
+    // (small copies take the plain call -- which, on the null stream, waits for the kernels there: the pieces of a pipelined call are
+    //  megabytes and go through the stager's own stream)
+    if (n < ((size_t)1 << 20) || pin_init(G) != MTS_OK) { MTS_HIP(hipMemcpy(d_dst, src, n, hipMemcpyHostToDevice)); return MTS_OK; }
     const size_t np = (n + PIN_PIECE - 1) / PIN_PIECE;
     auto len = [&](size_t k) { return k + 1 < np ? PIN_PIECE : n - k * PIN_PIECE; };
     for (size_t k = 0; k < np; k++) {
@@ -1209,10 +1213,10 @@ int mts_decompress_chunks(int device, const unsigned char *cdata, const long *c_
     if ((rc = E->h_out.ensure(otot + 256))) return rc;
     // piece by piece (see pipe_pieces) when the compressed chunks lie in file order in one range: piece k's bytes are then one
     // range of the caller's buffer as well
-    bool ascending = one_range;
+    bool ascending = true;
     for (int i = 1; i < n_chunks && ascending; i++) ascending = c_offsets[i] >= c_offsets[i - 1] + c_lengths[i - 1];
     std::vector<int> pb = {0, n_chunks};
-    if (ascending) pb = pipe_pieces(n_rows, false, n_chunks, row_bytes);
+    if (!one_range || ascending) pb = pipe_pieces(n_rows, false, n_chunks, row_bytes);
     const int np = (int)pb.size() - 1;
     const int dev = E->dev;
     auto copy_in = [&](int k) -> int {
@@ -1221,8 +1225,8 @@ int mts_decompress_chunks(int device, const unsigned char *cdata, const long *c_
             const long a = k == 0 ? lo : c_offsets[pb[k]], b = k + 1 == np ? hi : c_offsets[pb[k + 1]];
             return b > a ? staged_h2d(*E, E->h_in.as<u8>() + (a - lo), cdata + a, (size_t)(b - a)) : MTS_OK;
         }
-        for (int i = 0; i < n_chunks; i++)
-            if (c_lengths[i]) MTS_HIP(hipMemcpyAsync(E->h_in.as<u8>() + coff[i], cdata + c_offsets[i], (size_t)c_lengths[i], hipMemcpyHostToDevice, nullptr));
+        for (int i = pb[k]; i < pb[k + 1]; i++)                       // chunks that lie apart in the caller's memory: one copy each
+            if (c_lengths[i]) { const int rc1 = staged_h2d(*E, E->h_in.as<u8>() + coff[i], cdata + c_offsets[i], (size_t)c_lengths[i]); if (rc1) return rc1; }
         return MTS_OK;
     };
     auto copy_out = [&](int k) -> int {
