@@ -59,6 +59,7 @@ TOFILE_WRITERS = 4              # threads writing a piece: a fresh tmpfs file ta
 DEFAULT_DEVICE_CACHE_GB = 32    # decoded chunks a Reader may keep in HBM for slicing (allocated as touched; env MTSCOMP_DEVICE_CACHE_GB, 0 = off)
 DEVICE_CACHE_MAX_CHUNKS = 8     # longer slices are streamed through the host path instead of the cache
 READ_AHEAD_MAX = int(os.environ.get('MTSCOMP_READ_AHEAD', 4))   # chunks a cold slice may decode ahead of itself into the device cache (0 = off)
+MAP_CDATA = os.environ.get('MTSCOMP_MAP_CDATA', '1') not in ('', '0')      # slices read their compressed bytes out of a mapping of the .cbin (0: preadv into page-locked memory)
 PREAD_THREADS = int(os.environ.get('MTSCOMP_PREAD_THREADS', 8))      # threads that read the compressed bytes of a slice's missing chunks (a few MB and more)
 
 logger = logging.getLogger('mtscomp_amd')
@@ -574,6 +575,9 @@ class Reader:
         self._ra, self._ra_calls, self._ra_pending = 1, 0, {}     # read-ahead of the device cache (see _read_ahead)
         self._ra_lock = threading.Lock()                          # (slices may come from several threads)
         self._pin_lock = threading.Lock()
+        self._map_lock = threading.Lock()
+        self._cmap = self._cmap_view = None
+        self._cmap_size = -1
         self._io_pool = None
 
     @property
@@ -640,6 +644,34 @@ class Reader:
                 buf = self.cdata.read(length)
         assert len(buf) == length
         return buf
+
+    def _map_range(self, length, start):
+        """`length` bytes at `start` of the compressed file as a uint8 view of a read-only MAPPING of the file: no read call and no
+        copy on this side -- the library's host threads copy the bytes out of the page cache into its page-locked pieces while
+        the DMA of the piece before runs (mts_cache_*: staged copies).  A cold window's two chunks were 1.1 ms of preadv on eight
+        Python threads plus 0.65 ms of DMA before (round 6).  None when the file cannot be mapped, or the range is not inside it
+        (the caller's pread then fails the way the reference's does, mtscomp.py:609-612)."""
+        if not MAP_CDATA or length <= 0:
+            return None
+        try:
+            with self._map_lock:
+                size = os.fstat(self.cdata.fileno()).st_size
+                if start + length > size:
+                    return None
+                if self._cmap is None or self._cmap_size != size:
+                    import mmap
+                    self._cmap_view = None
+                    if self._cmap is not None:
+                        try:
+                            self._cmap.close()
+                        except (BufferError, ValueError):
+                            pass                                     # (a view of the old mapping is still out: it goes with its last user)
+                    self._cmap = mmap.mmap(self.cdata.fileno(), 0, access=mmap.ACCESS_READ)
+                    self._cmap_size = size
+                    self._cmap_view = np.frombuffer(self._cmap, dtype=np.uint8)
+                return self._cmap_view[start:min(start + length + 16, size)]      # (16 spare bytes where the file has them: the wrapper wants them behind the last chunk and would copy the range to get them)
+        except (OSError, ValueError, AttributeError):
+            return None
 
     def _pread_pinned(self, length, start):
         """`length` bytes at `start` of the compressed file as a uint8 view of a page-locked buffer (the codec's: the bytes go to
@@ -804,6 +836,17 @@ class Reader:
                 lens[k - first] = self.chunk_offsets[k + 1] - self.chunk_offsets[k]
             # (the page-locked buffer is the Reader's: held from the read until the codec has taken the bytes, released whatever
             #  either of them raises -- a short read of a truncated file is the reference's AssertionError, not a lock left behind)
+            buf = self._map_range(nbytes, base) if need else b''     # (a view of the file's mapping: nothing to lock, nothing read here)
+            if buf is not None:
+                try:
+                    status, out = self.codec.cache_read_rows(cache, keys, buf, offs, lens, rows, self.n_channels,
+                                                             self.dtype, self._flags(), a, b)
+                    break
+                except hip.HipError as e:
+                    if e.code != hip.E_MISS or attempt:
+                        raise
+                    present = [False] * n                          # dropped since the query: send everything
+                    continue
             with self._pin_lock:
                 buf = self._pread_pinned(nbytes, base) if need else b''
                 if buf is None:
@@ -1282,6 +1325,14 @@ class Reader:
                     self.codec.cache_destroy(cache)
                 except Exception:  # pragma: no cover
                     pass
+        with self._map_lock:
+            self._cmap_view = None
+            if self._cmap is not None:
+                try:
+                    self._cmap.close()
+                except (BufferError, ValueError):                  # (a view is still out somewhere: the mapping goes with it)
+                    pass
+                self._cmap = None
         with self._pin_lock:                                      # (a slice on another thread may be reading into the buffer)
             if self._io_pool is not None:
                 self._io_pool.close()

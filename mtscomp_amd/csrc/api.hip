@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <future>
 #include <mutex>
 #include <thread>
@@ -489,22 +490,64 @@ static int host_threads()
     return n;
 }
 
-// memcpy by several threads (a fresh destination is faulted in by all of them at once)
+// memcpy by several threads (a fresh destination is faulted in by all of them at once).  The threads are a pool that lives as
+// long as the library (round 6): started per call they cost ~100 us per copy -- nothing against a 32 MiB piece, a third of the
+// time of the 4 MiB pieces a cold Reader window is moved in.  One copy at a time uses the pool; a second caller (the other
+// direction of a pipelined host call) copies on its own thread instead of waiting.
+namespace {
+struct CopyPool {
+    std::mutex mu, use;                                 // mu: the job; use: one parallel copy at a time
+    std::condition_variable cv_go, cv_done;
+    std::vector<std::thread> th;
+    u8 *dst = nullptr; const u8 *src = nullptr; size_t n = 0, per = 0;
+    u64 gen = 0; int pending = 0; bool stop = false;
+    void worker(int t)
+    {
+        u64 seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_go.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            const size_t a = (size_t)t * per;
+            u8 *d = dst; const u8 *s = src; const size_t nn = n, pp = per;
+            lk.unlock();
+            if (a < nn) memcpy(d + a, s + a, nn - a < pp ? nn - a : pp);
+            lk.lock();
+            if (--pending == 0) cv_done.notify_one();
+        }
+    }
+    void run(void *d, const void *s, size_t bytes, int nt)
+    {
+        if ((int)th.size() + 1 < nt) { for (int t = (int)th.size() + 1; t < nt; t++) th.emplace_back(&CopyPool::worker, this, t); }
+        // (the share is rounded UP before it is aligned: with n / nt an exact multiple of 4096 and n % nt != 0 the threads' shares
+        //  ended n % nt bytes short of n -- the last bytes of such a copy were never made; found by tools/fuzz_gpu.py, seed 301)
+        const size_t p = ((bytes + nt - 1) / nt + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            dst = (u8 *)d; src = (const u8 *)s; n = bytes; per = p; pending = (int)th.size(); gen++;
+        }
+        cv_go.notify_all();
+        memcpy(d, s, bytes < p ? bytes : p);                            // share 0 on the calling thread
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
+CopyPool g_copy_pool;
+}  // namespace
 static void par_memcpy(void *dst, const void *src, size_t n)
 {
-    const int nt = n < ((size_t)4 << 20) ? 1 : host_threads();
+    const int nt = n < ((size_t)1 << 20) ? 1 : host_threads();
     if (nt == 1) { memcpy(dst, src, n); return; }
-    std::vector<std::thread> th;
-    // (the share is rounded UP before it is aligned: with n / nt an exact multiple of 4096 and n % nt != 0 the threads' shares
-    //  ended n % nt bytes short of n -- the last bytes of such a copy were never made; found by tools/fuzz_gpu.py, seed 301)
-    const size_t per = ((n + nt - 1) / nt + 4095) & ~(size_t)4095;
-    for (int t = 1; t < nt; t++) {
-        const size_t a = (size_t)t * per;
-        if (a >= n) break;
-        th.emplace_back([=] { memcpy((u8 *)dst + a, (const u8 *)src + a, n - a < per ? n - a : per); });
-    }
-    memcpy(dst, src, n < per ? n : per);
-    for (auto &t : th) t.join();
+    std::unique_lock<std::mutex> one(g_copy_pool.use, std::try_to_lock);
+    if (!one.owns_lock()) { memcpy(dst, src, n); return; }            // (the pool is busy with the other direction's copy)
+    g_copy_pool.run(dst, src, n, nt);
 }
 
 static int pin_init(Engine::Stager &G)
@@ -584,12 +627,16 @@ static int staged_h2d(Engine &E, void *d_dst, const void *src, size_t n)
     // (small copies take the plain call -- which, on the null stream, waits for the kernels there: the pieces of a pipelined call are
     //  megabytes and go through the stager's own stream)
     if (n < ((size_t)1 << 20) || pin_init(G) != MTS_OK) { MTS_HIP(hipMemcpy(d_dst, src, n, hipMemcpyHostToDevice)); return MTS_OK; }
-    const size_t np = (n + PIN_PIECE - 1) / PIN_PIECE;
-    auto len = [&](size_t k) { return k + 1 < np ? PIN_PIECE : n - k * PIN_PIECE; };
+    // pieces of the page-locked buffers' size -- or, for a transfer of a few MB (the compressed bytes of a cold window), a quarter
+    // of it, so that the DMA of one piece runs under the host copy of the next
+    size_t piece = PIN_PIECE;
+    if (n < 4 * PIN_PIECE) { piece = ((n + 3) / 4 + 4095) & ~(size_t)4095; if (piece < ((size_t)2 << 20)) piece = (size_t)2 << 20; if (piece > PIN_PIECE) piece = PIN_PIECE; }
+    const size_t np = (n + piece - 1) / piece;
+    auto len = [&](size_t k) { return k + 1 < np ? piece : n - k * piece; };
     for (size_t k = 0; k < np; k++) {
         if (k >= 2) MTS_HIP(hipEventSynchronize(G.ev[k & 1]));       // the DMA out of this piece two rounds ago
-        par_memcpy(G.pin[k & 1], (const u8 *)src + k * PIN_PIECE, len(k));
-        MTS_HIP(hipMemcpyAsync((u8 *)d_dst + k * PIN_PIECE, G.pin[k & 1], len(k), hipMemcpyHostToDevice, G.st));
+        par_memcpy(G.pin[k & 1], (const u8 *)src + k * piece, len(k));
+        MTS_HIP(hipMemcpyAsync((u8 *)d_dst + k * piece, G.pin[k & 1], len(k), hipMemcpyHostToDevice, G.st));
         MTS_HIP(hipEventRecord(G.ev[k & 1], G.st));
     }
     MTS_HIP(hipStreamSynchronize(G.st));
@@ -1354,14 +1401,27 @@ static int cache_ensure(DevCache *c, Engine *E, int n_chunks, const long *chunk_
     for (int k = 0; k < m; k++) {
         const int i = miss[k];
         clen[k] = c_lengths[i]; rows[k] = n_rows[i];
-        coff[k] = (long)ctot; ctot += align_up((u64)clen[k] + 8, 16);
+        // (chunks that lie back to back in the caller's buffer keep their distances on the device: one copy moves the run)
+        const bool joins = k > 0 && c_offsets[i] == c_offsets[miss[k - 1]] + clen[k - 1];
+        if (!joins) ctot = align_up(ctot + (k ? 16 : 0), 16);
+        coff[k] = (long)ctot; ctot += (u64)clen[k];
         ooff[k] = (long)otot; otot += align_up((u64)rows[k] * row_bytes, 256);
     }
+    ctot += 16;
     if ((rc = E->h_in.ensure(ctot + 256))) return rc;
     if ((rc = E->h_out.ensure(otot + 256))) return rc;
-    for (int k = 0; k < m; k++)
-        MTS_HIP(hipMemcpyAsync(E->h_in.as<u8>() + coff[k], cdata + c_offsets[miss[k]], (size_t)clen[k], hipMemcpyHostToDevice, nullptr));
-    if (times) { (void)hipStreamSynchronize(nullptr); t_h2d = since(); }
+    // the compressed bytes: chunks that lie back to back in the caller's buffer (a range read or mapped from a .cbin) cross in ONE
+    // staged copy -- page-locked memory by DMA as it is, anything else (a mapping of the file, a bytes object) through the
+    // page-locked pieces, copied by the host threads while the DMA of the piece before runs
+    for (int k = 0; k < m;) {
+        int j = k + 1;
+        while (j < m && c_offsets[miss[j]] == c_offsets[miss[j - 1]] + clen[j - 1] && coff[j] == coff[j - 1] + clen[j - 1]) j++;
+        u64 len = 0;
+        for (int q = k; q < j; q++) len += (u64)clen[q];
+        if (len && (rc = staged_h2d(*E, E->h_in.as<u8>() + coff[k], cdata + c_offsets[miss[k]], (size_t)len))) return rc;
+        k = j;
+    }
+    if (times) t_h2d = since();
     rc = dev_decompress(*E, nullptr, E->h_in.as<u8>(), coff.data(), clen.data(), rows.data(), m, n_cols, itemsize, flags,
                         E->h_out.as<u8>(), ooff.data(), st.data(), n_channels);
     if (rc) return rc;

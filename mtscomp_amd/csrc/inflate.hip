@@ -630,6 +630,58 @@ struct BitL {
         return v;
     }
 };
+// Window reader (round 6, pass A): no state but the position.  Every token reads the 64 bits at its position from the LDS copy
+// (three words, two funnel shifts) instead of carrying a 64-bit buffer, its fill count and a prefetched word through the loop:
+// the buffered reader spends two 64-bit shifts (slow-class opcodes, profiles/r6_valu_issue_table.txt), two refills under
+// branches and their selects per token -- pass A is bound by vector issue (NOTEBOOK.md, round 6), not by the LDS.
+struct BitW {
+    const u32 *w;
+    u32 pos;           // bits consumed (relative to word 0)
+    u32 p, p2;         // the bits [pos, pos + 32) and [pos + 32, pos + 64) of the token being decoded
+    __device__ __forceinline__ void seek(u32 q) { pos = q; }
+    __device__ __forceinline__ void load()
+    {
+        const u32 i = pos >> 5, sh = pos & 31;
+        const u32 a = w[i], b = w[i + 1], c = w[i + 2];
+        p = __builtin_amdgcn_alignbit(b, a, sh);
+        p2 = __builtin_amdgcn_alignbit(c, b, sh);
+    }
+};
+// decode_token_lut on the window reader: the same tables, verdicts and token words
+__device__ __forceinline__ int decode_token_w(BitW &br, LaneLds &L, const u32 *lutl, const u32 *lutd, u32 &tok, u32 &olen)
+{
+    const u32 *LC = lutd + (1 << LUT_DBITS), *DC = LC + 16;
+    br.load();
+    const u32 p = br.p;
+    u32 e = lutl[p & ((1u << LUT_LBITS) - 1)];
+    if (!(e & 15)) {                                             // (rare) longer than the table index
+        u32 cl;
+        const int si = chain_decode_mem_from<15, LUT_LBITS>(__brev(p) >> 17, LC, cl);
+        if (si < 0) return INF_CORRUPT;
+        e = lut_len_entry(L.ls(si), cl);
+    }
+    const u32 type = (e >> 4) & 3, cl = e & 15, eb = e >> 24, val = (e >> 8) & 0xffff;
+    const bool is_match = type == 1;
+    const u32 length = val + __builtin_amdgcn_ubfe(p, cl, eb);    // code + extra bits: <= 15 + 5 of the 32
+    const u32 n1 = cl + eb;
+    const u32 q = __builtin_amdgcn_alignbit(br.p2, p, n1);        // the 32 bits behind them (n1 <= 20)
+    u32 d = lutd[q & ((1u << LUT_DBITS) - 1)];
+    if (is_match && !(d & 15)) {
+        u32 dl;
+        const int si = chain_decode_mem_from<15, LUT_DBITS>(__brev(q) >> 17, DC, dl);
+        if (si < 0) return INF_CORRUPT;
+        d = lut_dist_entry(L.ds(si), dl);
+    }
+    const u32 dcl = d & 15, deb = d >> 24;
+    const u32 dist = ((d >> 8) & 0xffff) + __builtin_amdgcn_ubfe(q, dcl, deb);      // <= 15 + 13 bits
+    br.pos += n1 + (is_match ? dcl + deb : 0u);
+    tok = is_match ? 0x80000000u | ((length - 3) << 16) | (dist - 1) : val & 0xff;
+    olen = is_match ? length : 1u;
+    if (type >= 2) return type == 2 ? 1 : INF_CORRUPT;
+    if (is_match && ((d >> 4) & 3) == 3) return INF_CORRUPT;
+    return 0;
+}
+
 // One whole deflate block, sequentially by one lane, starting at br.pos (reads BFINAL/BTYPE itself).
 // EMIT: write tokens to tk[ntok...].  nout = bytes produced so far in the stream (distance check).
 template <bool EMIT>
@@ -850,6 +902,9 @@ static inline u64 rows_rounds_of(u64 c_len) { return c_len * 8 / (64 * 640) + 32
 
 #ifndef MTS_SCAN_SPANS
 #define MTS_SCAN_SPANS 1
+#endif
+#ifndef MTS_PA_LEAN
+#define MTS_PA_LEAN 1      // pass A on the window reader (BitW): 2.82 -> 2.51 ms for the 60-chunk recording, same tokens (round 6)
 #endif
 constexpr int SCAN_SPANS = MTS_SCAN_SPANS;   // spans per workgroup (2, 4, 8: the stage takes 4.2 ms instead of 3.25 -- the Kraft table made once per
                                              // workgroup does not pay for the fewer, longer workgroups)
@@ -1132,6 +1187,36 @@ __device__ __forceinline__ void decode_span_rows(BitL &br, LaneLds &L, const u32
     }
 }
 
+// the two span decoders pass A uses, on the window reader
+__device__ __forceinline__ void decode_span_exit_w(BitW &br, LaneLds &L, const u32 *lutl, const u32 *lutd, u32 stop, u32 end, int &flag)
+{
+    flag = SPAN_CONT;
+    for (;;) {
+        if (br.pos >= stop) break;
+        u32 tok, olen;
+        const int t = decode_token_w(br, L, lutl, lutd, tok, olen);
+        if (t < 0 || br.pos > end) { flag = SPAN_ERR; break; }
+        if (t == 1) { flag = SPAN_EOB; break; }
+    }
+}
+__device__ __forceinline__ void decode_span_rows_w(BitW &br, LaneLds &L, const u32 *lutl, const u32 *lutd, u32 stop, u32 end, u32 &ntok,
+                                                   u32 &nout, int &flag, u32 *row, u32 cap, bool &ovf)
+{
+    flag = SPAN_CONT;
+    ntok = 0; nout = 0; ovf = false;
+    for (;;) {
+        if (br.pos >= stop) break;
+        u32 tok, olen;
+        const int t = decode_token_w(br, L, lutl, lutd, tok, olen);
+        if (t < 0 || br.pos > end) { flag = SPAN_ERR; break; }
+        if (t == 1) { flag = SPAN_EOB; break; }
+        const u32 np = lz_pieces(tok, olen);
+        if (ntok + np <= cap) lz_emit_pieces(row + ntok, tok, olen);
+        else ovf = true;
+        ntok += np; nout += olen;
+    }
+}
+
 // position of the first lane (>= 1 bit set) in a ballot, or 64
 __device__ __forceinline__ int first_lane(u64 m) { return m ? __ffsll((long long)m) - 1 : 64; }
 
@@ -1201,7 +1286,11 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
     // overshoot) is staged in LDS; positions inside a round are relative to its first staged word
     // (reading the stream straight from memory instead -- no LDS copy, 20 waves per CU -- was measured at 6.55 ms against 3.22)
     br.lw = nullptr; br.lwn = 0;                                     // (the header's copy makes way for the rounds')
+#if MTS_PA_LEAN
+    BitW bl;
+#else
     BitL bl;
+#endif
     bl.w = stage;
     while (!done && !fail) {
         const u64 wb0 = base >> 5;
@@ -1224,7 +1313,11 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
         bool ovf = false;
         // speculative pass: exits only
         bl.seek(start);
+#if MTS_PA_LEAN
+        decode_span_exit_w(bl, L, lutl, lutd, stop, end_rel, fl);
+#else
         decode_span_fast<0>(bl, L, lutl, lutd, stop, end_rel, nt, no, fl, nullptr, 0);
+#endif
         ex = bl.pos;
         bool counted = false;
         for (int it = 0; it < 66; it++) {
@@ -1241,7 +1334,11 @@ __global__ __launch_bounds__(64) void k_inf_passA(const u8 *__restrict__ cdata, 
             if (redo) {
                 start = want_start;
                 bl.seek(start);
+#if MTS_PA_LEAN
+                decode_span_rows_w(bl, L, lutl, lutd, stop, end_rel, nt, no, fl, row, have_rows ? ROWCAP : 0u, ovf);
+#else
                 decode_span_rows(bl, L, lutl, lutd, stop, end_rel, nt, no, fl, row, have_rows ? ROWCAP : 0u, ovf);
+#endif
                 ex = bl.pos;
                 counted = true;
             }
