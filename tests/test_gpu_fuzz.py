@@ -2,7 +2,7 @@
 shares, k_match6's look-back race) run for a fixed budget each, with seeds that CHANGE from day to day and are printed, so
 that the driver's GPU run sees fresh cases every round and a failure can be replayed:
 
-    MTS_FUZZ_SEED=<seed printed by the failing run> MTS_FUZZ_SECONDS=40 python -m pytest tests/test_gpu_fuzz.py -m gpu -s
+    MTS_FUZZ_SEED=<seed printed by the failing run> MTS_FUZZ_SECONDS=30 python -m pytest tests/test_gpu_fuzz.py -m gpu -s
     (or directly: python tools/fuzz_gpu.py <seed> <seconds>, FUZZ_LEVELS=2 for levels 1..9)
 
 What is compared (all through the C ABI, mtscomp_amd/hip.py):
@@ -27,7 +27,7 @@ ROOT = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
 
 BASE_SEED = int(os.environ.get('MTS_FUZZ_SEED', datetime.date.today().strftime('%Y%m%d')))
-SECONDS = float(os.environ.get('MTS_FUZZ_SECONDS', 40))
+SECONDS = float(os.environ.get('MTS_FUZZ_SECONDS', 30))
 
 CASES = [
     # (id, script, seed offset, extra environment)
