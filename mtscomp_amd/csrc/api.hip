@@ -49,16 +49,51 @@ static const LevelCfg LEVELS[10] = {{0, 0, 0, 0},     {4, 4, 8, 4},       {4, 5,
 void drop_device_caches();      // frees the decoded-chunk caches of the current device (called when a workspace allocation fails)
 
 // grow-only device buffer
+// MTS_ARENA_GB=N (experiment, round 6; default off): the workspaces of a device come out of ONE allocation of N GiB made when
+// the first of them is asked for, 2 MiB-aligned pieces handed out one behind the other (a buffer that grows takes a new piece;
+// the arena is given back by mts_release).  Asks whether k_match5's three times -- the physical placement of its workspace,
+// tools/m5_addr_times.py -- go away when the placement is one big block instead of a dozen allocations made between others.
+struct Arena { u8 *base = nullptr; size_t cap = 0, used = 0; bool tried = false; };
+static Arena g_arena[64];
+static size_t arena_gb() { static const size_t v = [] { const char *e = getenv("MTS_ARENA_GB"); return e ? (size_t)atoll(e) : (size_t)0; }(); return v; }
+static void *arena_take(size_t bytes)
+{
+    if (!arena_gb()) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    Arena &A = g_arena[dev];
+    if (!A.tried) {
+        A.tried = true;
+        if (hipMalloc((void **)&A.base, arena_gb() << 30) == hipSuccess) A.cap = arena_gb() << 30; else { (void)hipGetLastError(); A.base = nullptr; }
+    }
+    const size_t need = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    if (!A.base || A.used + need > A.cap) return nullptr;
+    void *p = A.base + A.used;
+    A.used += need;
+    return p;
+}
+static void arena_reset()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    Arena &A = g_arena[dev];
+    if (A.base) (void)hipFree(A.base);
+    A = Arena();
+}
+
 struct DBuf {
     void *p = nullptr;
     size_t cap = 0;
     u64 gen = 0;              // bumped whenever the buffer is (re)allocated, freed or an allocation fails: what it held is gone
+    bool in_arena = false;
     int ensure(size_t bytes)
     {
         if (bytes <= cap) return MTS_OK;
         gen++;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        if (p && !in_arena) (void)hipFree(p);
+        p = nullptr; cap = 0; in_arena = false;
         const size_t want = bytes + bytes / 8 + 4096;
+        if (void *a = arena_take(want)) { p = a; cap = want; in_arena = true; return MTS_OK; }
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             e = hipMalloc(&p, bytes);
@@ -68,7 +103,7 @@ struct DBuf {
         } else cap = want;
         return MTS_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; gen++; }
+    void release() { if (p && !in_arena) (void)hipFree(p); p = nullptr; cap = 0; in_arena = false; gen++; }
     template <typename T> T *as() { return (T *)p; }
 };
 
@@ -159,6 +194,7 @@ struct Engine {
         DBuf *all[] = {&stream, &sort_a, &sort_b, &sort_ws, &tables, &tokens, &marks, &segbuf, &blk, &blkcodes, &blkhdr, &desc,
                        &adler, &misc, &h_in, &h_out, &inf_scratch, &inf_desc, &segsums, &fast_lists, &fast_state};
         for (DBuf *b : all) b->release();
+        arena_reset();                                   // (every piece of it has just been let go)
         geo_n.clear();
         for (auto &g : stg) g.release();
         if (fast_st) (void)hipStreamDestroy(fast_st);
