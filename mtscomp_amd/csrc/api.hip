@@ -684,6 +684,20 @@ static int staged_h2d(Engine &E, void *d_dst, const void *src, size_t n)
 // out: 21 / 31 GB/s for the 60-chunk recording where the kernels alone do 46 / 134).  A piece is MTS_PIPE_BYTES of raw data
 // (default 256 MiB; 0 = one piece, the old behaviour): big enough that the kernels lose nothing, small enough that a recording
 // of a few hundred MB already overlaps.
+// a piece's copy on a helper thread; when no thread can be started (std::system_error) the copy is made at once, on this one
+template <class F>
+static std::future<int> copy_beside(F &&f, int k)
+{
+    try {
+        return std::async(std::launch::async, f, k);
+    } catch (...) {
+        std::promise<int> p;
+        int rc = MTS_E_INTERNAL;
+        try { rc = f(k); } catch (...) {}
+        p.set_value(rc);
+        return p.get_future();
+    }
+}
 static size_t pipe_piece_bytes()
 {
     const char *e = getenv("MTS_PIPE_BYTES");
@@ -1057,8 +1071,8 @@ int mts_compress_chunks(int device, const void *raw, int n_channels, int itemsiz
     if ((rc = copy_in(0))) return rc;
     for (int k = 0; k < np; k++) {
         std::future<int> f_in, f_out;
-        if (k + 1 < np) f_in = std::async(std::launch::async, copy_in, k + 1);
-        if (k >= 1) f_out = std::async(std::launch::async, copy_out, k - 1);
+        if (k + 1 < np) f_in = copy_beside(copy_in, k + 1);
+        if (k >= 1) f_out = copy_beside(copy_out, k - 1);
         const u64 off = (u64)(chunk_bounds[pb[k]] - chunk_bounds[0]) * row_bytes;
         rc = dev_compress(*E, nullptr, E->h_in.as<u8>() + off, n_channels, itemsize, chunk_bounds + pb[k], pb[k + 1] - pb[k], flags, level,
                           E->h_out.as<u8>(), slots.data() + pb[k], out_sizes + pb[k], k > 0);
@@ -1323,8 +1337,8 @@ int mts_decompress_chunks(int device, const unsigned char *cdata, const long *c_
     if ((rc = copy_in(0))) return rc;
     for (int k = 0; k < np; k++) {
         std::future<int> f_in, f_out;
-        if (k + 1 < np) f_in = std::async(std::launch::async, copy_in, k + 1);
-        if (k >= 1) f_out = std::async(std::launch::async, copy_out, k - 1);
+        if (k + 1 < np) f_in = copy_beside(copy_in, k + 1);
+        if (k >= 1) f_out = copy_beside(copy_out, k - 1);
         rc = dev_decompress(*E, nullptr, E->h_in.as<u8>(), coff.data() + pb[k], c_lengths + pb[k], n_rows + pb[k], pb[k + 1] - pb[k], n_channels,
                             itemsize, flags, E->h_out.as<u8>(), ooff.data() + pb[k], chunk_status + pb[k], 0, k > 0);
         const int rc_in = f_in.valid() ? f_in.get() : MTS_OK, rc_out = f_out.valid() ? f_out.get() : MTS_OK;
