@@ -77,7 +77,10 @@ __device__ __forceinline__ u32 lds_u32(const u32 *win, u32 addr)
 // scored candidates is about the number of times the best length improves.
 // ------------------------------------------------------------------------------------------------
 #ifndef MTS_M5_NT_KEYS
-#define MTS_M5_NT_KEYS 1     // the sorted keys are read once: non-temporal loads keep them from pushing table lines out of L2 (same time, 17.0 -> 13.4 GB written)
+#define MTS_M5_NT_KEYS 0     // 1: the sorted keys, read once, by non-temporal loads (round 3: they keep table lines in L2, 17.0 -> 13.4 GB written, same time).
+                             // Round 6: with plain loads the kernel takes 18.2-18.3 ms in every process; with the non-temporal ones it took one of three
+                             // times from process to process (18.4 / 18.8 / 19.0: the physical placement of the workspace, tools/m5_addr_times.py) -- six
+                             // alternating runs each: 18.21-18.32 against 18.55-18.96.  The bytes written are not what the kernel waits for.
 #endif
 #ifndef MTS_M5_STATS
 #define MTS_M5_STATS 0
