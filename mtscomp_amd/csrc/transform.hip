@@ -8,9 +8,6 @@
 
 namespace mts {
 
-#ifndef MTS_K12_NT_STORE
-#define MTS_K12_NT_STORE 0     // (experiment) K1 / K2 write their output with non-temporal stores
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // helpers
@@ -258,11 +255,7 @@ __global__ __launch_bounds__(256) void k_delta_rows(const u8 *__restrict__ raw, 
                     sa += bs;
                     sb += (nbytes - I * sizeof(T)) * bs - bw;
                 }
-#if MTS_K12_NT_STORE
-                if (t0 + tt + IPL <= nt) { __builtin_nontemporal_store(w[0], (u32 *)&out[I]); __builtin_nontemporal_store(w[1], (u32 *)&out[I] + 1); }
-#else
                 if (t0 + tt + IPL <= nt) *(uint2 *)&out[I] = make_uint2(w[0], w[1]);
-#endif
                 else for (int j = 0; t0 + tt + j < nt; j++) out[I + j] = (T)(w[j / EPD] >> (8 * sizeof(T) * (j % EPD)));
             }
         }
@@ -752,11 +745,7 @@ __global__ __launch_bounds__(256) void k_cumsum_rows(const u8 *__restrict__ stre
                 w[j / EPD] |= (u32)tile[r * pitch + c] << (8 * sizeof(T) * (j % EPD));
                 if (++c == (u32)nc) { c = 0; r++; }
             }
-#if MTS_K12_NT_STORE
-            { u32 *o4 = (u32 *)&oq[i]; __builtin_nontemporal_store(w[0], o4); __builtin_nontemporal_store(w[1], o4 + 1); __builtin_nontemporal_store(w[2], o4 + 2); __builtin_nontemporal_store(w[3], o4 + 3); }
-#else
             oq[i] = make_uint4(w[0], w[1], w[2], w[3]);
-#endif
         }
         for (long e = n_full * VW + threadIdx.x; e < e_n; e += 256) {
             const u32 r = __umulhi((u32)e, nc_magic), c = (u32)e - r * nc;
