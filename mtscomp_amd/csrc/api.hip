@@ -537,9 +537,8 @@ struct CopyPool {
     std::vector<std::thread> th;
     u8 *dst = nullptr; const u8 *src = nullptr; size_t n = 0, per = 0;
     u64 gen = 0; int pending = 0; bool stop = false;
-    void worker(int t)
+    void worker(int t, u64 seen /* the job counter when the thread was made: jobs published before are not its */)
     {
-        u64 seen = 0;
         for (;;) {
             std::unique_lock<std::mutex> lk(mu);
             cv_go.wait(lk, [&] { return stop || gen != seen; });
@@ -555,7 +554,10 @@ struct CopyPool {
     }
     void run(void *d, const void *s, size_t bytes, int nt)
     {
-        if ((int)th.size() + 1 < nt) { for (int t = (int)th.size() + 1; t < nt; t++) th.emplace_back(&CopyPool::worker, this, t); }
+        if ((int)th.size() + 1 < nt) {
+            std::lock_guard<std::mutex> lk(mu);
+            for (int t = (int)th.size() + 1; t < nt; t++) th.emplace_back(&CopyPool::worker, this, t, gen);
+        }
         // (the share is rounded UP before it is aligned: with n / nt an exact multiple of 4096 and n % nt != 0 the threads' shares
         //  ended n % nt bytes short of n -- the last bytes of such a copy were never made; found by tools/fuzz_gpu.py, seed 301)
         const size_t p = ((bytes + nt - 1) / nt + 4095) & ~(size_t)4095;
