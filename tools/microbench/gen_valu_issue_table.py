@@ -131,6 +131,12 @@ MIX = [
     ('v_cmp->vcc + v_bitop3(vcc_lo as data)', ['v_cmp_ne_u32 vcc, {d}, {a}', 'v_bitop3_b32 {d}, {d}, vcc_lo, {b} bitop3:0x60'], 'vcc'),
     ('v_readlane + s_add (dependent)', ['v_readlane_b32 s22, {a}, 3', 's_add_u32 s23, s22, s23'], 's22,s23,scc'),
     ('s_cbranch_scc0 not taken + v_add', ['s_cmp_eq_u32 s20, s21', 'v_add_u32 {d}, {d}, {a}'], 'scc'),
+    # a lane mask combined on the scalar unit, then used by a select: through VCC / through another SGPR pair
+    ('v_cmp->vcc; s_and vcc; v_cndmask(vcc)', ['v_cmp_ne_u32 vcc, {d}, {a}', 's_and_b64 vcc, vcc, s[20:21]', 'v_cndmask_b32 {d}, {d}, {a}, vcc'], 'vcc,scc'),
+    ('v_cmp->sgpr; s_and sgpr; v_cndmask(sgpr)', ['v_cmp_ne_u32_e64 s[22:23], {d}, {a}', 's_and_b64 s[22:23], s[22:23], s[20:21]', 'v_cndmask_b32_e64 {d}, {d}, {a}, s[22:23]'], 's22,s23,scc'),
+    ('v_cmp->vcc; s_and sgpr<-vcc; v_cndmask(sgpr)', ['v_cmp_ne_u32 vcc, {d}, {a}', 's_and_b64 s[22:23], vcc, s[20:21]', 'v_cndmask_b32_e64 {d}, {d}, {a}, s[22:23]'], 'vcc,s22,s23,scc'),
+    ('s_mov vcc; v_cndmask(vcc)', ['s_mov_b64 vcc, s[20:21]', 'v_cndmask_b32 {d}, {d}, {a}, vcc'], 'vcc'),
+    ('s_mov sgpr; v_cndmask(sgpr)', ['s_mov_b64 s[22:23], s[20:21]', 'v_cndmask_b32_e64 {d}, {d}, {a}, s[22:23]'], 's22,s23'),
 ]
 N = 64            # instructions per asm block
 
